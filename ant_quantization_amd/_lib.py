@@ -1,0 +1,254 @@
+"""ctypes binding of libantq.so (include/antq.h) for torch tensors.
+
+PyTorch is plumbing here: it owns the HBM buffers and the HIP stream; every
+computation is done by the hand-written gfx950 kernels behind the C ABI.
+There is NO CPU or PyTorch fallback: if the shared library is missing, or a
+tensor is not on a HIP device, the call raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+import torch  # must be imported before libantq.so so that ONE libamdhip64 is shared
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libantq.so")
+
+F32, BF16, F16, F64 = 0, 1, 2, 3
+FLAG_OVP = 1
+IDX_NONE = -1
+IDX_VICTIM = -2
+MAX_GRID = 1024
+PLAN_MAX_BYTES = 64 + 4 * MAX_GRID + 16 * 3072
+
+_DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.float64: F64}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class AntqError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise AntqError(
+                        "libantq.so not found at %s -- build it with `make -C %s/csrc` "
+                        "(or __graft_entry__.build()); there is no CPU fallback" % (LIB_PATH, _HERE))
+                L = ctypes.CDLL(LIB_PATH)
+                L.antq_strerror.restype = ctypes.c_char_p
+                for name in ("antq_abi_version", "antq_nearest", "antq_plan_build", "antq_plan_kind",
+                             "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
+                             "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
+                             "antq_copy"):
+                    getattr(L, name).restype = ctypes.c_int
+                _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise AntqError("%s failed: %s (%d)" % (what, lib().antq_strerror(rc).decode(), rc))
+
+
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise AntqError("%s must live on a HIP device (got %s); libantq has no CPU path" % (name, t.device))
+    if not t.is_contiguous():
+        raise AntqError("%s must be contiguous" % name)
+
+
+# ---------------------------------------------------------------------------------
+# plans
+# ---------------------------------------------------------------------------------
+class Plan:
+    """Host blob + lazily uploaded per-device copies of one grid's decision table."""
+
+    def __init__(self, grid):
+        g = np.ascontiguousarray(np.asarray(grid, dtype=np.float32).reshape(-1))
+        if g.size < 1 or g.size > MAX_GRID:
+            raise AntqError("grid must have 1..%d entries" % MAX_GRID)
+        buf = np.zeros(PLAN_MAX_BYTES, dtype=np.uint8)
+        n = lib().antq_plan_build(g.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(g.size),
+                                  buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.size))
+        if n <= 0:
+            _check(n, "antq_plan_build")
+        self.grid = g
+        self.host = buf[:n].copy()
+        self.kind = int(lib().antq_plan_kind(self.host.ctypes.data_as(ctypes.c_void_p)))
+        self._dev = {}
+
+    @property
+    def is_table(self):
+        return self.kind == 1
+
+    def host_ptr(self):
+        return self.host.ctypes.data_as(ctypes.c_void_p)
+
+    def dev(self, device):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        t = self._dev.get(key)
+        if t is None:
+            t = torch.from_numpy(self.host).to(device)
+            self._dev[key] = t
+        return t
+
+    def eval_host(self, d):
+        """CPU model of the device element path (test utility)."""
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        q = np.empty_like(d)
+        idx = np.empty(d.shape, dtype=np.int16)
+        _check(lib().antq_plan_eval_host(self.host_ptr(), d.ctypes.data_as(ctypes.c_void_p),
+                                         q.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.c_size_t(d.size)), "antq_plan_eval_host")
+        return q, idx
+
+
+_plan_cache = {}
+
+
+def plan_for(grid):
+    """Cached Plan keyed by the grid's bytes (grids are tiny; plans are immutable)."""
+    g = np.ascontiguousarray(np.asarray(grid, dtype=np.float32).reshape(-1))
+    key = g.tobytes()
+    p = _plan_cache.get(key)
+    if p is None:
+        p = Plan(g)
+        _plan_cache[key] = p
+    return p
+
+
+# ---------------------------------------------------------------------------------
+# entry points
+# ---------------------------------------------------------------------------------
+def nearest(x, grid, want_idx=False):
+    """quant_cuda.quant body: z = nearest grid value of every element of flat x."""
+    _require_gpu(x, "x")
+    _require_gpu(grid, "grid")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    want_grid = x.dtype if dt in (F32, F64) else torch.float32
+    if grid.dtype != want_grid:
+        raise AntqError("grid dtype %s, expected %s" % (grid.dtype, want_grid))
+    z = torch.empty_like(x)
+    idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
+    with torch.cuda.device(x.device):
+        _check(lib().antq_nearest(_vp(x), _vp(z), _vp(idx), ctypes.c_size_t(x.numel()), _vp(grid),
+                                  ctypes.c_int(grid.numel()), ctypes.c_int(dt), _stream(x.device)), "antq_nearest")
+    return (z, idx) if want_idx else z
+
+
+def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=False, out=None):
+    """Fused Quantizer._forward on a contiguous tensor viewed as [rows, row_len]."""
+    _require_gpu(x, "x")
+    _require_gpu(alpha, "alpha")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    if alpha.dtype != torch.float32:
+        raise AntqError("alpha must be float32")
+    if rows * row_len != x.numel():
+        raise AntqError("rows*row_len != numel")
+    if alpha.numel() != (rows if per_row else 1):
+        raise AntqError("alpha has %d entries, expected %d" % (alpha.numel(), rows if per_row else 1))
+    if out is None:
+        out = torch.empty_like(x)
+    idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
+    pd = plan.dev(x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().antq_fakequant(_vp(x), _vp(out), _vp(idx), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
+                                    _vp(alpha), ctypes.c_int(1 if per_row else 0), ctypes.c_float(gmax),
+                                    plan.host_ptr(), _vp(pd), ctypes.c_uint(FLAG_OVP if ovp else 0),
+                                    ctypes.c_int(dt), _stream(x.device)), "antq_fakequant")
+    return (out, idx) if want_idx else out
+
+
+def fakequant_dynamic(x, plan, gmax, rows, row_len, ratio=1.0, ovp=False, want_idx=False, out=None,
+                      want_alpha=True):
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    if rows * row_len != x.numel():
+        raise AntqError("rows*row_len != numel")
+    if out is None:
+        out = torch.empty_like(x)
+    idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
+    alpha = torch.empty(rows, dtype=torch.float32, device=x.device) if want_alpha else None
+    pd = plan.dev(x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().antq_fakequant_dynamic(_vp(x), _vp(out), _vp(idx), _vp(alpha), ctypes.c_size_t(rows),
+                                            ctypes.c_size_t(row_len), ctypes.c_float(ratio), ctypes.c_float(gmax),
+                                            plan.host_ptr(), _vp(pd), ctypes.c_uint(FLAG_OVP if ovp else 0),
+                                            ctypes.c_int(dt), _stream(x.device)), "antq_fakequant_dynamic")
+    return out, alpha, idx
+
+
+def absmax(x, rows, row_len, per_row=True):
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    amax = torch.zeros(rows if per_row else 1, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().antq_absmax(_vp(x), _vp(amax), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
+                                 ctypes.c_int(1 if per_row else 0), ctypes.c_int(dt), _stream(x.device)),
+               "antq_absmax")
+    return amax
+
+
+def search_sse(x, rows, row_len, xmax, per_row, ratios, plan, gmax, ovp=False):
+    """sum of squared errors of every clip candidate: [ncand, rows] (or [ncand, 1]) float64."""
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    ncand = ratios.numel()
+    na = rows if per_row else 1
+    sse = torch.zeros(ncand, na, dtype=torch.float64, device=x.device)
+    pd = plan.dev(x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().antq_search_sse(_vp(x), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), _vp(xmax),
+                                     ctypes.c_int(1 if per_row else 0), _vp(ratios), ctypes.c_int(ncand),
+                                     ctypes.c_float(gmax), plan.host_ptr(), _vp(pd),
+                                     ctypes.c_uint(FLAG_OVP if ovp else 0), ctypes.c_int(dt), _vp(sse),
+                                     _stream(x.device)), "antq_search_sse")
+    return sse
+
+
+def affine(x, k, xmin, xmax, rows, row_len, per_row, want_q=False):
+    _require_gpu(x, "x")
+    if x.dtype != torch.float32:
+        raise AntqError("antq_affine is fp32 only")
+    out = torch.empty_like(x)
+    q = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_q else None
+    with torch.cuda.device(x.device):
+        _check(lib().antq_affine(_vp(x), _vp(out), _vp(q), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
+                                 ctypes.c_int(k), _vp(xmin), _vp(xmax), ctypes.c_int(1 if per_row else 0),
+                                 _stream(x.device)), "antq_affine")
+    return (out, q) if want_q else out
+
+
+def copy(src, dst):
+    _require_gpu(src, "src")
+    _require_gpu(dst, "dst")
+    nbytes = src.numel() * src.element_size()
+    with torch.cuda.device(src.device):
+        _check(lib().antq_copy(_vp(src), _vp(dst), ctypes.c_size_t(nbytes), _stream(src.device)), "antq_copy")
+    return dst

@@ -1,0 +1,64 @@
+// antq_internal.h -- plan blob layout shared by the host plan builder and the kernels.
+#pragma once
+#include <stdint.h>
+
+namespace antq {
+
+constexpr uint32_t kPlanMagic = 0x51544E41u;  // "ANTQ"
+constexpr uint32_t kPlanVersion = 3;
+
+constexpr uint32_t kPlanScan = 0;  // kernels run the literal scan for every element
+constexpr uint32_t kPlanLut = 1;   // table plan: one LDS lookup + one compare per element
+
+// Fast exact division (see div_fast in antq_kernels.hip) is proven for
+// |scale| in [2^-40, 2^40]; with |d| < 2^20 this bounds |x| < 2^60, and any x the
+// proof excludes on the small side (|x| < 2^-78) maps to |d| < 2^-38.
+constexpr float kScaleLo = 0x1p-40f;
+constexpr float kScaleHi = 0x1p+40f;
+constexpr float kSmallD = 0x1p-37f;   // no threshold may be closer to zero than this
+constexpr float kFastDMax = 0x1p+20f; // d at or above this magnitude takes the slow path
+
+struct PlanHeader {      // 64 bytes
+    uint32_t magic;
+    uint32_t version;
+    uint32_t kind;       // kPlanScan / kPlanLut
+    uint32_t m;          // grid entries, scan order
+    uint32_t m_pad;      // m rounded up to a multiple of 4 (grid area = m_pad floats)
+    uint32_t shift;      // key = ((int32)bits(d) >> shift) & keymask
+    uint32_t kmin, kmax; // clamp range of the key (signed clamp)
+    uint32_t nb;         // buckets per sign = kmax - kmin + 1
+    uint32_t keymask;    // 2^(31-shift)-1 when the grid has negative thresholds (key = magnitude key),
+                         // 0xffffffff otherwise (negative d keeps a negative key and clamps to kmin)
+    uint32_t nbneg;      // table offset of the negative half: nb, or 0 when there is none
+    uint32_t n_entries;  // nb + nbneg  (positive buckets, then negative buckets)
+    uint32_t bytes;      // total blob size
+    float fastlim;       // |d| < fastlim -> table path; otherwise (huge, Inf, NaN) literal scan
+    float lo_valid;      // d in [lo_valid, hi_valid] has a grid entry within 102400
+    float hi_valid;
+};
+static_assert(sizeof(PlanHeader) == 64, "PlanHeader must be 64 bytes");
+
+// One bucket of the table: at most one decision threshold T lies inside it.
+//   q   = (d >= T) ? v_hi : v_lo
+//   idx = (d >= T) ? idx >> 16 : idx & 0xffff      (scan-order index, last duplicate)
+struct LutEntry {
+    float T;
+    float v_lo;
+    float v_hi;
+    uint32_t idx;
+};
+static_assert(sizeof(LutEntry) == 16, "LutEntry must be 16 bytes");
+
+// blob layout:  PlanHeader | float grid[m_pad] | LutEntry entries[n_entries]
+inline const float *plan_grid(const void *blob)
+{
+    return reinterpret_cast<const float *>(static_cast<const char *>(blob) + sizeof(PlanHeader));
+}
+inline const LutEntry *plan_entries(const void *blob)
+{
+    const PlanHeader *h = static_cast<const PlanHeader *>(blob);
+    return reinterpret_cast<const LutEntry *>(static_cast<const char *>(blob) + sizeof(PlanHeader) +
+                                              sizeof(float) * h->m_pad);
+}
+
+}  // namespace antq

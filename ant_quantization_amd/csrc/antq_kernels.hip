@@ -1,0 +1,788 @@
+// antq_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ANT / OliVe
+// fake-quant hot path + their C-ABI launchers (include/antq.h).
+//
+// Reference semantics being reproduced (bit-exact):
+//   nearest-value scan   ant_quantization/quant/quant_kernel.cu:20-38
+//   Quantizer._forward   ant_quantization/antquant/quant_modules.py:535-551
+//   OliVe _forward + outlier-victim pairs  olive_quantization/antquant/quant_modules.py:294-330
+//   AsymmetricQuantFunction  ant_quantization/antquant/quant_affine.py:95-115
+//
+// Design: the op is element-wise and HBM-bound, so the kernels are
+// shaped by bytes, not flops: 16 B per lane per access (global_load_dwordx4), a
+// wavefront owns a contiguous 1-4 KiB run of ONE quant group (row) so the scale is
+// wave-uniform (SGPRs), the grid's decision table sits in LDS (one ds_read_b128 +
+// one compare per element instead of the reference's M-step scan), the division
+// x/scale is an exact 5-FMA sequence on a per-row reciprocal, and everything the
+// reference does in 7-17 separate PyTorch kernels (div, scan, OVP mask ops, STE
+// add, rescale) happens in registers between one load and one store.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no fast-math: every
+// float op below must round exactly as written).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/antq.h"
+#include "antq_internal.h"
+
+namespace antq {
+
+// ------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+
+struct bf16_tag {};
+struct f16_tag {};
+
+// 16-byte vector <-> EPL floats.  Conversions to the storage type round to nearest-even
+// (v_cvt_pk_bf16_f32 / v_cvt_f16_f32), which is what `tensor.to(dtype)` does.
+template <typename T> struct IO;
+template <> struct IO<float> {
+    static constexpr int EPL = 4;
+    static constexpr int ESIZE = 4;
+    __device__ __forceinline__ static void unpack(const uint4 &v, float (&f)[4])
+    {
+        f[0] = u2f(v.x); f[1] = u2f(v.y); f[2] = u2f(v.z); f[3] = u2f(v.w);
+    }
+    __device__ __forceinline__ static uint4 pack(const float (&f)[4])
+    {
+        return make_uint4(f2u(f[0]), f2u(f[1]), f2u(f[2]), f2u(f[3]));
+    }
+    __device__ __forceinline__ static float load1(const void *p, size_t i) { return static_cast<const float *>(p)[i]; }
+    __device__ __forceinline__ static void store1(void *p, size_t i, float v) { static_cast<float *>(p)[i] = v; }
+};
+template <> struct IO<bf16_tag> {
+    static constexpr int EPL = 8;
+    static constexpr int ESIZE = 2;
+    __device__ __forceinline__ static void unpack(const uint4 &v, float (&f)[8])
+    {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f[2 * i] = u2f(w[i] << 16);
+            f[2 * i + 1] = u2f(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ static uint32_t pk(float a, float b)
+    {
+        floatx2_t f = {a, b};
+        bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+        return *reinterpret_cast<uint32_t *>(&h);
+    }
+    __device__ __forceinline__ static uint4 pack(const float (&f)[8])
+    {
+        return make_uint4(pk(f[0], f[1]), pk(f[2], f[3]), pk(f[4], f[5]), pk(f[6], f[7]));
+    }
+    __device__ __forceinline__ static float load1(const void *p, size_t i)
+    {
+        return u2f((uint32_t) static_cast<const uint16_t *>(p)[i] << 16);
+    }
+    __device__ __forceinline__ static void store1(void *p, size_t i, float v)
+    {
+        static_cast<uint16_t *>(p)[i] = (uint16_t)(pk(v, 0.0f) & 0xffffu);
+    }
+};
+template <> struct IO<f16_tag> {
+    static constexpr int EPL = 8;
+    static constexpr int ESIZE = 2;
+    __device__ __forceinline__ static float h2f(uint32_t bits16)
+    {
+        uint16_t b = (uint16_t)bits16;
+        _Float16 h = *reinterpret_cast<_Float16 *>(&b);
+        return (float)h;
+    }
+    __device__ __forceinline__ static uint32_t f2h(float f)
+    {
+        _Float16 h = (_Float16)f;
+        return (uint32_t) * reinterpret_cast<uint16_t *>(&h);
+    }
+    __device__ __forceinline__ static void unpack(const uint4 &v, float (&f)[8])
+    {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f[2 * i] = h2f(w[i] & 0xffffu);
+            f[2 * i + 1] = h2f(w[i] >> 16);
+        }
+    }
+    __device__ __forceinline__ static uint4 pack(const float (&f)[8])
+    {
+        return make_uint4(f2h(f[0]) | (f2h(f[1]) << 16), f2h(f[2]) | (f2h(f[3]) << 16),
+                          f2h(f[4]) | (f2h(f[5]) << 16), f2h(f[6]) | (f2h(f[7]) << 16));
+    }
+    __device__ __forceinline__ static float load1(const void *p, size_t i)
+    {
+        return h2f(static_cast<const uint16_t *>(p)[i]);
+    }
+    __device__ __forceinline__ static void store1(void *p, size_t i, float v)
+    {
+        static_cast<uint16_t *>(p)[i] = (uint16_t)f2h(v);
+    }
+};
+
+// Plan fields the kernels need, passed by value (lands in SGPRs).
+struct PlanArgs {
+    uint32_t kind;
+    uint32_t m;
+    uint32_t m_pad;
+    uint32_t shift;
+    uint32_t kmin;
+    uint32_t kmax;
+    uint32_t keymask;
+    uint32_t nbneg;
+    float fastlim;
+    uint32_t n_entries;
+    uint32_t tab_units;  // 16-byte units to stage into LDS: n_entries + m_pad/4
+};
+
+// LDS view of the plan: [entries | grid]
+struct PlanLds {
+    const LutEntry *lut;
+    const float *grid;
+};
+
+// Stage the table into LDS.  plan_tab points at the blob's grid area; the blob stores
+// grid first, entries second, LDS wants entries first (16-byte aligned reads).
+__device__ __forceinline__ PlanLds stage_plan(const PlanArgs &pa, const uint4 *__restrict__ plan_tab, uint4 *smem)
+{
+    const uint32_t grid_units = pa.m_pad >> 2;
+    for (uint32_t i = threadIdx.x; i < pa.tab_units; i += blockDim.x) {
+        // source unit i: [0, grid_units) grid, then entries
+        uint4 v = plan_tab[i];
+        uint32_t dst = (i < grid_units) ? (pa.n_entries + i) : (i - grid_units);
+        smem[dst] = v;
+    }
+    PlanLds L;
+    L.lut = reinterpret_cast<const LutEntry *>(smem);
+    L.grid = reinterpret_cast<const float *>(smem + pa.n_entries);
+    return L;
+}
+
+// ------------------------------------------------------------------------------------
+// Scale of one quant group.  AQ/quant_modules.py:536: scale = alpha / max(grid)  (true
+// fp32 division); rs = RN(1/scale) feeds the exact fast division below.
+// ------------------------------------------------------------------------------------
+struct Scale {
+    float s;
+    float rs;
+    bool ok;  // |s| within [2^-40, 2^40]: div_fast is exact
+};
+__device__ __forceinline__ Scale make_scale(float alpha, float gmax)
+{
+    Scale sc;
+    sc.s = alpha / gmax;
+    float a = fabsf(sc.s);
+    sc.ok = (a >= kScaleLo) && (a <= kScaleHi);
+    sc.rs = 1.0f / sc.s;
+    return sc;
+}
+
+// Correctly rounded x/s from rs = RN(1/s) with 1 mul + 4 fma (Markstein): q1 is a
+// faithful quotient, the exact residual x - q1*s (one fma) times rs corrects it to
+// RN(x/s).  Exact provided no intermediate under/overflows: |s| in [2^-40, 2^40] and
+// x == 0 or |x| in [2^-78, 2^60]; callers guarantee that through Scale::ok and the
+// kfast / kSmallD plan conditions (antq_internal.h).
+__device__ __forceinline__ float div_fast(float x, float s, float rs)
+{
+    float q0 = x * rs;
+    float e0 = __builtin_fmaf(-q0, s, x);
+    float q1 = __builtin_fmaf(e0, rs, q0);
+    float e1 = __builtin_fmaf(-q1, s, x);
+    return __builtin_fmaf(e1, rs, q1);
+}
+
+// literal scan, quant_kernel.cu:25-37 (grid in LDS: every lane reads the same address,
+// a broadcast).  Used for scan plans and for the rare lanes outside the table's domain.
+__device__ __forceinline__ float scan_lds(float d, const float *grid, int m, int &j)
+{
+    float sub_min = 102400.0f, z_min = 0.0f;
+    j = ANTQ_IDX_NONE;
+    for (int i = 0; i < m; i++) {
+        float g = grid[i];
+        float sub_v = fabsf(d - g);
+        if (sub_v <= sub_min) { sub_min = sub_v; z_min = g; j = i; }
+    }
+    return z_min;
+}
+
+// ------------------------------------------------------------------------------------
+// Core: EPL elements of one lane, all from the same quant group.
+//   in : x[e]           out: o[e] = fl(fl(fl(q-d)+d)*s), j[e] (if IDX)
+// ------------------------------------------------------------------------------------
+template <int EPL, bool OVP, bool IDX>
+__device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, const Scale &sc,
+                                          const float (&x)[EPL], float (&o)[EPL], int (&j)[EPL])
+{
+    float d[EPL], q[EPL];
+    bool fast = (pa.kind == kPlanLut) && sc.ok;
+    if (fast) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            d[e] = div_fast(x[e], sc.s, sc.rs);
+            fast = fast && (fabsf(d[e]) < pa.fastlim);  // false for NaN / Inf / huge
+        }
+    }
+    if (fast) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int32_t u = (int32_t)f2u(d[e]);
+            const int32_t ks = (int32_t)((uint32_t)(u >> pa.shift) & pa.keymask);
+            uint32_t k = (uint32_t)(min(max(ks, (int32_t)pa.kmin), (int32_t)pa.kmax) - (int32_t)pa.kmin);
+            k += (uint32_t)(u >> 31) & pa.nbneg;
+            const uint4 ent = *reinterpret_cast<const uint4 *>(&L.lut[k]);
+            const bool c = d[e] >= u2f(ent.x);
+            q[e] = c ? u2f(ent.z) : u2f(ent.y);
+            if (IDX) j[e] = (int)(c ? (ent.w >> 16) : (ent.w & 0xffffu));
+        }
+    } else {
+        // exact slow path: true division + literal scan (scan plans, odd scales, huge/NaN/Inf)
+        for (int e = 0; e < EPL; e++) {
+            d[e] = x[e] / sc.s;
+            int jj;
+            q[e] = scan_lds(d[e], L.grid, (int)pa.m, jj);
+            if (IDX) j[e] = jj;
+        }
+    }
+    if (OVP) {
+        // OQ/quant_modules.py:313-320 on pairs (2p, 2p+1): the odd element is a victim when
+        // its even partner is an outlier; the even one when its odd partner is an outlier and
+        // it is not one itself.  q * (~victim) keeps the sign of zero, as float*bool does.
+#pragma unroll
+        for (int p = 0; p < EPL / 2; p++) {
+            const bool me = fabsf(q[2 * p]) > 32.0f;
+            const bool mo = fabsf(q[2 * p + 1]) > 32.0f;
+            const bool ve = mo && !me;
+            q[2 * p] = q[2 * p] * (ve ? 0.0f : 1.0f);
+            q[2 * p + 1] = q[2 * p + 1] * (me ? 0.0f : 1.0f);
+            if (IDX) {
+                if (ve) j[2 * p] = ANTQ_IDX_VICTIM;
+                if (me) j[2 * p + 1] = ANTQ_IDX_VICTIM;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        float t = (q[e] - d[e]) + d[e];  // AQ:544 / OQ:323 straight-through form
+        o[e] = t * sc.s;                 // AQ:546-549
+    }
+}
+
+template <int EPL>
+__device__ __forceinline__ void store_idx(int16_t *idx, size_t vec, const int (&j)[EPL])
+{
+    // EPL int16 = 8 or 16 bytes, naturally aligned at vec*EPL
+    if (EPL == 8) {
+        uint4 v = make_uint4(((uint32_t)j[0] & 0xffffu) | ((uint32_t)j[1] << 16),
+                             ((uint32_t)j[2] & 0xffffu) | ((uint32_t)j[3] << 16),
+                             ((uint32_t)j[4 % EPL] & 0xffffu) | ((uint32_t)j[5 % EPL] << 16),
+                             ((uint32_t)j[6 % EPL] & 0xffffu) | ((uint32_t)j[7 % EPL] << 16));
+        reinterpret_cast<uint4 *>(idx)[vec] = v;
+    } else {
+        uint2 v = make_uint2(((uint32_t)j[0] & 0xffffu) | ((uint32_t)j[1] << 16),
+                             ((uint32_t)j[2] & 0xffffu) | ((uint32_t)j[3] << 16));
+        reinterpret_cast<uint2 *>(idx)[vec] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1a  wave-uniform scale.  A wavefront owns up to U*64 consecutive 16-byte vectors of
+// ONE row; the row's alpha is a scalar load and scale / reciprocal live in SGPR-uniform
+// registers.  Rows need row_len % EPL == 0; lanes past the row end are masked.
+//   vpr = vectors per row, tpr = tasks per row = ceil(vpr / (64*U)).
+// Launch: 256 threads (4 wavefronts), grid = ceil(rows*tpr / 4).
+// ------------------------------------------------------------------------------------
+template <typename T, bool OVP, bool IDX, int U>
+__global__ void __launch_bounds__(256)
+k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+             uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
+             const float *__restrict__ alpha, int per_row, float gmax,
+             PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    constexpr int EPL = IO<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const bool active = task < total_tasks;
+    uint32_t row = 0, g = 0;
+    if (active) { row = task / tpr; g = task - row * tpr; }
+    const uint32_t v0 = g * (64u * U) + lane;            // vector index inside the row
+    const size_t base = (size_t)row * vpr;               // first vector of the row
+
+    // issue the HBM loads before anything else so they fly during the table staging
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (active && v0 + 64u * u < vpr) v[u] = x[base + v0 + 64u * u];
+    }
+    float a = 1.0f;
+    if (active) a = alpha[per_row ? row : 0];
+
+    const PlanLds L = stage_plan(pa, plan_tab, smem);
+    __syncthreads();
+    if (!active) return;
+    const Scale sc = make_scale(a, gmax);
+
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (v0 + 64u * u < vpr) {
+            float xf[EPL], of[EPL];
+            int j[EPL];
+            IO<T>::unpack(v[u], xf);
+            quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
+            out[base + v0 + 64u * u] = IO<T>::pack(of);
+            if (IDX) store_idx<EPL>(idx, base + v0 + 64u * u, j);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1b  per-lane scale: small rows / small groups (vpr < 64: several quant groups share a
+// wavefront, e.g. group-16 = 2 bf16 lanes or 4 fp32 lanes per group).  Each lane gathers
+// its own alpha and builds its own scale.  vshift >= 0 when vpr is a power of two.
+// ------------------------------------------------------------------------------------
+template <typename T, bool OVP, bool IDX, int U>
+__global__ void __launch_bounds__(256)
+k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+          size_t n_vec, uint32_t vpr, int vshift,
+          const float *__restrict__ alpha, int per_row, float gmax,
+          PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    constexpr int EPL = IO<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
+    uint4 v[U];
+    float a[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t vi = first + (size_t)u * 256u;
+        v[u] = make_uint4(0, 0, 0, 0);
+        a[u] = 1.0f;
+        if (vi < n_vec) {
+            v[u] = x[vi];
+            size_t row = 0;
+            if (per_row) row = (vshift >= 0) ? (vi >> vshift) : (vi / vpr);
+            a[u] = alpha[row];
+        }
+    }
+    const PlanLds L = stage_plan(pa, plan_tab, smem);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t vi = first + (size_t)u * 256u;
+        if (vi < n_vec) {
+            const Scale sc = make_scale(a[u], gmax);
+            float xf[EPL], of[EPL];
+            int j[EPL];
+            IO<T>::unpack(v[u], xf);
+            quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
+            out[vi] = IO<T>::pack(of);
+            if (IDX) store_idx<EPL>(idx, vi, j);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1c  element-granular fallback: any row_len (e.g. conv1's K = 147), any alignment,
+// and the < EPL tail of a per-tensor launch.  One thread per PAIR (2p, 2p+1) of the flat
+// tensor so the OliVe victim rule stays inside a thread; with an odd element count the
+// last element's "partner" is element 0 (torch.roll wrap-around, OQ:315-318).
+//   elements [e0, e0 + n_here) of a tensor with n_total elements, e0 even.
+// ------------------------------------------------------------------------------------
+template <typename T, bool OVP, bool IDX>
+__global__ void __launch_bounds__(256)
+k_fq_scalar(const void *__restrict__ x, void *__restrict__ out, int16_t *__restrict__ idx,
+            size_t e0, size_t n_here, size_t n_total, size_t row_len,
+            const float *__restrict__ alpha, int per_row, float gmax,
+            PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const PlanLds L = stage_plan(pa, plan_tab, smem);
+    __syncthreads();
+    const size_t p = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const size_t i0 = e0 + 2 * p;
+    if (2 * p >= n_here) return;
+    const bool has_odd = (2 * p + 1 < n_here);
+    const size_t i1 = has_odd ? i0 + 1 : 0;  // wrap partner (only read when !has_odd && OVP)
+    const bool need1 = has_odd || (OVP && i0 + 1 == n_total);
+
+    float xs[2] = {IO<T>::load1(x, i0), need1 ? IO<T>::load1(x, i1) : 0.0f};
+    float d[2], q[2];
+    float s[2];
+    int j[2] = {ANTQ_IDX_NONE, ANTQ_IDX_NONE};
+    for (int e = 0; e < 2; e++) {
+        const size_t ii = e ? i1 : i0;
+        const float a = alpha[per_row ? (ii / row_len) : 0];
+        s[e] = a / gmax;
+        d[e] = xs[e] / s[e];
+        int jj;
+        q[e] = scan_lds(d[e], L.grid, (int)pa.m, jj);
+        j[e] = jj;
+    }
+    if (OVP && need1) {
+        const bool me = fabsf(q[0]) > 32.0f;
+        const bool mo = fabsf(q[1]) > 32.0f;
+        if (has_odd) {
+            const bool ve = mo && !me;
+            q[0] = q[0] * (ve ? 0.0f : 1.0f);
+            q[1] = q[1] * (me ? 0.0f : 1.0f);
+            if (ve) j[0] = ANTQ_IDX_VICTIM;
+            if (me) j[1] = ANTQ_IDX_VICTIM;
+        } else {
+            // odd numel: the last (even-indexed) element is zeroed iff element 0 is an outlier
+            q[0] = q[0] * (mo ? 0.0f : 1.0f);
+            if (mo) j[0] = ANTQ_IDX_VICTIM;
+        }
+    }
+    {
+        float t = (q[0] - d[0]) + d[0];
+        IO<T>::store1(out, i0, t * s[0]);
+        if (IDX) idx[i0] = (int16_t)j[0];
+    }
+    if (has_odd) {
+        float t = (q[1] - d[1]) + d[1];
+        IO<T>::store1(out, i1, t * s[1]);
+        if (IDX) idx[i1] = (int16_t)j[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// quant_cuda.quant replacement: literal scan, grid arrives as a device array of unknown
+// content (no host plan possible without a sync).  Grid -> LDS once per workgroup, four
+// elements per thread, every LDS read is a wave-wide broadcast.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nearest(const T *__restrict__ x, T *__restrict__ z, int16_t *__restrict__ idx, size_t n,
+          const T *__restrict__ grid, int m)
+{
+    __shared__ float y[ANTQ_MAX_GRID];
+    for (int i = threadIdx.x; i < m; i += 256) y[i] = (float)grid[i];  // quant_kernel.cu:23 narrows to float
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * 1024u + threadIdx.x;
+    float xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const size_t i = base + 256u * u;
+        xv[u] = (i < n) ? (float)x[i] : 0.0f;  // :28 narrows x to float
+    }
+    float sub_min[4], z_min[4];
+    int jm[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { sub_min[u] = 102400.0f; z_min[u] = 0.0f; jm[u] = ANTQ_IDX_NONE; }
+    for (int i = 0; i < m; i++) {
+        const float g = y[i];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float sub_v = fabsf(xv[u] - g);
+            if (sub_v <= sub_min[u]) { sub_min[u] = sub_v; z_min[u] = g; jm[u] = i; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const size_t i = base + 256u * u;
+        if (i < n) {
+            z[i] = (T)z_min[u];
+            if (idx) idx[i] = (int16_t)jm[u];
+        }
+    }
+}
+
+// bf16 / f16 storage variant of k_nearest (grid is float)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nearest16(const void *__restrict__ x, void *__restrict__ z, int16_t *__restrict__ idx, size_t n,
+            const float *__restrict__ grid, int m)
+{
+    __shared__ float y[ANTQ_MAX_GRID];
+    for (int i = threadIdx.x; i < m; i += 256) y[i] = grid[i];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float xv = IO<T>::load1(x, i);
+    int j;
+    const float q = scan_lds(xv, y, m, j);
+    IO<T>::store1(z, i, q);
+    if (idx) idx[i] = (int16_t)j;
+}
+
+// ------------------------------------------------------------------------------------
+// AsymmetricQuantFunction.forward, quant_affine.py:95-115.  fp32, element-wise; rintf is
+// round-half-to-even like torch.round.  Expression order follows the reference exactly:
+//   scale*x - zp  (linear_quantize :39), (q + zp) / scale  (linear_dequantize :62).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_affine(const float *__restrict__ x, float *__restrict__ out, int32_t *__restrict__ qout,
+         size_t n, size_t row_len, int k,
+         const float *__restrict__ xmin, const float *__restrict__ xmax, int per_row)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = per_row ? i / row_len : 0;
+    const float nlev = (float)((1 << k) - 1);
+    const float half = (float)(1 << (k - 1));
+    float range = xmax[r] - xmin[r];
+    if (range < 1e-8f) range = 1e-8f;   // torch.clamp(min=1e-8): NaN stays NaN
+    const float scale = nlev / range;
+    float zp = rintf(scale * xmin[r]);
+    zp = zp + half;
+    float q = rintf(scale * x[i] - zp);
+    if (q < -half) q = -half;           // torch.clamp(q, -n, n-1): NaN stays NaN
+    if (q > half - 1.0f) q = half - 1.0f;
+    if (qout) qout[i] = (int32_t)q;
+    out[i] = (q + zp) / scale;
+}
+
+// 16 B per lane streaming copy: the empirical HBM ceiling for this access pattern.
+__global__ void __launch_bounds__(256)
+k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec)
+{
+    const size_t first = (size_t)blockIdx.x * 1024u + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const size_t i = first + 256u * u;
+        if (i < n_vec) v[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const size_t i = first + 256u * u;
+        if (i < n_vec) dst[i] = v[u];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------
+static bool plan_args_from_host(const void *plan_host, PlanArgs &pa)
+{
+    const PlanHeader *h = static_cast<const PlanHeader *>(plan_host);
+    if (h->magic != kPlanMagic || h->version != kPlanVersion) return false;
+    if (h->m < 1 || h->m > ANTQ_MAX_GRID || h->m_pad != ((h->m + 3) & ~3u)) return false;
+    pa.kind = h->kind;
+    pa.m = h->m;
+    pa.m_pad = h->m_pad;
+    pa.shift = h->shift;
+    pa.kmin = h->kmin;
+    pa.kmax = h->kmax;
+    pa.keymask = h->keymask;
+    pa.nbneg = h->nbneg;
+    pa.fastlim = h->fastlim;
+    pa.n_entries = (h->kind == kPlanLut) ? h->n_entries : 0;
+    pa.tab_units = pa.n_entries + (pa.m_pad >> 2);
+    return true;
+}
+
+static inline const uint4 *plan_tab_ptr(const void *plan_dev)
+{
+    return reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev) + sizeof(PlanHeader));
+}
+
+template <typename T, bool OVP, bool IDX>
+static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,
+                     const float *alpha, int per_row, float gmax, const PlanArgs &pa,
+                     const void *plan_dev, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const size_t n = rows * row_len;
+    const size_t lds = (size_t)pa.tab_units * 16;
+    const uint4 *tab = plan_tab_ptr(plan_dev);
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
+                         (!idx || reinterpret_cast<uintptr_t>(idx) % 16 == 0);
+    if (!per_row) { rows = 1; row_len = n; }
+
+    if (aligned && row_len % EPL == 0) {
+        const size_t vpr = row_len / EPL;
+        if (vpr >= 64) {
+            if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
+            // U: 1 KiB .. 4 KiB of one row per wavefront, keeping lane utilisation high
+            int U = 4;
+            if (vpr % 256 != 0) {
+                const double u4 = (double)vpr / (double)(((vpr + 255) / 256) * 256);
+                const double u2 = (double)vpr / (double)(((vpr + 127) / 128) * 128);
+                const double u1 = (double)vpr / (double)(((vpr + 63) / 64) * 64);
+                if (u2 > u4 + 0.05) U = 2;
+                if (u1 > (U == 2 ? u2 : u4) + 0.05) U = 1;
+            }
+            const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
+            const size_t total = rows * tpr;
+            if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+            const dim3 grid((unsigned)((total + 3) / 4)), block(256);
+            const uint4 *xv = static_cast<const uint4 *>(x);
+            uint4 *ov = static_cast<uint4 *>(out);
+            if (U == 4)
+                hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, 4>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,
+                                   (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, pa, tab);
+            else if (U == 2)
+                hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, 2>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,
+                                   (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, pa, tab);
+            else
+                hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, 1>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,
+                                   (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, pa, tab);
+        } else {
+            const size_t n_vec = n / EPL;
+            int vshift = -1;
+            if ((vpr & (vpr - 1)) == 0) { vshift = 0; while (((size_t)1 << vshift) < vpr) vshift++; }
+            constexpr int U = 2;
+            const size_t blocks = (n_vec + 256 * U - 1) / (256 * U);
+            if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U>), dim3((unsigned)blocks), dim3(256), lds, st,
+                               static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
+                               vshift, alpha, per_row, gmax, pa, tab);
+        }
+    } else if (aligned && !per_row && n >= (size_t)64 * EPL) {
+        // per-tensor scale with a ragged tail: vector body + element tail
+        const size_t n_body = (n / EPL) * EPL;
+        int rc = launch_fq<T, OVP, IDX>(x, out, idx, 1, n_body, alpha, 0, gmax, pa, plan_dev, st);
+        if (rc != ANTQ_OK) return rc;
+        const size_t n_tail = n - n_body;
+        const size_t pairs = (n_tail + 1) / 2;
+        hipLaunchKernelGGL((k_fq_scalar<T, OVP, IDX>), dim3((unsigned)((pairs + 255) / 256)), dim3(256), lds, st, x, out,
+                           idx, n_body, n_tail, n, n, alpha, 0, gmax, pa, tab);
+    } else {
+        const size_t pairs = (n + 1) / 2;
+        const size_t blocks = (pairs + 255) / 256;
+        if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((k_fq_scalar<T, OVP, IDX>), dim3((unsigned)blocks), dim3(256), lds, st, x, out, idx,
+                           (size_t)0, n, n, row_len, alpha, per_row, gmax, pa, tab);
+    }
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+template <typename T>
+static int launch_fq_flags(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,
+                           const float *alpha, int per_row, float gmax, const PlanArgs &pa,
+                           const void *plan_dev, unsigned flags, hipStream_t st)
+{
+    const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
+    if (ovp) {
+        if (idx) return launch_fq<T, true, true>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, st);
+        return launch_fq<T, true, false>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, st);
+    }
+    if (idx) return launch_fq<T, false, true>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, st);
+    return launch_fq<T, false, false>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, st);
+}
+
+}  // namespace antq
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+using namespace antq;
+
+extern "C" int antq_abi_version(void) { return ANTQ_ABI_VERSION; }
+
+extern "C" const char *antq_strerror(int code)
+{
+    switch (code) {
+    case ANTQ_OK: return "ok";
+    case ANTQ_ERR_ARG: return "invalid argument";
+    case ANTQ_ERR_UNSUPPORTED: return "unsupported dtype / size for this entry point";
+    case ANTQ_ERR_PLAN: return "malformed or undersized plan blob";
+    case ANTQ_ERR_LAUNCH: return "HIP kernel launch failed";
+    case ANTQ_ERR_ALIGN: return "pointer not aligned to the element size";
+    default: return "unknown antq error";
+    }
+}
+
+extern "C" int antq_nearest(const void *x, void *z, int16_t *idx, size_t n, const void *grid, int m, int dtype,
+                            void *stream)
+{
+    if (n == 0) return ANTQ_OK;
+    if (!x || !z || !grid || m < 1) return ANTQ_ERR_ARG;
+    if (m > ANTQ_MAX_GRID) return ANTQ_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ANTQ_F32 || dtype == ANTQ_F64) {
+        const size_t blocks = (n + 1023) / 1024;
+        if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+        if (dtype == ANTQ_F32)
+            hipLaunchKernelGGL((k_nearest<float>), dim3((unsigned)blocks), dim3(256), 0, st,
+                               static_cast<const float *>(x), static_cast<float *>(z), idx, n,
+                               static_cast<const float *>(grid), m);
+        else
+            hipLaunchKernelGGL((k_nearest<double>), dim3((unsigned)blocks), dim3(256), 0, st,
+                               static_cast<const double *>(x), static_cast<double *>(z), idx, n,
+                               static_cast<const double *>(grid), m);
+    } else if (dtype == ANTQ_BF16 || dtype == ANTQ_F16) {
+        const size_t blocks = (n + 255) / 256;
+        if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+        if (dtype == ANTQ_BF16)
+            hipLaunchKernelGGL((k_nearest16<bf16_tag>), dim3((unsigned)blocks), dim3(256), 0, st, x, z, idx, n,
+                               static_cast<const float *>(grid), m);
+        else
+            hipLaunchKernelGGL((k_nearest16<f16_tag>), dim3((unsigned)blocks), dim3(256), 0, st, x, z, idx, n,
+                               static_cast<const float *>(grid), m);
+    } else {
+        return ANTQ_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+extern "C" int antq_fakequant(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,
+                              const float *alpha, int alpha_per_row, float gmax, const void *plan_host,
+                              const void *plan_dev, unsigned flags, int dtype, void *stream)
+{
+    if (rows == 0 || row_len == 0) return ANTQ_OK;
+    if (!x || !out || !alpha || !plan_host || !plan_dev) return ANTQ_ERR_ARG;
+    PlanArgs pa;
+    if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int per_row = alpha_per_row ? 1 : 0;
+    switch (dtype) {
+    case ANTQ_F32:
+        if (reinterpret_cast<uintptr_t>(x) % 4 || reinterpret_cast<uintptr_t>(out) % 4) return ANTQ_ERR_ALIGN;
+        return launch_fq_flags<float>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, flags, st);
+    case ANTQ_BF16:
+        if (reinterpret_cast<uintptr_t>(x) % 2 || reinterpret_cast<uintptr_t>(out) % 2) return ANTQ_ERR_ALIGN;
+        return launch_fq_flags<bf16_tag>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, flags, st);
+    case ANTQ_F16:
+        if (reinterpret_cast<uintptr_t>(x) % 2 || reinterpret_cast<uintptr_t>(out) % 2) return ANTQ_ERR_ALIGN;
+        return launch_fq_flags<f16_tag>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, flags, st);
+    default:
+        return ANTQ_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int antq_affine(const float *x, float *out, int32_t *q, size_t rows, size_t row_len, int k,
+                           const float *xmin, const float *xmax, int per_row, void *stream)
+{
+    if (rows == 0 || row_len == 0) return ANTQ_OK;
+    if (!x || !out || !xmin || !xmax || k < 1 || k > 24) return ANTQ_ERR_ARG;
+    const size_t n = rows * row_len;
+    const size_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_affine, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, q, n,
+                       row_len, k, xmin, xmax, per_row ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+extern "C" int antq_copy(const void *src, void *dst, size_t bytes, void *stream)
+{
+    if (bytes == 0) return ANTQ_OK;
+    if (!src || !dst || bytes % 16 || reinterpret_cast<uintptr_t>(src) % 16 || reinterpret_cast<uintptr_t>(dst) % 16)
+        return ANTQ_ERR_ARG;
+    const size_t n_vec = bytes / 16;
+    const size_t blocks = (n_vec + 1023) / 1024;
+    if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n_vec);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+// ---- TEMP stubs (implemented below in later commits) ----
+extern "C" int antq_fakequant_dynamic(const void *, void *, int16_t *, float *, size_t, size_t, float, float,
+                                      const void *, const void *, unsigned, int, void *)
+{
+    return ANTQ_ERR_UNSUPPORTED;
+}
+extern "C" int antq_absmax(const void *, float *, size_t, size_t, int, int, void *) { return ANTQ_ERR_UNSUPPORTED; }
+extern "C" int antq_search_sse(const void *, size_t, size_t, const float *, int, const float *, int, float,
+                               const void *, const void *, unsigned, int, double *, void *)
+{
+    return ANTQ_ERR_UNSUPPORTED;
+}

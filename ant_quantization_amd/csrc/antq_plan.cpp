@@ -1,0 +1,326 @@
+// antq_plan.cpp -- host-side construction of the table plan for one value grid.
+//
+// The reference kernel (ant_quantization/quant/quant_kernel.cu:25-37) maps a float d
+// to  grid[j*],  j* = LAST j minimising fl32|d - grid[j]|  (update on `<=`), or to 0.0
+// when no distance is <= 102400.  As a function of d this is a monotone step function:
+// Voronoi cells in 1-D are intervals whatever the array order; the array order only
+// decides exact / rounding-induced ties and which duplicate is reported.  The plan
+// stores that step function EXACTLY:
+//   * thresholds T_i = smallest float that the scan maps to the upper of two adjacent
+//     distinct grid values, found by bisection over the float total order using the very
+//     comparison the scan performs (so rounding-induced ties are reproduced, not modelled);
+//   * a bucket table keyed by the top bits of |d| (exponent + a few mantissa bits) such
+//     that no bucket holds more than one threshold -> one LDS read + one compare per
+//     element on the device;
+//   * the validity interval [lo_valid, hi_valid] outside which the scan yields 0.0.
+// Conditions that make the step-function view provably complete (no "plateau" where
+// far-apart entries tie after rounding) are checked; a grid that fails any of them, or
+// fails the self-check against the literal scan, gets a scan plan (kind 0) and the
+// kernels run the literal scan for it.  Pure CPU code: no HIP calls in this file.
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/antq.h"
+#include "antq_internal.h"
+
+namespace antq {
+namespace {
+
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// monotone map float -> uint32 (total order, -0 < +0)
+inline uint32_t ord(float f)
+{
+    uint32_t u = f2u(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float unord(uint32_t o)
+{
+    return u2f((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+inline float next_up(float f) { return unord(ord(f) + 1); }
+inline float next_dn(float f) { return unord(ord(f) - 1); }
+
+// literal scan of quant_kernel.cu:25-37
+inline float scan_one(float x, const float *y, int m, int *j_out)
+{
+    float sub_min = 102400.0f, z_min = 0.0f;
+    int j = ANTQ_IDX_NONE;
+    for (int i = 0; i < m; i++) {
+        float sub_v = fabsf(x - y[i]);
+        if (sub_v <= sub_min) { sub_min = sub_v; z_min = y[i]; j = i; }
+    }
+    *j_out = j;
+    return z_min;
+}
+
+struct Distinct { float v; int win; };
+
+inline bool pick_hi(float d, const Distinct &lo, const Distinct &hi)
+{
+    float r_lo = fabsf(d - lo.v);
+    float r_hi = fabsf(d - hi.v);
+    return r_hi < r_lo || (r_hi == r_lo && hi.win > lo.win);
+}
+
+inline uint32_t mag_key(float d, uint32_t shift) { return (f2u(d) & 0x7fffffffu) >> shift; }
+
+void write_scan_plan(void *blob, const float *grid, int m)
+{
+    PlanHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = kPlanMagic;
+    h.version = kPlanVersion;
+    h.kind = kPlanScan;
+    h.m = (uint32_t)m;
+    h.m_pad = (uint32_t)((m + 3) & ~3);
+    h.bytes = (uint32_t)(sizeof(PlanHeader) + sizeof(float) * h.m_pad);
+    h.lo_valid = -INFINITY;
+    h.hi_valid = INFINITY;
+    memcpy(blob, &h, sizeof(h));
+    float *g = reinterpret_cast<float *>(static_cast<char *>(blob) + sizeof(PlanHeader));
+    for (uint32_t i = 0; i < h.m_pad; i++) g[i] = (i < (uint32_t)m) ? grid[i] : 0.0f;
+}
+
+// CPU model of the device table path (the kernels implement exactly this).
+inline float eval_lut(const PlanHeader &h, const float *grid, const LutEntry *ent, float d, int *idx)
+{
+    uint32_t u = f2u(d);
+    if (!(fabsf(d) < h.fastlim)) return scan_one(d, grid, (int)h.m, idx);  // slow path (also NaN)
+    int32_t ks = (int32_t)(((uint32_t)((int32_t)u >> h.shift)) & h.keymask);
+    uint32_t k = (uint32_t)(std::min(std::max(ks, (int32_t)h.kmin), (int32_t)h.kmax) - (int32_t)h.kmin);
+    const LutEntry &e = ent[k + ((u >> 31) ? h.nbneg : 0u)];
+    bool c = d >= e.T;
+    uint32_t id = c ? (e.idx >> 16) : (e.idx & 0xffffu);
+    *idx = (int)id;
+    return c ? e.v_hi : e.v_lo;
+}
+
+}  // namespace
+}  // namespace antq
+
+using namespace antq;
+
+extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
+{
+    if (!grid || !blob || m < 1 || m > ANTQ_MAX_GRID) return ANTQ_ERR_ARG;
+    const size_t m_pad = (size_t)((m + 3) & ~3);
+    if (cap < sizeof(PlanHeader) + 4 * m_pad) return ANTQ_ERR_PLAN;
+    write_scan_plan(blob, grid, m);  // default; upgraded below when every check passes
+    const int scan_bytes = (int)(sizeof(PlanHeader) + 4 * m_pad);
+
+    for (int i = 0; i < m; i++)
+        if (!isfinite(grid[i]) || fabsf(grid[i]) > 65536.0f) return scan_bytes;
+
+    // distinct values in ascending order; win = last scan index holding that value
+    std::vector<int> order(m);
+    for (int i = 0; i < m; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return grid[a] < grid[b]; });
+    std::vector<Distinct> dv;
+    for (int t = 0; t < m; t++) {
+        int i = order[t];
+        if (!dv.empty() && dv.back().v == grid[i]) dv.back().win = std::max(dv.back().win, i);
+        else dv.push_back({grid[i], i});
+    }
+    const int k = (int)dv.size();
+    if (k < 2) return scan_bytes;
+
+    // no-plateau conditions (see file header)
+    std::vector<double> gap(k - 1);
+    for (int i = 0; i + 1 < k; i++) gap[i] = (double)dv[i + 1].v - (double)dv[i].v;
+    for (int i = 0; i + 2 < k; i++) {
+        double r = gap[i] / gap[i + 1];
+        if (r > 1048576.0 || r < 1.0 / 1048576.0) return scan_bytes;
+    }
+    // Outside [v_0, v_{k-1}] the two outermost entries on that side keep distinct rounded
+    // distances while gap > ulp(distance), i.e. for |d| < gap * 2^23 - max|v|; the table path
+    // is only used below that magnitude (fastlim), the literal scan beyond it.
+    double vabs = std::max(fabs((double)dv[0].v), fabs((double)dv[k - 1].v));
+    double d_plateau = std::min(gap[0], gap[k - 2]) * 8388608.0 - vabs;
+    if (d_plateau < 4.0 * vabs) return scan_bytes;
+
+    // thresholds
+    std::vector<float> T(k - 1);
+    for (int i = 0; i + 1 < k; i++) {
+        uint32_t lo = ord(dv[i].v), hi = ord(dv[i + 1].v);  // pick_hi(lo)=false, pick_hi(hi)=true
+        if (pick_hi(dv[i].v, dv[i], dv[i + 1]) || !pick_hi(dv[i + 1].v, dv[i], dv[i + 1])) return scan_bytes;
+        while (hi - lo > 1) {
+            uint32_t mid = lo + (hi - lo) / 2;
+            if (pick_hi(unord(mid), dv[i], dv[i + 1])) hi = mid; else lo = mid;
+        }
+        T[i] = unord(hi);
+        if (T[i] == 0.0f || fabsf(T[i]) < kSmallD) return scan_bytes;
+        if (i > 0 && !(T[i] > T[i - 1])) return scan_bytes;
+    }
+    // the region containing d = 0 must dequantise to 0 (small-|d| shortcut of the kernels)
+    {
+        int rho = 0;
+        for (int i = 0; i + 1 < k; i++) if (T[i] <= 0.0f) rho = i + 1;
+        if (dv[rho].v != 0.0f) return scan_bytes;
+    }
+    // validity interval
+    float hi_valid, lo_valid;
+    {
+        uint32_t lo = ord(dv[k - 1].v), hi = ord(3.0e38f);
+        while (hi - lo > 1) {
+            uint32_t mid = lo + (hi - lo) / 2;
+            if (fabsf(unord(mid) - dv[k - 1].v) <= 102400.0f) lo = mid; else hi = mid;
+        }
+        hi_valid = unord(lo);
+        lo = ord(-3.0e38f); hi = ord(dv[0].v);
+        while (hi - lo > 1) {
+            uint32_t mid = lo + (hi - lo) / 2;
+            if (fabsf(unord(mid) - dv[0].v) <= 102400.0f) hi = mid; else lo = mid;
+        }
+        lo_valid = unord(hi);
+    }
+
+    // bucketisation: smallest number of mantissa bits that separates the thresholds
+    PlanHeader h;
+    memset(&h, 0, sizeof(h));
+    bool found = false;
+    const bool has_neg = T[0] < 0.0f;
+    for (uint32_t mb = 0; mb <= 10 && !found; mb++) {
+        uint32_t shift = 23 - mb;
+        uint32_t kmin = 0xffffffffu, kmax = 0;
+        bool ok = true;
+        uint32_t prev_pos = 0xffffffffu, prev_neg = 0xffffffffu;
+        for (int i = 0; i + 1 < k && ok; i++) {
+            uint32_t key = mag_key(T[i], shift);
+            kmin = std::min(kmin, key);
+            kmax = std::max(kmax, key);
+            if (T[i] > 0) { if (key == prev_pos) ok = false; prev_pos = key; }
+            else          { if (key == prev_neg) ok = false; prev_neg = key; }
+        }
+        if (!ok) continue;
+        uint32_t nb = kmax - kmin + 1;
+        if (nb * (has_neg ? 2u : 1u) > 3072) break;  // 48 KiB of LDS for the table
+        h.shift = shift; h.kmin = kmin; h.kmax = kmax; h.nb = nb;
+        found = true;
+    }
+    if (!found) return scan_bytes;
+    h.keymask = has_neg ? ((1u << (31 - h.shift)) - 1u) : 0xffffffffu;
+    h.nbneg = has_neg ? h.nb : 0u;
+    h.magic = kPlanMagic;
+    h.version = kPlanVersion;
+    h.kind = kPlanLut;
+    h.m = (uint32_t)m;
+    h.m_pad = (uint32_t)m_pad;
+    h.n_entries = h.nb + h.nbneg;
+    h.lo_valid = lo_valid;
+    h.hi_valid = hi_valid;
+    {
+        double lim = std::min(std::min(fabs((double)lo_valid), fabs((double)hi_valid)), (double)kFastDMax);
+        lim = std::min(lim, d_plateau);
+        h.fastlim = (float)lim;
+        if ((double)h.fastlim > lim) h.fastlim = next_dn(h.fastlim);
+        // every threshold must be strictly inside the table's domain
+        if (!(fabsf(T[0]) < h.fastlim) || !(fabsf(T[k - 2]) < h.fastlim)) return scan_bytes;
+    }
+    h.bytes = (uint32_t)(sizeof(PlanHeader) + 4 * m_pad + sizeof(LutEntry) * h.n_entries);
+    if (cap < h.bytes) return ANTQ_ERR_PLAN;
+
+    std::vector<LutEntry> ent(h.n_entries);
+    auto region_of = [&](float d) {  // number of thresholds <= d
+        return (int)(std::upper_bound(T.begin(), T.end(), d) - T.begin());
+    };
+    auto mk = [&](int rho_lo, int rho_hi, float thr) {
+        LutEntry e;
+        e.T = thr;
+        e.v_lo = grid[dv[rho_lo].win];
+        e.v_hi = grid[dv[rho_hi].win];
+        e.idx = (uint32_t)dv[rho_lo].win | ((uint32_t)dv[rho_hi].win << 16);
+        return e;
+    };
+    for (uint32_t b = 0; b < h.nb; b++) {
+        uint32_t key = h.kmin + b;
+        float edge = u2f(key << h.shift);  // smallest magnitude of the bucket
+        int tp = -1, tn = -1;
+        for (int i = 0; i + 1 < k; i++) {
+            if (mag_key(T[i], h.shift) != key) continue;
+            if (T[i] > 0) tp = i; else tn = i;
+        }
+        if (tp >= 0) ent[b] = mk(tp, tp + 1, T[tp]);
+        else { int r = region_of(edge); ent[b] = mk(r, r, INFINITY); }
+        if (has_neg) {
+            if (tn >= 0) ent[h.nb + b] = mk(tn, tn + 1, T[tn]);
+            else { int r = region_of(-edge); ent[h.nb + b] = mk(r, r, INFINITY); }
+        }
+    }
+
+    // self-check against the literal scan
+    {
+        std::vector<float> pts;
+        auto around = [&](float v) {
+            float a = v, b = v;
+            pts.push_back(v);
+            for (int s = 0; s < 3; s++) { a = next_up(a); b = next_dn(b); pts.push_back(a); pts.push_back(b); }
+        };
+        for (int i = 0; i + 1 < k; i++) around(T[i]);
+        for (int i = 0; i < k; i++) around(dv[i].v);
+        for (uint32_t b = 0; b <= h.nb; b++) { float e = u2f((h.kmin + b) << h.shift); around(e); around(-e); }
+        around(0.0f); around(-0.0f); around(lo_valid); around(hi_valid);
+        around(h.fastlim); around(-h.fastlim);
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        double span = (double)dv[k - 1].v - (double)dv[0].v;
+        for (int i = 0; i < 8192; i++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            double u = (double)(s >> 11) / 9007199254740992.0;
+            pts.push_back((float)((double)dv[0].v - 0.25 * span + 1.5 * span * u));
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            pts.push_back(u2f((uint32_t)s));  // arbitrary bit patterns incl. NaN / Inf / denormals
+        }
+        for (float d : pts) {
+            int j_ref, j_lut;
+            float z_ref = scan_one(d, grid, m, &j_ref);
+            float z_lut = eval_lut(h, grid, ent.data(), d, &j_lut);
+            if (j_ref != j_lut || f2u(z_ref) != f2u(z_lut)) return scan_bytes;
+        }
+    }
+
+    char *p = static_cast<char *>(blob);
+    memcpy(p, &h, sizeof(h));
+    float *g = reinterpret_cast<float *>(p + sizeof(PlanHeader));
+    for (size_t i = 0; i < m_pad; i++) g[i] = (i < (size_t)m) ? grid[i] : 0.0f;
+    memcpy(p + sizeof(PlanHeader) + 4 * m_pad, ent.data(), sizeof(LutEntry) * h.n_entries);
+    return (int)h.bytes;
+}
+
+extern "C" int antq_plan_kind(const void *blob)
+{
+    if (!blob) return ANTQ_ERR_ARG;
+    const PlanHeader *h = static_cast<const PlanHeader *>(blob);
+    if (h->magic != kPlanMagic || h->version != kPlanVersion) return ANTQ_ERR_PLAN;
+    return (int)h->kind;
+}
+
+extern "C" int antq_plan_bytes(const void *blob)
+{
+    if (!blob) return ANTQ_ERR_ARG;
+    const PlanHeader *h = static_cast<const PlanHeader *>(blob);
+    if (h->magic != kPlanMagic || h->version != kPlanVersion) return ANTQ_ERR_PLAN;
+    return (int)h->bytes;
+}
+
+// Host model of the device element path: lets the CPU test-suite check the plan against
+// the oracle scan without a GPU.  q/idx: n outputs for the n inputs d (grid domain).
+extern "C" int antq_plan_eval_host(const void *blob, const float *d, float *q, int16_t *idx, size_t n)
+{
+    if (!blob || !d || !q) return ANTQ_ERR_ARG;
+    const PlanHeader *h = static_cast<const PlanHeader *>(blob);
+    if (h->magic != kPlanMagic || h->version != kPlanVersion) return ANTQ_ERR_PLAN;
+    const float *grid = plan_grid(blob);
+    const LutEntry *ent = plan_entries(blob);
+    for (size_t i = 0; i < n; i++) {
+        int j;
+        q[i] = (h->kind == kPlanLut) ? eval_lut(*h, grid, ent, d[i], &j) : scan_one(d[i], grid, (int)h->m, &j);
+        if (idx) idx[i] = (int16_t)j;
+    }
+    return ANTQ_OK;
+}

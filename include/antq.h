@@ -1,0 +1,168 @@
+/*
+ * antq.h -- C ABI of libantq.so: MI355X (gfx950) fake-quant hot path of ANT / OliVe.
+ *
+ * This is the drop-in boundary for the reference's ONLY native operator,
+ *     quant_cuda.quant(x, grid) -> (z, idx)
+ *         ant_quantization/quant/quant.cpp:17-29        (pybind entry)
+ *         ant_quantization/quant/quant_kernel.cu:11-62  (kernel + launcher)
+ * plus fused entry points that replace the PyTorch op sequences the reference
+ * runs around that operator on every forward:
+ *     Quantizer._forward            ant_quantization/antquant/quant_modules.py:535-551
+ *     Quantizer._forward (OliVe)    olive_quantization/antquant/quant_modules.py:294-330
+ *     AsymmetricQuantFunction       ant_quantization/antquant/quant_affine.py:95-115
+ *     mse_loss / search_mse         ant_quantization/antquant/quant_modules.py:280-326
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary;
+ *   - every *_dev pointer is device (HBM) memory owned by the caller; the library
+ *     never allocates, frees or synchronises; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream);
+ *   - return 0 on success, a negative ANTQ_ERR_* otherwise; no exceptions;
+ *   - re-entrant and thread-safe (no global mutable state).
+ *   - results: grid index bit-exact with the reference scan; dequantised floats
+ *     bit-identical to the reference's fp32 op sequence (bf16/f16 outputs are the
+ *     fp32 result rounded to nearest-even).
+ */
+#ifndef ANTQ_H
+#define ANTQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANTQ_ABI_VERSION 1
+
+/* element types of x / out */
+#define ANTQ_F32  0
+#define ANTQ_BF16 1
+#define ANTQ_F16  2
+#define ANTQ_F64  3   /* antq_nearest only (AT_DISPATCH_FLOATING_TYPES: float, double) */
+
+/* error codes */
+#define ANTQ_OK               0
+#define ANTQ_ERR_ARG        (-1)   /* null pointer, bad size, bad enum               */
+#define ANTQ_ERR_UNSUPPORTED (-2)  /* dtype / grid size not supported by this entry  */
+#define ANTQ_ERR_PLAN       (-3)   /* plan blob malformed or too small               */
+#define ANTQ_ERR_LAUNCH     (-4)   /* hipLaunchKernel failed (hipGetLastError)       */
+#define ANTQ_ERR_ALIGN      (-5)   /* pointer not aligned to the element size        */
+
+/* flags of antq_fakequant* */
+#define ANTQ_FLAG_OVP        1u    /* OliVe outlier-victim pair masking (OQ:311-320) */
+
+/* values written to the optional int16 index output */
+#define ANTQ_IDX_NONE    (-1)      /* no grid entry within 102400 (NaN/Inf/huge)     */
+#define ANTQ_IDX_VICTIM  (-2)      /* OliVe victim: value forced to zero             */
+
+#define ANTQ_MAX_GRID     1024     /* entries; the reference's LDS array holds 256   */
+#define ANTQ_PLAN_MAX_BYTES (64 + 4 * ANTQ_MAX_GRID + 16 * 3072)
+
+int         antq_abi_version(void);
+const char *antq_strerror(int code);
+
+/* ---------------------------------------------------------------------------
+ * quant_cuda.quant replacement (ant_quantization/quant/quant_kernel.cu:11-62).
+ *   z[i] = grid[j*],  j* = last j minimising fl32|fl32(x[i]) - fl32(grid[j])|,
+ *   z[i] = 0 when no distance is <= 102400 (NaN / Inf / huge inputs).
+ * x, z: n elements of `dtype` (F32, F64, BF16, F16).  grid_dev: m entries of the
+ * SAME dtype as x for F32/F64 (the reference casts grid.type_as(x)); float for
+ * BF16/F16.  idx_dev (nullable): int16 j* per element (the reference allocates an
+ * index tensor but never writes it; see quant_kernel.cu:18,49).
+ * ------------------------------------------------------------------------- */
+int antq_nearest(const void *x_dev, void *z_dev, int16_t *idx_dev, size_t n,
+                 const void *grid_dev, int m, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Plan: host-side, exact pre-computation of the decision thresholds of the
+ * reference scan for one grid (pure CPU, no HIP calls).  The caller keeps the
+ * host blob and uploads a copy to the device; both are passed to the fused
+ * entry points.  Returns the number of bytes written (>0) or ANTQ_ERR_*.
+ *   grid_host : m floats in the order the reference would pass them to the
+ *               kernel (ANT: sorted quant_grid; OliVe: cat(quant_grid, outliers)).
+ * antq_plan_kind(): 1 = table plan (fast path), 0 = scan plan (the grid is not
+ * representable as a table; the kernels fall back to the literal scan).
+ * ------------------------------------------------------------------------- */
+int antq_plan_build(const float *grid_host, int m, void *plan_host, size_t plan_capacity);
+int antq_plan_kind(const void *plan_host);
+int antq_plan_bytes(const void *plan_host);
+
+/* Host model of the device element path for one plan (pure CPU): q[i], idx[i] for the
+ * grid-domain inputs d[i].  The kernels implement exactly this function; the CPU test
+ * suite uses it to check a plan against the literal scan without a GPU. */
+int antq_plan_eval_host(const void *plan_host, const float *d, float *q, int16_t *idx, size_t n);
+
+/* ---------------------------------------------------------------------------
+ * Fused Quantizer._forward with a calibrated (static) alpha:
+ *     scale = alpha / gmax ; d = x / scale ; q = nearest(d) ; [OVP] ;
+ *     out = ((q - d) + d) * scale
+ * x/out: [rows, row_len] row-major, dtype F32 / BF16 / F16 (in place allowed).
+ * alpha_dev: `rows` floats when alpha_per_row != 0 (is_perchannel), else 1.
+ * Group-G quantisation = rows := numel/G, row_len := G on the same buffer.
+ * gmax: max of the NORMAL grid (OliVe: without outliers, OQ:296).
+ * idx_dev nullable.  flags: ANTQ_FLAG_OVP.
+ * ------------------------------------------------------------------------- */
+int antq_fakequant(const void *x_dev, void *out_dev, int16_t *idx_dev,
+                   size_t rows, size_t row_len,
+                   const float *alpha_dev, int alpha_per_row, float gmax,
+                   const void *plan_host, const void *plan_dev,
+                   unsigned flags, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Same, with alpha computed in the kernel from the data (the initial alpha of
+ * _init_quant_para, AQ:473-477, times one clip ratio as in search_mse AQ:300):
+ *     alpha[r] = fl32(max_c |x[r,c]| * ratio)
+ * One quant group (row) per wavefront / workgroup, single read of x.
+ * alpha_out_dev (nullable): receives the `rows` alphas.  Per-row only.
+ * ------------------------------------------------------------------------- */
+int antq_fakequant_dynamic(const void *x_dev, void *out_dev, int16_t *idx_dev,
+                           float *alpha_out_dev, size_t rows, size_t row_len,
+                           float ratio, float gmax,
+                           const void *plan_host, const void *plan_dev,
+                           unsigned flags, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Row abs-max (AQ:289,474 / per-tensor AQ:308,477):  amax[r] = max_c |x[r,c]|.
+ * per_row == 0: one value for the whole tensor; amax_dev must then be zeroed by
+ * the caller beforehand (the kernel combines workgroup partials with atomicMax).
+ * ------------------------------------------------------------------------- */
+int antq_absmax(const void *x_dev, float *amax_dev, size_t rows, size_t row_len,
+                int per_row, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * mse_loss of a fake-quantised tensor against its source without materialising
+ * it (AQ:280-285 applied to AQ:535-551): for every candidate c in [0,ncand)
+ *     alpha_c[r] = fl32(xmax[r] * ratios[c])
+ *     sse[c, r]  = sum_col ( fl32|fakequant(x; alpha_c)[r,col] - x[r,col]| )^2
+ * accumulated in fp32 per lane and fp64 across lanes.  The caller divides by
+ * row_len and picks the arg-min (strict '<', first best), as search_mse does.
+ * sse_dev: [ncand, rows] doubles (per_row) or [ncand] (per tensor), zeroed by
+ * the caller.  ratios_dev: ncand floats.  xmax_dev: rows floats or 1.
+ * ------------------------------------------------------------------------- */
+int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
+                    const float *xmax_dev, int per_row,
+                    const float *ratios_dev, int ncand, float gmax,
+                    const void *plan_host, const void *plan_dev,
+                    unsigned flags, int dtype, double *sse_dev, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * AsymmetricQuantFunction.forward (ant_quantization/antquant/quant_affine.py:95-115)
+ *     scale = (2^k-1)/clamp(max-min,1e-8); zp = round(scale*min) + 2^(k-1)
+ *     q = clamp(round(scale*x - zp), -2^(k-1), 2^(k-1)-1); out = (q+zp)/scale
+ * xmin_dev/xmax_dev: `rows` floats (per_row) or 1.  q_dev nullable (int32).
+ * F32 only (the reference path is fp32 PyTorch).
+ * ------------------------------------------------------------------------- */
+int antq_affine(const float *x_dev, float *out_dev, int32_t *q_dev,
+                size_t rows, size_t row_len, int k,
+                const float *xmin_dev, const float *xmax_dev, int per_row,
+                void *stream);
+
+/* Plain device copy with the fake-quant kernels' access pattern (16 B per lane):
+ * used by bench.py to measure the empirical HBM ceiling on the same buffers. */
+int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANTQ_H */

@@ -1,0 +1,455 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the REFERENCE's own Python.
+
+Runs only in the build container (needs /root/reference); nothing under
+tests/ reads /root/reference at test time -- the committed .npz files are the
+pins.  Recipe:
+
+  * a stand-in module `quant_cuda` is injected whose quant(x, grid) is the
+    literal CPU restatement of ant_quantization/quant/quant_kernel.cu:25-37
+    (oracle/antq_oracle.c, via ctypes) and returns (z, zeros_like(x));
+  * the reference's antquant/ directory is put first on sys.path and its
+    quant_modules.py imported unmodified (one subprocess per tree: both trees
+    use the same module names);
+  * ANT needs a 1-rank gloo process group (quant_modules.py:525-531).
+
+Usage:  python tests/golden/make_golden.py            (regenerates everything)
+"""
+import argparse
+import os
+import subprocess
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+
+def _install_shim():
+    import torch
+    from oracle import antq_oracle as orc
+
+    shim = types.ModuleType("quant_cuda")
+    shim.last_idx = None
+
+    def quant(x, grid):
+        xn = x.detach().contiguous().cpu().numpy()
+        gn = grid.detach().contiguous().cpu().numpy()
+        z, idx = orc.nearest(xn, gn)
+        shim.last_idx = idx
+        return torch.from_numpy(z).to(x.dtype), torch.zeros_like(x)
+
+    shim.quant = quant
+    sys.modules["quant_cuda"] = shim
+    return shim
+
+
+def _args(**kw):
+    d = dict(w_up=150, a_up=150, w_low=75, a_low=75, percent=100, search=False, no_outlier=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _adversarial_inputs(grid, rng):
+    """Values that exercise every rule of the scan for a given grid."""
+    g = np.asarray(grid, dtype=np.float32)
+    gs = np.unique(g)
+    mids = ((gs[:-1].astype(np.float64) + gs[1:].astype(np.float64)) / 2).astype(np.float32)
+    around = []
+    for v in np.concatenate([gs, mids]):
+        around += [v, np.nextafter(v, np.float32(np.inf)), np.nextafter(v, np.float32(-np.inf))]
+    special = [0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-38, np.nan, np.inf, -np.inf,
+               1e5, -1e5, 102400.0, -102400.0, 102400.0 + float(gs[-1]), -102400.0 + float(gs[0]),
+               102401.0 + float(gs[-1]), -102401.0 + float(gs[0]), 2e5, -2e5, 1e8, -1e8, 3e38, -3e38]
+    lo, hi = float(gs[0]), float(gs[-1])
+    span = hi - lo
+    rnd = np.concatenate([
+        rng.standard_normal(1500).astype(np.float32) * np.float32(hi / 3),
+        rng.uniform(lo - 0.3 * span, hi + 0.3 * span, 1500).astype(np.float32),
+    ])
+    return np.concatenate([np.asarray(around, np.float32), np.asarray(special, np.float32), rnd]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+def gen_ant(outdir):
+    import torch
+    import torch.distributed as dist
+    from oracle import antq_oracle as orc
+
+    shim = _install_shim()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    sys.path.insert(0, os.path.join(REF, "ant_quantization", "antquant"))
+    import quant_modules as qm
+
+    def mk(mode, bit, signed, is_input=False, **kw):
+        q = qm.TensorQuantizer(mode=mode, bit=bit, is_signed=signed, is_enable=True,
+                               is_input=is_input, args=_args(**kw))
+        q.name = "golden"
+        return q
+
+    # ---- (1) every codebook ------------------------------------------------
+    grids = {}
+    types_ = ["int", "flint", "pot", "float", "float1", "float2", "float3", "float4", "apot"]
+    for bit in range(2, 9):
+        for signed in (True, False):
+            for t in types_:
+                q = mk(t, bit, signed)
+                key = "%s_b%d_%s" % (t, bit, "s" if signed else "u")
+                try:
+                    if t == "int":
+                        g = q.int_value()
+                    elif t == "flint":
+                        g = q.flint_value()
+                    elif t == "pot":
+                        g = q.pot_value()
+                    elif t == "apot":
+                        g = q.apot_value()
+                    elif t == "float":
+                        g = q.float_value()
+                    else:
+                        g = q.float_value(int(t[-1]))
+                    grids[key] = g.numpy().astype(np.float32)
+                except Exception as e:  # assertion in convert_tensor, etc.
+                    grids["INVALID_" + key] = np.array([0], dtype=np.int8)
+    np.savez_compressed(os.path.join(outdir, "ant_grids.npz"), **grids)
+
+    # ---- (2) nearest: literal scan on adversarial inputs -------------------
+    rng = np.random.default_rng(20240601)
+    near = {}
+    for key in ["flint_b4_s", "flint_b4_u", "int_b4_s", "int_b4_u", "pot_b4_s", "pot_b4_u",
+                "float_b4_u", "apot_b4_s", "int_b8_s", "int_b8_u", "flint_b6_s", "pot_b6_s", "int_b2_s"]:
+        g = grids[key]
+        x = _adversarial_inputs(g, rng)
+        z, _ = qm.QuantBase.forward(torch.from_numpy(x), torch.from_numpy(g)), None
+        near[key + "_x"] = x
+        near[key + "_z"] = z[0].numpy() if isinstance(z, tuple) else z.numpy()
+        near[key + "_idx"] = shim.last_idx.astype(np.int16)
+    # float64 dispatch
+    g = grids["flint_b4_s"]
+    x64 = _adversarial_inputs(g, rng).astype(np.float64) * (1 + 1e-9)
+    z64 = qm.QuantBase.forward(torch.from_numpy(x64), torch.from_numpy(g))
+    near["f64_flint_b4_s_x"] = x64
+    near["f64_flint_b4_s_z"] = z64.numpy()
+    near["f64_flint_b4_s_idx"] = shim.last_idx.astype(np.int16)
+    np.savez_compressed(os.path.join(outdir, "ant_nearest.npz"), **near)
+
+    # ---- (3) _forward with fixed alpha --------------------------------------
+    fwd = {}
+    torch.manual_seed(3)
+    shapes = {"w8x64": (8, 64), "conv1": (64, 3, 7, 7), "w4x768": (4, 768)}
+    for sname, shp in shapes.items():
+        w = torch.randn(*shp) * 0.05
+        w.view(-1)[::97] *= 6.0  # a few clipped values
+        fwd[sname + "_x"] = w.numpy()
+        for t in ["int", "flint", "pot", "float"]:
+            for signed in (True, False):
+                x = w if signed else w.abs()
+                for per_channel in (True, False):
+                    q = mk(t, 4, signed, is_input=not per_channel)
+                    q.quant_grid.data = {"int": q.int_value, "flint": q.flint_value,
+                                         "pot": q.pot_value, "float": q.float_value}[t]()
+                    if per_channel:
+                        alpha = x.view(x.shape[0], -1).abs().max(1).values.unsqueeze(1) * 0.9
+                    else:
+                        alpha = x.abs().max() * 0.8
+                    q.alpha.data = alpha
+                    with torch.no_grad():
+                        out = q._forward(x)
+                    k = "%s_%s_%s_%s" % (sname, t, "s" if signed else "u", "pc" if per_channel else "pt")
+                    fwd[k + "_alpha"] = alpha.numpy().reshape(-1)
+                    fwd[k + "_out"] = out.numpy()
+                    fwd[k + "_idx"] = shim.last_idx.reshape(-1).astype(np.int16)
+    # 8-bit int per-tensor (configs[0] second leg: TensorQuantizer int8, 256-entry grid)
+    torch.manual_seed(0)
+    c0 = torch.randn(64, 3, 7, 7) * float(np.sqrt(2.0 / (64 * 49)))
+    q = mk("int", 8, True, is_input=True)
+    q.quant_grid.data = q.int_value()
+    q.alpha.data = c0.abs().max()
+    with torch.no_grad():
+        out = q._forward(c0)
+    fwd["c0_x"] = c0.numpy()
+    fwd["c0_int8_pt_alpha"] = q.alpha.data.numpy().reshape(-1)
+    fwd["c0_int8_pt_out"] = out.numpy()
+    fwd["c0_int8_pt_idx"] = shim.last_idx.reshape(-1).astype(np.int16)
+    # group-16 oracle = per-channel reference on x.view(-1, 16)
+    torch.manual_seed(8)
+    wg = torch.randn(32, 64) * 0.03
+    xg = wg.view(-1, 16)
+    q = mk("flint", 4, True)
+    q.quant_grid.data = q.flint_value()
+    q.alpha.data = xg.abs().max(1).values.unsqueeze(1)
+    with torch.no_grad():
+        out = q._forward(xg)
+    fwd["g16_x"] = wg.numpy()
+    fwd["g16_flint_alpha"] = q.alpha.data.numpy().reshape(-1)
+    fwd["g16_flint_out"] = out.numpy().reshape(32, 64)
+    fwd["g16_flint_idx"] = shim.last_idx.reshape(-1).astype(np.int16)
+    np.savez_compressed(os.path.join(outdir, "ant_forward.npz"), **fwd)
+
+    # ---- (5) search_mse traces ----------------------------------------------
+    srch = {}
+    scores = []
+    orig_mse = qm.Quantizer.mse_loss
+
+    def rec_mse(self, qt, st, p=2.0, is_perchannel=True):
+        r = orig_mse(self, qt, st, p, is_perchannel)
+        scores.append(r.detach().reshape(-1).clone().numpy())
+        return r
+
+    qm.Quantizer.mse_loss = rec_mse
+    torch.manual_seed(5)
+    w = torch.randn(16, 256) * 0.02
+    a = torch.nn.functional.gelu(torch.randn(8, 512))
+    for t in ["int", "flint", "pot"]:
+        for name, x, is_input, signed in [("w", w, False, True), ("a", a, True, True), ("au", a.abs(), True, False)]:
+            q = mk(t, 4, signed, is_input=is_input)
+            q.quant_grid.data = {"int": q.int_value, "flint": q.flint_value, "pot": q.pot_value}[t]()
+            del scores[:]
+            with torch.no_grad():
+                best, alpha, ratio = q.search_mse(x)
+            k = "%s_%s" % (name, t)
+            srch[k + "_trace"] = np.stack(scores)
+            srch[k + "_best_sum"] = np.float32(best.item() if hasattr(best, "item") else best)
+            srch[k + "_alpha"] = alpha.numpy().reshape(-1)
+            srch[k + "_ratio"] = np.float32(ratio)
+    srch["w_x"] = w.numpy()
+    srch["a_x"] = a.numpy()
+    np.savez_compressed(os.path.join(outdir, "ant_search.npz"), **srch)
+
+    # ---- (6) full TensorQuantizer: type select + calibration + forward ------
+    sel = {}
+    torch.manual_seed(7)
+    cases = {
+        "w_gauss": (torch.randn(32, 128) * 0.02, False),
+        "w_unif": ((torch.rand(32, 128) * 2 - 1) * 0.05, False),
+        "w_laplace": (torch.distributions.Laplace(0.0, 0.02).sample((32, 128)), False),
+        "x_relu": (torch.relu(torch.randn(16, 256)), True),
+        "x_gelu": (torch.nn.functional.gelu(torch.randn(16, 256)), True),
+    }
+    for name, (x, is_input) in cases.items():
+        for mode in ["ant-int-pot-flint", "ant-int-flint", "flint", "int"]:
+            q = mk(mode, 4, not is_input, is_input=is_input)
+            if not is_input:
+                q.alpha.data = torch.ones(x.shape[0], 1)
+            del scores[:]
+            out = q(x)
+            k = "%s__%s" % (name, mode)
+            sel[k + "__mode"] = np.array(q.mode)
+            sel[k + "__signed"] = np.array(bool(q.is_signed))
+            sel[k + "__alpha"] = q.alpha.data.numpy().reshape(-1)
+            sel[k + "__grid"] = q.quant_grid.data.numpy()
+            sel[k + "__out"] = out.detach().numpy()
+            sel[k + "__mse"] = np.float32(q.mse.item())
+            sel[k + "__ncand"] = np.int32(len(scores))
+        sel[name + "__x"] = x.numpy()
+    # 8-bit forces int (AQ:482-483) with lb=95 (AQ:296-297)
+    x = cases["w_gauss"][0]
+    q = mk("ant-int-pot-flint", 8, True)
+    q.alpha.data = torch.ones(x.shape[0], 1)
+    out = q(x)
+    sel["w_gauss__b8__mode"] = np.array(q.mode)
+    sel["w_gauss__b8__alpha"] = q.alpha.data.numpy().reshape(-1)
+    sel["w_gauss__b8__out"] = out.detach().numpy()
+    np.savez_compressed(os.path.join(outdir, "ant_select.npz"), **sel)
+    qm.Quantizer.mse_loss = orig_mse
+
+    # ---- (7) quant_affine -----------------------------------------------------
+    import quant_affine as qa
+    aff = {}
+    aff["c0_x"] = c0.numpy()
+    for k in (4, 8):
+        out = qa.AsymmetricQuantFunction.apply(c0, k, c0.min(), c0.max())
+        aff["c0_k%d_pt_out" % k] = out.numpy()
+        mn = c0.view(64, -1).min(1).values
+        mx = c0.view(64, -1).max(1).values
+        out = qa.AsymmetricQuantFunction.apply(c0, k, mn, mx)
+        aff["c0_k%d_pc_out" % k] = out.numpy()
+    torch.manual_seed(11)
+    l = torch.randn(16, 48)
+    aff["lin_x"] = l.numpy()
+    aff["lin_k4_pc_out"] = qa.AsymmetricQuantFunction.apply(l, 4, l.min(1).values, l.max(1).values).numpy()
+    aff["lin_k8_pt_out"] = qa.AsymmetricQuantFunction.apply(l, 8, l.min(), l.max()).numpy()
+    np.savez_compressed(os.path.join(outdir, "affine.npz"), **aff)
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------
+def gen_olive(outdir):
+    import torch
+    from oracle import antq_oracle as orc
+
+    shim = _install_shim()
+    sys.path.insert(0, os.path.join(REF, "olive_quantization", "antquant"))
+    import quant_modules as qm
+
+    def mk(mode, bit, signed, is_input=False, **kw):
+        kw.setdefault("w_up", 250)
+        kw.setdefault("a_up", 250)
+        q = qm.TensorQuantizer(mode=mode, bit=bit, is_signed=signed, is_enable=True,
+                               is_input=is_input, args=_args(**kw))
+        q.name = "golden"
+        return q
+
+    grids = {}
+    for bit in range(3, 9):
+        for signed in (True, False):
+            q = mk("int", bit, signed)
+            s = "s" if signed else "u"
+            for t, fn in (("int", q.int_value), ("flint", q.flint_value), ("outlier", q.outlier_value)):
+                try:
+                    grids["%s_b%d_%s" % (t, bit, s)] = fn().numpy().astype(np.float32)
+                except Exception:
+                    grids["INVALID_%s_b%d_%s" % (t, bit, s)] = np.array([0], dtype=np.int8)
+    np.savez_compressed(os.path.join(outdir, "olive_grids.npz"), **grids)
+
+    rng = np.random.default_rng(20240602)
+    near = {}
+    for t in ("int", "flint"):
+        for s in ("s", "u"):
+            g = np.concatenate([grids["%s_b4_%s" % (t, s)], grids["outlier_b4_%s" % s]])
+            x = _adversarial_inputs(g, rng)
+            x = np.concatenate([x, np.float32([40, -40, 36, -36, 33, 32.000004, 31.999998, 400, -400, 1000])])
+            z = qm.QuantBase.forward(torch.from_numpy(x), torch.from_numpy(g))
+            k = "%s_b4_%s" % (t, s)
+            near[k + "_grid"] = g
+            near[k + "_x"] = x
+            near[k + "_z"] = z.numpy()
+            near[k + "_idx"] = shim.last_idx.astype(np.int16)
+    np.savez_compressed(os.path.join(outdir, "olive_nearest.npz"), **near)
+
+    # ---- _forward with OVP ------------------------------------------------------
+    fwd = {}
+    torch.manual_seed(4)
+
+    def planted(shape, frac=0.02):
+        w = torch.randn(*shape) * 0.02
+        m = torch.rand(*shape) < frac
+        w[m] *= (torch.rand(int(m.sum())) * 56 + 8)
+        return w
+
+    tens = {
+        "w16x64": planted((16, 64)),
+        "w5x33": planted((5, 33), 0.08),       # odd numel: roll wrap-around
+        "w3x7": planted((3, 7), 0.3),
+        "conv1": planted((64, 3, 7, 7)),
+    }
+    # force specific pair patterns at the front of w16x64 / w5x33:
+    for k in ("w16x64", "w5x33", "w3x7"):
+        f = tens[k].view(-1)
+        f[0] = 1.5      # element 0 outlier -> victim is 1; with odd numel also the LAST element
+        f[1] = 0.3
+        f[2] = 1.2      # both outliers: odd one is zeroed
+        f[3] = -1.4
+        f[4] = 0.01     # even non-outlier, odd outlier -> even zeroed
+        f[5] = -2.0
+    for name, w in tens.items():
+        fwd[name + "_x"] = w.numpy()
+        for t in ("int", "flint"):
+            for per_channel in (True, False):
+                for no_outlier in (False, True):
+                    q = mk(t, 4, True, is_input=not per_channel, no_outlier=no_outlier)
+                    q.outliers.data = q.outlier_value()
+                    q.quant_grid.data = q.int_value() if t == "int" else q.flint_value()
+                    w2 = w.view(w.shape[0], -1)
+                    if per_channel:
+                        mean, std = w2.mean(-1), w2.std(-1)
+                        alpha = torch.maximum((mean + 3 * std).abs(), (mean - 3 * std).abs()).unsqueeze(1)
+                    else:
+                        alpha = torch.maximum((w.mean() + 3 * w.std()).abs(), (w.mean() - 3 * w.std()).abs())
+                    q.alpha.data = alpha
+                    out = q._forward(w)
+                    k = "%s_%s_%s_%s" % (name, t, "pc" if per_channel else "pt", "noout" if no_outlier else "ovp")
+                    fwd[k + "_alpha"] = alpha.numpy().reshape(-1)
+                    fwd[k + "_out"] = out.numpy()
+                    fwd[k + "_idx"] = shim.last_idx.reshape(-1).astype(np.int16)
+    # unsigned activations
+    torch.manual_seed(14)
+    a = torch.relu(planted((6, 50), 0.05))
+    fwd["a6x50_x"] = a.numpy()
+    for t in ("int", "flint"):
+        q = mk(t, 4, False, is_input=True)
+        q.outliers.data = q.outlier_value()
+        q.quant_grid.data = q.int_value() if t == "int" else q.flint_value()
+        q.alpha.data = (a.mean() + 3 * a.std()).abs()
+        out = q._forward(a)
+        fwd["a6x50_%s_pt_ovp_alpha" % t] = q.alpha.data.numpy().reshape(-1)
+        fwd["a6x50_%s_pt_ovp_out" % t] = out.numpy()
+        fwd["a6x50_%s_pt_ovp_idx" % t] = shim.last_idx.reshape(-1).astype(np.int16)
+    np.savez_compressed(os.path.join(outdir, "olive_forward.npz"), **fwd)
+
+    # ---- search_mse + full quantiser ---------------------------------------------
+    srch = {}
+    scores = []
+    orig_mse = qm.Quantizer.mse_loss
+
+    def rec_mse(self, qt, st, p=2.0, is_perchannel=True):
+        r = orig_mse(self, qt, st, p, is_perchannel)
+        scores.append(r.detach().reshape(-1).clone().numpy())
+        return r
+
+    qm.Quantizer.mse_loss = rec_mse
+    torch.manual_seed(6)
+    w = planted((16, 256), 0.01)
+    a = torch.nn.functional.gelu(planted((8, 512), 0.01) * 40)
+    srch["w_x"] = w.numpy()
+    srch["a_x"] = a.numpy()
+    for t in ("int", "flint"):
+        for name, x, is_input in (("w", w, False), ("a", a, True)):
+            for no_outlier in (False, True):
+                q = mk(t, 4, True, is_input=is_input, no_outlier=no_outlier)
+                q.outliers.data = q.outlier_value()
+                q.quant_grid.data = q.int_value() if t == "int" else q.flint_value()
+                del scores[:]
+                best, alpha, ratio = q.search_mse(x)
+                k = "%s_%s_%s" % (name, t, "noout" if no_outlier else "ovp")
+                srch[k + "_trace"] = np.stack(scores)
+                srch[k + "_best_sum"] = np.float32(best.item() if hasattr(best, "item") else best)
+                srch[k + "_alpha"] = alpha.numpy().reshape(-1)
+                srch[k + "_ratio"] = np.float32(ratio)
+    for name, x, is_input in (("w", w, False), ("a", a, True)):
+        for mode in ("ant-int-flint", "flint", "int"):
+            q = mk(mode, 4, not is_input, is_input=is_input)
+            if not is_input:
+                q.alpha.data = torch.ones(x.shape[0], 1)
+            del scores[:]
+            out = q(x)
+            k = "full_%s__%s" % (name, mode)
+            srch[k + "__mode"] = np.array(q.mode)
+            srch[k + "__signed"] = np.array(bool(q.is_signed))
+            srch[k + "__alpha"] = q.alpha.data.numpy().reshape(-1)
+            srch[k + "__grid"] = q.quant_grid.data.numpy()
+            srch[k + "__outliers"] = q.outliers.data.numpy()
+            srch[k + "__out"] = out.numpy()
+            srch[k + "__mse"] = np.float32(q.mse.item())
+            srch[k + "__ncand"] = np.int32(len(scores))
+    qm.Quantizer.mse_loss = orig_mse
+    np.savez_compressed(os.path.join(outdir, "olive_search.npz"), **srch)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tree", choices=["ant", "olive", "all"], default="all")
+    ap.add_argument("--out", default=HERE)
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
+    if a.tree == "all":
+        for t in ("ant", "olive"):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", t, "--out", a.out])
+        return
+    import torch
+    torch.set_num_threads(1)   # deterministic reductions for the recorded MSE traces
+    if a.tree == "ant":
+        gen_ant(a.out)
+    else:
+        gen_olive(a.out)
+
+
+if __name__ == "__main__":
+    main()
