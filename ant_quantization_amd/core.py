@@ -1,0 +1,99 @@
+"""Fused building blocks shared by the ANT and OliVe host mirrors.
+
+Everything here launches hand-written gfx950 kernels through the C ABI (`_lib`); the only
+torch ops are O(rows) bookkeeping on tiny tensors (arg-min over the clip candidates,
+divisions of a few scalars).  No `.item()` / `if cuda_tensor:` in the steady-state
+forward: the reference's hidden device->host syncs are gone.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def view_rows(t, per_channel):
+    """(rows, row_len) of the reference's `tensor.view(shape[0], -1)` (AQ:538-539) or the
+    flat per-tensor view."""
+    if per_channel and t.dim() >= 1 and t.shape[0] > 0:
+        rows = t.shape[0]
+        return rows, t.numel() // rows
+    return 1, t.numel()
+
+
+class FakeQuantSTE(torch.autograd.Function):
+    """out = ((q - d).detach() + d) * s with d = x / s, s = alpha / gmax  (AQ:535-551).
+
+    Forward: one fused kernel.  Backward (QAT, ANT only): the straight-through estimator
+    the reference's autograd graph yields -- d out/d x = 1 (no clip mask), and
+    d out/d alpha = sum_row g * (q - d) / gmax = sum_row g * (out - x) / alpha.
+    """
+
+    @staticmethod
+    def forward(ctx, x, alpha, plan, gmax, per_channel, ovp):
+        xc = x.contiguous()
+        rows, row_len = view_rows(xc, per_channel)
+        a = alpha.detach().reshape(-1).to(torch.float32).contiguous()
+        out = _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp)
+        ctx.save_for_backward(xc, out, alpha)
+        ctx.per_channel = per_channel
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, out, alpha = ctx.saved_tensors
+        gx = g if ctx.needs_input_grad[0] else None
+        ga = None
+        if ctx.needs_input_grad[1]:
+            diff = (out.float() - x.float()) * g.float()
+            if ctx.per_channel:
+                ga = diff.reshape(x.shape[0], -1).sum(1).reshape(alpha.shape) / alpha
+            else:
+                ga = (diff.sum() / alpha).reshape(alpha.shape)
+            ga = ga.to(alpha.dtype)
+        return gx, ga, None, None, None, None
+
+
+def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False):
+    """Steady-state Quantizer._forward.  Uses autograd only when a gradient is wanted."""
+    if torch.is_grad_enabled() and (x.requires_grad or alpha.requires_grad):
+        return FakeQuantSTE.apply(x, alpha, plan, gmax, per_channel, ovp)
+    xc = x.detach().contiguous()
+    rows, row_len = view_rows(xc, per_channel)
+    a = alpha.detach().reshape(-1).to(torch.float32).contiguous()
+    return _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp)
+
+
+def clip_search(x, x_max, per_channel, lo, hi, step, plan, gmax, ovp=False):
+    """search_mse (AQ:287-326 / OQ:189-233) without materialising a single quantised tensor.
+
+    x_max: float32 device tensor with `rows` entries (per-channel) or 1.
+    Returns (best_score [rows or 1] float32, best_alpha same shape, ratios float32 tensor).
+    Candidates i in range(lo, hi, step) use alpha_i = x_max * fl32(i * 0.01); the first
+    strict minimum wins, per row for weights and per tensor for activations.
+    """
+    xc = x.detach().contiguous()
+    rows, row_len = view_rows(xc, per_channel)
+    cand = list(range(int(lo), int(hi), int(step)))
+    if not cand:
+        # the reference's loop body never runs: best_score stays 1e10, alpha = x_max
+        na = rows if per_channel else 1
+        return torch.full((na,), 1e10, dtype=torch.float32, device=x.device), x_max.clone(), None
+    ratios_np = np.asarray([float(np.float32(i * 0.01)) for i in cand], dtype=np.float32)
+    ratios = torch.from_numpy(ratios_np).to(x.device)
+    xm = x_max.reshape(-1).to(torch.float32).contiguous()
+    sse = _lib.search_sse(xc, rows, row_len, xm, per_channel, ratios, plan, gmax, ovp=ovp)  # [ncand, na] f64
+    mse = (sse / float(row_len)).to(torch.float32)
+    best = torch.argmin(mse, dim=0, keepdim=True)           # first minimum = strict '<' sweep
+    best_score = torch.gather(mse, 0, best).reshape(-1)
+    best_alpha = xm * ratios[best.reshape(-1)]
+    # the reference starts from best_score = 1e10 and only replaces on score < best:
+    keep = best_score < 1e10
+    best_alpha = torch.where(keep, best_alpha, xm)
+    best_score = torch.where(keep, best_score, torch.full_like(best_score, 1e10))
+    return best_score, best_alpha, ratios
+
+
+def row_absmax(x, per_channel):
+    xc = x.detach().contiguous()
+    rows, row_len = view_rows(xc, per_channel)
+    return _lib.absmax(xc, rows, row_len, per_row=per_channel)

@@ -32,8 +32,27 @@ namespace antq {
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
+// Streaming (nontemporal) 16-byte accesses: x is read once and out written once, so the
+// lines are marked evict-first instead of thrashing L2 / MALL.  Measured on MI355X
+// (tools/ubench.hip): a 4 KiB-per-wave copy runs 5.4 TB/s with nt, 2.9 TB/s without.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p)
+{
+    u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v)
+{
+    u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
+}
+
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float floatx2_t __attribute__((ext_vector_type(2)));
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2_t as_u16x2(uint32_t u) { return *reinterpret_cast<u16x2_t *>(&u); }
+__device__ __forceinline__ uint32_t as_u32(u16x2_t v) { return *reinterpret_cast<uint32_t *>(&v); }
 
 struct bf16_tag {};
 struct f16_tag {};
@@ -54,6 +73,12 @@ template <> struct IO<float> {
     }
     __device__ __forceinline__ static float load1(const void *p, size_t i) { return static_cast<const float *>(p)[i]; }
     __device__ __forceinline__ static void store1(void *p, size_t i, float v) { static_cast<float *>(p)[i] = v; }
+    // running |x| maximum kept as fp32 magnitude bits (order like unsigned ints; NaN on top)
+    __device__ __forceinline__ static uint32_t amax_acc(uint32_t m, const uint4 &v)
+    {
+        return max(max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, v.z & 0x7fffffffu)), v.w & 0x7fffffffu);
+    }
+    __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return m; }
 };
 template <> struct IO<bf16_tag> {
     static constexpr int EPL = 8;
@@ -85,6 +110,17 @@ template <> struct IO<bf16_tag> {
     {
         static_cast<uint16_t *>(p)[i] = (uint16_t)(pk(v, 0.0f) & 0xffffu);
     }
+    // running |x| maximum on the packed 16-bit magnitudes (v_pk_max_u16: 2 elements per op)
+    __device__ __forceinline__ static uint32_t amax_acc(uint32_t m, const uint4 &v)
+    {
+        u16x2_t a = as_u16x2(m);
+        a = __builtin_elementwise_max(a, as_u16x2(v.x & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.y & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.z & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.w & 0x7fff7fffu));
+        return as_u32(a);
+    }
+    __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return max(m & 0xffffu, m >> 16) << 16; }
 };
 template <> struct IO<f16_tag> {
     static constexpr int EPL = 8;
@@ -122,6 +158,17 @@ template <> struct IO<f16_tag> {
     {
         static_cast<uint16_t *>(p)[i] = (uint16_t)f2h(v);
     }
+    __device__ __forceinline__ static uint32_t amax_acc(uint32_t m, const uint4 &v)
+    {
+        u16x2_t a = as_u16x2(m);
+        a = __builtin_elementwise_max(a, as_u16x2(v.x & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.y & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.z & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.w & 0x7fff7fffu));
+        return as_u32(a);
+    }
+    // half magnitude bits -> fp32 magnitude bits (exact widening)
+    __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return f2u(h2f(max(m & 0xffffu, m >> 16))); }
 };
 
 // Plan fields the kernels need, passed by value (lands in SGPRs).
@@ -147,15 +194,19 @@ struct PlanLds {
 
 // Stage the table into LDS.  plan_tab points at the blob's grid area; the blob stores
 // grid first, entries second, LDS wants entries first (16-byte aligned reads).
-__device__ __forceinline__ PlanLds stage_plan(const PlanArgs &pa, const uint4 *__restrict__ plan_tab, uint4 *smem)
+__device__ __forceinline__ PlanLds stage_plan(const PlanArgs &pa, const uint4 *__restrict__ plan_tab, uint4 *smem,
+                                              uint4 first)
 {
+    // `first` = plan_tab[threadIdx.x], fetched by the caller ahead of its HBM loads so that
+    // the (in-order) wait for it does not cover them.  Source unit i: [0, grid_units) is the
+    // grid, the rest are table entries; LDS wants entries first (16-byte aligned b128 reads).
     const uint32_t grid_units = pa.m_pad >> 2;
-    for (uint32_t i = threadIdx.x; i < pa.tab_units; i += blockDim.x) {
-        // source unit i: [0, grid_units) grid, then entries
-        uint4 v = plan_tab[i];
-        uint32_t dst = (i < grid_units) ? (pa.n_entries + i) : (i - grid_units);
-        smem[dst] = v;
+    if (threadIdx.x < pa.tab_units) {
+        const uint32_t i = threadIdx.x;
+        smem[(i < grid_units) ? (pa.n_entries + i) : (i - grid_units)] = first;
     }
+    for (uint32_t i = threadIdx.x + blockDim.x; i < pa.tab_units; i += blockDim.x)
+        smem[(i < grid_units) ? (pa.n_entries + i) : (i - grid_units)] = plan_tab[i];
     PlanLds L;
     L.lut = reinterpret_cast<const LutEntry *>(smem);
     L.grid = reinterpret_cast<const float *>(smem + pa.n_entries);
@@ -189,6 +240,9 @@ __device__ __forceinline__ Scale make_scale(float alpha, float gmax)
 __device__ __forceinline__ float div_fast(float x, float s, float rs)
 {
     float q0 = x * rs;
+#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 1)
+    return q0;  // ablation only: inexact
+#endif
     float e0 = __builtin_fmaf(-q0, s, x);
     float q1 = __builtin_fmaf(e0, rs, q0);
     float e1 = __builtin_fmaf(-q1, s, x);
@@ -201,6 +255,7 @@ __device__ __forceinline__ float scan_lds(float d, const float *grid, int m, int
 {
     float sub_min = 102400.0f, z_min = 0.0f;
     j = ANTQ_IDX_NONE;
+#pragma unroll 1
     for (int i = 0; i < m; i++) {
         float g = grid[i];
         float sub_v = fabsf(d - g);
@@ -227,19 +282,32 @@ __device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, 
         }
     }
     if (fast) {
+        // byte offset of the bucket: key*16 straight from the float's bits (exponent + top
+        // mantissa bits, shifted so the key lands on bit 4), clamped, plus the negative half.
+        const int32_t sh4 = (int32_t)pa.shift - 4;                 // shift >= 13 always
+        const int32_t km16 = (int32_t)(pa.keymask << 4);
+        const int32_t lo16 = (int32_t)(pa.kmin << 4), hi16 = (int32_t)(pa.kmax << 4);
+        const uint32_t neg16 = pa.nbneg << 4;
+        const char *lut0 = reinterpret_cast<const char *>(L.lut) - lo16;
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
             const int32_t u = (int32_t)f2u(d[e]);
-            const int32_t ks = (int32_t)((uint32_t)(u >> pa.shift) & pa.keymask);
-            uint32_t k = (uint32_t)(min(max(ks, (int32_t)pa.kmin), (int32_t)pa.kmax) - (int32_t)pa.kmin);
-            k += (uint32_t)(u >> 31) & pa.nbneg;
-            const uint4 ent = *reinterpret_cast<const uint4 *>(&L.lut[k]);
+            const int32_t t = (u >> sh4) & km16;
+            const int32_t c16 = min(max(t, lo16), hi16);
+            const uint32_t sg = (uint32_t)(u >> 31) & neg16;
+#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 2)
+            uint4 ent = make_uint4(f2u(1.0f), (uint32_t)(c16 + sg), (uint32_t)u, 0);  // ablation only: no LDS
+#else
+            uint4 ent = *reinterpret_cast<const uint4 *>(lut0 + c16 + sg);
+#endif
+            if (!IDX) asm volatile("" : "+v"(ent.w));  // keep the read a single ds_read_b128 (b96 is 2x slower)
             const bool c = d[e] >= u2f(ent.x);
             q[e] = c ? u2f(ent.z) : u2f(ent.y);
             if (IDX) j[e] = (int)(c ? (ent.w >> 16) : (ent.w & 0xffffu));
         }
     } else {
         // exact slow path: true division + literal scan (scan plans, odd scales, huge/NaN/Inf)
+#pragma unroll
         for (int e = 0; e < EPL; e++) {
             d[e] = x[e] / sc.s;
             int jj;
@@ -289,45 +357,74 @@ __device__ __forceinline__ void store_idx(int16_t *idx, size_t vec, const int (&
 }
 
 // ------------------------------------------------------------------------------------
-// K1a  wave-uniform scale.  A wavefront owns up to U*64 consecutive 16-byte vectors of
-// ONE row; the row's alpha is a scalar load and scale / reciprocal live in SGPR-uniform
-// registers.  Rows need row_len % EPL == 0; lanes past the row end are masked.
+// K1a  wave-uniform scale.  A task = up to U*64 consecutive 16-byte vectors of ONE row
+// (quant group) = one wavefront; the row's alpha is a scalar load and scale / reciprocal
+// are wave-uniform.  All U loads of the task are issued before anything else; with 6-8
+// resident wavefronts per SIMD that keeps > 100 KiB per CU in flight, which is what hides
+// HBM latency (a persistent ping-pong variant measured slower: it doubles the registers).
+// Rows need row_len % EPL == 0; lanes past the row end are masked.
 //   vpr = vectors per row, tpr = tasks per row = ceil(vpr / (64*U)).
-// Launch: 256 threads (4 wavefronts), grid = ceil(rows*tpr / 4).
+// DYN: alpha is not read but computed: alpha = max|row| * ratio (requires tpr == 1, the
+// whole row sits in this wave's registers; one HBM read of x in total).
+// Launch: 256 threads (4 wavefronts); grid = ceil(total_tasks / 4).
 // ------------------------------------------------------------------------------------
-template <typename T, bool OVP, bool IDX, int U>
-__global__ void __launch_bounds__(256)
-k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
-             uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
-             const float *__restrict__ alpha, int per_row, float gmax,
-             PlanArgs pa, const uint4 *__restrict__ plan_tab)
+template <typename T, int U>
+__device__ __forceinline__ void task_load(const uint4 *__restrict__ x, const float *__restrict__ alpha, int per_row,
+                                          uint32_t task, uint32_t vpr, uint32_t tpr, uint32_t lane, bool dyn,
+                                          uint4 (&v)[U], float &a)
+{
+    uint32_t row = task, g = 0;
+    if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+    const uint32_t v0 = g * (64u * U) + lane;
+    const uint4 *p = x + (size_t)row * vpr;
+    // Unconditional loads (lanes past the row end re-read the row's last vector and are
+    // masked at the store): no exec-mask branches between the loads, so all U of them are
+    // in flight together.
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = ld_stream(p + min(v0 + 64u * u, vpr - 1u));
+    a = 1.0f;
+    if (!dyn) a = alpha[per_row ? row : 0];
+}
+
+// wave-wide max of a non-negative float (bit patterns order like integers); NaN propagates
+// as in torch.max because a NaN's magnitude bits exceed every finite value's.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    return m;
+}
+
+template <typename T, bool OVP, bool IDX, int U, bool DYN>
+__device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__restrict__ idx,
+                                         float *__restrict__ alpha_out, float ratio,
+                                         uint32_t task, uint32_t vpr, uint32_t tpr, uint32_t lane, float gmax,
+                                         const PlanArgs &pa, const PlanLds &L, const uint4 (&v)[U], float a)
 {
     constexpr int EPL = IO<T>::EPL;
-    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const bool active = task < total_tasks;
-    uint32_t row = 0, g = 0;
-    if (active) { row = task / tpr; g = task - row * tpr; }
-    const uint32_t v0 = g * (64u * U) + lane;            // vector index inside the row
-    const size_t base = (size_t)row * vpr;               // first vector of the row
-
-    // issue the HBM loads before anything else so they fly during the table staging
-    uint4 v[U];
+    uint32_t row = task, g = 0;
+    if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+    const uint32_t v0 = g * (64u * U) + lane;
+    const size_t base = (size_t)row * vpr + v0;
+    if (DYN) {
+        // alpha = fl32(max|x| * ratio): AQ/quant_modules.py:474 (x_max) and :300 (x_max * ratio)
+        uint32_t m = 0;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        v[u] = make_uint4(0, 0, 0, 0);
-        if (active && v0 + 64u * u < vpr) v[u] = x[base + v0 + 64u * u];
+        for (int u = 0; u < U; u++) {
+            const uint32_t mu = IO<T>::amax_acc(0u, v[u]);
+            if (v0 + 64u * u < vpr) m = IO<T>::amax_acc(m, v[u]);  // lanes past the row end hold a duplicate
+            (void)mu;
+        }
+        m = IO<T>::amax_bits(m);
+        m = wave_max_u32(m);
+        a = u2f(m) * ratio;
+        if (alpha_out && lane == 0) alpha_out[row] = a;
     }
-    float a = 1.0f;
-    if (active) a = alpha[per_row ? row : 0];
-
-    const PlanLds L = stage_plan(pa, plan_tab, smem);
-    __syncthreads();
-    if (!active) return;
+#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 8)
+    Scale sc; sc.s = a; sc.rs = gmax; sc.ok = true;   // ablation only: no divisions in the prologue
+#else
     const Scale sc = make_scale(a, gmax);
-
+#endif
 #pragma unroll
     for (int u = 0; u < U; u++) {
         if (v0 + 64u * u < vpr) {
@@ -335,10 +432,42 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
             int j[EPL];
             IO<T>::unpack(v[u], xf);
             quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
-            out[base + v0 + 64u * u] = IO<T>::pack(of);
-            if (IDX) store_idx<EPL>(idx, base + v0 + 64u * u, j);
+            st_stream(out + base + 64u * u, IO<T>::pack(of));
+            if (IDX) store_idx<EPL>(idx, base + 64u * u, j);
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep one vector's working set live at a time
     }
+}
+
+template <typename T, bool OVP, bool IDX, int U, bool DYN>
+__global__ void __launch_bounds__(256)
+k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+             uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
+             const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+             float *__restrict__ alpha_out, PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+
+    // table fetch is issued FIRST (L2 hit) so that its wait (vmcnt is in-order) does not
+    // also wait for the HBM loads of the task, which are issued right behind it
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+
+    uint4 v[U];
+    float a;
+    const bool active = task < total_tasks;
+    task_load<T, U>(x, alpha, per_row, active ? task : total_tasks - 1u, vpr, tpr, lane, DYN, v, a);
+
+#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 4)
+    PlanLds L; L.lut = reinterpret_cast<const LutEntry *>(smem); L.grid = reinterpret_cast<const float *>(smem);
+    asm volatile("" :: "v"(tab0.x));
+#else
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+#endif
+    if (active) task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
 }
 
 // ------------------------------------------------------------------------------------
@@ -346,15 +475,17 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
 // wavefront, e.g. group-16 = 2 bf16 lanes or 4 fp32 lanes per group).  Each lane gathers
 // its own alpha and builds its own scale.  vshift >= 0 when vpr is a power of two.
 // ------------------------------------------------------------------------------------
-template <typename T, bool OVP, bool IDX, int U>
+template <typename T, bool OVP, bool IDX, int U, bool DYN>
 __global__ void __launch_bounds__(256)
 k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
           size_t n_vec, uint32_t vpr, int vshift,
-          const float *__restrict__ alpha, int per_row, float gmax,
-          PlanArgs pa, const uint4 *__restrict__ plan_tab)
+          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+          float *__restrict__ alpha_out, PlanArgs pa, const uint4 *__restrict__ plan_tab)
 {
     constexpr int EPL = IO<T>::EPL;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
     uint4 v[U];
     float a[U];
@@ -364,24 +495,35 @@ k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
         v[u] = make_uint4(0, 0, 0, 0);
         a[u] = 1.0f;
         if (vi < n_vec) {
-            v[u] = x[vi];
-            size_t row = 0;
-            if (per_row) row = (vshift >= 0) ? (vi >> vshift) : (vi / vpr);
-            a[u] = alpha[row];
+            v[u] = ld_stream(x + vi);
+            if (!DYN) {
+                size_t row = 0;
+                if (per_row) row = (vshift >= 0) ? (vi >> vshift) : (vi / vpr);
+                a[u] = alpha[row];
+            }
         }
     }
-    const PlanLds L = stage_plan(pa, plan_tab, smem);
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const size_t vi = first + (size_t)u * 256u;
+        float xf[EPL];
+        IO<T>::unpack(v[u], xf);
+        if (DYN) {
+            // group = vpr (power of two <= 32) adjacent lanes; butterfly max inside the group.
+            // Lanes past n_vec hold zeros and belong to no real group (n_vec % vpr == 0).
+            uint32_t m = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
+            for (uint32_t off = 1; off < vpr; off <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, (int)off, 64));
+            a[u] = u2f(m) * ratio;
+            if (alpha_out && vi < n_vec && (vi & (vpr - 1)) == 0) alpha_out[vi >> vshift] = a[u];
+        }
         if (vi < n_vec) {
             const Scale sc = make_scale(a[u], gmax);
-            float xf[EPL], of[EPL];
+            float of[EPL];
             int j[EPL];
-            IO<T>::unpack(v[u], xf);
             quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
-            out[vi] = IO<T>::pack(of);
+            st_stream(out + vi, IO<T>::pack(of));
             if (IDX) store_idx<EPL>(idx, vi, j);
         }
     }
@@ -402,7 +544,9 @@ k_fq_scalar(const void *__restrict__ x, void *__restrict__ out, int16_t *__restr
             PlanArgs pa, const uint4 *__restrict__ plan_tab)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-    const PlanLds L = stage_plan(pa, plan_tab, smem);
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
     const size_t p = (size_t)blockIdx.x * 256u + threadIdx.x;
     const size_t i0 = e0 + 2 * p;
@@ -528,7 +672,7 @@ k_affine(const float *__restrict__ x, float *__restrict__ out, int32_t *__restri
     const float half = (float)(1 << (k - 1));
     float range = xmax[r] - xmin[r];
     if (range < 1e-8f) range = 1e-8f;   // torch.clamp(min=1e-8): NaN stays NaN
-    const float scale = nlev / range;
+    const float scale = (1.0f / range) * nlev;  // `n / tensor` is reciprocal(tensor) * n in torch (__rtruediv__)
     float zp = rintf(scale * xmin[r]);
     zp = zp + half;
     float q = rintf(scale * x[i] - zp);
@@ -542,17 +686,193 @@ k_affine(const float *__restrict__ x, float *__restrict__ out, int32_t *__restri
 __global__ void __launch_bounds__(256)
 k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec)
 {
-    const size_t first = (size_t)blockIdx.x * 1024u + threadIdx.x;
+    const size_t first = ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 256u + (threadIdx.x & 63u);
     uint4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        const size_t i = first + 256u * u;
-        if (i < n_vec) v[u] = src[i];
+        const size_t i = first + 64u * u;
+        if (i < n_vec) v[u] = ld_stream(src + i);
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        const size_t i = first + 256u * u;
-        if (i < n_vec) dst[i] = v[u];
+        const size_t i = first + 64u * u;
+        if (i < n_vec) st_stream(dst + i, v[u]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale_inplace(float *__restrict__ a, size_t n, float ratio)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) a[i] = a[i] * ratio;
+}
+
+// ------------------------------------------------------------------------------------
+// Row abs-max (the x_max of search_mse, AQ:289 / AQ:308).  One wavefront per row; rows
+// with row_len % EPL == 0 and 16-byte alignment use vector loads, anything else element
+// loads.  per_row == 0: every wavefront folds its strip into amax[0] with atomicMax on the
+// float's bit pattern (non-negative floats order like unsigned ints; NaN sorts above Inf,
+// so a NaN anywhere yields NaN like torch.max).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size_t row_len, int per_row, int vec_ok)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t wave = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4u;
+    if (per_row) {
+        for (size_t r = wave; r < rows; r += nwaves) {
+            uint32_t m = 0;
+            if (vec_ok) {
+                const uint4 *p = static_cast<const uint4 *>(x) + r * (row_len / EPL);
+                uint32_t mp = 0;
+                for (size_t i = lane; i < row_len / EPL; i += 64) mp = IO<T>::amax_acc(mp, p[i]);
+                m = IO<T>::amax_bits(mp);
+            } else {
+                for (size_t i = lane; i < row_len; i += 64) m = max(m, f2u(IO<T>::load1(x, r * row_len + i)) & 0x7fffffffu);
+            }
+            m = wave_max_u32(m);
+            if (lane == 0) amax[r] = u2f(m);
+        }
+    } else {
+        const size_t n = rows * row_len;
+        uint32_t m = 0;
+        if (vec_ok) {
+            const uint4 *p = static_cast<const uint4 *>(x);
+            const size_t nv = n / EPL;
+            uint32_t mp = 0;
+            for (size_t i = wave * 64 + lane; i < nv; i += nwaves * 64) mp = IO<T>::amax_acc(mp, p[i]);
+            m = IO<T>::amax_bits(mp);
+            for (size_t i = nv * EPL + wave * 64 + lane; i < n; i += nwaves * 64)
+                m = max(m, f2u(IO<T>::load1(x, i)) & 0x7fffffffu);
+        } else {
+            for (size_t i = wave * 64 + lane; i < n; i += nwaves * 64) m = max(m, f2u(IO<T>::load1(x, i)) & 0x7fffffffu);
+        }
+        m = wave_max_u32(m);
+        if (lane == 0 && m) atomicMax(reinterpret_cast<unsigned int *>(amax), m);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Clip search (search_mse, AQ:287-326): for every candidate ratio the squared error of the
+// fake-quantised row against the row itself, WITHOUT writing the quantised tensor: x is
+// read once into registers and all `ncand` candidates are evaluated on it.
+//   sse[c, r] += sum_col fl32( fl32|out - x| ^ 2 )      (fp32 terms, fp64 accumulation)
+// Same task decomposition as K1a (U*64 vectors of one row per task); tasks of one row add
+// their partial sums with a double atomicAdd.
+// ------------------------------------------------------------------------------------
+template <typename T, bool OVP, int U>
+__global__ void __launch_bounds__(256)
+k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
+             const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand, float gmax,
+             double *__restrict__ sse, PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    constexpr int EPL = IO<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+    const size_t na = per_row ? rows : 1;
+    for (uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6); task < total_tasks; task += gridDim.x * 4u) {
+        uint4 v[U];
+        float xm;
+        task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
+        uint32_t row = task, g = 0;
+        if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+        const uint32_t v0 = g * (64u * U) + lane;
+        for (int c = 0; c < ncand; c++) {
+            const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
+            const Scale sc = make_scale(a, gmax);
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (v0 + 64u * u < vpr) {
+                    float xf[EPL], of[EPL];
+                    int j[EPL];
+                    IO<T>::unpack(v[u], xf);
+                    quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
+                    float part = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) {
+                        const float df = fabsf(of[e] - xf[e]);  // AQ:282 (q - x).abs().pow(2)
+                        part += df * df;
+                    }
+                    acc += (double)part;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) {
+                double *dst = sse + (size_t)c * na + (per_row ? row : 0);
+                if (per_row && tpr == 1) *dst = acc; else atomicAdd(dst, acc);
+            }
+        }
+    }
+}
+
+// Element-granular clip search for ragged rows (row_len % EPL != 0, e.g. 3x3x3 conv rows) or
+// unaligned buffers: one wavefront per row (per strip of 16 Ki elements for a per-tensor
+// scale), exact slow-path arithmetic (true division + literal scan).  With OVP the partner
+// element (i ^ 1, or element 0 for the last element of an odd-sized tensor) is quantised
+// with ITS row's candidate alpha, as the reference does when it quantises the whole tensor.
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(256)
+k_search_sse_scalar(const void *__restrict__ x, size_t rows, size_t row_len, const float *__restrict__ xmax,
+                    int per_row, const float *__restrict__ ratios, int ncand, float gmax, double *__restrict__ sse,
+                    PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t n = rows * row_len;
+    const size_t strip = per_row ? row_len : (size_t)16384;
+    const size_t nstrips = per_row ? rows : (n + strip - 1) / strip;
+    const size_t na = per_row ? rows : 1;
+    for (size_t st = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6); st < nstrips; st += (size_t)gridDim.x * 4u) {
+        const size_t b = st * strip;
+        const size_t e = per_row ? b + row_len : (b + strip < n ? b + strip : n);
+        for (int c = 0; c < ncand; c++) {
+            const float r = ratios[c];
+            double acc = 0.0;
+            for (size_t i = b + lane; i < e; i += 64) {
+                const float xv = IO<T>::load1(x, i);
+                const float s0 = (xmax[per_row ? i / row_len : 0] * r) / gmax;
+                const float d = xv / s0;
+                int j;
+                float q = scan_lds(d, L.grid, (int)pa.m, j);
+                if (OVP) {
+                    size_t ip = i ^ (size_t)1;
+                    if (ip >= n) ip = 0;                       // odd numel: torch.roll wrap-around
+                    const bool has_partner = (ip != i);
+                    if (has_partner) {
+                        const float s1 = (xmax[per_row ? ip / row_len : 0] * r) / gmax;
+                        int jp;
+                        const float qp = scan_lds(IO<T>::load1(x, ip) / s1, L.grid, (int)pa.m, jp);
+                        const bool me = fabsf(q) > 32.0f, mp = fabsf(qp) > 32.0f;
+                        bool victim;
+                        if (i & 1) victim = mp;                 // odd element: victim iff its even partner is an outlier
+                        else if ((i ^ 1) < n) victim = mp && !me;  // even element with a real odd partner
+                        else victim = mp;                       // last element of an odd-sized tensor
+                        q = q * (victim ? 0.0f : 1.0f);
+                    }
+                }
+                const float t = (q - d) + d;
+                const float df = fabsf(t * s0 - xv);
+                acc += (double)(df * df);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) {
+                double *dst = sse + (size_t)c * na + (per_row ? st : 0);
+                if (per_row) *dst = acc; else atomicAdd(dst, acc);
+            }
+        }
     }
 }
 
@@ -583,6 +903,49 @@ static inline const uint4 *plan_tab_ptr(const void *plan_dev)
     return reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev) + sizeof(PlanHeader));
 }
 
+// tuning knobs (dev / bench only; see antq_debug_set)
+static int g_knob_u = 0;        // force U of the uniform kernel (0 = heuristic)
+static int g_knob_blocks = 0;   // force the persistent grid size (0 = heuristic)
+
+template <typename T, bool OVP, bool IDX, bool DYN>
+static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, size_t vpr, const float *alpha,
+                          int per_row, float gmax, float ratio, float *alpha_out, const PlanArgs &pa,
+                          const uint4 *tab, size_t lds, hipStream_t st)
+{
+    // U: 1 .. 8 KiB of one row per task, keeping lane utilisation high at the row tail
+    int U = 4;
+    if (DYN) {
+        U = vpr <= 64 ? 1 : vpr <= 128 ? 2 : vpr <= 256 ? 4 : 8;
+        if (vpr > 512) return ANTQ_ERR_UNSUPPORTED;  // caller falls back to absmax + static
+    } else {
+        double best = -1.0;
+        for (int cand : {4, 2, 1}) {
+            const size_t span = (size_t)64 * cand;
+            const double util = (double)vpr / (double)(((vpr + span - 1) / span) * span);
+            if (util > best + 0.05) { best = util; U = cand; }
+        }
+        if (g_knob_u) U = g_knob_u;
+    }
+    const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
+    const size_t total = rows * tpr;
+    if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+    const size_t blocks = (total + 3) / 4;
+    const dim3 grid((unsigned)blocks), block(256);
+    const uint4 *xv = static_cast<const uint4 *>(x);
+    uint4 *ov = static_cast<uint4 *>(out);
+#define ANTQ_LAUNCH_U(UU)                                                                                          \
+    hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, UU, DYN>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,  \
+                       (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out, pa, tab)
+    switch (U) {
+    case 8: ANTQ_LAUNCH_U(8); break;
+    case 4: ANTQ_LAUNCH_U(4); break;
+    case 2: ANTQ_LAUNCH_U(2); break;
+    default: ANTQ_LAUNCH_U(1); break;
+    }
+#undef ANTQ_LAUNCH_U
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
 template <typename T, bool OVP, bool IDX>
 static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,
                      const float *alpha, int per_row, float gmax, const PlanArgs &pa,
@@ -600,30 +963,8 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
         const size_t vpr = row_len / EPL;
         if (vpr >= 64) {
             if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
-            // U: 1 KiB .. 4 KiB of one row per wavefront, keeping lane utilisation high
-            int U = 4;
-            if (vpr % 256 != 0) {
-                const double u4 = (double)vpr / (double)(((vpr + 255) / 256) * 256);
-                const double u2 = (double)vpr / (double)(((vpr + 127) / 128) * 128);
-                const double u1 = (double)vpr / (double)(((vpr + 63) / 64) * 64);
-                if (u2 > u4 + 0.05) U = 2;
-                if (u1 > (U == 2 ? u2 : u4) + 0.05) U = 1;
-            }
-            const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
-            const size_t total = rows * tpr;
-            if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
-            const dim3 grid((unsigned)((total + 3) / 4)), block(256);
-            const uint4 *xv = static_cast<const uint4 *>(x);
-            uint4 *ov = static_cast<uint4 *>(out);
-            if (U == 4)
-                hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, 4>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,
-                                   (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, pa, tab);
-            else if (U == 2)
-                hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, 2>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,
-                                   (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, pa, tab);
-            else
-                hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, 1>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,
-                                   (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, pa, tab);
+            return launch_uniform<T, OVP, IDX, false>(x, out, idx, rows, vpr, alpha, per_row, gmax, 1.0f, nullptr, pa,
+                                                      tab, lds, st);
         } else {
             const size_t n_vec = n / EPL;
             int vshift = -1;
@@ -631,9 +972,9 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
             constexpr int U = 2;
             const size_t blocks = (n_vec + 256 * U - 1) / (256 * U);
             if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U>), dim3((unsigned)blocks), dim3(256), lds, st,
+            hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, false>), dim3((unsigned)blocks), dim3(256), lds, st,
                                static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
-                               vshift, alpha, per_row, gmax, pa, tab);
+                               vshift, alpha, per_row, gmax, 1.0f, (float *)nullptr, pa, tab);
         }
     } else if (aligned && !per_row && n >= (size_t)64 * EPL) {
         // per-tensor scale with a ragged tail: vector body + element tail
@@ -774,15 +1115,167 @@ extern "C" int antq_copy(const void *src, void *dst, size_t bytes, void *stream)
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
-// ---- TEMP stubs (implemented below in later commits) ----
-extern "C" int antq_fakequant_dynamic(const void *, void *, int16_t *, float *, size_t, size_t, float, float,
-                                      const void *, const void *, unsigned, int, void *)
+extern "C" int antq_debug_set(int key, int value)
 {
-    return ANTQ_ERR_UNSUPPORTED;
+    if (key == 0) g_knob_u = value;
+    else if (key == 1) g_knob_blocks = value;
+    else return ANTQ_ERR_ARG;
+    return ANTQ_OK;
 }
-extern "C" int antq_absmax(const void *, float *, size_t, size_t, int, int, void *) { return ANTQ_ERR_UNSUPPORTED; }
-extern "C" int antq_search_sse(const void *, size_t, size_t, const float *, int, const float *, int, float,
-                               const void *, const void *, unsigned, int, double *, void *)
+
+namespace antq {
+
+template <typename T>
+static int launch_absmax(const void *x, float *amax, size_t rows, size_t row_len, int per_row, hipStream_t st)
 {
-    return ANTQ_ERR_UNSUPPORTED;
+    constexpr int EPL = IO<T>::EPL;
+    const bool al = reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    const int vec_ok = per_row ? (al && row_len % EPL == 0) : al;
+    size_t waves = per_row ? rows : (rows * row_len + 64 * EPL * 8 - 1) / (64 * EPL * 8);
+    size_t blocks = (waves + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_absmax<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, amax, rows, row_len, per_row, vec_ok);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+template <typename T, bool OVP, bool IDX>
+static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_out, size_t rows, size_t row_len,
+                          float ratio, float gmax, const PlanArgs &pa, const void *plan_dev, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const size_t lds = (size_t)pa.tab_units * 16;
+    const uint4 *tab = plan_tab_ptr(plan_dev);
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
+                         (!idx || reinterpret_cast<uintptr_t>(idx) % 16 == 0);
+    if (aligned && row_len % EPL == 0) {
+        const size_t vpr = row_len / EPL;
+        const bool pow2 = (vpr & (vpr - 1)) == 0;
+        if (vpr <= 32 && pow2) {
+            // several groups per wavefront: butterfly max over vpr adjacent lanes
+            int vshift = 0;
+            while (((size_t)1 << vshift) < vpr) vshift++;
+            const size_t n_vec = rows * vpr;
+            constexpr int U = 2;
+            const size_t blocks = (n_vec + 256 * U - 1) / (256 * U);
+            if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, true>), dim3((unsigned)blocks), dim3(256), lds, st,
+                               static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
+                               vshift, (const float *)nullptr, 1, gmax, ratio, alpha_out, pa, tab);
+            return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+        }
+        if (vpr <= 512) {
+            // one quant group (row) per wavefront, the row lives in registers: single HBM read
+            return launch_uniform<T, OVP, IDX, true>(x, out, idx, rows, vpr, nullptr, 1, gmax, ratio, alpha_out, pa, tab,
+                                                     lds, st);
+        }
+    }
+    // long or ragged rows: abs-max pass (read) + static pass (read + write)
+    if (!alpha_out) return ANTQ_ERR_ARG;
+    int rc = launch_absmax<T>(x, alpha_out, rows, row_len, 1, st);
+    if (rc != ANTQ_OK) return rc;
+    hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, alpha_out, rows, ratio);
+    return launch_fq<T, OVP, IDX>(x, out, idx, rows, row_len, alpha_out, 1, gmax, pa, plan_dev, st);
+}
+
+template <typename T>
+static int launch_dynamic_flags(const void *x, void *out, int16_t *idx, float *alpha_out, size_t rows, size_t row_len,
+                                float ratio, float gmax, const PlanArgs &pa, const void *plan_dev, unsigned flags,
+                                hipStream_t st)
+{
+    const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
+    if (ovp) {
+        if (idx) return launch_dynamic<T, true, true>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, st);
+        return launch_dynamic<T, true, false>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, st);
+    }
+    if (idx) return launch_dynamic<T, false, true>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, st);
+    return launch_dynamic<T, false, false>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, st);
+}
+
+template <typename T, bool OVP>
+static int launch_search(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
+                         const float *ratios, int ncand, float gmax, const PlanArgs &pa, const void *plan_dev,
+                         double *sse, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const size_t lds = (size_t)pa.tab_units * 16;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) {
+        size_t strips = per_row ? rows : (rows * row_len + 16383) / 16384;
+        size_t blocks = (strips + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL((k_search_sse_scalar<T, OVP>), dim3((unsigned)blocks), dim3(256), lds, st, x, rows, row_len,
+                           xmax, per_row, ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev));
+        return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+    }
+    if (!per_row) { row_len = rows * row_len; rows = 1; }
+    const size_t vpr = row_len / EPL;
+    if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
+    constexpr int U = 4;
+    const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
+    const size_t total = rows * tpr;
+    if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+    size_t blocks = (total + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((k_search_sse<T, OVP, U>), dim3((unsigned)blocks), dim3(256), lds, st,
+                       static_cast<const uint4 *>(x), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row,
+                       ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev));
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+}  // namespace antq
+
+extern "C" int antq_fakequant_dynamic(const void *x, void *out, int16_t *idx, float *alpha_out, size_t rows,
+                                      size_t row_len, float ratio, float gmax, const void *plan_host,
+                                      const void *plan_dev, unsigned flags, int dtype, void *stream)
+{
+    if (rows == 0 || row_len == 0) return ANTQ_OK;
+    if (!x || !out || !plan_host || !plan_dev) return ANTQ_ERR_ARG;
+    PlanArgs pa;
+    if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case ANTQ_F32: return launch_dynamic_flags<float>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, flags, st);
+    case ANTQ_BF16: return launch_dynamic_flags<bf16_tag>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, flags, st);
+    case ANTQ_F16: return launch_dynamic_flags<f16_tag>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, flags, st);
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int antq_absmax(const void *x, float *amax, size_t rows, size_t row_len, int per_row, int dtype, void *stream)
+{
+    if (rows == 0 || row_len == 0) return ANTQ_OK;
+    if (!x || !amax) return ANTQ_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case ANTQ_F32: return launch_absmax<float>(x, amax, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_BF16: return launch_absmax<bf16_tag>(x, amax, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_F16: return launch_absmax<f16_tag>(x, amax, rows, row_len, per_row ? 1 : 0, st);
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
+                               const float *ratios, int ncand, float gmax, const void *plan_host, const void *plan_dev,
+                               unsigned flags, int dtype, double *sse, void *stream)
+{
+    if (rows == 0 || row_len == 0 || ncand == 0) return ANTQ_OK;
+    if (!x || !xmax || !ratios || !plan_host || !plan_dev || !sse || ncand < 0) return ANTQ_ERR_ARG;
+    PlanArgs pa;
+    if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
+    const int pr = per_row ? 1 : 0;
+    switch (dtype) {
+    case ANTQ_F32:
+        return ovp ? launch_search<float, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st)
+                   : launch_search<float, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st);
+    case ANTQ_BF16:
+        return ovp ? launch_search<bf16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st)
+                   : launch_search<bf16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st);
+    case ANTQ_F16:
+        return ovp ? launch_search<f16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st)
+                   : launch_search<f16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st);
+    default:
+        return ANTQ_ERR_UNSUPPORTED;
+    }
 }

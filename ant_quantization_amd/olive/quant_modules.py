@@ -1,0 +1,348 @@
+"""MI355X-native mirror of olive_quantization/antquant/quant_modules.py (OliVe, ISCA'23).
+
+Differences from the ANT quantiser that matter to the kernels:
+  * codebooks normalised so that the outlier threshold is 32 (int / flint), plus the
+    abfloat `outliers` codebook; the kernel scans cat(quant_grid, outliers)  (OQ:303-306);
+  * scale = alpha / max(quant_grid) -- the NORMAL grid only (OQ:296);
+  * outlier-victim pairs on the flattened tensor after the nearest-value step (OQ:311-320):
+    done inside the same kernel, each lane owns whole (2k, 2k+1) pairs;
+  * clip search starts from the 3-sigma rule, candidates i in range(lb, ub, 2) (OQ:189-233);
+  * PTQ only: the whole quantiser is `torch.no_grad()`.
+
+The reference runs ~17 PyTorch launches (~100 B/elem) per forward; here it is one kernel
+moving 8 B/elem (fp32) or 4 B/elem (bf16).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib, core, grids
+
+
+class QuantBase():
+    """OQ:8-21 (reshape(-1) instead of view(-1): non-contiguous inputs are accepted)."""
+
+    def _quantization(x, quant_grid):
+        shape = x.shape
+        quant_array = x.reshape(-1)
+        quant_grid = quant_grid.type_as(quant_array) if quant_array.dtype in (torch.float32, torch.float64) \
+            else quant_grid.float()
+        quant_array = _lib.nearest(quant_array.contiguous(), quant_grid.contiguous())
+        return quant_array.view(shape)
+
+    @staticmethod
+    def forward(real_val, quant_grid):
+        with torch.no_grad():
+            return QuantBase._quantization(real_val, quant_grid)
+
+
+class Quantizer(nn.Module):
+    def __init__(self, mode="base", bit=8, is_signed=True, is_enable=False, is_input=False, args=None, operator=None):
+        super(Quantizer, self).__init__()
+        self.mode = mode
+        self.is_input = is_input
+        self.is_signed = is_signed
+        self.is_enable = is_enable
+        self.is_enable_activation = is_enable
+        self.is_enable_weight = is_enable
+        self.args = args
+        self.operator = operator
+
+        self.w_up = self.args.w_up
+        self.a_up = self.args.a_up
+        self.w_low = self.args.w_low
+        self.a_low = self.args.a_low
+
+        # registration order / names of OQ:41-45
+        self.alpha = nn.Parameter(torch.tensor(1.0, requires_grad=True))
+        self.register_buffer('bit', torch.tensor(bit))
+        self.register_buffer('has_inited_quant_para', torch.tensor(0.0))
+        self.register_buffer('quant_grid', torch.ones(2 ** bit))
+        self.register_buffer('outliers', torch.ones(2 ** bit))
+        self.percent = self.args.percent / 100
+        self.is_perchannel = True
+        if is_input:
+            self.is_perchannel = False
+        self.search = args.search
+        self.mse = torch.tensor(0.0)
+        self.name = None
+
+        self._steady = False
+        self._plan = None
+        self._gmax = 32.0
+
+    # ---------------------------------------------------------------- bookkeeping
+    def disable_input_quantization(self):
+        self.is_enable_activation = False
+
+    def enable_quantization(self, name):
+        self.name = name
+        self.is_enable = True
+
+    def disable_quantization(self, name):
+        self.name = name
+        self.is_enable = False
+
+    def update_signed(self, tensor):
+        if tensor.min() < 0:
+            self.is_signed = True
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
+        self._steady = False
+        self._plan = None
+
+    def rearm(self):
+        self._steady = False
+        self._plan = None
+
+    @property
+    def _no_outlier(self):
+        return bool(getattr(self.args, "no_outlier", False))
+
+    # ---------------------------------------------------------------- codebooks (OQ:72-179)
+    def _bits(self):
+        return int(self.bit.item())
+
+    def _to_grid(self, values):
+        return torch.from_numpy(np.ascontiguousarray(values)).to(self.quant_grid.device)
+
+    @torch.no_grad()
+    def int_value(self):
+        return self._to_grid(grids.olive_int(self._bits(), self.is_signed))
+
+    @torch.no_grad()
+    def flint_value(self, exp_base=0):
+        return self._to_grid(grids.olive_flint(self._bits(), self.is_signed))
+
+    @torch.no_grad()
+    def outlier_value(self, exp_bit=2, exp_base=5):
+        return self._to_grid(grids.olive_outliers(self._bits(), self.is_signed, exp_bit, exp_base))
+
+    def _install(self, normal, outl):
+        """quant_grid / outliers <- host arrays; the kernel's grid is their concatenation."""
+        normal = np.ascontiguousarray(normal, dtype=np.float32)
+        outl = np.ascontiguousarray(outl, dtype=np.float32)
+        self.quant_grid.data = self._to_grid(normal)
+        self.outliers.data = self._to_grid(outl)
+        self._set_plan(normal, outl)
+
+    def _set_plan(self, normal, outl):
+        full = normal if self._no_outlier else np.concatenate([normal, outl])
+        self._plan = _lib.plan_for(full)
+        self._gmax = float(np.max(normal))
+
+    def _ensure_plan(self):
+        if self._plan is None:
+            self._set_plan(self.quant_grid.detach().float().cpu().numpy(),
+                           self.outliers.detach().float().cpu().numpy())
+        return self._plan
+
+    # ---------------------------------------------------------------- calibration
+    @torch.no_grad()
+    def mse_loss(self, quant_tensor, source_tensor, p=2.0, is_perchannel=True):
+        if is_perchannel:
+            return (quant_tensor - source_tensor).abs().pow(p).view(quant_tensor.shape[0], -1).mean(-1).unsqueeze(1)
+        return (quant_tensor - source_tensor).abs().pow(p).mean()
+
+    def _three_sigma(self, tensor, per_channel):
+        """OQ:193-197 / :213-218: x_max = max(|mean + 3 std|, |mean - 3 std|) (unbiased std), or the
+        abs-max when outliers are disabled.  O(N) statistics stay in torch (mean / std are the
+        reference's own reductions; they run once per calibration)."""
+        if self._no_outlier:
+            return core.row_absmax(tensor, per_channel)
+        t = tensor.detach().float()
+        if per_channel:
+            t2 = t.reshape(t.shape[0], -1)
+            mean, std = t2.mean(dim=-1), t2.std(dim=-1)
+        else:
+            mean, std = t.mean(), t.std()
+        return torch.maximum((mean + 3 * std).abs(), (mean - 3 * std).abs()).reshape(-1)
+
+    @torch.no_grad()
+    def search_mse(self, tensor):
+        per_channel = self.is_perchannel and (not self.is_input)
+        x_max = self._three_sigma(tensor, per_channel)
+        lb = int(self.w_low) if per_channel else int(self.a_low)
+        ub = int(self.w_up) if per_channel else int(self.a_up)
+        plan = self._ensure_plan()
+        best_score, alpha, _ = core.clip_search(tensor, x_max, per_channel, lb, ub, 2, plan, self._gmax,
+                                                ovp=not self._no_outlier)
+        ratio = (alpha / x_max).mean().item()
+        if per_channel:
+            return best_score.sum(), alpha.unsqueeze(1), ratio
+        return best_score.sum(), alpha.reshape(()), ratio
+
+    @torch.no_grad()
+    def search_adaptive_numeric_type(self, data):
+        """OQ:235-256: int vs flint, smallest summed best-MSE wins."""
+        modes, mse_list = [], []
+        mode = self.mode
+        outl = grids.olive_outliers(self._bits(), self.is_signed)
+        for t in ("int", "flint"):
+            if ("-" + t) not in mode:
+                continue
+            self.mode = t
+            self._install(grids.olive_grid(t, self._bits(), self.is_signed), outl)
+            best, _, _ = self.search_mse(data)
+            modes.append(t)
+            mse_list.append(best.item())
+        self.mode = modes[np.argsort(np.array(mse_list))[0]]
+
+    @torch.no_grad()
+    def _init_quant_para(self, data, data_b):
+        """OQ:258-292."""
+        if self._steady:
+            return
+        if self.has_inited_quant_para.item() != 0:
+            self._ensure_plan()
+            self._steady = True
+            return
+        self.update_signed(data)
+        outl = grids.olive_outliers(self._bits(), self.is_signed)
+        self.outliers.data = self._to_grid(outl)
+
+        if self.is_perchannel:
+            self.alpha.data = core.row_absmax(data, True).unsqueeze(1)
+        else:
+            self.alpha.data = core.row_absmax(data, False).reshape(())
+
+        if self._bits() > 6:
+            self.mode = 'int'
+        elif "ant-" in self.mode:
+            self.search_adaptive_numeric_type(data)
+
+        if self.mode not in ("flint", "int"):
+            raise RuntimeError("Unsupported mode: " + self.mode)
+        self._install(grids.olive_grid(self.mode, self._bits(), self.is_signed), outl)
+
+        _, self.alpha.data, alpha_ratio = self.search_mse(data)
+
+        quant_data = self._forward(data)
+        self.mse = self.mse_loss(quant_data, data, 2, is_perchannel=self.is_perchannel).mean()
+        print(self.mode, end="\t")
+        print("%d-bit \t %s," % (self.bit.item(), self.name))
+
+        self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
+        self._steady = True
+
+    # ---------------------------------------------------------------- steady state
+    @torch.no_grad()
+    def _forward(self, data, display=False):
+        """OQ:294-330 as one fused kernel (nearest over normal||outliers + victim masking)."""
+        plan = self._ensure_plan()
+        return core.fake_quant(data, self.alpha, plan, self._gmax, self.is_perchannel, ovp=not self._no_outlier)
+
+    @torch.no_grad()
+    def tensor_forward(self, tensor, input_tensor=None):
+        if self.mode == "base":
+            return tensor
+        if not self.is_enable:
+            return tensor
+        if self.is_input:
+            if not self.is_enable_activation:
+                return tensor
+        else:
+            if not self.is_enable_weight:
+                return tensor
+        self._init_quant_para(tensor, input_tensor)
+        return self._forward(tensor)
+
+
+class TensorQuantizer(Quantizer):
+    def __init__(self, **kwargs):
+        super(TensorQuantizer, self).__init__(**kwargs)
+
+    def forward(self, tensor, input_tensor=None):
+        return self.tensor_forward(tensor, input_tensor)
+
+
+def _make_pair(owner, mode, wbit, abit, args, operator):
+    owner.quant_weight = TensorQuantizer(mode=mode, bit=wbit, is_signed=True, is_enable=True, args=args,
+                                         operator=operator)
+    owner.quant_input = TensorQuantizer(mode=mode, bit=abit, is_signed=False, is_enable=True, args=args,
+                                        operator=operator, is_input=True)
+
+
+def _clone_wb(owner, src):
+    owner.weight = nn.Parameter(src.weight.data.clone())
+    try:
+        owner.bias = nn.Parameter(src.bias.data.clone())
+    except AttributeError:
+        owner.bias = None
+
+
+class Conv1dQuantizer(nn.Module):
+    """HF GPT-2 `Conv1D` (y = x @ W + b, weight [in, out]) with quantised operands (OQ:358-386)."""
+
+    def __init__(self, mode=None, wbit=None, abit=None, args=None):
+        super(Conv1dQuantizer, self).__init__()
+        assert mode is not None, 'Quantizer is not initilized!'
+        _make_pair(self, mode, wbit, abit, args, self._conv_forward)
+
+    def set_param(self, conv):
+        self.nf = conv.nf
+        _clone_wb(self, conv)
+
+    def _conv_forward(self, x, weight):
+        size_out = x.size()[:-1] + (self.nf,)
+        x = torch.addmm(self.bias, x.view(-1, x.size(-1)), weight)
+        return x.view(size_out)
+
+    def forward(self, input):
+        weight = self.quant_weight(self.weight, input)
+        input = self.quant_input(input, self.weight)
+        return self._conv_forward(input, weight)
+
+
+class Conv2dQuantizer(nn.Module):
+    """OQ:389-423."""
+
+    def __init__(self, mode=None, wbit=None, abit=None, args=None):
+        super(Conv2dQuantizer, self).__init__()
+        assert mode is not None, 'Quantizer is not initilized!'
+        _make_pair(self, mode, wbit, abit, args, self._conv_forward)
+
+    def set_param(self, conv):
+        self.in_channels = conv.in_channels
+        self.out_channels = conv.out_channels
+        self.quant_weight.alpha.data = torch.ones([self.out_channels, 1])
+        self.kernel_size = conv.kernel_size
+        self.stride = conv.stride
+        self.padding = conv.padding
+        self.dilation = conv.dilation
+        self.groups = conv.groups
+        _clone_wb(self, conv)
+
+    def _conv_forward(self, input, weight):
+        return F.conv2d(input, weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+    def forward(self, input):
+        weight = self.quant_weight(self.weight, input)
+        input = self.quant_input(input, self.weight)
+        return self._conv_forward(input, weight)
+
+
+class LinearQuantizer(nn.Module):
+    """OQ:426-450."""
+
+    def __init__(self, mode=None, wbit=None, abit=None, args=None):
+        super(LinearQuantizer, self).__init__()
+        assert mode is not None, 'Quantizer is not initilized!'
+        _make_pair(self, mode, wbit, abit, args, F.linear)
+
+    def set_param(self, linear):
+        self.in_features = linear.in_features
+        self.out_features = linear.out_features
+        self.quant_weight.alpha.data = torch.ones([self.out_features, 1])
+        _clone_wb(self, linear)
+
+    def forward(self, input):
+        weight = self.quant_weight(self.weight, input)
+        input = self.quant_input(input, self.weight)
+        return F.linear(input, weight, self.bias)
+
+
+QuantConv2d = Conv2dQuantizer
+QuantLinear = LinearQuantizer

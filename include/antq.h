@@ -162,6 +162,11 @@ int antq_affine(const float *x_dev, float *out_dev, int32_t *q_dev,
  * used by bench.py to measure the empirical HBM ceiling on the same buffers. */
 int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
 
+/* Development / benchmark tuning knobs (process-global; not part of the stable surface):
+ *   key 0: force the per-task unroll U of the row kernels (0 = heuristic)
+ *   key 1: force the persistent grid size in workgroups   (0 = heuristic) */
+int antq_debug_set(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -210,7 +210,7 @@ void antq_oracle_forward_bf16(const uint16_t *x, uint16_t *out, int32_t *idx,
                               const float *grid, int m, float gmax, int ovp)
 {
     size_t n = rows * row_len;
-    float *xf = (float *)__builtin_malloc(n * sizeof(float) + 4);
+    float *xf = (float *)__builtin_calloc(n + 1, sizeof(float));
     float *of = (float *)__builtin_malloc(n * sizeof(float) + 4);
     for (size_t i = 0; i < n; i++) xf[i] = bf16_to_f32(x[i]);
     forward_row_major(xf, of, idx, rows, row_len, alpha, alpha_per_row, grid, m, gmax, ovp);
@@ -336,6 +336,8 @@ int antq_oracle_search_mse_f32(const float *x, size_t rows, size_t row_len, int 
 /* a14. AsymmetricQuantFunction.forward  AQ/quant_affine.py:95-115      */
 /*   n     = 2^k - 1                                         :75        */
 /*   scale = n / clamp(max - min, 1e-8)                      :76        */
+/*           python-int / tensor = Tensor.__rtruediv__, i.e.            */
+/*           reciprocal(range) * n  -> fl(fl(1/range) * n)              */
 /*   zp    = round(scale * min) + 2^(k-1)                    :77-85     */
 /*   q     = clamp(round(scale*x - zp), -2^(k-1), 2^(k-1)-1) :108-110   */
 /*   out   = (q + zp) / scale                                :111-114   */
@@ -353,7 +355,7 @@ void antq_oracle_affine_f32(const float *x, float *out, int32_t *qout,
         float mx = per_row ? x_max[r] : x_max[0];
         float range = mx - mn;
         if (range < 1e-8f) range = 1e-8f;
-        float scale = nlev / range;
+        float scale = (1.0f / range) * nlev;
         float zp = nearbyintf(scale * mn);
         zp = zp + half;
         for (size_t c = 0; c < row_len; c++) {

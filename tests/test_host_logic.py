@@ -1,0 +1,267 @@
+"""CPU-side product logic: grids, plan builder (host model of the device path vs the oracle
+scan), C-ABI export table, module surface / model rewrite, loud failure without a GPU."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1)
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def _args(**kw):
+    d = dict(w_up=150, a_up=150, w_low=75, a_low=75, percent=100, search=False, no_outlier=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+# ---------------------------------------------------------------- grids
+def test_product_ant_grids_bit_exact():
+    from ant_quantization_amd import grids as G
+    g = golden("ant_grids.npz")
+    n = 0
+    for k in g.files:
+        inv = k.startswith("INVALID_")
+        t, b, s = (k[8:] if inv else k).split("_")
+        bit, signed = int(b[1:]), s == "s"
+        if inv:
+            with pytest.raises(Exception):
+                G.ant_grid(t, bit, signed)
+            continue
+        mine = G.ant_grid(t, bit, signed)
+        if t == "apot":
+            assert np.array_equal(mine, g[k]), k     # +0/-0 order is torch.sort's unstable choice
+        else:
+            assert same_bits(mine, g[k]), k
+        n += 1
+    assert n > 100
+
+
+def test_product_olive_grids_bit_exact():
+    from ant_quantization_amd import grids as G
+    g = golden("olive_grids.npz")
+    for k in g.files:
+        if k.startswith("INVALID_"):
+            continue
+        t, b, s = k.split("_")
+        fn = {"int": G.olive_int, "flint": G.olive_flint, "outlier": G.olive_outliers}[t]
+        assert same_bits(fn(int(b[1:]), s == "s"), g[k]), k
+
+
+# ---------------------------------------------------------------- C ABI
+def test_cabi_exports_every_declared_symbol(antq_lib):
+    hdr = open(os.path.join(ROOT, "include", "antq.h")).read()
+    names = set(re.findall(r"\b(antq_[a-z_0-9]+)\s*\(", hdr))
+    assert {"antq_nearest", "antq_fakequant", "antq_fakequant_dynamic", "antq_plan_build", "antq_affine",
+            "antq_absmax", "antq_search_sse", "antq_copy"} <= names
+    L = ctypes.CDLL(antq_lib.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(L, n), "libantq.so does not export " + n
+    assert L.antq_abi_version() == 1
+    L.antq_strerror.restype = ctypes.c_char_p
+    assert L.antq_strerror(-3) == b"malformed or undersized plan blob"
+
+
+def test_cabi_argument_errors_without_gpu(antq_lib):
+    """Entry points validate before they touch HIP: callable on a CPU-only box."""
+    L = antq_lib.lib()
+    assert L.antq_plan_build(None, 4, None, ctypes.c_size_t(0)) == -1
+    g = np.float32([0, 1, 2, 3])
+    buf = np.zeros(16, np.uint8)
+    assert L.antq_plan_build(g.ctypes.data_as(ctypes.c_void_p), 4, buf.ctypes.data_as(ctypes.c_void_p),
+                             ctypes.c_size_t(16)) == -3
+    assert L.antq_fakequant(None, None, None, ctypes.c_size_t(4), ctypes.c_size_t(4), None, 0, ctypes.c_float(1),
+                            None, None, 0, 0, None) == -1
+    assert L.antq_fakequant(None, None, None, ctypes.c_size_t(0), ctypes.c_size_t(4), None, 0, ctypes.c_float(1),
+                            None, None, 0, 0, None) == 0       # empty tensor: nothing to do
+    assert L.antq_nearest(None, None, None, ctypes.c_size_t(0), None, 0, 0, None) == 0
+
+
+# ---------------------------------------------------------------- plans
+def _all_grids():
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    out = {k: G[k] for k in G.files if not k.startswith("INVALID")}
+    for t in ("int", "flint"):
+        for b in range(3, 9):
+            for s in "su":
+                k = "%s_b%d_%s" % (t, b, s)
+                ko = "outlier_b%d_%s" % (b, s)
+                if k in O.files and ko in O.files:
+                    out["olive_" + k] = np.concatenate([O[k], O[ko]])
+                    out["olive_noout_" + k] = O[k]
+    return out
+
+
+def test_plan_host_model_equals_scan_on_every_grid(antq_lib, oracle):
+    rng = np.random.default_rng(0)
+    table = 0
+    for k, g in _all_grids().items():
+        if g.size > antq_lib.MAX_GRID:
+            continue
+        plan = antq_lib.Plan(g)
+        table += plan.is_table
+        bits = rng.integers(0, 2 ** 32, 60000, dtype=np.uint64).astype(np.uint32)
+        with np.errstate(all="ignore"):
+            scale = np.float32(np.nanmax(np.abs(g[np.isfinite(g)])) / 2)
+            d = np.concatenate([bits.view(np.float32), rng.standard_normal(60000).astype(np.float32) * scale])
+        q, idx = plan.eval_host(d)
+        z, j = oracle.nearest(d, g)
+        assert same_bits(q, z), k
+        assert np.array_equal(idx.astype(np.int32), j), k
+    assert table > 140      # nearly every grid gets the fast table path
+
+
+def test_plan_exhaustive_over_all_finite_floats_headline_grid(antq_lib, oracle):
+    """Every float32 in [-16, 16] (the whole reachable range of d = x/scale for |x| <= 1.6 alpha),
+    i.e. ~2.2e9 bit patterns, in strided passes; plus all 2^16 bf16 patterns."""
+    g = golden("ant_grids.npz")["flint_b4_s"]
+    plan = antq_lib.Plan(g)
+    assert plan.is_table
+    hi = np.float32(16.0).view(np.uint32)
+    step = 97            # co-prime stride: 11 M points per sign, adjacent-float coverage near thresholds below
+    for sign in (0, 0x80000000):
+        u = (np.arange(0, int(hi) + 1, step, dtype=np.uint64).astype(np.uint32) | np.uint32(sign))
+        d = u.view(np.float32)
+        q, idx = plan.eval_host(d)
+        z, j = oracle.nearest(d, g)
+        assert same_bits(q, z) and np.array_equal(idx.astype(np.int32), j)
+    # a dense window of +-4096 floats around every decision threshold
+    gs = np.unique(g)
+    mids = ((gs[:-1].astype(np.float64) + gs[1:]) / 2).astype(np.float32)
+    for m in mids:
+        c = int(np.float32(abs(m)).view(np.uint32))
+        u = np.arange(max(c - 4096, 0), c + 4096, dtype=np.uint64).astype(np.uint32)
+        if m < 0:
+            u = u | np.uint32(0x80000000)
+        d = u.view(np.float32)
+        q, idx = plan.eval_host(d)
+        z, j = oracle.nearest(d, g)
+        assert same_bits(q, z) and np.array_equal(idx.astype(np.int32), j)
+    allbf = (np.arange(65536, dtype=np.uint32) << 16).view(np.float32)
+    q, idx = plan.eval_host(allbf)
+    z, j = oracle.nearest(allbf, g)
+    assert same_bits(q, z) and np.array_equal(idx.astype(np.int32), j)
+
+
+def test_plan_falls_back_to_scan_for_hostile_grids(antq_lib, oracle):
+    rng = np.random.default_rng(1)
+    hostile = [np.float32([3, 1, 2, 1, 3, -7]),                 # unsorted, duplicates, no zero
+               np.float32([1.0, 1.0000001, 5.0]),               # near-duplicate entries (plateau)
+               np.float32([0.0, np.inf, 1.0]), np.float32([np.nan, 0.0]),
+               np.float32([5.0]), np.float32([-1.0, 1.0]),
+               rng.standard_normal(300).astype(np.float32) * 1e4]
+    d = np.concatenate([rng.standard_normal(5000).astype(np.float32) * 10,
+                        rng.integers(0, 2 ** 32, 5000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    for g in hostile:
+        plan = antq_lib.Plan(g)
+        q, idx = plan.eval_host(d)
+        with np.errstate(all="ignore"):
+            z, j = oracle.nearest(d, g)
+        assert same_bits(q, z) and np.array_equal(idx.astype(np.int32), j)
+
+
+# ---------------------------------------------------------------- no CPU fallback
+def test_loud_failure_on_cpu_tensors(antq_lib):
+    import torch
+    x = torch.randn(8, 64)
+    plan = antq_lib.plan_for(golden("ant_grids.npz")["flint_b4_s"])
+    with pytest.raises(antq_lib.AntqError, match="HIP device"):
+        antq_lib.fakequant(x, torch.ones(8), plan, 10.0, 8, 64, True)
+    with pytest.raises(antq_lib.AntqError, match="HIP device"):
+        antq_lib.nearest(x.view(-1), torch.ones(4))
+    from ant_quantization_amd.ant import quant_modules as qm
+    q = qm.TensorQuantizer(mode="flint", bit=4, is_signed=True, is_enable=True, args=_args())
+    with pytest.raises(antq_lib.AntqError):
+        q(x)
+    from ant_quantization_amd import quant_cuda
+    with pytest.raises(antq_lib.AntqError):
+        quant_cuda.quant(x.view(-1), torch.ones(4))
+
+
+def test_loud_failure_when_library_missing(monkeypatch, antq_lib):
+    monkeypatch.setattr(antq_lib, "_lib", None)
+    monkeypatch.setattr(antq_lib, "LIB_PATH", "/nonexistent/libantq.so")
+    with pytest.raises(antq_lib.AntqError, match="no CPU fallback"):
+        antq_lib.lib()
+
+
+# ---------------------------------------------------------------- module surface
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_module_surface_and_state_dict_keys(tree):
+    import importlib
+    import torch
+    import torch.nn as nn
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qm = importlib.import_module("ant_quantization_amd.%s.quant_modules" % tree)
+    for name in ("quantize_model", "set_first_last_layer", "set_8_bit_layer_n", "set_8_bit_layer_l",
+                 "load_ant_state_dict"):
+        assert hasattr(qmod, name)
+    for name in ("set_quantizer", "enable_quantization", "disable_quantization", "disable_input_quantization",
+                 "get_ckpt_path", "get_ckpt_filename", "set_util_logging", "get_model", "quant_args", "logging"):
+        assert hasattr(qutil, name)
+    assert qm.QuantConv2d is qm.Conv2dQuantizer and qm.QuantLinear is qm.LinearQuantizer
+
+    args = _args(mode="ant-int-flint", wbit=4, abit=4)
+    qutil.set_quantizer(args)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(nn.Conv2d(3, 8, 3, bias=False), nn.ReLU())
+            self.blocks = nn.ModuleList([nn.Linear(8, 8), nn.Linear(8, 4)])
+            self.lm_head = nn.Linear(4, 2)
+
+    m = qmod.quantize_model(Net())
+    assert type(m.features[0]) is qm.Conv2dQuantizer
+    assert type(m.blocks) is nn.Sequential and type(m.blocks[1]) is qm.LinearQuantizer   # ModuleList -> Sequential
+    if tree == "olive":
+        assert type(m.lm_head) is nn.Linear              # OliVe never descends into lm_head
+    else:
+        assert type(m.lm_head) is qm.LinearQuantizer
+    keys = set(m.state_dict().keys())
+    base = {"features.0.weight", "features.0.quant_weight.alpha", "features.0.quant_weight.bit",
+            "features.0.quant_weight.has_inited_quant_para", "features.0.quant_weight.quant_grid",
+            "features.0.quant_input.alpha", "blocks.0.weight", "blocks.0.bias", "blocks.1.quant_input.quant_grid"}
+    assert base <= keys
+    assert ("features.0.quant_weight.outliers" in keys) == (tree == "olive")
+    assert m.features[0].bias is None and m.features[0].quant_weight.alpha.shape == (8, 1)
+    # enable / disable walkers name the quantisers like the reference
+    qutil.enable_quantization(m)
+    assert m.blocks[0].quant_weight.name == "blocks.0.quant_weight" and m.blocks[0].quant_weight.is_enable
+    qutil.disable_quantization(m)
+    assert not m.blocks[0].quant_input.is_enable
+    x = torch.randn(2, 3, 5, 5)
+    assert m.features(x).shape == (2, 8, 3, 3)          # disabled quantisers are pass-through, CPU ok
+    qutil.disable_input_quantization(m)
+    assert not m.blocks[0].quant_input.is_enable_activation
+    # re-arm policy
+    qmod.set_8_bit_layer_l(m, "0")
+    assert int(m.features[0].quant_weight.bit) == 8 and int(m.blocks[0].quant_weight.bit) == 4
+    # load_ant_state_dict pre-sizes quant_grid so that a strict load works (8-bit layer -> 256 entries)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["features.0.quant_weight.quant_grid"] = torch.arange(256.0)
+    qmod.load_ant_state_dict(m, sd)
+    m.load_state_dict(sd, strict=True)
+    assert m.features[0].quant_weight.quant_grid.numel() == 256
+
+
+def test_quant_affine_helpers_match_reference_formulas():
+    import torch
+    from ant_quantization_amd.ant import quant_affine as qa
+    x = torch.randn(4, 6)
+    mn, mx = x.min(1).values, x.max(1).values
+    scale, zp = qa.asymmetric_linear_quantization_params(4, mn, mx)
+    assert torch.equal(scale, (mx - mn).clamp(min=1e-8).reciprocal() * 15)
+    assert torch.equal(zp, (scale * mn).round() + 8)
+    q = qa.linear_quantize(x, scale, zp)
+    assert torch.equal(q, scale.view(-1, 1) * x - zp.view(-1, 1))
+    assert torch.equal(qa.linear_dequantize(q.round(), scale, zp), (q.round() + zp.view(-1, 1)) / scale.view(-1, 1))
