@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fake-quant hot path on MI355X.
+
+Metric (BASELINE.json): Gelements/s of quantize->dequantize, 4-bit ANT, plus the achieved HBM
+bandwidth of the dominant kernel against the 8 TB/s roofline.
+
+Workload (config.workload): `nbuf` distinct 4096x4096 bf16 weight tensors per GPU (synthetic
+randn*0.02, seed 6+rank), signed 4-bit flint grid, calibrated per-row alpha (= row abs-max), steady
+state Quantizer._forward (ant_quantization/antquant/quant_modules.py:535-551) through the C ABI
+(antq_fakequant).  One STEP = one pass over all `nbuf` tensors; the set (nbuf x 33.5 MB in, same
+out) is far larger than the 256 MB Infinity Cache, so every launch streams from / to HBM.
+Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns its own
+`nbuf` tensors, there is no data-path collective; ranks only meet at the barriers that
+bracket the timed region and at the MAX-reduction of the elapsed time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes of one launch (4 B/elem:
+read bf16 + write bf16, x 16.7 M elements) / average duration of that launch, measured here with
+HIP events recorded on the launch stream around individual launches.  `cpu_baseline` times the CPU
+oracle (oracle/antq_oracle.c, a literal restatement of the reference's op sequence: "port") on the
+host cores for one tensor of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+ROWS = COLS = 4096
+BYTES_PER_ELEM = 4               # algorithmic: read one bf16 + write one bf16
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """Oracle (port of the reference op sequence) on the host cores, one 4096x4096 bf16 tensor
+    split by rows over all cores; repeated until ~seconds_budget of CPU work is done."""
+    import numpy as np
+    from oracle import antq_oracle as orc
+    from ant_quantization_amd import grids
+    orc.build()
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(6)
+    rows = 1024                                                   # bounded sample: 1/4 of one tensor
+    x = orc.f32_to_bf16((rng.standard_normal((rows, COLS)) * 0.02).astype(np.float32))
+    out = np.empty_like(x)
+    g = grids.ant_flint(4, True)
+    alpha = orc.absmax(orc.bf16_to_f32(x), True, 1.0)
+    bounds = [(rows * t // cores, rows * (t + 1) // cores) for t in range(cores)]
+
+    def work(b, e):
+        orc.forward_rows(x, out, b, e, alpha, g, 10.0)           # ctypes call: releases the GIL
+
+    def one_pass():
+        ts = [threading.Thread(target=work, args=be) for be in bounds]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return time.perf_counter() - t0
+
+    one_pass()
+    best, spent, passes = 1e30, 0.0, 0
+    while spent * cores < seconds_budget and passes < 50:
+        dt = one_pass()
+        best = min(best, dt)
+        spent += dt
+        passes += 1
+    return {"value": round(rows * COLS / best / 1e9, 5), "unit": "Gelem/s", "cores": cores, "kind": "port",
+            "sample": "%d rows x %d cols bf16 (1/4 of one headline tensor), flint 4-bit per-row alpha, "
+                      "best of %d passes, %d threads" % (rows, COLS, passes, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nbuf", type=int, default=32, help="distinct 4096x4096 bf16 tensors per GPU (one step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ant_quantization_amd import _lib, grids
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X; there is no CPU fallback (the CPU oracle is only the reported baseline)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL; only barriers + one MAX reduce
+
+    # ---- workload: resident in HBM before the timed region -----------------------------------
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(6 + rank)
+    plan = _lib.plan_for(grids.ant_flint(4, True))
+    xs, alphas, outs = [], [], []
+    for _ in range(args.nbuf):
+        x = (torch.randn(ROWS, COLS, device=dev, generator=gen) * 0.02).to(torch.bfloat16)
+        xs.append(x)
+        alphas.append(_lib.absmax(x, ROWS, COLS, per_row=True))           # calibrated alpha = row abs-max
+        outs.append(torch.empty_like(x))
+    torch.cuda.synchronize()
+
+    def step():
+        for i in range(args.nbuf):
+            _lib.fakequant(xs[i], alphas[i], plan, 10.0, ROWS, COLS, True, out=outs[i])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                  # HIP events on the launch stream (= torch's current stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    # ---- roofline of the dominant kernel: the timed region is nothing but back-to-back launches of
+    # it on one stream, so its average launch duration = event time / number of launches.
+    launch_s = ev0.elapsed_time(ev1) * 1e-3 / (args.steps * args.nbuf)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    algo_bytes = ROWS * COLS * BYTES_PER_ELEM
+    achieved = algo_bytes / launch_s / 1e9
+
+    # ---- parity spot check of what was just measured (cheap, outside the timed region) --------
+    ok = bool(torch.equal(_lib.fakequant(outs[0], alphas[0], plan, 10.0, ROWS, COLS, True), outs[0]))
+
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # rocprofv3 --pmc result, see profiles/README.md
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_fq_uniform_bf16_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    total_elems = world * args.nbuf * ROWS * COLS * args.steps
+    res = {
+        "metric": "Gelements/s quant-dequant + achieved HBM GB/s %peak, 4-bit ANT, 1/8 MI355X",
+        "value": round(total_elems / elapsed / 1e9, 3),
+        "unit": "Gelem/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "headline: %d x [4096,4096] bf16 weight tensors per GPU, ANT 4-bit signed flint grid, "
+                               "calibrated per-row alpha, steady-state _forward (antq_fakequant)" % args.nbuf,
+                   "io_dtype": "bf16", "elements_per_step_per_gpu": args.nbuf * ROWS * COLS,
+                   "sharding": "independent tensors per rank, no data-path collective",
+                   "idempotence_check": ok},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "kernel": "antq::k_fq_uniform<bf16,...>", "launch_us": round(launch_s * 1e6, 2),
+                     "algorithmic_bytes_per_launch": algo_bytes},
+    }
+    if world == 1 and not args.no_cpu_baseline:      # reported baseline, N=1 only
+        res["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
