@@ -5,7 +5,7 @@
 namespace antq {
 
 constexpr uint32_t kPlanMagic = 0x51544E41u;  // "ANTQ"
-constexpr uint32_t kPlanVersion = 3;
+constexpr uint32_t kPlanVersion = 4;
 
 constexpr uint32_t kPlanScan = 0;  // kernels run the literal scan for every element
 constexpr uint32_t kPlanLut = 1;   // table plan: one LDS lookup + one compare per element
@@ -18,7 +18,7 @@ constexpr float kScaleHi = 0x1p+40f;
 constexpr float kSmallD = 0x1p-37f;   // no threshold may be closer to zero than this
 constexpr float kFastDMax = 0x1p+20f; // d at or above this magnitude takes the slow path
 
-struct PlanHeader {      // 64 bytes
+struct PlanHeader {      // 80 bytes
     uint32_t magic;
     uint32_t version;
     uint32_t kind;       // kPlanScan / kPlanLut
@@ -35,8 +35,19 @@ struct PlanHeader {      // 64 bytes
     float fastlim;       // |d| < fastlim -> table path; otherwise (huge, Inf, NaN) literal scan
     float lo_valid;      // d in [lo_valid, hi_valid] has a grid entry within 102400
     float hi_valid;
+    // x-domain fast path (k_fq_xrow): usable when xdom != 0.  Per row the kernel rebuilds the
+    // bucket table with thresholds moved into the x domain, U = min{x : fl(x/s) >= T}, and
+    // outputs fl(v*s); buckets are then chosen from the APPROXIMATE quotient x*rcp(s) (within
+    // 2 ulp of fl(x/s)), which is safe because no threshold lies within 2^-20 (relative) of a
+    // bucket edge, and the straight-through step (q-d)+d is provably == q for |d| <= 2 max|v|.
+    uint32_t xdom;
+    float xlim;          // |x*rcp(s)| < xlim  ->  x-domain table path
+    uint32_t reserved[2];
 };
-static_assert(sizeof(PlanHeader) == 64, "PlanHeader must be 64 bytes");
+static_assert(sizeof(PlanHeader) == 80, "PlanHeader must be 80 bytes");
+
+// bits 15 / 31 of LutEntry::idx flag |v_lo| > 32 / |v_hi| > 32 (OliVe outlier test, OQ:314)
+constexpr uint32_t kIdxMask = 0x7fffu;
 
 // One bucket of the table: at most one decision threshold T lies inside it.
 //   q   = (d >= T) ? v_hi : v_lo

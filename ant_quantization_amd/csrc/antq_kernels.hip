@@ -303,7 +303,7 @@ __device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, 
             if (!IDX) asm volatile("" : "+v"(ent.w));  // keep the read a single ds_read_b128 (b96 is 2x slower)
             const bool c = d[e] >= u2f(ent.x);
             q[e] = c ? u2f(ent.z) : u2f(ent.y);
-            if (IDX) j[e] = (int)(c ? (ent.w >> 16) : (ent.w & 0xffffu));
+            if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
         }
     } else {
         // exact slow path: true division + literal scan (scan plans, odd scales, huge/NaN/Inf)
@@ -468,6 +468,207 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
     __syncthreads();
 #endif
     if (active) task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
+}
+
+// ------------------------------------------------------------------------------------
+// K1x  x-domain row kernel: the fast path for rows of >= 256 vectors (the headline shape).
+//
+// K1a spends most of its VALU time on per-element work that only depends on the ROW:
+// dividing by the row's scale, and mapping the quotient back (straight-through add,
+// multiply by the scale).  Here each wavefront first rebuilds the grid's bucket table for
+// ITS row -- lane b owns bucket b:
+//     U_b   = min { x : fl(x / s) >= T_b }       (threshold moved into the x domain, exact)
+//     O_lo  = fl(v_lo * s),  O_hi = fl(v_hi * s)  (= the reference's output: (q-d)+d == q
+//                                                  for |d| <= 2 max|v|, see antq_plan.cpp)
+// into a wave-private 1 KiB LDS table (no workgroup barrier), then per element does
+//     bucket from x * rcp(s)  (approximate quotient: only picks the bucket; thresholds keep
+//                              2^-20 clear of bucket edges, so a 2-ulp error cannot matter)
+//     out = (x >= U_b) ? O_hi : O_lo
+// i.e. 1 mul + 5 integer ops + 1 LDS read + compare/select: ~10 VALU ops per element instead
+// of ~18.  Lanes whose |x * rcp(s)| >= xlim (clipped far beyond the grid, Inf, NaN) and rows
+// with an odd scale take the exact reference sequence (true division, literal scan).
+// ------------------------------------------------------------------------------------
+struct XArgs {
+    uint32_t m;
+    uint32_t shift;
+    uint32_t kmin;
+    uint32_t kmax;
+    uint32_t keymask;
+    uint32_t nbneg;
+    uint32_t n_entries;
+    float xlim;
+};
+
+__device__ __forceinline__ float f_up(float c)   // next float towards +inf (c != 0)
+{
+    const uint32_t u = f2u(c);
+    return u2f((int32_t)u >= 0 ? u + 1u : u - 1u);
+}
+__device__ __forceinline__ float f_dn(float c)   // next float towards -inf (c != 0)
+{
+    const uint32_t u = f2u(c);
+    return u2f((int32_t)u >= 0 ? u - 1u : u + 1u);
+}
+
+// U = min { x : RN(x / s) >= T } for a scale inside div_fast's domain, s > 0, T finite, non-zero.
+__device__ __forceinline__ float x_threshold(float T, float s, float rs, bool &ok)
+{
+    float c = T * s;   // within an ulp or two of the boundary
+#pragma unroll
+    for (int it = 0; it < 2; it++) { const float p = f_dn(c); if (div_fast(p, s, rs) >= T) c = p; }
+#pragma unroll
+    for (int it = 0; it < 2; it++) { if (!(div_fast(c, s, rs) >= T)) c = f_up(c); }
+    ok = (div_fast(c, s, rs) >= T) && !(div_fast(f_dn(c), s, rs) >= T);
+    return c;
+}
+
+template <int EPL, bool OVP, bool IDX>
+__device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, const float *__restrict__ grid,
+                                            const Scale &sc, bool rowfast, const float (&x)[EPL], float (&o)[EPL],
+                                            int (&j)[EPL])
+{
+    bool fast = rowfast;
+    float dt[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        dt[e] = x[e] * sc.rs;
+        fast = fast && (fabsf(dt[e]) < xa.xlim);
+    }
+    if (fast) {
+        const int32_t sh4 = (int32_t)xa.shift - 4;
+        const int32_t km16 = (int32_t)(xa.keymask << 4);
+        const int32_t lo16 = (int32_t)(xa.kmin << 4), hi16 = (int32_t)(xa.kmax << 4);
+        const uint32_t neg16 = xa.nbneg << 4;
+        const char *t0 = reinterpret_cast<const char *>(wtab) - lo16;
+        bool isout[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int32_t u = (int32_t)f2u(dt[e]);
+            const int32_t t = (u >> sh4) & km16;
+            const int32_t c16 = min(max(t, lo16), hi16);
+            const uint32_t sg = (uint32_t)(u >> 31) & neg16;
+#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 32)
+            uint4 ent = make_uint4(f2u(1.0f), (uint32_t)(c16 + sg), (uint32_t)u, 0);   // ablation only: no LDS read
+#else
+            uint4 ent = *reinterpret_cast<const uint4 *>(t0 + c16 + sg);
+#endif
+            if (!IDX && !OVP) asm volatile("" : "+v"(ent.w));
+            const bool c = x[e] >= u2f(ent.x);
+            o[e] = c ? u2f(ent.z) : u2f(ent.y);
+            if (OVP) isout[e] = ((c ? (ent.w >> 31) : (ent.w >> 15)) & 1u) != 0;
+            if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
+        }
+        if (OVP) {
+#pragma unroll
+            for (int p = 0; p < EPL / 2; p++) {
+                const bool me = isout[2 * p], mo = isout[2 * p + 1];
+                const bool ve = mo && !me;
+                o[2 * p] = ve ? 0.0f : o[2 * p];          // ((q*0 - d) + d) * s == +0 for s > 0
+                o[2 * p + 1] = me ? 0.0f : o[2 * p + 1];
+                if (IDX) {
+                    if (ve) j[2 * p] = ANTQ_IDX_VICTIM;
+                    if (me) j[2 * p + 1] = ANTQ_IDX_VICTIM;
+                }
+            }
+        }
+    } else {
+        // exact reference sequence for this lane's EPL elements
+        float d[EPL], q[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            d[e] = x[e] / sc.s;
+            int jj;
+            q[e] = scan_lds(d[e], grid, (int)xa.m, jj);
+            if (IDX) j[e] = jj;
+        }
+        if (OVP) {
+#pragma unroll
+            for (int p = 0; p < EPL / 2; p++) {
+                const bool me = fabsf(q[2 * p]) > 32.0f;
+                const bool mo = fabsf(q[2 * p + 1]) > 32.0f;
+                const bool ve = mo && !me;
+                q[2 * p] = q[2 * p] * (ve ? 0.0f : 1.0f);
+                q[2 * p + 1] = q[2 * p + 1] * (me ? 0.0f : 1.0f);
+                if (IDX) {
+                    if (ve) j[2 * p] = ANTQ_IDX_VICTIM;
+                    if (me) j[2 * p + 1] = ANTQ_IDX_VICTIM;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const float t = (q[e] - d[e]) + d[e];
+            o[e] = t * sc.s;
+        }
+    }
+}
+
+template <typename T, bool OVP, bool IDX, int U, bool DYN>
+__global__ void __launch_bounds__(256)
+k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+          uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
+          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+          float *__restrict__ alpha_out, XArgs xa, const uint4 *__restrict__ entries,
+          const float *__restrict__ grid)
+{
+    constexpr int EPL = IO<T>::EPL;
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    uint4 *wtab = wtab_all[wv];
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    if (task >= total_tasks) return;   // no workgroup barrier in this kernel
+
+    // static bucket entry of this lane (L2 hit), issued ahead of the HBM loads
+    uint4 ent = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u);
+    if (lane < xa.n_entries) ent = entries[lane];
+
+    uint4 v[U];
+    float a;
+    task_load<T, U>(x, alpha, per_row, task, vpr, tpr, lane, DYN, v, a);
+
+    uint32_t row = task, g = 0;
+    if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+    const uint32_t v0 = g * (64u * U) + lane;
+    const size_t base = (size_t)row * vpr + v0;
+    if (DYN) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (v0 + 64u * u < vpr) m = IO<T>::amax_acc(m, v[u]);
+        m = wave_max_u32(IO<T>::amax_bits(m));
+        a = u2f(m) * ratio;
+        if (alpha_out && lane == 0) alpha_out[row] = a;
+    }
+    const Scale sc = make_scale(a, gmax);
+
+    // per-row table: thresholds into the x domain, outputs pre-multiplied by the scale
+    bool rowfast = sc.ok && (sc.s > 0.0f);
+    {
+        bool ok = true;
+        float Ux = u2f(ent.x);
+        if (rowfast && lane < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
+        rowfast = rowfast && __all(ok);
+        wtab[lane] = make_uint4(f2u(Ux), f2u(u2f(ent.y) * sc.s), f2u(u2f(ent.z) * sc.s), ent.w);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (v0 + 64u * u < vpr) {
+            float xf[EPL], of[EPL];
+            int j[EPL];
+            IO<T>::unpack(v[u], xf);
+#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 16)
+            for (int e = 0; e < EPL; e++) of[e] = xf[e] * sc.rs;   // ablation only
+#else
+            quant_vec_x<EPL, OVP, IDX>(xa, wtab, grid, sc, rowfast, xf, of, j);
+#endif
+            st_stream(out + base + 64u * u, IO<T>::pack(of));
+            if (IDX) store_idx<EPL>(idx, base + 64u * u, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -905,14 +1106,51 @@ static inline const uint4 *plan_tab_ptr(const void *plan_dev)
 
 // tuning knobs (dev / bench only; see antq_debug_set)
 static int g_knob_u = 0;        // force U of the uniform kernel (0 = heuristic)
-static int g_knob_blocks = 0;   // force the persistent grid size (0 = heuristic)
+static int g_knob_blocks = 0;   // (unused since the kernels are one-shot)
+static int g_knob_x = 1;        // 0 disables the x-domain row kernel (A/B measurements)
 
 template <typename T, bool OVP, bool IDX, bool DYN>
 static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, size_t vpr, const float *alpha,
                           int per_row, float gmax, float ratio, float *alpha_out, const PlanArgs &pa,
-                          const uint4 *tab, size_t lds, hipStream_t st)
+                          const void *plan_host, const void *plan_dev, size_t lds, hipStream_t st)
 {
-    // U: 1 .. 8 KiB of one row per task, keeping lane utilisation high at the row tail
+    const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
+    const uint4 *tab = plan_tab_ptr(plan_dev);
+    const uint4 *xv = static_cast<const uint4 *>(x);
+    uint4 *ov = static_cast<uint4 *>(out);
+    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 256 && (!DYN || vpr <= 512);
+    if (use_x) {
+        // x-domain row kernel: 4 or 8 KiB of one row per wavefront (the per-row table is rebuilt per task)
+        int U = 8;
+        {
+            const double u8 = (double)vpr / (double)(((vpr + 511) / 512) * 512);
+            const double u4 = (double)vpr / (double)(((vpr + 255) / 256) * 256);
+            if (u4 > u8 + 0.05) U = 4;
+        }
+        if (DYN) U = vpr <= 256 ? 4 : 8;
+        if (g_knob_u) U = DYN ? U : g_knob_u;
+        const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
+        const size_t total = rows * tpr;
+        if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+        XArgs xa;
+        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim;
+        const uint4 *entries = tab + (pa.m_pad >> 2);
+        const float *grid = reinterpret_cast<const float *>(tab);
+        const dim3 grid_dim((unsigned)((total + 3) / 4)), block(256);
+#define ANTQ_LAUNCH_X(UU)                                                                                           \
+    hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, UU, DYN>), grid_dim, block, 0, st, xv, ov, idx, (uint32_t)total,     \
+                       (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries, grid)
+        switch (U) {
+        case 8: ANTQ_LAUNCH_X(8); break;
+        case 4: ANTQ_LAUNCH_X(4); break;
+        case 2: ANTQ_LAUNCH_X(2); break;
+        default: ANTQ_LAUNCH_X(1); break;
+        }
+#undef ANTQ_LAUNCH_X
+        return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+    }
+    // U: 1 .. 4 KiB of one row per task, keeping lane utilisation high at the row tail
     int U = 4;
     if (DYN) {
         U = vpr <= 64 ? 1 : vpr <= 128 ? 2 : vpr <= 256 ? 4 : 8;
@@ -931,8 +1169,6 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
     const size_t blocks = (total + 3) / 4;
     const dim3 grid((unsigned)blocks), block(256);
-    const uint4 *xv = static_cast<const uint4 *>(x);
-    uint4 *ov = static_cast<uint4 *>(out);
 #define ANTQ_LAUNCH_U(UU)                                                                                          \
     hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, UU, DYN>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,  \
                        (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out, pa, tab)
@@ -949,7 +1185,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
 template <typename T, bool OVP, bool IDX>
 static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,
                      const float *alpha, int per_row, float gmax, const PlanArgs &pa,
-                     const void *plan_dev, hipStream_t st)
+                     const void *plan_host, const void *plan_dev, hipStream_t st)
 {
     constexpr int EPL = IO<T>::EPL;
     const size_t n = rows * row_len;
@@ -964,7 +1200,7 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
         if (vpr >= 64) {
             if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
             return launch_uniform<T, OVP, IDX, false>(x, out, idx, rows, vpr, alpha, per_row, gmax, 1.0f, nullptr, pa,
-                                                      tab, lds, st);
+                                                      plan_host, plan_dev, lds, st);
         } else {
             const size_t n_vec = n / EPL;
             int vshift = -1;
@@ -979,7 +1215,7 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
     } else if (aligned && !per_row && n >= (size_t)64 * EPL) {
         // per-tensor scale with a ragged tail: vector body + element tail
         const size_t n_body = (n / EPL) * EPL;
-        int rc = launch_fq<T, OVP, IDX>(x, out, idx, 1, n_body, alpha, 0, gmax, pa, plan_dev, st);
+        int rc = launch_fq<T, OVP, IDX>(x, out, idx, 1, n_body, alpha, 0, gmax, pa, plan_host, plan_dev, st);
         if (rc != ANTQ_OK) return rc;
         const size_t n_tail = n - n_body;
         const size_t pairs = (n_tail + 1) / 2;
@@ -998,15 +1234,15 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
 template <typename T>
 static int launch_fq_flags(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,
                            const float *alpha, int per_row, float gmax, const PlanArgs &pa,
-                           const void *plan_dev, unsigned flags, hipStream_t st)
+                           const void *plan_host, const void *plan_dev, unsigned flags, hipStream_t st)
 {
     const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
     if (ovp) {
-        if (idx) return launch_fq<T, true, true>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, st);
-        return launch_fq<T, true, false>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, st);
+        if (idx) return launch_fq<T, true, true>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_host, plan_dev, st);
+        return launch_fq<T, true, false>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_host, plan_dev, st);
     }
-    if (idx) return launch_fq<T, false, true>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, st);
-    return launch_fq<T, false, false>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, st);
+    if (idx) return launch_fq<T, false, true>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_host, plan_dev, st);
+    return launch_fq<T, false, false>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_host, plan_dev, st);
 }
 
 }  // namespace antq
@@ -1077,13 +1313,13 @@ extern "C" int antq_fakequant(const void *x, void *out, int16_t *idx, size_t row
     switch (dtype) {
     case ANTQ_F32:
         if (reinterpret_cast<uintptr_t>(x) % 4 || reinterpret_cast<uintptr_t>(out) % 4) return ANTQ_ERR_ALIGN;
-        return launch_fq_flags<float>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, flags, st);
+        return launch_fq_flags<float>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_host, plan_dev, flags, st);
     case ANTQ_BF16:
         if (reinterpret_cast<uintptr_t>(x) % 2 || reinterpret_cast<uintptr_t>(out) % 2) return ANTQ_ERR_ALIGN;
-        return launch_fq_flags<bf16_tag>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, flags, st);
+        return launch_fq_flags<bf16_tag>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_host, plan_dev, flags, st);
     case ANTQ_F16:
         if (reinterpret_cast<uintptr_t>(x) % 2 || reinterpret_cast<uintptr_t>(out) % 2) return ANTQ_ERR_ALIGN;
-        return launch_fq_flags<f16_tag>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_dev, flags, st);
+        return launch_fq_flags<f16_tag>(x, out, idx, rows, row_len, alpha, per_row, gmax, pa, plan_host, plan_dev, flags, st);
     default:
         return ANTQ_ERR_UNSUPPORTED;
     }
@@ -1119,6 +1355,7 @@ extern "C" int antq_debug_set(int key, int value)
 {
     if (key == 0) g_knob_u = value;
     else if (key == 1) g_knob_blocks = value;
+    else if (key == 2) g_knob_x = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }
@@ -1141,7 +1378,7 @@ static int launch_absmax(const void *x, float *amax, size_t rows, size_t row_len
 
 template <typename T, bool OVP, bool IDX>
 static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_out, size_t rows, size_t row_len,
-                          float ratio, float gmax, const PlanArgs &pa, const void *plan_dev, hipStream_t st)
+                          float ratio, float gmax, const PlanArgs &pa, const void *plan_host, const void *plan_dev, hipStream_t st)
 {
     constexpr int EPL = IO<T>::EPL;
     const size_t lds = (size_t)pa.tab_units * 16;
@@ -1166,8 +1403,8 @@ static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_o
         }
         if (vpr <= 512) {
             // one quant group (row) per wavefront, the row lives in registers: single HBM read
-            return launch_uniform<T, OVP, IDX, true>(x, out, idx, rows, vpr, nullptr, 1, gmax, ratio, alpha_out, pa, tab,
-                                                     lds, st);
+            return launch_uniform<T, OVP, IDX, true>(x, out, idx, rows, vpr, nullptr, 1, gmax, ratio, alpha_out, pa,
+                                                     plan_host, plan_dev, lds, st);
         }
     }
     // long or ragged rows: abs-max pass (read) + static pass (read + write)
@@ -1175,21 +1412,21 @@ static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_o
     int rc = launch_absmax<T>(x, alpha_out, rows, row_len, 1, st);
     if (rc != ANTQ_OK) return rc;
     hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, alpha_out, rows, ratio);
-    return launch_fq<T, OVP, IDX>(x, out, idx, rows, row_len, alpha_out, 1, gmax, pa, plan_dev, st);
+    return launch_fq<T, OVP, IDX>(x, out, idx, rows, row_len, alpha_out, 1, gmax, pa, plan_host, plan_dev, st);
 }
 
 template <typename T>
 static int launch_dynamic_flags(const void *x, void *out, int16_t *idx, float *alpha_out, size_t rows, size_t row_len,
-                                float ratio, float gmax, const PlanArgs &pa, const void *plan_dev, unsigned flags,
+                                float ratio, float gmax, const PlanArgs &pa, const void *plan_host, const void *plan_dev, unsigned flags,
                                 hipStream_t st)
 {
     const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
     if (ovp) {
-        if (idx) return launch_dynamic<T, true, true>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, st);
-        return launch_dynamic<T, true, false>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, st);
+        if (idx) return launch_dynamic<T, true, true>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, st);
+        return launch_dynamic<T, true, false>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, st);
     }
-    if (idx) return launch_dynamic<T, false, true>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, st);
-    return launch_dynamic<T, false, false>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, st);
+    if (idx) return launch_dynamic<T, false, true>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, st);
+    return launch_dynamic<T, false, false>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, st);
 }
 
 template <typename T, bool OVP>
@@ -1234,9 +1471,9 @@ extern "C" int antq_fakequant_dynamic(const void *x, void *out, int16_t *idx, fl
     if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (dtype) {
-    case ANTQ_F32: return launch_dynamic_flags<float>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, flags, st);
-    case ANTQ_BF16: return launch_dynamic_flags<bf16_tag>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, flags, st);
-    case ANTQ_F16: return launch_dynamic_flags<f16_tag>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_dev, flags, st);
+    case ANTQ_F32: return launch_dynamic_flags<float>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, flags, st);
+    case ANTQ_BF16: return launch_dynamic_flags<bf16_tag>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, flags, st);
+    case ANTQ_F16: return launch_dynamic_flags<f16_tag>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, flags, st);
     default: return ANTQ_ERR_UNSUPPORTED;
     }
 }

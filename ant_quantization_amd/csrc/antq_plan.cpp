@@ -97,7 +97,7 @@ inline float eval_lut(const PlanHeader &h, const float *grid, const LutEntry *en
     uint32_t k = (uint32_t)(std::min(std::max(ks, (int32_t)h.kmin), (int32_t)h.kmax) - (int32_t)h.kmin);
     const LutEntry &e = ent[k + ((u >> 31) ? h.nbneg : 0u)];
     bool c = d >= e.T;
-    uint32_t id = c ? (e.idx >> 16) : (e.idx & 0xffffu);
+    uint32_t id = (c ? (e.idx >> 16) : e.idx) & kIdxMask;
     *idx = (int)id;
     return c ? e.v_hi : e.v_lo;
 }
@@ -236,6 +236,8 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         e.v_lo = grid[dv[rho_lo].win];
         e.v_hi = grid[dv[rho_hi].win];
         e.idx = (uint32_t)dv[rho_lo].win | ((uint32_t)dv[rho_hi].win << 16);
+        if (fabsf(e.v_lo) > 32.0f) e.idx |= 0x8000u;
+        if (fabsf(e.v_hi) > 32.0f) e.idx |= 0x80000000u;
         return e;
     };
     for (uint32_t b = 0; b < h.nb; b++) {
@@ -252,6 +254,22 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
             if (tn >= 0) ent[h.nb + b] = mk(tn, tn + 1, T[tn]);
             else { int r = region_of(-edge); ent[h.nb + b] = mk(r, r, INFINITY); }
         }
+    }
+
+    // x-domain path eligibility (see PlanHeader::xdom)
+    {
+        bool ok = h.n_entries <= 64;
+        for (int i = 0; i + 1 < k && ok; i++) {
+            const float t = T[i];
+            const uint32_t key = mag_key(t, h.shift);
+            if (mag_key(t * (1.0f + 0x1p-20f), h.shift) != key || mag_key(t * (1.0f - 0x1p-20f), h.shift) != key) ok = false;
+        }
+        const double stelim = 2.0 * vabs;   // (q-d)+d == q whenever |q-d| <= |d| <= 2|q| (Sterbenz) or q == 0
+        double xl = std::min((double)h.fastlim, stelim) * (1.0 - 0x1p-18);
+        h.xlim = (float)xl;
+        if ((double)h.xlim > xl) h.xlim = next_dn(h.xlim);
+        if (!(fabsf(T[0]) < h.xlim) || !(fabsf(T[k - 2]) < h.xlim)) ok = false;
+        h.xdom = ok ? 1u : 0u;
     }
 
     // self-check against the literal scan

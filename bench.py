@@ -185,7 +185,7 @@ def main():
                    "idempotence_check": ok},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "kernel": "antq::k_fq_uniform<bf16,...>", "launch_us": round(launch_s * 1e6, 2),
+                     "kernel": "antq::k_fq_xrow<bf16,...,U=8>", "launch_us": round(launch_s * 1e6, 2),
                      "algorithmic_bytes_per_launch": algo_bytes},
     }
     if world == 1 and not args.no_cpu_baseline:      # reported baseline, N=1 only

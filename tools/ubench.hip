@@ -199,15 +199,16 @@ int main(int argc, char **argv)
     run(B, "hipMemcpyAsync D2D", reps, moved, [&](void *s, void *d) { CK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, B.st)); });
 
     // libantq entry points (bf16 4096x4096 flint 4-bit per-row), natively timed
-    if (bytes == 4096ull * 4096ull * 2ull) {
+    const size_t fq_rows = bytes / (4096ull * 2ull);
+    if (bytes % (4096ull * 2ull) == 0) {
         static const float flint4[16] = {-10.f, -5.f, -3.75f, -2.5f, -1.875f, -1.25f, -0.625f, 0.f, 0.f,
                                          0.625f, 1.25f, 1.875f, 2.5f, 3.75f, 5.f, 10.f};
         std::vector<unsigned char> plan(ANTQ_PLAN_MAX_BYTES);
         int pb = antq_plan_build(flint4, 16, plan.data(), plan.size());
         printf("plan bytes %d kind %d\n", pb, antq_plan_kind(plan.data()));
         void *plan_dev; CK(hipMalloc(&plan_dev, pb)); CK(hipMemcpy(plan_dev, plan.data(), pb, hipMemcpyHostToDevice));
-        std::vector<float> alpha(4096, 0.08f);
-        float *alpha_dev; CK(hipMalloc(&alpha_dev, 4096 * 4)); CK(hipMemcpy(alpha_dev, alpha.data(), 4096 * 4, hipMemcpyHostToDevice));
+        std::vector<float> alpha(fq_rows, 0.08f);
+        float *alpha_dev; CK(hipMalloc(&alpha_dev, fq_rows * 4)); CK(hipMemcpy(alpha_dev, alpha.data(), fq_rows * 4, hipMemcpyHostToDevice));
         // fill inputs with bf16 gaussian-ish data
         std::vector<uint16_t> h(bytes / 2);
         uint64_t s = 88172645463325252ull;
@@ -218,7 +219,7 @@ int main(int argc, char **argv)
         }
         for (int i = 0; i < nbuf; i++) CK(hipMemcpy(B.in[i], h.data(), bytes, hipMemcpyHostToDevice));
         run(B, "antq_fakequant bf16 flint4 per-row", reps, moved, [&](void *x, void *o) {
-            int rc = antq_fakequant(x, o, nullptr, 4096, 4096, alpha_dev, 1, 10.0f, plan.data(), plan_dev, 0, ANTQ_BF16, B.st);
+            int rc = antq_fakequant(x, o, nullptr, fq_rows, 4096, alpha_dev, 1, 10.0f, plan.data(), plan_dev, 0, ANTQ_BF16, B.st);
             if (rc) { printf("antq_fakequant rc=%d\n", rc); exit(1); }
         });
         run(B, "antq_copy", reps, moved, [&](void *x, void *o) { antq_copy(x, o, bytes, B.st); });
@@ -226,13 +227,21 @@ int main(int argc, char **argv)
             antq_debug_set(0, U); antq_debug_set(1, blocks);
             char nm[64]; snprintf(nm, 64, "fakequant U=%d blocks=%d", U, blocks);
             run(B, nm, reps, moved, [&](void *x, void *o) {
-                antq_fakequant(x, o, nullptr, 4096, 4096, alpha_dev, 1, 10.0f, plan.data(), plan_dev, 0, ANTQ_BF16, B.st);
+                antq_fakequant(x, o, nullptr, fq_rows, 4096, alpha_dev, 1, 10.0f, plan.data(), plan_dev, 0, ANTQ_BF16, B.st);
             });
         }
         antq_debug_set(0, 0); antq_debug_set(1, 0);
-        float *aout; CK(hipMalloc(&aout, 4096 * 4));
+        for (int rep = 0; rep < 2; rep++) for (int xk : {0, 1}) for (int U : {1, 2, 4, 8}) {
+            antq_debug_set(2, xk); antq_debug_set(0, U);
+            char nm[64]; snprintf(nm, 64, "fakequant xkernel=%d U=%d", xk, U);
+            run(B, nm, reps, moved, [&](void *x, void *o) {
+                antq_fakequant(x, o, nullptr, fq_rows, 4096, alpha_dev, 1, 10.0f, plan.data(), plan_dev, 0, ANTQ_BF16, B.st);
+            });
+        }
+        antq_debug_set(0, 0); antq_debug_set(2, 1);
+        float *aout; CK(hipMalloc(&aout, fq_rows * 4));
         run(B, "antq_fakequant_dynamic bf16", reps, moved, [&](void *x, void *o) {
-            int rc = antq_fakequant_dynamic(x, o, nullptr, aout, 4096, 4096, 1.0f, 10.0f, plan.data(), plan_dev, 0, ANTQ_BF16, B.st);
+            int rc = antq_fakequant_dynamic(x, o, nullptr, aout, fq_rows, 4096, 1.0f, 10.0f, plan.data(), plan_dev, 0, ANTQ_BF16, B.st);
             if (rc) { printf("dyn rc=%d\n", rc); exit(1); }
         });
     }
