@@ -603,7 +603,7 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
     }
 }
 
-template <typename T, bool OVP, bool IDX, int U, bool DYN>
+template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR = 1>
 __global__ void __launch_bounds__(256)
 k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
           uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
@@ -637,8 +637,15 @@ k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
         for (int u = 0; u < U; u++)
             if (v0 + 64u * u < vpr) m = IO<T>::amax_acc(m, v[u]);
         m = wave_max_u32(IO<T>::amax_bits(m));
+        if (WPR == 4) {
+            // the row spans the 4 wavefronts of this workgroup (tpr == 4): combine their maxima
+            __shared__ uint32_t wmax[4];
+            if (lane == 0) wmax[wv] = m;
+            __syncthreads();
+            m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        }
         a = u2f(m) * ratio;
-        if (alpha_out && lane == 0) alpha_out[row] = a;
+        if (alpha_out && lane == 0 && (WPR == 1 || wv == 0)) alpha_out[row] = a;
     }
     const Scale sc = make_scale(a, gmax);
 
@@ -1118,7 +1125,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const uint4 *tab = plan_tab_ptr(plan_dev);
     const uint4 *xv = static_cast<const uint4 *>(x);
     uint4 *ov = static_cast<uint4 *>(out);
-    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 256 && (!DYN || vpr <= 512);
+    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 256 && (!DYN || vpr <= 2048);
     if (use_x) {
         // x-domain row kernel: 4 or 8 KiB of one row per wavefront (the per-row table is rebuilt per task)
         int U = 8;
@@ -1127,9 +1134,10 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
             const double u4 = (double)vpr / (double)(((vpr + 255) / 256) * 256);
             if (u4 > u8 + 0.05) U = 4;
         }
-        if (DYN) U = vpr <= 256 ? 4 : 8;
+        if (DYN) U = (vpr <= 256 || (vpr > 512 && vpr <= 1024)) ? 4 : 8;
         if (g_knob_u) U = DYN ? U : g_knob_u;
-        const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
+        const bool wpr4 = DYN && vpr > 512;            // one row per workgroup: 4 wavefronts x U x 64 vectors
+        const size_t tpr = wpr4 ? 4 : (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
         const size_t total = rows * tpr;
         if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
         XArgs xa;
@@ -1141,6 +1149,17 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
 #define ANTQ_LAUNCH_X(UU)                                                                                           \
     hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, UU, DYN>), grid_dim, block, 0, st, xv, ov, idx, (uint32_t)total,     \
                        (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries, grid)
+        if (wpr4) {
+            if (U == 8)
+                hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, 8, DYN, DYN ? 4 : 1>), grid_dim, block, 0, st, xv, ov, idx,
+                                   (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out,
+                                   xa, entries, grid);
+            else
+                hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, 4, DYN, DYN ? 4 : 1>), grid_dim, block, 0, st, xv, ov, idx,
+                                   (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out,
+                                   xa, entries, grid);
+            return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+        }
         switch (U) {
         case 8: ANTQ_LAUNCH_X(8); break;
         case 4: ANTQ_LAUNCH_X(4); break;
@@ -1401,10 +1420,13 @@ static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_o
                                vshift, (const float *)nullptr, 1, gmax, ratio, alpha_out, pa, tab);
             return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
         }
-        if (vpr <= 512) {
-            // one quant group (row) per wavefront, the row lives in registers: single HBM read
-            return launch_uniform<T, OVP, IDX, true>(x, out, idx, rows, vpr, nullptr, 1, gmax, ratio, alpha_out, pa,
-                                                     plan_host, plan_dev, lds, st);
+        if (vpr <= 2048) {
+            // one quant group (row) per wavefront (<= 512 vectors) or per workgroup (<= 2048): the row
+            // lives in registers, single HBM read.  Plans without the x-domain table only have the
+            // wavefront variant; longer rows fall through to the two-pass scheme.
+            int rc = launch_uniform<T, OVP, IDX, true>(x, out, idx, rows, vpr, nullptr, 1, gmax, ratio, alpha_out, pa,
+                                                       plan_host, plan_dev, lds, st);
+            if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
         }
     }
     // long or ragged rows: abs-max pass (read) + static pass (read + write)

@@ -252,7 +252,8 @@ def test_dynamic_absmax_fakequant(antq_lib, oracle, dev, bf16):
     rng = np.random.default_rng(11)
     g = golden("ant_grids.npz")["flint_b4_s"]
     plan = antq_lib.plan_for(g)
-    for rows, K in [(64, 4096), (300, 16), (128, 64), (40, 576), (16, 8192), (64, 147), (5, 2048), (1000, 32), (3, 28672)]:
+    for rows, K in [(64, 4096), (300, 16), (128, 64), (40, 576), (16, 8192), (64, 147), (5, 2048), (1000, 32), (3, 28672),
+                    (9, 16384), (7, 5120), (6, 11008), (2, 16392)]:
         x = make_x(rng, rows, K, specials=False)
         for ratio in (1.0, 0.83):
             if bf16:

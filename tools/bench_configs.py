@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE.json configs (C1-C3 + variants of the headline) on one MI355X.
+
+Not the contract benchmark (that is bench.py); this script produces the per-config table quoted in
+DESIGN.md.  Synthetic data of the stated shapes, everything resident before timing,
+graph-free plain launches on the current stream, HIP events around `reps` passes over the config.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from ant_quantization_amd import _lib, core, grids  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def resnet50_shapes():
+    s = [(64, 3, 7, 7)]
+    inp = 64
+    for planes, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
+        for b in range(blocks):
+            s += [(planes, inp, 1, 1), (planes, planes, 3, 3), (planes * 4, planes, 1, 1)]
+            if b == 0:
+                s.append((planes * 4, inp, 1, 1))
+            inp = planes * 4
+    s.append((1000, 2048))
+    return s
+
+
+def bert_base_shapes():
+    s = []
+    for _ in range(12):
+        s += [(768, 768)] * 4 + [(3072, 768), (768, 3072)]
+    s += [(768, 768), (2, 768)]
+    return s
+
+
+def opt67_shapes(layers=32):
+    s = []
+    for _ in range(layers):
+        s += [(4096, 4096)] * 4 + [(16384, 4096), (4096, 16384)]
+    return s
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def report(name, elems, bytes_per_elem, secs, launches, extra=""):
+    print("%-58s %9.1f Gelem/s %7.3f TB/s (%4.1f%% of 8)  %8.1f us/pass %4d launches %s" % (
+        name, elems / secs / 1e9, elems * bytes_per_elem / secs / 1e12, elems * bytes_per_elem / secs / 8e10,
+        secs * 1e6, launches, extra), flush=True)
+
+
+def main():
+    torch.manual_seed(1)
+    out = {}
+    # ---------------- C1: ResNet-50 weights, ANT 4-bit flint: per-channel and group-16, fp32
+    plan = _lib.plan_for(grids.ant_flint(4, True))
+    ws = [torch.randn(*s, device=dev) * float(np.sqrt(2.0 / (s[0] * np.prod(s[2:], dtype=np.int64)))) for s in resnet50_shapes()]
+    elems = sum(w.numel() for w in ws)
+    outs = [torch.empty_like(w) for w in ws]
+    a_pc = [_lib.absmax(w, w.shape[0], w.numel() // w.shape[0]) for w in ws]
+    a_g16 = [_lib.absmax(w, w.numel() // 16, 16) for w in ws]
+
+    def c1_pc():
+        for w, a, o in zip(ws, a_pc, outs):
+            _lib.fakequant(w, a, plan, 10.0, w.shape[0], w.numel() // w.shape[0], True, out=o)
+
+    def c1_g16():
+        for w, a, o in zip(ws, a_g16, outs):
+            _lib.fakequant(w, a, plan, 10.0, w.numel() // 16, 16, True, out=o)
+
+    def c1_g16_dyn():
+        for w, o in zip(ws, outs):
+            _lib.fakequant_dynamic(w, plan, 10.0, w.numel() // 16, 16, out=o, want_alpha=False)
+
+    report("C1 ResNet-50 54 W, flint4 per-channel, fp32 (static alpha)", elems, 8, timed(c1_pc, 20), len(ws))
+    report("C1 ResNet-50 54 W, flint4 group-16, fp32 (static alpha)", elems, 8, timed(c1_g16, 20), len(ws))
+    report("C1 ResNet-50 54 W, flint4 group-16, fp32 (dynamic abs-max)", elems, 8, timed(c1_g16_dyn, 20), len(ws))
+    # one big concatenated buffer: what a multi-tensor launch could reach for group-16
+    flat = torch.cat([w.reshape(-1) for w in ws]).contiguous()
+    fo = torch.empty_like(flat)
+    af = _lib.absmax(flat, flat.numel() // 16, 16)
+    report("   (same bytes as ONE group-16 launch over a flat buffer)", elems, 8,
+           timed(lambda: _lib.fakequant(flat, af, plan, 10.0, flat.numel() // 16, 16, True, out=fo), 50), 1)
+    del ws, outs, flat, fo
+
+    # ---------------- C2: BERT-base Linear weights: steady state + calibration (ant-int-pot-flint)
+    ws = [torch.randn(*s, device=dev) * 0.02 for s in bert_base_shapes()]
+    elems = sum(w.numel() for w in ws)
+    outs = [torch.empty_like(w) for w in ws]
+    al = [_lib.absmax(w, w.shape[0], w.shape[1]) for w in ws]
+    report("C2 BERT-base 74 Linear W, flint4 per-channel, fp32", elems, 8,
+           timed(lambda: [_lib.fakequant(w, a, plan, 10.0, w.shape[0], w.shape[1], True, out=o) for w, a, o in zip(ws, al, outs)], 20), len(ws))
+    plans = {t: _lib.plan_for(grids.ant_grid(t, 4, True)) for t in ("int", "pot", "flint")}
+
+    def c2_cal():
+        for w, a in zip(ws, al):
+            for t in ("int", "pot", "flint"):
+                core.clip_search(w, a, True, 80, 150, 1, plans[t], 10.0)
+
+    secs = timed(c2_cal, 2)
+    evals = elems * 3 * 70
+    print("%-58s %9.1f G candidate-evals/s  %8.1f ms/pass (3 types x 70 clip ratios, %d tensors)" % (
+        "C2 BERT-base calibration (type select + clip search)", evals / secs / 1e9, secs * 1e3, len(ws)), flush=True)
+    x = torch.nn.functional.gelu(torch.randn(64, 128, 3072, device=dev))
+    pu = _lib.plan_for(grids.ant_flint(4, True))
+    ax = x.abs().max().reshape(1)
+    ox = torch.empty_like(x)
+    report("C2 activation [64,128,3072] fp32, per-tensor flint4", x.numel(), 8,
+           timed(lambda: _lib.fakequant(x, ax, pu, 10.0, 1, x.numel(), False, out=ox), 20), 1)
+    del ws, outs, x, ox
+
+    # ---------------- C3: OPT-6.7B weights (4 of 32 layers resident), OliVe flint4 + outliers, OVP
+    gn, go = grids.olive_flint(4, True), grids.olive_outliers(4, True)
+    pol = _lib.plan_for(np.concatenate([gn, go]))
+    for dt, bpe in ((torch.bfloat16, 4), (torch.float32, 8)):
+        ws = []
+        for s in opt67_shapes(4 if dt == torch.bfloat16 else 2):
+            w = torch.randn(*s, device=dev) * 0.02
+            m = torch.rand_like(w) < 0.001
+            w[m] *= torch.empty(int(m.sum()), device=dev).uniform_(8, 64)
+            ws.append(w.to(dt))
+        elems = sum(w.numel() for w in ws)
+        al = [(3 * w.float().std(1)).contiguous() for w in ws]
+        outs = [torch.empty_like(w) for w in ws]
+        report("C3 OPT-6.7B W (%d tensors), OliVe flint4 OVP, %s" % (len(ws), str(dt)[6:]), elems, bpe,
+               timed(lambda: [_lib.fakequant(w, a, pol, 32.0, w.shape[0], w.shape[1], True, ovp=True, out=o) for w, a, o in zip(ws, al, outs)], 5), len(ws))
+        del ws, outs, al
+
+    # ---------------- headline variants
+    for dt, bpe in ((torch.bfloat16, 4), (torch.float32, 8)):
+        nb = 16
+        xs = [(torch.randn(4096, 4096, device=dev) * 0.02).to(dt) for _ in range(nb)]
+        al = [_lib.absmax(x, 4096, 4096) for x in xs]
+        outs = [torch.empty_like(x) for x in xs]
+        report("headline 4096x4096 %s flint4 per-row (static)" % str(dt)[6:], nb * 4096 * 4096, bpe,
+               timed(lambda: [_lib.fakequant(x, a, plan, 10.0, 4096, 4096, True, out=o) for x, a, o in zip(xs, al, outs)], 10), nb)
+        report("headline 4096x4096 %s flint4 per-row (dynamic abs-max)" % str(dt)[6:], nb * 4096 * 4096, bpe,
+               timed(lambda: [_lib.fakequant_dynamic(x, plan, 10.0, 4096, 4096, out=o, want_alpha=False) for x, o in zip(xs, outs)], 10), nb)
+        report("copy (antq_copy) same buffers %s" % str(dt)[6:], nb * 4096 * 4096, bpe,
+               timed(lambda: [_lib.copy(x, o) for x, o in zip(xs, outs)], 10), nb)
+        del xs, outs
+
+
+if __name__ == "__main__":
+    main()
