@@ -47,8 +47,9 @@ def lib():
                 for name in ("antq_abi_version", "antq_nearest", "antq_plan_build", "antq_plan_kind",
                              "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
-                             "antq_copy"):
+                             "antq_copy", "antq_batch_build", "antq_fakequant_batch"):
                     getattr(L, name).restype = ctypes.c_int
+                L.antq_batch_capacity.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
                 vp, sz, ci, cf, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_uint
                 L.antq_fakequant.argtypes = [vp, vp, vp, sz, sz, vp, ci, cf, vp, vp, cu, ci, vp]
@@ -295,3 +296,64 @@ def copy(src, dst):
     with torch.cuda.device(src.device):
         _check(lib().antq_copy(_vp(src), _vp(dst), ctypes.c_size_t(nbytes), _stream(src.device)), "antq_copy")
     return dst
+
+
+# ---------------------------------------------------------------------------------
+# batched launch: many tensors, one kernel
+# ---------------------------------------------------------------------------------
+class _Job(ctypes.Structure):
+    _fields_ = [("x_dev", ctypes.c_void_p), ("out_dev", ctypes.c_void_p), ("alpha_dev", ctypes.c_void_p),
+                ("rows", ctypes.c_size_t), ("row_len", ctypes.c_size_t), ("alpha_per_row", ctypes.c_int),
+                ("gmax", ctypes.c_float), ("plan_host", ctypes.c_void_p), ("plan_dev", ctypes.c_void_p)]
+
+
+class Batch:
+    """Fake-quant of many (static-alpha) tensors in ONE launch (antq_fakequant_batch).
+
+    jobs: iterable of dicts / tuples (x, out, alpha, plan, gmax, rows, row_len, per_row); all tensors on
+    one device with one dtype.  Jobs the batch kernel cannot express (row_len not a multiple of 16 bytes,
+    e.g. conv1's K = 147) are kept aside and launched one by one by run().  The descriptor table is
+    built once and stays resident: weights and calibrated alphas do not move between forwards."""
+
+    def __init__(self, jobs, ovp=False):
+        jobs = [tuple(j) for j in jobs]
+        if not jobs:
+            raise AntqError("empty batch")
+        x0 = jobs[0][0]
+        _require_gpu(x0, "x")
+        self.device, self.dtype, self.ovp = x0.device, _DTYPES[x0.dtype], ovp
+        self._keep = jobs                       # keeps tensors and plans alive
+        epl = 4 if self.dtype == F32 else 8
+        self.singles, batched = [], []
+        for j in jobs:
+            x, out, alpha, plan, gmax, rows, row_len, per_row = j
+            rl = row_len if per_row else rows * row_len
+            if rl % epl or x.data_ptr() % 16 or out.data_ptr() % 16 or x.dtype != x0.dtype:
+                self.singles.append(j)
+            else:
+                batched.append(j)
+        self.n_batched = len(batched)
+        self.host = self.dev = None
+        if batched:
+            arr = (_Job * len(batched))()
+            for k, (x, out, alpha, plan, gmax, rows, row_len, per_row) in enumerate(batched):
+                arr[k] = _Job(x.data_ptr(), out.data_ptr(), alpha.data_ptr(), rows, row_len, 1 if per_row else 0, gmax,
+                              plan.host_addr, plan.dev(self.device).data_ptr())
+            cap = lib().antq_batch_capacity(arr, len(batched), self.dtype)
+            host = np.zeros(cap, dtype=np.uint8)
+            n = lib().antq_batch_build(arr, len(batched), self.dtype, FLAG_OVP if ovp else 0,
+                                       host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
+            if n <= 0:
+                _check(n, "antq_batch_build")
+            self.host = host[:n].copy()
+            self.dev = torch.from_numpy(self.host).to(self.device)
+
+    def run(self):
+        if self.host is not None:
+            with _on_device(self.device):
+                rc = lib().antq_fakequant_batch(ctypes.c_void_p(self.host.ctypes.data), ctypes.c_void_p(self.dev.data_ptr()),
+                                                ctypes.c_void_p(_stream_int(self.device)))
+            if rc:
+                _check(rc, "antq_fakequant_batch")
+        for x, out, alpha, plan, gmax, rows, row_len, per_row in self.singles:
+            fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=self.ovp, out=out)

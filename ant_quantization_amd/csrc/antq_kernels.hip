@@ -20,6 +20,9 @@
 // float op below must round exactly as written).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include "../../include/antq.h"
 #include "antq_internal.h"
@@ -1537,4 +1540,206 @@ extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const
     default:
         return ANTQ_ERR_UNSUPPORTED;
     }
+}
+
+// ======================================================================================
+// Batched launch (antq_batch_build / antq_fakequant_batch)
+// ======================================================================================
+namespace antq {
+
+constexpr uint32_t kBatchMagic = 0x42544E41u;  // "ANTB"
+constexpr int kBatchU = 2;                      // vectors per lane per task in the batch kernel
+
+struct BatchDesc {   // 128 bytes, device-visible
+    const uint4 *x;
+    uint4 *out;
+    const float *alpha;
+    const uint4 *plan_tab;
+    uint64_t n_vec;        // lane kind: number of 16-byte vectors
+    uint32_t total_tasks;  // row kind: wavefront tasks
+    uint32_t vpr;
+    uint32_t tpr;
+    int32_t vshift;
+    uint32_t first_block;
+    uint32_t kind;         // 0 = one row-run per wavefront (vpr >= 64), 1 = per-lane scale (vpr < 64)
+    int32_t per_row;
+    float gmax;
+    PlanArgs pa;
+    uint32_t pad[3];
+};
+static_assert(sizeof(BatchDesc) == 128, "BatchDesc must be 128 bytes");
+
+struct BatchHeader {   // 32 bytes
+    uint32_t magic, n, total_blocks, dtype, flags, lds_bytes, map_offset, bytes;
+};
+
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(256)
+k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
+{
+    constexpr int EPL = IO<T>::EPL;
+    constexpr int U = kBatchU;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t j = block_map[blockIdx.x];
+    const BatchDesc &D = descs[j];
+    const PlanArgs pa = D.pa;
+    const uint32_t lb = blockIdx.x - D.first_block;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint4 *plan_tab = D.plan_tab;
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+
+    if (D.kind == 0) {
+        const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
+        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+        const bool active = task < total;
+        uint4 v[U];
+        float a;
+        task_load<T, U>(D.x, D.alpha, D.per_row, active ? task : total - 1u, vpr, tpr, lane, false, v, a);
+        const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+        __syncthreads();
+        if (active)
+            task_run<T, OVP, false, U, false>(D.out, nullptr, nullptr, 1.0f, task, vpr, tpr, lane, D.gmax, pa, L, v, a);
+    } else {
+        const size_t n_vec = D.n_vec;
+        const size_t first = ((size_t)lb * U) * 256u + threadIdx.x;
+        uint4 v[U];
+        float a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t vi = first + (size_t)u * 256u;
+            v[u] = make_uint4(0, 0, 0, 0);
+            a[u] = 1.0f;
+            if (vi < n_vec) {
+                v[u] = ld_stream(D.x + vi);
+                size_t row = 0;
+                if (D.per_row) row = (D.vshift >= 0) ? (vi >> D.vshift) : (vi / D.vpr);
+                a[u] = D.alpha[row];
+            }
+        }
+        const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t vi = first + (size_t)u * 256u;
+            if (vi < n_vec) {
+                const Scale sc = make_scale(a[u], D.gmax);
+                float xf[EPL], of[EPL];
+                int jj[EPL];
+                IO<T>::unpack(v[u], xf);
+                quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, jj);
+                st_stream(D.out + vi, IO<T>::pack(of));
+            }
+        }
+    }
+}
+
+static int epl_of(int dtype) { return dtype == ANTQ_F32 ? 4 : (dtype == ANTQ_BF16 || dtype == ANTQ_F16) ? 8 : 0; }
+
+// blocks a job needs, or 0 if it cannot be expressed (ragged / unaligned)
+static size_t job_blocks(const antq_job &J, int epl, BatchDesc *d)
+{
+    size_t rows = J.rows, row_len = J.row_len;
+    const size_t n = rows * row_len;
+    if (!J.alpha_per_row) { rows = 1; row_len = n; }
+    if (n == 0 || row_len % epl != 0) return 0;
+    if (reinterpret_cast<uintptr_t>(J.x_dev) % 16 || reinterpret_cast<uintptr_t>(J.out_dev) % 16) return 0;
+    const size_t vpr = row_len / epl;
+    if (vpr > 0xffffffffull) return 0;
+    size_t blocks;
+    if (vpr >= 64) {
+        const size_t tpr = (vpr + 64 * kBatchU - 1) / (64 * kBatchU);
+        const size_t total = rows * tpr;
+        if (total > 0xfffffff0ull) return 0;
+        blocks = (total + 3) / 4;
+        if (d) { d->kind = 0; d->total_tasks = (uint32_t)total; d->vpr = (uint32_t)vpr; d->tpr = (uint32_t)tpr; d->vshift = -1; d->n_vec = n / epl; }
+    } else {
+        const size_t n_vec = n / epl;
+        blocks = (n_vec + 256 * kBatchU - 1) / (256 * kBatchU);
+        int vshift = -1;
+        if ((vpr & (vpr - 1)) == 0) { vshift = 0; while (((size_t)1 << vshift) < vpr) vshift++; }
+        if (d) { d->kind = 1; d->total_tasks = 0; d->vpr = (uint32_t)vpr; d->tpr = 1; d->vshift = vshift; d->n_vec = n_vec; }
+    }
+    return blocks;
+}
+
+}  // namespace antq
+
+extern "C" size_t antq_batch_capacity(const antq_job *jobs, int n, int dtype)
+{
+    const int epl = epl_of(dtype);
+    if (!jobs || n < 1 || !epl) return 0;
+    size_t blocks = 0;
+    for (int i = 0; i < n; i++) blocks += job_blocks(jobs[i], epl, nullptr);
+    return sizeof(BatchHeader) + sizeof(BatchDesc) * (size_t)n + 4 * blocks;
+}
+
+extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned flags, void *blob, size_t cap)
+{
+    const int epl = epl_of(dtype);
+    if (!jobs || !blob || n < 1 || n > 65535) return ANTQ_ERR_ARG;
+    if (!epl) return ANTQ_ERR_UNSUPPORTED;
+    char *p = static_cast<char *>(blob);
+    BatchHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = kBatchMagic; h.n = (uint32_t)n; h.dtype = (uint32_t)dtype; h.flags = flags;
+    h.map_offset = (uint32_t)(sizeof(BatchHeader) + sizeof(BatchDesc) * (size_t)n);
+    if (cap < h.map_offset) return ANTQ_ERR_PLAN;
+    BatchDesc *descs = reinterpret_cast<BatchDesc *>(p + sizeof(BatchHeader));
+    uint32_t *map = reinterpret_cast<uint32_t *>(p + h.map_offset);
+    size_t total_blocks = 0, lds = 0;
+    for (int i = 0; i < n; i++) {
+        const antq_job &J = jobs[i];
+        if (!J.x_dev || !J.out_dev || !J.alpha_dev || !J.plan_host || !J.plan_dev) return ANTQ_ERR_ARG;
+        BatchDesc d;
+        memset(&d, 0, sizeof(d));
+        const size_t blocks = job_blocks(J, epl, &d);
+        if (blocks == 0) return ANTQ_ERR_UNSUPPORTED;
+        if (!plan_args_from_host(J.plan_host, d.pa)) return ANTQ_ERR_PLAN;
+        if (total_blocks + blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+        if (cap < h.map_offset + 4 * (total_blocks + blocks)) return ANTQ_ERR_PLAN;
+        d.x = static_cast<const uint4 *>(J.x_dev);
+        d.out = static_cast<uint4 *>(J.out_dev);
+        d.alpha = J.alpha_dev;
+        d.plan_tab = plan_tab_ptr(J.plan_dev);
+        d.first_block = (uint32_t)total_blocks;
+        d.per_row = J.alpha_per_row ? 1 : 0;
+        d.gmax = J.gmax;
+        descs[i] = d;
+        for (size_t b = 0; b < blocks; b++) map[total_blocks + b] = (uint32_t)i;
+        total_blocks += blocks;
+        lds = std::max(lds, (size_t)d.pa.tab_units * 16);
+    }
+    h.total_blocks = (uint32_t)total_blocks;
+    h.lds_bytes = (uint32_t)lds;
+    h.bytes = (uint32_t)(h.map_offset + 4 * total_blocks);
+    memcpy(p, &h, sizeof(h));
+    return (int)h.bytes;
+}
+
+extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_dev, void *stream)
+{
+    if (!batch_host || !batch_dev) return ANTQ_ERR_ARG;
+    const BatchHeader *h = static_cast<const BatchHeader *>(batch_host);
+    if (h->magic != kBatchMagic) return ANTQ_ERR_PLAN;
+    if (h->total_blocks == 0) return ANTQ_OK;
+    const char *pd = static_cast<const char *>(batch_dev);
+    const BatchDesc *descs = reinterpret_cast<const BatchDesc *>(pd + sizeof(BatchHeader));
+    const uint32_t *map = reinterpret_cast<const uint32_t *>(pd + h->map_offset);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(h->total_blocks), block(256);
+    const bool ovp = (h->flags & ANTQ_FLAG_OVP) != 0;
+#define ANTQ_LAUNCH_B(TT)                                                                                         \
+    do {                                                                                                          \
+        if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true>), grid, block, h->lds_bytes, st, descs, map);           \
+        else hipLaunchKernelGGL((k_fq_batch<TT, false>), grid, block, h->lds_bytes, st, descs, map);              \
+    } while (0)
+    switch (h->dtype) {
+    case ANTQ_F32: ANTQ_LAUNCH_B(float); break;
+    case ANTQ_BF16: ANTQ_LAUNCH_B(bf16_tag); break;
+    case ANTQ_F16: ANTQ_LAUNCH_B(f16_tag); break;
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+#undef ANTQ_LAUNCH_B
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }

@@ -158,6 +158,33 @@ int antq_affine(const float *x_dev, float *out_dev, int32_t *q_dev,
                 const float *xmin_dev, const float *xmax_dev, int per_row,
                 void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Batched launch: many independent fake-quant jobs (e.g. the 54 weight tensors of a ResNet-50,
+ * SURVEY 8a C1) in ONE kernel launch.  Small tensors are launch-bound when issued one by one
+ * (~6 us of host time each vs < 1 us of HBM time); here every workgroup looks up its job in a
+ * descriptor table that the caller builds once (weights and alphas are static between
+ * forwards) and keeps resident on the device.
+ *   antq_batch_build : pure host code; writes the descriptor blob (returns its size in bytes,
+ *                      or ANTQ_ERR_UNSUPPORTED if some job needs the element-granular kernel:
+ *                      row_len not a multiple of 16 bytes, or unaligned pointers -- launch
+ *                      those with antq_fakequant).  All jobs share dtype and flags.
+ *   antq_fakequant_batch : one launch for all jobs; batch_dev is the caller's device copy.
+ * ------------------------------------------------------------------------- */
+typedef struct antq_job {
+    const void  *x_dev;
+    void        *out_dev;
+    const float *alpha_dev;
+    size_t       rows, row_len;
+    int          alpha_per_row;
+    float        gmax;
+    const void  *plan_host;
+    const void  *plan_dev;
+} antq_job;
+
+size_t antq_batch_capacity(const antq_job *jobs, int n, int dtype);   /* bytes antq_batch_build needs */
+int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned flags, void *batch_host, size_t capacity);
+int antq_fakequant_batch(const void *batch_host, const void *batch_dev, void *stream);
+
 /* Plain device copy with the fake-quant kernels' access pattern (16 B per lane):
  * used by bench.py to measure the empirical HBM ceiling on the same buffers. */
 int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);

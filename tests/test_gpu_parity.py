@@ -469,3 +469,43 @@ def test_olive_full_size_pair_invariant(antq_lib, dev):
     assert (is_vic.sum(1) <= 1).all()
     assert (is_vic.any(1) == is_out.any(1)).all()             # a victim iff its partner is an outlier
     assert (out.view(-1, 2)[is_vic] == 0).all()
+
+
+def test_batched_launch_equals_individual_launches(antq_lib, dev):
+    """ResNet-50's 54 weight tensors in ONE launch: per-channel, group-16 and OliVe."""
+    import torch
+    sys_path = __import__("sys").path
+    import os
+    sys_path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_configs import resnet50_shapes
+    g = golden("ant_grids.npz")["flint_b4_s"]
+    plan = antq_lib.plan_for(g)
+    plan_i = antq_lib.plan_for(golden("ant_grids.npz")["int_b4_s"])
+    torch.manual_seed(1)
+    shapes = resnet50_shapes()
+    assert len(shapes) == 54 and sum(int(np.prod(s)) for s in shapes) == 25502912
+    for dtype in (torch.float32, torch.bfloat16):
+        ws = [(torch.randn(*s, device=dev) * 0.05).to(dtype) for s in shapes]
+        for mode in ("per_channel", "group16"):
+            jobs, refs = [], []
+            for k, w in enumerate(ws):
+                rows, K = (w.shape[0], w.numel() // w.shape[0]) if mode == "per_channel" else (w.numel() // 16, 16)
+                a = antq_lib.absmax(w, rows, K)
+                p = plan if k % 2 == 0 else plan_i                   # mixed grids inside one launch
+                refs.append(antq_lib.fakequant(w, a, p, 10.0, rows, K, True))
+                jobs.append((w, torch.zeros_like(w), a, p, 10.0, rows, K, True))
+            b = antq_lib.Batch(jobs)
+            assert len(b.singles) == (1 if (mode == "per_channel") else 0) or dtype == torch.bfloat16
+            b.run()
+            for j, r in zip(jobs, refs):
+                assert torch.equal(j[1], r), (mode, dtype, tuple(j[0].shape))
+    O = golden("olive_grids.npz")
+    pol = antq_lib.plan_for(np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]]))
+    ws = [torch.randn(256, 512, device=dev) * 0.02 for _ in range(3)]
+    for w in ws:
+        w.view(-1)[::301] *= 30
+    al = [(3 * w.std(1)).contiguous() for w in ws]
+    refs = [antq_lib.fakequant(w, a, pol, 32.0, 256, 512, True, ovp=True) for w, a in zip(ws, al)]
+    jobs = [(w, torch.zeros_like(w), a, pol, 32.0, 256, 512, True) for w, a in zip(ws, al)]
+    antq_lib.Batch(jobs, ovp=True).run()
+    assert all(torch.equal(j[1], r) for j, r in zip(jobs, refs))

@@ -93,6 +93,14 @@ def main():
     report("C1 ResNet-50 54 W, flint4 per-channel, fp32 (static alpha)", elems, 8, timed(c1_pc, 20), len(ws))
     report("C1 ResNet-50 54 W, flint4 group-16, fp32 (static alpha)", elems, 8, timed(c1_g16, 20), len(ws))
     report("C1 ResNet-50 54 W, flint4 group-16, fp32 (dynamic abs-max)", elems, 8, timed(c1_g16_dyn, 20), len(ws))
+    for nm, al_, rl in (("per-channel", a_pc, None), ("group-16", a_g16, 16)):
+        jobs = []
+        for w, a, o in zip(ws, al_, outs):
+            rows, K = (w.shape[0], w.numel() // w.shape[0]) if rl is None else (w.numel() // 16, 16)
+            jobs.append((w, o, a, plan, 10.0, rows, K, True))
+        bt = _lib.Batch(jobs)
+        report("C1 ResNet-50 54 W, flint4 %s, fp32, BATCHED launch" % nm, elems, 8, timed(bt.run, 50),
+               1 + len(bt.singles))
     # one big concatenated buffer: what a multi-tensor launch could reach for group-16
     flat = torch.cat([w.reshape(-1) for w in ws]).contiguous()
     fo = torch.empty_like(flat)
@@ -108,6 +116,8 @@ def main():
     al = [_lib.absmax(w, w.shape[0], w.shape[1]) for w in ws]
     report("C2 BERT-base 74 Linear W, flint4 per-channel, fp32", elems, 8,
            timed(lambda: [_lib.fakequant(w, a, plan, 10.0, w.shape[0], w.shape[1], True, out=o) for w, a, o in zip(ws, al, outs)], 20), len(ws))
+    bt = _lib.Batch([(w, o, a, plan, 10.0, w.shape[0], w.shape[1], True) for w, a, o in zip(ws, al, outs)])
+    report("C2 BERT-base 74 Linear W, flint4 per-channel, fp32, BATCHED", elems, 8, timed(bt.run, 50), 1)
     plans = {t: _lib.plan_for(grids.ant_grid(t, 4, True)) for t in ("int", "pot", "flint")}
 
     def c2_cal():
@@ -154,6 +164,8 @@ def main():
                timed(lambda: [_lib.fakequant(x, a, plan, 10.0, 4096, 4096, True, out=o) for x, a, o in zip(xs, al, outs)], 10), nb)
         report("headline 4096x4096 %s flint4 per-row (dynamic abs-max)" % str(dt)[6:], nb * 4096 * 4096, bpe,
                timed(lambda: [_lib.fakequant_dynamic(x, plan, 10.0, 4096, 4096, out=o, want_alpha=False) for x, o in zip(xs, outs)], 10), nb)
+        bt = _lib.Batch([(x, o, a, plan, 10.0, 4096, 4096, True) for x, a, o in zip(xs, al, outs)])
+        report("headline 16 x 4096x4096 %s, BATCHED (one launch)" % str(dt)[6:], nb * 4096 * 4096, bpe, timed(bt.run, 10), 1)
         report("copy (antq_copy) same buffers %s" % str(dt)[6:], nb * 4096 * 4096, bpe,
                timed(lambda: [_lib.copy(x, o) for x, o in zip(xs, outs)], 10), nb)
         del xs, outs
