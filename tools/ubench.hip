@@ -54,6 +54,33 @@ __global__ void __launch_bounds__(256) copy_wave_nt(const uint4 *__restrict__ s,
 #pragma unroll
     for (int u = 0; u < U; u++) if (first + 64 * u < n) __builtin_nontemporal_store(v[u], dp + first + 64 * u);
 }
+// C2: nontemporal variant of A (block-contiguous rounds)
+template <int U>
+__global__ void __launch_bounds__(256) copy_blk_nt(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
+{
+    size_t first = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 *sp = reinterpret_cast<const u4 *>(s);
+    u4 *dp = reinterpret_cast<u4 *>(d);
+    u4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (first + 256 * u < n) v[u] = __builtin_nontemporal_load(sp + first + 256 * u);
+#pragma unroll
+    for (int u = 0; u < U; u++) if (first + 256 * u < n) __builtin_nontemporal_store(v[u], dp + first + 256 * u);
+}
+// C3: 512-thread blocks, one vector per lane (8 KiB per block)
+__global__ void __launch_bounds__(512) copy_nt_512(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const u4 *>(s) + i), reinterpret_cast<u4 *>(d) + i);
+}
+__global__ void __launch_bounds__(1024) copy_nt_1024(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const u4 *>(s) + i), reinterpret_cast<u4 *>(d) + i);
+}
 // D: persistent grid-stride, G blocks, each iteration block copies 4 KiB*U, prefetch depth 1
 template <int U, bool NT>
 __global__ void __launch_bounds__(256) copy_persist(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
@@ -180,6 +207,11 @@ int main(int argc, char **argv)
     run(B, "copy_wave_nt<1>", reps, moved, L(copy_wave_nt<1>, (n + 255) / 256));
     run(B, "copy_wave_nt<2>", reps, moved, L(copy_wave_nt<2>, (n + 511) / 512));
     run(B, "copy_wave_nt<4>", reps, moved, L(copy_wave_nt<4>, (n + 1023) / 1024));
+    run(B, "copy_blk_nt<2>", reps, moved, L(copy_blk_nt<2>, (n + 511) / 512));
+    run(B, "copy_blk_nt<4>", reps, moved, L(copy_blk_nt<4>, (n + 1023) / 1024));
+    run(B, "copy_blk_nt<8>", reps, moved, L(copy_blk_nt<8>, (n + 2047) / 2048));
+    run(B, "copy_nt_512", reps, moved, [&](void *s, void *d) { hipLaunchKernelGGL(copy_nt_512, dim3((unsigned)((n + 511) / 512)), dim3(512), 0, B.st, (const uint4 *)s, (uint4 *)d, n); });
+    run(B, "copy_nt_1024", reps, moved, [&](void *s, void *d) { hipLaunchKernelGGL(copy_nt_1024, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, B.st, (const uint4 *)s, (uint4 *)d, n); });
     for (int g : {256, 512, 1024, 2048, 4096}) {
         char nm[64];
         snprintf(nm, 64, "copy_persist<1,0> g=%d", g); run(B, nm, reps, moved, L((copy_persist<1, false>), g));
