@@ -47,7 +47,7 @@ def lib():
                 for name in ("antq_abi_version", "antq_nearest", "antq_plan_build", "antq_plan_kind",
                              "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
-                             "antq_copy", "antq_batch_build", "antq_fakequant_batch"):
+                             "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
@@ -296,6 +296,39 @@ def copy(src, dst):
     with torch.cuda.device(src.device):
         _check(lib().antq_copy(_vp(src), _vp(dst), ctypes.c_size_t(nbytes), _stream(src.device)), "antq_copy")
     return dst
+
+
+def encode4(x, alpha, plan, gmax, rows, row_len, per_row, n_normal=0, ovp=False):
+    """Packed 4-bit codes (two per byte) of the quantised tensor: uint8 tensor of numel/2 bytes."""
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    codes = torch.empty(x.numel() // 2, dtype=torch.uint8, device=x.device)
+    pd = plan.dev(x.device)
+    with _on_device(x.device):
+        rc = lib().antq_encode4(_vp(x), _vp(codes), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), _vp(alpha),
+                                ctypes.c_int(1 if per_row else 0), ctypes.c_float(gmax), plan.host_ptr(), _vp(pd),
+                                ctypes.c_int(n_normal), ctypes.c_uint(FLAG_OVP if ovp else 0), ctypes.c_int(dt),
+                                _stream(x.device))
+    _check(rc, "antq_encode4")
+    return codes
+
+
+def decode4(codes, alpha, plan, gmax, rows, row_len, per_row, dtype, n_normal=0, ovp=False):
+    _require_gpu(codes, "codes")
+    dt = _DTYPES.get(dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % dtype)
+    out = torch.empty(rows * row_len, dtype=dtype, device=codes.device)
+    pd = plan.dev(codes.device)
+    with _on_device(codes.device):
+        rc = lib().antq_decode4(_vp(codes), _vp(out), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), _vp(alpha),
+                                ctypes.c_int(1 if per_row else 0), ctypes.c_float(gmax), plan.host_ptr(), _vp(pd),
+                                ctypes.c_int(n_normal), ctypes.c_uint(FLAG_OVP if ovp else 0), ctypes.c_int(dt),
+                                _stream(codes.device))
+    _check(rc, "antq_decode4")
+    return out.view(rows, row_len)
 
 
 # ---------------------------------------------------------------------------------

@@ -185,6 +185,30 @@ size_t antq_batch_capacity(const antq_job *jobs, int n, int dtype);   /* bytes a
 int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned flags, void *batch_host, size_t capacity);
 int antq_fakequant_batch(const void *batch_host, const void *batch_dev, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Packed 4-bit codec: the quantised tensor itself instead of its fake-quant image
+ * (SURVEY 8f N4).  Two codes per byte, element 2k in the low nibble.
+ *   code = scan-order grid index of the element (what antq_fakequant's idx output holds),
+ *   m <= 16 for plain grids (ANT 4-bit: the 16-entry grid incl. its duplicate zero).
+ * With ANTQ_FLAG_OVP the grid is OliVe's cat(normal[n_normal <= 15], outliers[<= 15]):
+ *   normal value  -> its index 0..n_normal-1
+ *   victim        -> 15, the outlier identifier (the paper's reserved code)
+ *   outlier       -> index INTO THE OUTLIER LIST; the partner nibble of the pair is 15,
+ *                    which is what tells the decoder to use the outlier codebook.
+ * antq_decode4(antq_encode4(x)) is bit-identical to antq_fakequant(x) for finite inputs whose
+ * quotient x/scale stays within 2 max|grid| (where the straight-through step is exact);
+ * elements outside the scan's validity range (code would be ANTQ_IDX_NONE) encode as the
+ * grid entry holding 0.0.  row_len must be a multiple of 8; x: F32 / BF16 / F16; codes: rows*row_len/2 bytes.
+ * ------------------------------------------------------------------------- */
+int antq_encode4(const void *x_dev, uint8_t *codes_dev, size_t rows, size_t row_len,
+                 const float *alpha_dev, int alpha_per_row, float gmax,
+                 const void *plan_host, const void *plan_dev, int n_normal,
+                 unsigned flags, int dtype, void *stream);
+int antq_decode4(const uint8_t *codes_dev, void *out_dev, size_t rows, size_t row_len,
+                 const float *alpha_dev, int alpha_per_row, float gmax,
+                 const void *plan_host, const void *plan_dev, int n_normal,
+                 unsigned flags, int dtype, void *stream);
+
 /* Plain device copy with the fake-quant kernels' access pattern (16 B per lane):
  * used by bench.py to measure the empirical HBM ceiling on the same buffers. */
 int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);

@@ -509,3 +509,56 @@ def test_batched_launch_equals_individual_launches(antq_lib, dev):
     jobs = [(w, torch.zeros_like(w), a, pol, 32.0, 256, 512, True) for w, a in zip(ws, al)]
     antq_lib.Batch(jobs, ovp=True).run()
     assert all(torch.equal(j[1], r) for j, r in zip(jobs, refs))
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+def test_packed_4bit_codec_roundtrip_equals_fakequant(antq_lib, oracle, dev, dtype_name):
+    """decode4(encode4(x)) == fakequant(x) bit for bit; the codes are the oracle's grid indices."""
+    import torch
+    dtype = getattr(torch, dtype_name)
+    rng = np.random.default_rng(5)
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    for rows, K in [(64, 4096), (33, 24), (128, 64), (5, 1000)]:
+        x_np = (rng.standard_normal((rows, K)) * 0.02).astype(np.float32)
+        x_np[rng.random((rows, K)) < 0.02] *= 30
+        x = torch.from_numpy(x_np).to(dev).to(dtype)
+        # ANT: flint / int / pot 4-bit, per-row alpha
+        for gname in ("flint_b4_s", "int_b4_s", "pot_b4_u"):
+            g = G[gname]
+            xx = x.abs() if gname.endswith("_u") else x
+            plan = antq_lib.plan_for(g)
+            alpha = (xx.float().abs().amax(1) * 0.9).contiguous()
+            ref, ridx = antq_lib.fakequant(xx, alpha, plan, 10.0, rows, K, True, want_idx=True)
+            codes = antq_lib.encode4(xx, alpha, plan, 10.0, rows, K, True)
+            assert codes.numel() == rows * K // 2 and codes.dtype == torch.uint8
+            lo, hi = (codes & 15).to(torch.int16), (codes >> 4).to(torch.int16)
+            assert torch.equal(torch.stack([lo, hi], 1).reshape(rows, K), ridx)
+            dec = antq_lib.decode4(codes, alpha, plan, 10.0, rows, K, True, dtype)
+            assert torch.equal(dec, ref), (gname, rows, K)
+        # OliVe: normal + outlier codebooks, outlier-victim pairs, identifier code 15
+        for t in ("int", "flint"):
+            gn, go = O["%s_b4_s" % t], O["outlier_b4_s"]
+            plan = antq_lib.plan_for(np.concatenate([gn, go]))
+            alpha = (3 * x.float().std(1)).contiguous()
+            ref, ridx = antq_lib.fakequant(x, alpha, plan, float(gn.max()), rows, K, True, ovp=True, want_idx=True)
+            codes = antq_lib.encode4(x, alpha, plan, float(gn.max()), rows, K, True, n_normal=gn.size, ovp=True)
+            nib = torch.stack([(codes & 15), (codes >> 4)], 1).reshape(rows, K).to(torch.int16)
+            vic = ridx == antq_lib.IDX_VICTIM
+            assert vic.any() and (nib[vic] == 15).all()
+            is_out = ridx >= gn.size
+            assert torch.equal(nib[is_out], (ridx[is_out] - gn.size)) and torch.equal(nib[~vic & ~is_out], ridx[~vic & ~is_out])
+            dec = antq_lib.decode4(codes, alpha, plan, float(gn.max()), rows, K, True, dtype, n_normal=gn.size, ovp=True)
+            assert torch.equal(dec, ref), (t, rows, K)
+    # group-16 view and per-tensor scale
+    g = G["flint_b4_s"]
+    plan = antq_lib.plan_for(g)
+    x = (torch.randn(256, 512, device=dev) * 0.05).to(dtype)
+    a16 = antq_lib.absmax(x, x.numel() // 16, 16)
+    ref = antq_lib.fakequant(x, a16, plan, 10.0, x.numel() // 16, 16, True)
+    dec = antq_lib.decode4(antq_lib.encode4(x, a16, plan, 10.0, x.numel() // 16, 16, True), a16, plan, 10.0,
+                           x.numel() // 16, 16, True, dtype)
+    assert torch.equal(dec.reshape(256, 512), ref)
+    at = x.float().abs().max().reshape(1)
+    ref = antq_lib.fakequant(x, at, plan, 10.0, 1, x.numel(), False)
+    dec = antq_lib.decode4(antq_lib.encode4(x, at, plan, 10.0, 1, x.numel(), False), at, plan, 10.0, 1, x.numel(), False, dtype)
+    assert torch.equal(dec.reshape(256, 512), ref)
