@@ -103,9 +103,11 @@ def main():
         sys.exit("bench.py needs an MI355X; there is no CPU fallback (the CPU oracle is only the reported baseline)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torchrun
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL; only barriers + one MAX reduce
+        dist.barrier()                      # builds the communicator now, so later barriers cost microseconds
 
     # ---- workload: resident in HBM before the timed region -----------------------------------
     gen = torch.Generator(device=dev)
@@ -132,7 +134,7 @@ def main():
             _lib.fakequant(xs[i], alphas[i], plan, 10.0, ROWS, COLS, True, out=outs[i])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +166,7 @@ def main():
     # ---- roofline of the dominant kernel (antq::k_fq_batch): the timed region is nothing but
     # back-to-back launches of it on one stream, so its average launch duration = event time / launches.
     launch_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -174,11 +176,10 @@ def main():
     # ---- parity spot check of what was just measured (cheap, outside the timed region) --------
     ok = bool(torch.equal(_lib.fakequant(outs[0], alphas[0], plan, 10.0, ROWS, COLS, True), outs[0]))
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     traffic = None
@@ -223,7 +224,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:      # reported baseline, N=1 only
         res["cpu_baseline"] = cpu_baseline()
     print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
