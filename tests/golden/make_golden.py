@@ -259,6 +259,24 @@ def gen_ant(outdir):
     np.savez_compressed(os.path.join(outdir, "ant_select.npz"), **sel)
     qm.Quantizer.mse_loss = orig_mse
 
+    # ---- (6b) 'outlier' baseline mode (int4 body + int16 outliers by percentile, AQ:417-465) ----
+    outl = {}
+    torch.manual_seed(9)
+    xo = torch.randn(24, 96) * 0.05
+    xo.view(-1)[::41] *= 12
+    outl["x"] = xo.numpy()
+    for pct in (99.0, 95.0):
+        for signed in (True, False):
+            xx = xo if signed else xo.abs()
+            q = mk("outlier", 4, signed, is_input=not signed, percent=pct)
+            out = q(xx)
+            k = "p%d_%s" % (int(pct), "s" if signed else "u")
+            outl[k + "_out"] = out.detach().numpy()
+            outl[k + "_p4"] = np.float32(q.percent_value_int4.item())
+            outl[k + "_p16"] = np.float32(q.percent_value_int16.item())
+            outl[k + "_out2"] = q(xx * 0.5).detach().numpy()      # second call: steady state on new data
+    np.savez_compressed(os.path.join(outdir, "ant_outlier.npz"), **outl)
+
     # ---- (7) quant_affine -----------------------------------------------------
     import quant_affine as qa
     aff = {}

@@ -562,3 +562,24 @@ def test_packed_4bit_codec_roundtrip_equals_fakequant(antq_lib, oracle, dev, dty
     ref = antq_lib.fakequant(x, at, plan, 10.0, 1, x.numel(), False)
     dec = antq_lib.decode4(antq_lib.encode4(x, at, plan, 10.0, 1, x.numel(), False), at, plan, 10.0, 1, x.numel(), False, dtype)
     assert torch.equal(dec.reshape(256, 512), ref)
+
+
+def test_ant_outlier_mode_vs_reference(antq_lib, dev, capsys):
+    """mode='outlier' (int4 body + int16 outliers by percentile, AQ:417-465) against the reference's outputs."""
+    import torch
+    from ant_quantization_amd.ant import quant_modules as qm
+    o = golden("ant_outlier.npz")
+    x = to_dev(o["x"], dev)
+    for pct in (99, 95):
+        for signed in (True, False):
+            xx = x if signed else x.abs()
+            q = qm.TensorQuantizer(mode="outlier", bit=4, is_signed=signed, is_enable=True, is_input=not signed,
+                                   args=_args(percent=float(pct))).to(dev)
+            q.name = "golden"
+            k = "p%d_%s" % (pct, "s" if signed else "u")
+            out = q(xx)
+            np.testing.assert_allclose(q.percent_value_int4.item(), o[k + "_p4"], rtol=1e-6)
+            np.testing.assert_allclose(q.percent_value_int16.item(), o[k + "_p16"], rtol=1e-6)
+            np.testing.assert_allclose(out.detach().cpu().numpy(), o[k + "_out"], rtol=2e-6, atol=1e-9)
+            np.testing.assert_allclose(q(xx * 0.5).detach().cpu().numpy(), o[k + "_out2"], rtol=2e-6, atol=1e-9)
+    capsys.readouterr()
