@@ -583,3 +583,36 @@ def test_ant_outlier_mode_vs_reference(antq_lib, dev, capsys):
             np.testing.assert_allclose(out.detach().cpu().numpy(), o[k + "_out"], rtol=2e-6, atol=1e-9)
             np.testing.assert_allclose(q(xx * 0.5).detach().cpu().numpy(), o[k + "_out2"], rtol=2e-6, atol=1e-9)
     capsys.readouterr()
+
+
+def test_multihead_attention_quantizer(antq_lib, dev):
+    """Wrapper math == nn.MultiheadAttention when the quantisers are off; with them on it runs end to end
+    and the four quantisers calibrate (weights per-channel, inputs per-tensor)."""
+    import torch
+    import torch.nn as nn
+    from ant_quantization_amd.ant import quant_model, quant_utils
+    from ant_quantization_amd.ant.multihead_attention import MultiheadAttentionQuantizer
+    torch.manual_seed(0)
+    quant_utils.set_quantizer(types.SimpleNamespace(mode="ant-int-flint", wbit=4, abit=4, **vars(_args())))
+    for batch_first in (False, True):
+        ma = nn.MultiheadAttention(64, 4, batch_first=batch_first).to(dev).eval()
+        enc = nn.Sequential(ma)
+        qenc = quant_model.quantize_model(enc).to(dev).eval()
+        qma = qenc[0]
+        assert type(qma) is MultiheadAttentionQuantizer
+        assert {"in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias", "in_quant_weight.alpha",
+                "out_quant_input.quant_grid"} <= set(qma.state_dict().keys())
+        x = torch.randn(10, 3, 64, device=dev) if not batch_first else torch.randn(3, 10, 64, device=dev)
+        quant_utils.disable_quantization(qenc)
+        ref, ref_w = ma(x, x, x)
+        out, w = qma(x, x, x)
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(w, ref_w, rtol=1e-4, atol=1e-5)
+        quant_utils.enable_quantization(qenc)
+        with torch.no_grad():
+            outq, _ = qma(x, x, x)
+        assert outq.shape == ref.shape and torch.isfinite(outq).all()
+        assert 0 < (outq - ref).abs().mean() < ref.abs().mean()         # quantised, but still the same function
+        assert qma.in_quant_weight.alpha.shape == (192, 1) and qma.out_quant_input.alpha.dim() == 0
+        assert all(float(t.has_inited_quant_para) == 1.0 for t in (qma.in_quant_weight, qma.in_quant_input,
+                                                                     qma.out_quant_weight, qma.out_quant_input))
