@@ -616,3 +616,24 @@ def test_multihead_attention_quantizer(antq_lib, dev):
         assert qma.in_quant_weight.alpha.shape == (192, 1) and qma.out_quant_input.alpha.dim() == 0
         assert all(float(t.has_inited_quant_para) == 1.0 for t in (qma.in_quant_weight, qma.in_quant_input,
                                                                      qma.out_quant_weight, qma.out_quant_input))
+
+
+def test_fp16_io_is_fp32_path_rounded_once(antq_lib, dev):
+    """fp16 storage (extension, like bf16): result == fp32 kernel on x.float(), rounded to half once."""
+    import torch
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    torch.manual_seed(2)
+    for rows, K in [(64, 4096), (16, 576), (128, 64), (512, 16), (9, 147)]:
+        x = (torch.randn(rows, K, device=dev) * 0.05).half()
+        x.view(-1)[::37] *= 20
+        alpha = (x.float().abs().amax(1) * 0.8).contiguous()
+        plan = antq_lib.plan_for(G["flint_b4_s"])
+        ref = antq_lib.fakequant(x.float(), alpha, plan, 10.0, rows, K, True).half()
+        assert torch.equal(antq_lib.fakequant(x, alpha, plan, 10.0, rows, K, True), ref)
+        od, ad, _ = antq_lib.fakequant_dynamic(x, plan, 10.0, rows, K, ratio=0.8)
+        assert torch.equal(ad, x.float().abs().amax(1) * 0.8) and torch.equal(od, ref)
+        gn = O["flint_b4_s"]
+        pol = antq_lib.plan_for(np.concatenate([gn, O["outlier_b4_s"]]))
+        a3 = (3 * x.float().std(1)).contiguous()
+        ref = antq_lib.fakequant(x.float(), a3, pol, 32.0, rows, K, True, ovp=True).half()
+        assert torch.equal(antq_lib.fakequant(x, a3, pol, 32.0, rows, K, True, ovp=True), ref)

@@ -81,6 +81,37 @@ __global__ void __launch_bounds__(1024) copy_nt_1024(const uint4 *__restrict__ s
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const u4 *>(s) + i), reinterpret_cast<u4 *>(d) + i);
 }
+// C4: U far-apart streams: wave w copies chunk w of each of U equal slices of the buffer
+template <int U>
+__global__ void __launch_bounds__(256) copy_streams_nt(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
+{
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 *sp = reinterpret_cast<const u4 *>(s);
+    u4 *dp = reinterpret_cast<u4 *>(d);
+    const size_t slice = n / U;                       // n % (U*64) == 0 assumed
+    const size_t i = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
+    u4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i < slice) v[u] = __builtin_nontemporal_load(sp + u * slice + i);
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i < slice) __builtin_nontemporal_store(v[u], dp + u * slice + i);
+}
+// C5: U streams 1 row (8 KiB) apart: wave w takes the w-th KiB of U consecutive 8-KiB rows
+template <int U>
+__global__ void __launch_bounds__(256) copy_rows_nt(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
+{
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 *sp = reinterpret_cast<const u4 *>(s);
+    u4 *dp = reinterpret_cast<u4 *>(d);
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t grp = wave / 8, k = wave % 8;        // group of U rows (512 vectors each), KiB k of each row
+    const size_t base = grp * (U * 512) + k * 64 + (threadIdx.x & 63);
+    u4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (base + u * 512 < n) v[u] = __builtin_nontemporal_load(sp + base + u * 512);
+#pragma unroll
+    for (int u = 0; u < U; u++) if (base + u * 512 < n) __builtin_nontemporal_store(v[u], dp + base + u * 512);
+}
 // D: persistent grid-stride, G blocks, each iteration block copies 4 KiB*U, prefetch depth 1
 template <int U, bool NT>
 __global__ void __launch_bounds__(256) copy_persist(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
@@ -207,6 +238,10 @@ int main(int argc, char **argv)
     run(B, "copy_wave_nt<1>", reps, moved, L(copy_wave_nt<1>, (n + 255) / 256));
     run(B, "copy_wave_nt<2>", reps, moved, L(copy_wave_nt<2>, (n + 511) / 512));
     run(B, "copy_wave_nt<4>", reps, moved, L(copy_wave_nt<4>, (n + 1023) / 1024));
+    run(B, "copy_streams_nt<2>", reps, moved, L(copy_streams_nt<2>, (n / 2 + 255) / 256));
+    run(B, "copy_streams_nt<4>", reps, moved, L(copy_streams_nt<4>, (n / 4 + 255) / 256));
+    run(B, "copy_rows_nt<2>", reps, moved, L(copy_rows_nt<2>, (n / 2 + 255) / 256));
+    run(B, "copy_rows_nt<4>", reps, moved, L(copy_rows_nt<4>, (n / 4 + 255) / 256));
     run(B, "copy_blk_nt<2>", reps, moved, L(copy_blk_nt<2>, (n + 511) / 512));
     run(B, "copy_blk_nt<4>", reps, moved, L(copy_blk_nt<4>, (n + 1023) / 1024));
     run(B, "copy_blk_nt<8>", reps, moved, L(copy_blk_nt<8>, (n + 2047) / 2048));
