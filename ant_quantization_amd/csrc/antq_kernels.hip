@@ -606,22 +606,16 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
     }
 }
 
-template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR = 1>
-__global__ void __launch_bounds__(256)
-k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
-          uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
-          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
-          float *__restrict__ alpha_out, XArgs xa, const uint4 *__restrict__ entries,
-          const float *__restrict__ grid)
+// Body of the x-domain row kernel for one wavefront task (shared by k_fq_xrow and k_fq_batch).
+template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR>
+__device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+                                          uint32_t task, uint32_t vpr, uint32_t tpr,
+                                          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+                                          float *__restrict__ alpha_out, const XArgs &xa,
+                                          const uint4 *__restrict__ entries, const float *__restrict__ grid,
+                                          uint4 *wtab, uint32_t lane, uint32_t wv)
 {
     constexpr int EPL = IO<T>::EPL;
-    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][64];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = threadIdx.x >> 6;
-    uint4 *wtab = wtab_all[wv];
-    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
-    if (task >= total_tasks) return;   // no workgroup barrier in this kernel
-
     // static bucket entry of this lane (L2 hit), issued ahead of the HBM loads
     uint4 ent = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u);
     if (lane < xa.n_entries) ent = entries[lane];
@@ -669,16 +663,29 @@ k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
             float xf[EPL], of[EPL];
             int j[EPL];
             IO<T>::unpack(v[u], xf);
-#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 16)
-            for (int e = 0; e < EPL; e++) of[e] = xf[e] * sc.rs;   // ablation only
-#else
             quant_vec_x<EPL, OVP, IDX>(xa, wtab, grid, sc, rowfast, xf, of, j);
-#endif
             st_stream(out + base + 64u * u, IO<T>::pack(of));
             if (IDX) store_idx<EPL>(idx, base + 64u * u, j);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR = 1>
+__global__ void __launch_bounds__(256)
+k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+          uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
+          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+          float *__restrict__ alpha_out, XArgs xa, const uint4 *__restrict__ entries,
+          const float *__restrict__ grid)
+{
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    if (task >= total_tasks) return;   // no workgroup barrier in this kernel (WPR == 4: whole workgroups exit)
+    xrow_task<T, OVP, IDX, U, DYN, WPR>(x, out, idx, task, vpr, tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries,
+                                        grid, wtab_all[wv], lane, wv);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1556,7 +1563,8 @@ struct BatchDesc {   // 128 bytes, device-visible
     uint32_t tpr;
     int32_t vshift;
     uint32_t first_block;
-    uint32_t kind;         // 0 = one row-run per wavefront (vpr >= 64), 1 = per-lane scale (vpr < 64)
+    uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < 64);
+                           // 2 = row-run per wavefront, x-domain table (pad[] = xlim bits, grid offset)
     int32_t per_row;
     float gmax;
     PlanArgs pa;
@@ -1581,9 +1589,23 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
     const uint32_t lb = blockIdx.x - D.first_block;
     const uint32_t lane = threadIdx.x & 63u;
     const uint4 *plan_tab = D.plan_tab;
+
+    if (D.kind == 2) {
+        // x-domain rows: wave-private table, no workgroup barrier
+        __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][64];
+        const uint32_t wv = threadIdx.x >> 6;
+        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
+        if (task >= D.total_tasks) return;
+        XArgs xa;
+        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]);
+        xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
+                                              nullptr, xa, plan_tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
+                                              wtab_all[wv], lane, wv);
+        return;
+    }
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
-
     if (D.kind == 0) {
         const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
@@ -1691,6 +1713,13 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         const size_t blocks = job_blocks(J, epl, &d);
         if (blocks == 0) return ANTQ_ERR_UNSUPPORTED;
         if (!plan_args_from_host(J.plan_host, d.pa)) return ANTQ_ERR_PLAN;
+        {
+            const PlanHeader *ph = static_cast<const PlanHeader *>(J.plan_host);
+            if (d.kind == 0 && g_knob_x && d.pa.kind == kPlanLut && ph->xdom && d.vpr >= 256) {
+                d.kind = 2;
+                memcpy(&d.pad[0], &ph->xlim, 4);
+            }
+        }
         if (total_blocks + blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
         if (cap < h.map_offset + 4 * (total_blocks + blocks)) return ANTQ_ERR_PLAN;
         d.x = static_cast<const uint4 *>(J.x_dev);

@@ -152,7 +152,10 @@ def main():
         outs = [torch.empty_like(w) for w in ws]
         report("C3 OPT-6.7B W (%d tensors), OliVe flint4 OVP, %s" % (len(ws), str(dt)[6:]), elems, bpe,
                timed(lambda: [_lib.fakequant(w, a, pol, 32.0, w.shape[0], w.shape[1], True, ovp=True, out=o) for w, a, o in zip(ws, al, outs)], 5), len(ws))
-        del ws, outs, al
+        bt = _lib.Batch([(w, o, a, pol, 32.0, w.shape[0], w.shape[1], True) for w, a, o in zip(ws, al, outs)], ovp=True)
+        report("C3 OPT-6.7B W (%d tensors), OliVe flint4 OVP, %s, BATCHED" % (len(ws), str(dt)[6:]), elems, bpe,
+               timed(bt.run, 5), 1)
+        del ws, outs, al, bt
 
     # ---------------- headline variants
     for dt, bpe in ((torch.bfloat16, 4), (torch.float32, 8)):
