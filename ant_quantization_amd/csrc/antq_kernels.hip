@@ -442,7 +442,7 @@ __device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__res
     }
 }
 
-template <typename T, bool OVP, bool IDX, int U, bool DYN>
+template <typename T, bool OVP, bool IDX, int U, bool DYN, bool LOOP = false>
 __global__ void __launch_bounds__(256)
 k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
              uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
@@ -451,7 +451,8 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t stride = gridDim.x * 4u;   // one-shot launch: stride >= total_tasks, the loop runs once
 
     // table fetch is issued FIRST (L2 hit) so that its wait (vmcnt is in-order) does not
     // also wait for the HBM loads of the task, which are issued right behind it
@@ -460,7 +461,7 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
 
     uint4 v[U];
     float a;
-    const bool active = task < total_tasks;
+    bool active = task < total_tasks;
     task_load<T, U>(x, alpha, per_row, active ? task : total_tasks - 1u, vpr, tpr, lane, DYN, v, a);
 
 #if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 4)
@@ -470,7 +471,18 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
     const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
 #endif
-    if (active) task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
+    // Big tables (8-bit grids: up to 48 KiB) are staged once per workgroup and amortised over a
+    // grid-stride loop of tasks; small tables use a one-shot grid (loop runs once).
+    if (!LOOP) {
+        if (active) task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
+        return;
+    }
+    while (active) {
+        task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
+        task += stride;
+        active = task < total_tasks;
+        if (active) task_load<T, U>(x, alpha, per_row, task, vpr, tpr, lane, DYN, v, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -616,9 +628,12 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
                                           uint4 *wtab, uint32_t lane, uint32_t wv)
 {
     constexpr int EPL = IO<T>::EPL;
-    // static bucket entry of this lane (L2 hit), issued ahead of the HBM loads
-    uint4 ent = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u);
+    // static bucket entries of this lane (L2 hits), issued ahead of the HBM loads; tables of
+    // 65..128 buckets (e.g. unsigned int-4) give every lane a second entry
+    uint4 ent = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u), ent2 = ent;
     if (lane < xa.n_entries) ent = entries[lane];
+    const bool two = xa.n_entries > 64u;
+    if (two && lane + 64u < xa.n_entries) ent2 = entries[lane + 64u];
 
     uint4 v[U];
     float a;
@@ -653,7 +668,15 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
         float Ux = u2f(ent.x);
         if (rowfast && lane < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
         rowfast = rowfast && __all(ok);
-        wtab[lane] = make_uint4(f2u(Ux), f2u(u2f(ent.y) * sc.s), f2u(u2f(ent.z) * sc.s), ent.w);
+        // (v + 0) * s: a -0.0 grid entry must come out as +0.0, like the reference's (q - d) + d
+        wtab[lane] = make_uint4(f2u(Ux), f2u((u2f(ent.y) + 0.0f) * sc.s), f2u((u2f(ent.z) + 0.0f) * sc.s), ent.w);
+        if (two) {
+            bool ok2 = true;
+            float U2 = u2f(ent2.x);
+            if (rowfast && lane + 64u < xa.n_entries && U2 < __builtin_inff()) U2 = x_threshold(U2, sc.s, sc.rs, ok2);
+            rowfast = rowfast && __all(ok2);
+            wtab[lane + 64u] = make_uint4(f2u(U2), f2u((u2f(ent2.y) + 0.0f) * sc.s), f2u((u2f(ent2.z) + 0.0f) * sc.s), ent2.w);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
 
@@ -679,7 +702,7 @@ k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
           float *__restrict__ alpha_out, XArgs xa, const uint4 *__restrict__ entries,
           const float *__restrict__ grid)
 {
-    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][64];
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][128];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
@@ -1191,7 +1214,18 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
-    const size_t blocks = (total + 3) / 4;
+    size_t blocks = (total + 3) / 4;
+    const bool loop = !DYN && lds > 16384;
+    if (loop) {
+        // staging a big table per 16 KiB of data would dominate: persistent workgroups instead
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (size_t)(144 * 1024) / lds));
+        blocks = std::min(blocks, (size_t)256 * per_cu);
+        const dim3 grid_l((unsigned)blocks), block_l(256);
+        hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, 4, false, true>), grid_l, block_l, lds, st, xv, ov, idx,
+                           (uint32_t)((rows * ((vpr + 255) / 256))), (uint32_t)vpr, (uint32_t)((vpr + 255) / 256), alpha,
+                           per_row, gmax, ratio, alpha_out, pa, tab);
+        return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+    }
     const dim3 grid((unsigned)blocks), block(256);
 #define ANTQ_LAUNCH_U(UU)                                                                                          \
     hipLaunchKernelGGL((k_fq_uniform<T, OVP, IDX, UU, DYN>), grid, block, lds, st, xv, ov, idx, (uint32_t)total,  \
@@ -1592,7 +1626,7 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
 
     if (D.kind == 2) {
         // x-domain rows: wave-private table, no workgroup barrier
-        __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][64];
+        __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][128];
         const uint32_t wv = threadIdx.x >> 6;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
         if (task >= D.total_tasks) return;

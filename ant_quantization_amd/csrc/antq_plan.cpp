@@ -256,13 +256,27 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         }
     }
 
-    // x-domain path eligibility (see PlanHeader::xdom)
+    // x-domain path eligibility (see PlanHeader::xdom).  The x-domain kernels pick the bucket from an
+    // approximate quotient (within 2 ulp of fl(x/s)), so a threshold that sits within 2^-20 (relative) of
+    // a bucket edge must also be found from the neighbouring bucket: it is duplicated into that
+    // neighbour when the neighbour has no threshold of its own (harmless for the exact d-domain path:
+    // every d of the neighbour lies on one side of it).  If the neighbour is taken, no x-domain path.
     {
-        bool ok = h.n_entries <= 64;
+        bool ok = h.n_entries <= 128;     // wave-private table: up to two entries per lane
+        auto entry_of = [&](float t) -> LutEntry * {
+            const uint32_t key = mag_key(t, h.shift);
+            if (key < h.kmin || key > h.kmax) return nullptr;       // clamped region: same bucket as the edge one
+            return &ent[(key - h.kmin) + ((t < 0.0f && has_neg) ? h.nb : 0u)];
+        };
         for (int i = 0; i + 1 < k && ok; i++) {
             const float t = T[i];
-            const uint32_t key = mag_key(t, h.shift);
-            if (mag_key(t * (1.0f + 0x1p-20f), h.shift) != key || mag_key(t * (1.0f - 0x1p-20f), h.shift) != key) ok = false;
+            LutEntry *own = entry_of(t);
+            for (float nb_t : {t * (1.0f + 0x1p-20f), t * (1.0f - 0x1p-20f)}) {
+                LutEntry *nb = entry_of(nb_t);
+                if (nb == nullptr || nb == own) continue;
+                if (nb->T == INFINITY) *nb = *own;                  // duplicate {T, v_lo, v_hi, idx}
+                else if (nb->T != t) ok = false;
+            }
         }
         const double stelim = 2.0 * vabs;   // (q-d)+d == q whenever |q-d| <= |d| <= 2|q| (Sterbenz) or q == 0
         double xl = std::min((double)h.fastlim, stelim) * (1.0 - 0x1p-18);
