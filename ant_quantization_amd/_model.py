@@ -35,9 +35,18 @@ def make_quantize_model(wrappers, quant_args, skip_attrs=()):
             return nn.Sequential(*[quantize_model(m) for _, m in model.named_children()])
         q_model = copy.deepcopy(model)
         for attr in dir(model):
-            mod = getattr(model, attr)
-            if isinstance(mod, nn.Module) and attr not in skip_attrs:
+            if attr in skip_attrs or isinstance(getattr(type(model), attr, None), property):
+                continue               # properties (HF `base_model`, ...) only alias children that are visited anyway
+            try:
+                mod = getattr(model, attr)
+            except Exception:          # properties that need context (HF models have a few)
+                continue
+            if not isinstance(mod, nn.Module) or mod is model:   # `base_model` of a HF backbone is the module itself
+                continue
+            try:
                 setattr(q_model, attr, quantize_model(mod))
+            except AttributeError:     # read-only property aliasing a child that is rewritten under its real name
+                pass
         return q_model
 
     return quantize_model
@@ -140,3 +149,8 @@ def load_ant_state_dict(model, checkpoint):
                 module.rearm()
         if name + ".outliers" in checkpoint.keys() and hasattr(module, "outliers"):
             module.outliers.data = checkpoint[name + ".outliers"]
+        # Conv1dQuantizer.set_param (like the reference's, OQ:368-375) leaves quant_weight.alpha 0-dim until
+        # calibration; pre-size it too so that calibrated GPT-2 checkpoints load with strict=True
+        if name + ".alpha" in checkpoint.keys() and hasattr(module, "alpha") and hasattr(module, "quant_grid"):
+            if module.alpha.shape != checkpoint[name + ".alpha"].shape:
+                module.alpha.data = checkpoint[name + ".alpha"].detach().clone().to(module.alpha.device)

@@ -637,3 +637,49 @@ def test_fp16_io_is_fp32_path_rounded_once(antq_lib, dev):
         a3 = (3 * x.float().std(1)).contiguous()
         ref = antq_lib.fakequant(x.float(), a3, pol, 32.0, rows, K, True, ovp=True).half()
         assert torch.equal(antq_lib.fakequant(x, a3, pol, 32.0, rows, K, True, ovp=True), ref)
+
+
+def test_hf_models_end_to_end_and_checkpoint_roundtrip(antq_lib, dev, capsys):
+    """Drop-in at module level: tiny HF BERT (ANT) and GPT-2 (OliVe), calibrate on the first batch, steady state
+    afterwards, and a checkpoint saved from the calibrated model restores alpha / grids / bit so that a freshly
+    rewritten model reproduces the outputs without calibrating."""
+    import torch
+    transformers = pytest.importorskip("transformers")
+    from transformers import BertConfig, BertModel, GPT2Config, GPT2LMHeadModel
+    from ant_quantization_amd.ant import quant_model as aqm, quant_utils as aqu
+    from ant_quantization_amd.olive import quant_model as oqm, quant_utils as oqu
+    args = _args(mode="ant-int-flint", wbit=4, abit=4)
+    torch.manual_seed(0)
+    ids = torch.randint(0, 100, (4, 16), device=dev)
+    cases = [
+        (aqm, aqu, lambda: BertModel(BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                                                 intermediate_size=128, vocab_size=100)), lambda o: o.last_hidden_state),
+        (oqm, oqu, lambda: GPT2LMHeadModel(GPT2Config(n_embd=64, n_layer=2, n_head=4, vocab_size=100, n_positions=32,
+                                                      bos_token_id=0, eos_token_id=0)), lambda o: o.logits),
+    ]
+    for qmod, qutil, make, pick in cases:
+        qutil.set_quantizer(args)
+        torch.manual_seed(1)
+        base = make().eval()
+        model = qmod.quantize_model(base).to(dev).eval()
+        qutil.enable_quantization(model)
+        with torch.no_grad():
+            y1 = pick(model(ids))          # calibrates every quantiser on this batch
+            y2 = pick(model(ids))          # steady state
+        assert torch.isfinite(y1).all() and torch.equal(y1, y2)
+        with torch.no_grad():
+            y_fp = pick(base.to(dev)(ids))
+        assert 0 < (y1 - y_fp).abs().mean() < y_fp.abs().mean()
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        assert any(k.endswith("quant_weight.quant_grid") for k in sd) and all(
+            float(v) == 1.0 for k, v in sd.items() if k.endswith("has_inited_quant_para"))
+        torch.manual_seed(2)                # different random weights: everything must come from the checkpoint
+        fresh = qmod.quantize_model(make().eval()).to(dev).eval()
+        qutil.enable_quantization(fresh)
+        qmod.load_ant_state_dict(fresh, sd)
+        fresh.load_state_dict(sd, strict=True)
+        capsys.readouterr()
+        with torch.no_grad():
+            y3 = pick(fresh(ids))
+        assert "4-bit" not in capsys.readouterr().out      # no calibration line: the checkpoint's state was used
+        assert torch.equal(y3, y1)

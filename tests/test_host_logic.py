@@ -265,3 +265,29 @@ def test_quant_affine_helpers_match_reference_formulas():
     q = qa.linear_quantize(x, scale, zp)
     assert torch.equal(q, scale.view(-1, 1) * x - zp.view(-1, 1))
     assert torch.equal(qa.linear_dequantize(q.round(), scale, zp), (q.round() + zp.view(-1, 1)) / scale.view(-1, 1))
+
+
+def test_quantize_model_on_hf_structures():
+    """HF BERT / GPT-2 skeletons (random init, tiny): every Linear / Conv1D is wrapped exactly once, aliases
+    such as `base_model` (a property returning a child or the module itself) neither recurse nor duplicate."""
+    import torch
+    transformers = pytest.importorskip("transformers")
+    from transformers import BertConfig, BertForSequenceClassification, BertModel, GPT2Config, GPT2LMHeadModel
+    from ant_quantization_amd.ant import quant_model as aqm, quant_modules as aq, quant_utils as aqu
+    from ant_quantization_amd.olive import quant_model as oqm, quant_modules as oq, quant_utils as oqu
+    args = _args(mode="ant-int-flint", wbit=4, abit=4)
+    aqu.set_quantizer(args)
+    oqu.set_quantizer(args)
+    cfg = BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=100)
+    q = aqm.quantize_model(BertModel(cfg))
+    assert sum(isinstance(m, aq.LinearQuantizer) for m in q.modules()) == 13
+    assert sum(type(m) is torch.nn.Linear for m in q.modules()) == 0
+    q = aqm.quantize_model(BertForSequenceClassification(cfg))
+    assert sum(isinstance(m, aq.LinearQuantizer) for m in q.modules()) == 14
+    assert not any(k.startswith("base_model.") for k in q.state_dict())
+    g = GPT2LMHeadModel(GPT2Config(n_embd=64, n_layer=2, n_head=4, vocab_size=100, n_positions=32, bos_token_id=0, eos_token_id=0))
+    q = oqm.quantize_model(g)
+    assert sum(isinstance(m, oq.Conv1dQuantizer) for m in q.modules()) == 8
+    assert type(q.lm_head) is torch.nn.Linear                 # OliVe never quantises lm_head
+    oqu.disable_quantization(q)
+    assert q(torch.randint(0, 100, (2, 8))).logits.shape == (2, 8, 100)
