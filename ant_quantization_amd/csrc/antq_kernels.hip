@@ -243,9 +243,6 @@ __device__ __forceinline__ Scale make_scale(float alpha, float gmax)
 __device__ __forceinline__ float div_fast(float x, float s, float rs)
 {
     float q0 = x * rs;
-#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 1)
-    return q0;  // ablation only: inexact
-#endif
     float e0 = __builtin_fmaf(-q0, s, x);
     float q1 = __builtin_fmaf(e0, rs, q0);
     float e1 = __builtin_fmaf(-q1, s, x);
@@ -298,11 +295,7 @@ __device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, 
             const int32_t t = (u >> sh4) & km16;
             const int32_t c16 = min(max(t, lo16), hi16);
             const uint32_t sg = (uint32_t)(u >> 31) & neg16;
-#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 2)
-            uint4 ent = make_uint4(f2u(1.0f), (uint32_t)(c16 + sg), (uint32_t)u, 0);  // ablation only: no LDS
-#else
             uint4 ent = *reinterpret_cast<const uint4 *>(lut0 + c16 + sg);
-#endif
             if (!IDX) asm volatile("" : "+v"(ent.w));  // keep the read a single ds_read_b128 (b96 is 2x slower)
             const bool c = d[e] >= u2f(ent.x);
             q[e] = c ? u2f(ent.z) : u2f(ent.y);
@@ -423,11 +416,7 @@ __device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__res
         a = u2f(m) * ratio;
         if (alpha_out && lane == 0) alpha_out[row] = a;
     }
-#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 8)
-    Scale sc; sc.s = a; sc.rs = gmax; sc.ok = true;   // ablation only: no divisions in the prologue
-#else
     const Scale sc = make_scale(a, gmax);
-#endif
 #pragma unroll
     for (int u = 0; u < U; u++) {
         if (v0 + 64u * u < vpr) {
@@ -464,13 +453,8 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
     bool active = task < total_tasks;
     task_load<T, U>(x, alpha, per_row, active ? task : total_tasks - 1u, vpr, tpr, lane, DYN, v, a);
 
-#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 4)
-    PlanLds L; L.lut = reinterpret_cast<const LutEntry *>(smem); L.grid = reinterpret_cast<const float *>(smem);
-    asm volatile("" :: "v"(tab0.x));
-#else
     const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
-#endif
     // Big tables (8-bit grids: up to 48 KiB) are staged once per workgroup and amortised over a
     // grid-stride loop of tasks; small tables use a one-shot grid (loop runs once).
     if (!LOOP) {
@@ -562,11 +546,7 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
             const int32_t t = (u >> sh4) & km16;
             const int32_t c16 = min(max(t, lo16), hi16);
             const uint32_t sg = (uint32_t)(u >> 31) & neg16;
-#if defined(ANTQ_ABLATE) && (ANTQ_ABLATE & 32)
-            uint4 ent = make_uint4(f2u(1.0f), (uint32_t)(c16 + sg), (uint32_t)u, 0);   // ablation only: no LDS read
-#else
             uint4 ent = *reinterpret_cast<const uint4 *>(t0 + c16 + sg);
-#endif
             if (!IDX && !OVP) asm volatile("" : "+v"(ent.w));
             const bool c = x[e] >= u2f(ent.x);
             o[e] = c ? u2f(ent.z) : u2f(ent.y);
@@ -878,6 +858,126 @@ k_nearest(const T *__restrict__ x, T *__restrict__ z, int16_t *__restrict__ idx,
     }
 }
 
+// ------------------------------------------------------------------------------------
+// quant_cuda.quant, fast variant.  The grid is only known on the device, so every workgroup
+// analyses it itself (M <= 256 threads, a few hundred instructions, amortised over 1024
+// elements): rank-sorts it (any order for M <= 64, e.g. OliVe's cat(normal, outliers);
+// larger grids must already be non-decreasing), records for every distinct value the LAST
+// scan index holding it, and derives the magnitude `fastlim` below which the scan's result
+// is decided by the two neighbouring values alone (no rounding plateau: all non-zero gaps
+// within 2^19 of each other, edge gaps > ulp of any distance below fastlim).  Elements then
+// binary-search their neighbours and apply the scan's own comparison to the two candidates
+// (ties -> later scan index); everything else falls back to the literal scan.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nearest_fast(const T *__restrict__ x, T *__restrict__ z, int16_t *__restrict__ idx, size_t n,
+               const T *__restrict__ grid, int m)
+{
+    __shared__ float y[256];      // scan order
+    __shared__ float sv[256];     // sorted values
+    __shared__ int16_t win[256];  // sorted position -> last scan index with that value
+    __shared__ int s_bad;
+    __shared__ float s_mingap, s_maxgap, s_fastlim;
+    const int t = threadIdx.x;
+    if (t == 0) { s_bad = 0; s_mingap = 3.0e38f; s_maxgap = 0.0f; }
+    sv[t] = __builtin_inff();                          // padding for the fixed-step search
+    if (t < m) y[t] = (float)grid[t];
+    __syncthreads();
+    if (t < m) {
+        const float v = y[t];
+        if (!(fabsf(v) <= 65536.0f)) s_bad = 1;          // NaN / Inf / huge entries: literal scan
+        int rank = t;
+        if (m <= 64) {
+            rank = 0;
+            for (int j = 0; j < m; j++) rank += (y[j] < v || (y[j] == v && j < t)) ? 1 : 0;
+        } else if (t + 1 < m && !(v <= y[t + 1])) {
+            s_bad = 1;                                   // big grids must arrive sorted
+        }
+        sv[rank] = v;
+        win[rank] = (int16_t)t;
+    }
+    __syncthreads();
+    // last scan index among equal values (equal values are adjacent and in scan order)
+    int w = 0;
+    float g = 0.0f;
+    if (t < m) {
+        w = win[t];
+        for (int j = t + 1; j < m && sv[j] == sv[t]; j++) w = max(w, (int)win[j]);
+        for (int j = t - 1; j >= 0 && sv[j] == sv[t]; j--) w = max(w, (int)win[j]);
+        g = (t + 1 < m) ? sv[t + 1] - sv[t] : 0.0f;
+    }
+    __syncthreads();
+    if (t < m) {
+        win[t] = (int16_t)w;
+        if (g > 0.0f) {
+            atomicMin(reinterpret_cast<unsigned int *>(&s_mingap), f2u(g));   // positive floats order like uints
+            atomicMax(reinterpret_cast<unsigned int *>(&s_maxgap), f2u(g));
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        float lim = 0.0f;
+        if (!s_bad && s_maxgap > 0.0f && s_maxgap <= s_mingap * 524288.0f) {
+            // first / last non-zero gap
+            float g0 = 0.0f, g1 = 0.0f;
+            for (int j = 0; j + 1 < m && g0 == 0.0f; j++) g0 = sv[j + 1] - sv[j];
+            for (int j = m - 1; j > 0 && g1 == 0.0f; j--) g1 = sv[j] - sv[j - 1];
+            const float vabs = fmaxf(fabsf(sv[0]), fabsf(sv[m - 1]));
+            lim = fminf(fminf(g0, g1) * 4194304.0f - vabs, 65536.0f);        // gap * 2^22 (one bit of margin)
+            lim = fminf(lim, 102399.0f - vabs);                              // every |x| < lim has an entry within 102400
+            if (!(lim > 2.0f * vabs)) lim = 0.0f;
+        }
+        s_fastlim = lim;
+    }
+    __syncthreads();
+    const float fastlim = s_fastlim;
+    // branch-free upper bound with a fixed number of steps (sv[] is padded with +inf beyond m), four
+    // elements per thread in flight so the dependent LDS reads of one element overlap the others'
+    int top = 1;
+    while (top * 2 <= m) top *= 2;
+    constexpr int E = 4;
+    const size_t base = (size_t)blockIdx.x * (256u * E * 2) + threadIdx.x;
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        float xv[E];
+        int p[E];
+        bool ok[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const size_t i = base + 256u * (half * E + e);
+            xv[e] = (i < n) ? (float)x[i] : 0.0f;
+            p[e] = 0;
+            ok[e] = fabsf(xv[e]) < fastlim;
+        }
+        for (int st = top; st >= 1; st >>= 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if (sv[p[e] + st - 1] <= xv[e]) p[e] += st;       // p = number of sorted entries <= x
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const size_t i = base + 256u * (half * E + e);
+            if (i >= n) continue;
+            int j;
+            float zq;
+            if (ok[e]) {
+                const int pl = max(p[e] - 1, 0), ph = min(p[e], m - 1);
+                const float r_lo = fabsf(xv[e] - sv[pl]);
+                const float r_hi = fabsf(xv[e] - sv[ph]);
+                const int w_lo = win[pl], w_hi = win[ph];
+                // p == 0 / p == m: pl == ph, both candidates are the same entry
+                j = (r_hi < r_lo || (r_hi == r_lo && w_hi > w_lo)) ? w_hi : w_lo;
+                zq = y[j];
+            } else {
+                zq = scan_lds(xv[e], y, m, j);
+            }
+            z[i] = (T)zq;
+            if (idx) idx[i] = (int16_t)j;
+        }
+    }
+}
+
 // bf16 / f16 storage variant of k_nearest (grid is float)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -1148,6 +1248,7 @@ static inline const uint4 *plan_tab_ptr(const void *plan_dev)
 static int g_knob_u = 0;        // force U of the uniform kernel (0 = heuristic)
 static int g_knob_blocks = 0;   // (unused since the kernels are one-shot)
 static int g_knob_x = 1;        // 0 disables the x-domain row kernel (A/B measurements)
+static int g_knob_nearest_fast = 1;   // 0: antq_nearest always runs the literal scan
 
 template <typename T, bool OVP, bool IDX, bool DYN>
 static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, size_t vpr, const float *alpha,
@@ -1335,14 +1436,25 @@ extern "C" int antq_nearest(const void *x, void *z, int16_t *idx, size_t n, cons
     if (dtype == ANTQ_F32 || dtype == ANTQ_F64) {
         const size_t blocks = (n + 1023) / 1024;
         if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
-        if (dtype == ANTQ_F32)
-            hipLaunchKernelGGL((k_nearest<float>), dim3((unsigned)blocks), dim3(256), 0, st,
-                               static_cast<const float *>(x), static_cast<float *>(z), idx, n,
-                               static_cast<const float *>(grid), m);
-        else
-            hipLaunchKernelGGL((k_nearest<double>), dim3((unsigned)blocks), dim3(256), 0, st,
-                               static_cast<const double *>(x), static_cast<double *>(z), idx, n,
-                               static_cast<const double *>(grid), m);
+        if (dtype == ANTQ_F32) {
+            if (m <= 256 && g_knob_nearest_fast)
+                hipLaunchKernelGGL((k_nearest_fast<float>), dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, st,
+                                   static_cast<const float *>(x), static_cast<float *>(z), idx, n,
+                                   static_cast<const float *>(grid), m);
+            else
+                hipLaunchKernelGGL((k_nearest<float>), dim3((unsigned)blocks), dim3(256), 0, st,
+                                   static_cast<const float *>(x), static_cast<float *>(z), idx, n,
+                                   static_cast<const float *>(grid), m);
+        } else {
+            if (m <= 256 && g_knob_nearest_fast)
+                hipLaunchKernelGGL((k_nearest_fast<double>), dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, st,
+                                   static_cast<const double *>(x), static_cast<double *>(z), idx, n,
+                                   static_cast<const double *>(grid), m);
+            else
+                hipLaunchKernelGGL((k_nearest<double>), dim3((unsigned)blocks), dim3(256), 0, st,
+                                   static_cast<const double *>(x), static_cast<double *>(z), idx, n,
+                                   static_cast<const double *>(grid), m);
+        }
     } else if (dtype == ANTQ_BF16 || dtype == ANTQ_F16) {
         const size_t blocks = (n + 255) / 256;
         if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
@@ -1414,6 +1526,7 @@ extern "C" int antq_debug_set(int key, int value)
     if (key == 0) g_knob_u = value;
     else if (key == 1) g_knob_blocks = value;
     else if (key == 2) g_knob_x = value;
+    else if (key == 3) g_knob_nearest_fast = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }

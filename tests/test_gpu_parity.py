@@ -683,3 +683,30 @@ def test_hf_models_end_to_end_and_checkpoint_roundtrip(antq_lib, dev, capsys):
             y3 = pick(fresh(ids))
         assert "4-bit" not in capsys.readouterr().out      # no calibration line: the checkpoint's state was used
         assert torch.equal(y3, y1)
+
+
+def test_nearest_fast_path_equals_literal_scan(antq_lib, oracle, dev):
+    """antq_nearest analyses the (device-resident) grid per workgroup and binary-searches; it must agree with
+    the literal scan on every kind of grid: sorted, two sorted runs (OliVe), unsorted, duplicates, hostile."""
+    import torch
+    rng = np.random.default_rng(12)
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    grids_ = [G[k] for k in ("flint_b4_s", "flint_b4_u", "int_b4_s", "pot_b4_u", "apot_b4_s", "int_b8_s", "int_b8_u",
+                             "flint_b6_s", "pot_b6_s", "float_b6_u", "int_b2_s")]
+    grids_ += [np.concatenate([O["%s_b4_%s" % (t, s)], O["outlier_b4_%s" % s]]) for t in ("int", "flint") for s in "su"]
+    grids_ += [np.float32([3, 1, 2, 1, 3, -7]), np.float32([1.0, 1.0000001, 5.0]), np.float32([0.0, 0.0, 0.0]),
+               np.float32([5.0]), np.float32([-1.0, 1.0]), np.float32([0, 1e-3, 1e4]),
+               np.sort(rng.standard_normal(200).astype(np.float32) * 3), rng.standard_normal(40).astype(np.float32)]
+    for g in grids_:
+        hi = float(np.abs(g).max()) + 1.0
+        x = np.concatenate([
+            rng.standard_normal(20000).astype(np.float32) * np.float32(hi / 2),
+            rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+            np.repeat(g, 3) + np.tile(np.float32([0, 1e-6, -1e-6]), g.size),
+            ((g[:-1].astype(np.float64) + g[1:]) / 2).astype(np.float32) if g.size > 1 else np.float32([0]),
+            np.float32([0.0, -0.0, 1e5, -1e5, 102400.0, 2e5, np.inf, -np.inf, np.nan, 36000.0, -36000.0, 65535.0])])
+        with np.errstate(all="ignore"):
+            zr, jr = oracle.nearest(x, g)
+        z, j = antq_lib.nearest(to_dev(x, dev), to_dev(g, dev), want_idx=True)
+        assert f32_same(z.cpu().numpy(), zr), g[:6]
+        assert np.array_equal(j.cpu().numpy().astype(np.int32), jr), g[:6]
