@@ -47,7 +47,8 @@ def lib():
                 for name in ("antq_abi_version", "antq_nearest", "antq_plan_build", "antq_plan_kind",
                              "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
-                             "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4"):
+                             "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
+                             "antq_search_pick"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
@@ -274,6 +275,18 @@ def search_sse(x, rows, row_len, xmax, per_row, ratios, plan, gmax, ovp=False):
                                      ctypes.c_uint(FLAG_OVP if ovp else 0), ctypes.c_int(dt), _vp(sse),
                                      _stream(x.device)), "antq_search_sse")
     return sse
+
+
+def search_pick(sse, xmax, ratios, row_len):
+    """(best_score, best_alpha) per row from the candidates' sums of squared errors (strict '<', first best)."""
+    ncand, na = sse.shape
+    best = torch.empty(na, dtype=torch.float32, device=sse.device)
+    alpha = torch.empty(na, dtype=torch.float32, device=sse.device)
+    with _on_device(sse.device):
+        _check(lib().antq_search_pick(_vp(sse), _vp(xmax), _vp(ratios), ctypes.c_int(ncand), ctypes.c_size_t(na),
+                                      ctypes.c_size_t(row_len), _vp(best), _vp(alpha), _stream(sse.device)),
+               "antq_search_pick")
+    return best, alpha
 
 
 def affine(x, k, xmin, xmax, rows, row_len, per_row, want_q=False):

@@ -78,19 +78,26 @@ def clip_search(x, x_max, per_channel, lo, hi, step, plan, gmax, ovp=False):
         # the reference's loop body never runs: best_score stays 1e10, alpha = x_max
         na = rows if per_channel else 1
         return torch.full((na,), 1e10, dtype=torch.float32, device=x.device), x_max.clone(), None
-    ratios_np = np.asarray([float(np.float32(i * 0.01)) for i in cand], dtype=np.float32)
-    ratios = torch.from_numpy(ratios_np).to(x.device)
+    ratios = _ratios(int(lo), int(hi), int(step), x.device)
     xm = x_max.reshape(-1).to(torch.float32).contiguous()
     sse = _lib.search_sse(xc, rows, row_len, xm, per_channel, ratios, plan, gmax, ovp=ovp)  # [ncand, na] f64
-    mse = (sse / float(row_len)).to(torch.float32)
-    best = torch.argmin(mse, dim=0, keepdim=True)           # first minimum = strict '<' sweep
-    best_score = torch.gather(mse, 0, best).reshape(-1)
-    best_alpha = xm * ratios[best.reshape(-1)]
-    # the reference starts from best_score = 1e10 and only replaces on score < best:
-    keep = best_score < 1e10
-    best_alpha = torch.where(keep, best_alpha, xm)
-    best_score = torch.where(keep, best_score, torch.full_like(best_score, 1e10))
+    # the reference's selection loop (best = 1e10, strict '<', candidates in ascending order) on the device
+    best_score, best_alpha = _lib.search_pick(sse, xm, ratios, row_len)
     return best_score, best_alpha, ratios
+
+
+_ratio_cache = {}
+
+
+def _ratios(lo, hi, step, device):
+    """fl32(i * 0.01) for i in range(lo, hi, step) as a device tensor (cached: the ranges are fixed per run)."""
+    key = (lo, hi, step, device.index)
+    t = _ratio_cache.get(key)
+    if t is None:
+        arr = np.asarray([float(np.float32(i * 0.01)) for i in range(lo, hi, step)], dtype=np.float32)
+        t = torch.from_numpy(arr).to(device)
+        _ratio_cache[key] = t
+    return t
 
 
 def row_absmax(x, per_channel):

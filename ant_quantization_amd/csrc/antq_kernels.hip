@@ -1107,11 +1107,14 @@ template <typename T, bool OVP, int U>
 __global__ void __launch_bounds__(256)
 k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
              const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand, float gmax,
-             double *__restrict__ sse, PlanArgs pa, const uint4 *__restrict__ plan_tab)
+             double *__restrict__ sse, PlanArgs pa, const uint4 *__restrict__ plan_tab, int cand_chunk)
 {
     constexpr int EPL = IO<T>::EPL;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     const uint32_t lane = threadIdx.x & 63u;
+    // small tensors do not have enough rows to fill the chip: blockIdx.y splits the candidate list
+    const int c_begin = (int)blockIdx.y * cand_chunk;
+    const int c_end = min(ncand, c_begin + cand_chunk);
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
@@ -1124,7 +1127,7 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
         uint32_t row = task, g = 0;
         if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
         const uint32_t v0 = g * (64u * U) + lane;
-        for (int c = 0; c < ncand; c++) {
+        for (int c = c_begin; c < c_end; c++) {
             const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
             const Scale sc = make_scale(a, gmax);
             double acc = 0.0;
@@ -1627,9 +1630,13 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
     size_t blocks = (total + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL((k_search_sse<T, OVP, U>), dim3((unsigned)blocks), dim3(256), lds, st,
+    // enough wavefronts to fill 256 CUs x 8 waves/SIMD: split the candidates when there are few rows
+    int chunks = (int)std::min<size_t>((size_t)ncand, std::max<size_t>(1, (size_t)2048 / blocks));
+    const int cand_chunk = (ncand + chunks - 1) / chunks;
+    chunks = (ncand + cand_chunk - 1) / cand_chunk;
+    hipLaunchKernelGGL((k_search_sse<T, OVP, U>), dim3((unsigned)blocks, (unsigned)chunks), dim3(256), lds, st,
                        static_cast<const uint4 *>(x), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row,
-                       ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev));
+                       ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev), cand_chunk);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
@@ -2062,4 +2069,37 @@ extern "C" int antq_decode4(const uint8_t *codes, void *out, size_t rows, size_t
     case ANTQ_F16: return launch_codec<f16_tag>(false, nullptr, out, codes, rows, row_len, alpha, per_row ? 1 : 0, gmax, pa, plan_host, plan_dev, n_normal, ovp, st);
     default: return ANTQ_ERR_UNSUPPORTED;
     }
+}
+
+
+namespace antq {
+// search_mse's selection loop, one thread per row (AQ:299-306): strict '<' keeps the earliest best.
+__global__ void __launch_bounds__(256)
+k_search_pick(const double *__restrict__ sse, const float *__restrict__ xmax, const float *__restrict__ ratios,
+              int ncand, size_t na, double row_len, float *__restrict__ best_score, float *__restrict__ best_alpha)
+{
+    const size_t r = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= na) return;
+    float best = 1e10f;
+    const float xm = xmax[r];
+    float alpha = xm;
+    for (int c = 0; c < ncand; c++) {
+        const float score = (float)(sse[(size_t)c * na + r] / row_len);
+        if (score < best) { best = score; alpha = xm * ratios[c]; }
+    }
+    best_score[r] = best;
+    best_alpha[r] = alpha;
+}
+}  // namespace antq
+
+extern "C" int antq_search_pick(const double *sse, const float *xmax, const float *ratios, int ncand, size_t na,
+                                size_t row_len, float *best_score, float *best_alpha, void *stream)
+{
+    if (na == 0) return ANTQ_OK;
+    if (!sse || !xmax || !ratios || !best_score || !best_alpha || ncand < 0 || row_len == 0) return ANTQ_ERR_ARG;
+    const size_t blocks = (na + 255) / 256;
+    if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(antq::k_search_pick, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), sse, xmax,
+                       ratios, ncand, na, (double)row_len, best_score, best_alpha);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }

@@ -141,7 +141,7 @@ def main():
     # ---- setup pass: the same work as one launch per tensor (k_fq_xrow, the reference's granularity).
     # Reported beside the headline; it also keeps the GPU busy for >= 0.3 s before anything is timed,
     # which is what it takes for an idle MI355X to reach steady clocks (the first ~50 ms of load run
-    # up to 20 % slower: tools/gpu_probe5.py).
+    # up to 20 % slower: tools/probe_clock_ramp.py).
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     pt_launch_s, t_setup = None, time.perf_counter()
     while time.perf_counter() - t_setup < 0.3:

@@ -146,6 +146,13 @@ int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
                     const void *plan_host, const void *plan_dev,
                     unsigned flags, int dtype, double *sse_dev, void *stream);
 
+/* The selection step of search_mse on the device (AQ:299-306 / :317-324): for every row r
+ *     score_c = fl32(sse[c, r] / row_len), c ascending; best starts at 1e10 and is replaced on a strict `<`
+ *     best_alpha[r] = fl32(xmax[r] * ratios[c*]) of the first best candidate, xmax[r] if none qualifies.
+ * na = rows (per-channel) or 1.  Keeps the whole calibration free of device->host syncs. */
+int antq_search_pick(const double *sse_dev, const float *xmax_dev, const float *ratios_dev, int ncand,
+                     size_t na, size_t row_len, float *best_score_dev, float *best_alpha_dev, void *stream);
+
 /* ---------------------------------------------------------------------------
  * AsymmetricQuantFunction.forward (ant_quantization/antquant/quant_affine.py:95-115)
  *     scale = (2^k-1)/clamp(max-min,1e-8); zp = round(scale*min) + 2^(k-1)

@@ -129,6 +129,12 @@ def main():
     evals = elems * 3 * 70
     print("%-58s %9.1f G candidate-evals/s  %8.1f ms/pass (3 types x 70 clip ratios, %d tensors)" % (
         "C2 BERT-base calibration (type select + clip search)", evals / secs / 1e9, secs * 1e3, len(ws)), flush=True)
+    big = torch.randn(4096, 4096, device=dev) * 0.02
+    ab = _lib.absmax(big, 4096, 4096)
+    secs = timed(lambda: core.clip_search(big, ab, True, 80, 150, 1, plans["flint"], 10.0), 3)
+    print("%-58s %9.1f G candidate-evals/s  %8.2f ms (one 4096x4096 fp32 tensor, 70 clip ratios)" % (
+        "clip search on a large tensor", big.numel() * 70 / secs / 1e9, secs * 1e3), flush=True)
+    del big
     x = torch.nn.functional.gelu(torch.randn(64, 128, 3072, device=dev))
     pu = _lib.plan_for(grids.ant_flint(4, True))
     ax = x.abs().max().reshape(1)
