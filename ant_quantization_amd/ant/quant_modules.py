@@ -201,49 +201,40 @@ class Quantizer(nn.Module):
         self.mode = modes[mse_idx[0]]
 
     def outlier_set(self, data):
-        """AQ:417-436 ('outlier' baseline mode: int4 body + int16 outliers by percentile)."""
-        def reduce_ave_tensor(tensor):
-            if not _dist_on():
-                return tensor.clone()
-            rt = tensor.clone()
-            dist.all_reduce(rt, op=dist.ReduceOp.SUM)
-            rt /= dist.get_world_size()
-            return rt
-
-        self.percent_value_int4 = torch.tensor(np.percentile(data.abs().cpu().numpy(), self.percent * 100),
-                                               device=data.device)
-        self.percent_value_int16 = data.abs().max()
-        self.percent_value_int4.data = reduce_ave_tensor(self.percent_value_int4.data)
-        self.percent_value_int16.data = reduce_ave_tensor(self.percent_value_int16.data)
+        """'outlier' baseline mode (AQ:417-436): an int4 body up to the `percent`-th percentile of |x| and an
+        int16 grid for what lies beyond; the two range ends are averaged over DDP ranks."""
+        absx = data.abs()
+        p4 = torch.tensor(np.percentile(absx.cpu().numpy(), self.percent * 100), device=data.device)
+        p16 = absx.max()
+        if _dist_on():
+            for t in (p4, p16):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t /= dist.get_world_size()
+        self.percent_value_int4, self.percent_value_int16 = p4, p16
         if _rank() == 0:
-            print(self.name, self.percent_value_int4.item(), self.percent_value_int16.item())
+            print(self.name, p4.item(), p16.item())
         self.is_perchannel = False
         self._install_grid(grids.ant_int(self._bits(), self.is_signed))
         self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
         self._steady = True
 
     def outlier_quant(self, data):
-        """AQ:438-465."""
-        mask_int16 = data.abs() > self.percent_value_int4
-        if self.percent_value_int4 > 0:
-            scale = self.percent_value_int4 / torch.max(self.quant_grid)
-            data_int4 = data / scale
-            quant_data = QuantBase.forward(data_int4, self.quant_grid)
-            tensor = quant_data.clone().detach()
-            tensor = tensor * scale
+        """AQ:438-465.  Body: nearest int4 value at scale p4/max(grid); elements with |x| > p4 are re-quantised
+        on a uniform int16 grid over (p4, p16] with a straight-through combination.  Same fp32 op order as the
+        reference, written with `where` instead of masked assignment."""
+        p4, p16 = self.percent_value_int4, self.percent_value_int16
+        if p4 > 0:
+            scale = p4 / torch.max(self.quant_grid)
+            body = QuantBase.forward(data / scale, self.quant_grid).clone().detach() * scale
         else:
-            tensor = data.clone().detach()
+            body = data.clone().detach()
+        if not (self.percent < 100):
+            return body
         level = 2 ** 16 - 1 if self.is_signed else 2 ** 15 - 1
-        if self.percent < 100:
-            scale = (self.percent_value_int16 - self.percent_value_int4) / level
-            data_int16 = data[mask_int16].abs()
-            sign_int16 = data[mask_int16].sign()
-            data_int16 = data_int16 - self.percent_value_int4
-            quant_data = (data_int16 / scale).round() * scale
-            quant_data = quant_data + self.percent_value_int4
-            quant_data = quant_data * sign_int16
-            tensor[mask_int16] = (quant_data - tensor[mask_int16]).detach() + tensor[mask_int16]
-        return tensor
+        step = (p16 - p4) / level
+        mag = ((data.abs() - p4) / step).round() * step + p4
+        fine = mag * data.sign()
+        return torch.where(data.abs() > p4, (fine - body).detach() + body, body)
 
     def _init_quant_para(self, data, data_b):
         """AQ:468-533.  The device read of `has_inited_quant_para` happens once; afterwards the
@@ -332,61 +323,54 @@ class TensorQuantizer(Quantizer):
         return self.tensor_forward(tensor, input_tensor)
 
 
+def _quantizer_pair(owner, mode, wbit, abit, args, operator):
+    """weight quantiser: signed, per output channel; input quantiser: unsigned until a negative value is seen
+    (update_signed), per tensor -- the pairing every wrapper of the reference uses (AQ:589-590, :627-628)."""
+    assert mode is not None, 'Quantizer is not initilized!'
+    owner.quant_weight = TensorQuantizer(mode=mode, bit=wbit, is_signed=True, is_enable=True, args=args,
+                                         operator=operator)
+    owner.quant_input = TensorQuantizer(mode=mode, bit=abit, is_signed=False, is_enable=True, args=args,
+                                        operator=operator, is_input=True)
+
+
+def _adopt_parameters(owner, src, out_channels):
+    """Clone weight / bias of the wrapped layer and pre-size the per-channel alpha (AQ:596-607, :634-640)."""
+    owner.quant_weight.alpha.data = torch.ones([out_channels, 1])
+    owner.weight = nn.Parameter(src.weight.data.clone())
+    owner.bias = nn.Parameter(src.bias.data.clone()) if getattr(src, "bias", None) is not None else None
+
+
 class Conv2dQuantizer(nn.Module):
-    """Class to quantize given convolutional layer (AQ:582-617)."""
+    """nn.Conv2d with fake-quantised weight and input (AQ:582-617)."""
 
     def __init__(self, mode=None, wbit=None, abit=None, args=None):
         super(Conv2dQuantizer, self).__init__()
-        assert mode is not None, 'Quantizer is not initilized!'
-        self.quant_weight = TensorQuantizer(mode=mode, bit=wbit, is_signed=True, is_enable=True, args=args, operator=self._conv_forward)
-        self.quant_input = TensorQuantizer(mode=mode, bit=abit, is_signed=False, is_enable=True, args=args, operator=self._conv_forward, is_input=True)
+        _quantizer_pair(self, mode, wbit, abit, args, self._conv_forward)
 
     def set_param(self, conv):
-        self.in_channels = conv.in_channels
-        self.out_channels = conv.out_channels
-
-        self.quant_weight.alpha.data = torch.ones([self.out_channels, 1])
-
-        self.kernel_size = conv.kernel_size
-        self.stride = conv.stride
-        self.padding = conv.padding
-        self.dilation = conv.dilation
-        self.groups = conv.groups
-        self.weight = nn.Parameter(conv.weight.data.clone())
-        try:
-            self.bias = nn.Parameter(conv.bias.data.clone())
-        except AttributeError:
-            self.bias = None
+        for name in ("in_channels", "out_channels", "kernel_size", "stride", "padding", "dilation", "groups"):
+            setattr(self, name, getattr(conv, name))
+        _adopt_parameters(self, conv, conv.out_channels)
 
     def _conv_forward(self, input, weight):
-        return F.conv2d(input, weight, self.bias, self.stride,
-                        self.padding, self.dilation, self.groups)
+        return F.conv2d(input, weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
     def forward(self, input):
-        weight = self.quant_weight(self.weight, input)
+        weight = self.quant_weight(self.weight, input)     # re-quantised on every forward, like the reference
         input = self.quant_input(input, self.weight)
         return self._conv_forward(input, weight)
 
 
 class LinearQuantizer(nn.Module):
-    """Class to quantize given linear layer (AQ:620-646)."""
+    """nn.Linear with fake-quantised weight and input (AQ:620-646)."""
 
     def __init__(self, mode=None, wbit=None, abit=None, args=None):
         super(LinearQuantizer, self).__init__()
-        assert mode is not None, 'Quantizer is not initilized!'
-        self.quant_weight = TensorQuantizer(mode=mode, bit=wbit, is_signed=True, is_enable=True, args=args, operator=F.linear)
-        self.quant_input = TensorQuantizer(mode=mode, bit=abit, is_signed=False, is_enable=True, args=args, operator=F.linear, is_input=True)
+        _quantizer_pair(self, mode, wbit, abit, args, F.linear)
 
     def set_param(self, linear):
-        self.in_features = linear.in_features
-        self.out_features = linear.out_features
-        self.quant_weight.alpha.data = torch.ones([self.out_features, 1])
-
-        self.weight = nn.Parameter(linear.weight.data.clone())
-        try:
-            self.bias = nn.Parameter(linear.bias.data.clone())
-        except AttributeError:
-            self.bias = None
+        self.in_features, self.out_features = linear.in_features, linear.out_features
+        _adopt_parameters(self, linear, linear.out_features)
 
     def forward(self, input):
         weight = self.quant_weight(self.weight, input)
