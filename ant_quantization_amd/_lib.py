@@ -13,7 +13,7 @@ import numpy as np
 import torch  # must be imported before libantq.so so that ONE libamdhip64 is shared
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libantq.so")
+LIB_PATH = os.environ.get("ANTQ_LIB") or os.path.join(_HERE, "libantq.so")   # ANTQ_LIB: A/B builds (dev)
 
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_OVP = 1

@@ -710,3 +710,43 @@ def test_nearest_fast_path_equals_literal_scan(antq_lib, oracle, dev):
         z, j = antq_lib.nearest(to_dev(x, dev), to_dev(g, dev), want_idx=True)
         assert f32_same(z.cpu().numpy(), zr), g[:6]
         assert np.array_equal(j.cpu().numpy().astype(np.int32), jr), g[:6]
+
+
+@pytest.mark.parametrize("gname", ["flint_b4_s", "int_b4_s", "pot_b4_u", "olive_flint", "olive_int"])
+def test_x_domain_thresholds_dense_sweep(antq_lib, oracle, dev, gname):
+    """The x-domain row kernel moves every decision threshold into the x domain per row.  Probe it where it
+    can go wrong: +-96 ulps around (mid-point * scale) of every pair of adjacent grid values, for 256 rows
+    with awkward random scales -- bit-exact values and indices against the oracle, fp32 and bf16."""
+    rng = np.random.default_rng(99)
+    if gname.startswith("olive"):
+        O = golden("olive_grids.npz")
+        gn = O[gname.split("_")[1] + "_b4_s"]
+        g = np.concatenate([gn, O["outlier_b4_s"]])
+        gmax, ovp = float(gn.max()), True
+    else:
+        g = golden("ant_grids.npz")[gname]
+        gmax, ovp = float(g.max()), False
+    plan = antq_lib.plan_for(g)
+    assert plan.is_table and plan.host[:80].view(np.uint32)[16] == 1      # x-domain eligible
+    gs = np.unique(g)
+    mids = ((gs[:-1].astype(np.float64) + gs[1:]) / 2)
+    rows, K = 256, 4096
+    alpha = (np.exp(rng.uniform(np.log(1e-3), np.log(50.0), rows)) * rng.uniform(1.0, 2.0, rows)).astype(np.float32)
+    scale = (alpha / np.float32(gmax)).astype(np.float32)
+    x = (rng.standard_normal((rows, K)) * (alpha[:, None] / 3)).astype(np.float32)
+    per = 2 * 96 + 1
+    offs = np.arange(-96, 97, dtype=np.int64)
+    for r in range(rows):
+        centers = (mids * float(scale[r])).astype(np.float32)
+        centers = centers[centers != 0]
+        n = min(len(centers), K // per)
+        sel = rng.choice(len(centers), n, replace=False)
+        for k, ci in enumerate(sel):
+            c = centers[ci]
+            bits = np.abs(c).view(np.uint32).astype(np.int64) + offs
+            vals = bits.astype(np.uint32).view(np.float32) * np.sign(c)
+            x[r, k * per:(k + 1) * per] = vals
+    if gname.endswith("_u"):
+        x = np.abs(x)
+    run_case(antq_lib, oracle, dev, x, alpha, g, gmax, True, ovp, False)
+    run_case(antq_lib, oracle, dev, x, alpha, g, gmax, True, ovp, True)

@@ -112,6 +112,21 @@ __global__ void __launch_bounds__(256) copy_rows_nt(const uint4 *__restrict__ s,
 #pragma unroll
     for (int u = 0; u < U; u++) if (base + u * 512 < n) __builtin_nontemporal_store(v[u], dp + base + u * 512);
 }
+// C6: mixed cache policies for the U=4 wave-contiguous copy
+template <int U, bool LNT, bool SNT>
+__global__ void __launch_bounds__(256) copy_mix(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
+{
+    size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    size_t first = wave * (64 * U) + (threadIdx.x & 63);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 *sp = reinterpret_cast<const u4 *>(s);
+    u4 *dp = reinterpret_cast<u4 *>(d);
+    u4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (first + 64 * u < n) v[u] = LNT ? __builtin_nontemporal_load(sp + first + 64 * u) : sp[first + 64 * u];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (first + 64 * u < n) { if (SNT) __builtin_nontemporal_store(v[u], dp + first + 64 * u); else dp[first + 64 * u] = v[u]; }
+}
 // D: persistent grid-stride, G blocks, each iteration block copies 4 KiB*U, prefetch depth 1
 template <int U, bool NT>
 __global__ void __launch_bounds__(256) copy_persist(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
@@ -238,6 +253,10 @@ int main(int argc, char **argv)
     run(B, "copy_wave_nt<1>", reps, moved, L(copy_wave_nt<1>, (n + 255) / 256));
     run(B, "copy_wave_nt<2>", reps, moved, L(copy_wave_nt<2>, (n + 511) / 512));
     run(B, "copy_wave_nt<4>", reps, moved, L(copy_wave_nt<4>, (n + 1023) / 1024));
+    run(B, "copy_mix<4> load nt, store plain", reps, moved, L((copy_mix<4, true, false>), (n + 1023) / 1024));
+    run(B, "copy_mix<4> load plain, store nt", reps, moved, L((copy_mix<4, false, true>), (n + 1023) / 1024));
+    run(B, "copy_mix<1> load nt, store plain", reps, moved, L((copy_mix<1, true, false>), (n + 255) / 256));
+    run(B, "copy_mix<1> load plain, store nt", reps, moved, L((copy_mix<1, false, true>), (n + 255) / 256));
     run(B, "copy_streams_nt<2>", reps, moved, L(copy_streams_nt<2>, (n / 2 + 255) / 256));
     run(B, "copy_streams_nt<4>", reps, moved, L(copy_streams_nt<4>, (n / 4 + 255) / 256));
     run(B, "copy_rows_nt<2>", reps, moved, L(copy_rows_nt<2>, (n / 2 + 255) / 256));
