@@ -5,7 +5,7 @@
 namespace antq {
 
 constexpr uint32_t kPlanMagic = 0x51544E41u;  // "ANTQ"
-constexpr uint32_t kPlanVersion = 4;
+constexpr uint32_t kPlanVersion = 5;
 
 constexpr uint32_t kPlanScan = 0;  // kernels run the literal scan for every element
 constexpr uint32_t kPlanLut = 1;   // table plan: one LDS lookup + one compare per element
@@ -42,7 +42,9 @@ struct PlanHeader {      // 80 bytes
     // bucket edge, and the straight-through step (q-d)+d is provably == q for |d| <= 2 max|v|.
     uint32_t xdom;
     float xlim;          // |x*rcp(s)| < xlim  ->  x-domain table path
-    uint32_t reserved[2];
+    float vout;          // smallest |v| > 32 in the grid (+inf if none): in the x-domain table an output o = fl(v*s)
+                         // belongs to an OliVe outlier (|v| > 32, OQ:314) iff |o| >= fl(vout*s)
+    uint32_t reserved;
 };
 static_assert(sizeof(PlanHeader) == 80, "PlanHeader must be 80 bytes");
 

@@ -496,6 +496,7 @@ struct XArgs {
     uint32_t nbneg;
     uint32_t n_entries;
     float xlim;
+    float vout;
 };
 
 __device__ __forceinline__ float f_up(float c)   // next float towards +inf (c != 0)
@@ -540,6 +541,7 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
         const uint32_t neg16 = xa.nbneg << 4;
         const char *t0 = reinterpret_cast<const char *>(wtab) - lo16;
         bool isout[EPL];
+        const float othr = xa.vout * sc.s;
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
             const int32_t u = (int32_t)f2u(dt[e]);
@@ -547,10 +549,10 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
             const int32_t c16 = min(max(t, lo16), hi16);
             const uint32_t sg = (uint32_t)(u >> 31) & neg16;
             uint4 ent = *reinterpret_cast<const uint4 *>(t0 + c16 + sg);
-            if (!IDX && !OVP) asm volatile("" : "+v"(ent.w));
+            if (!IDX) asm volatile("" : "+v"(ent.w));
             const bool c = x[e] >= u2f(ent.x);
             o[e] = c ? u2f(ent.z) : u2f(ent.y);
-            if (OVP) isout[e] = ((c ? (ent.w >> 31) : (ent.w >> 15)) & 1u) != 0;
+            if (OVP) isout[e] = fabsf(o[e]) >= othr;      // |v| > 32 (PlanHeader::vout)
             if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
         }
         if (OVP) {
@@ -1274,7 +1276,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
         if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
         XArgs xa;
         xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim;
+        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
         const uint4 *entries = tab + (pa.m_pad >> 2);
         const float *grid = reinterpret_cast<const float *>(tab);
         const dim3 grid_dim((unsigned)((total + 3) / 4)), block(256);
@@ -1752,7 +1754,7 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
         if (task >= D.total_tasks) return;
         XArgs xa;
         xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]);
+        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]); xa.vout = u2f(D.pad[1]);
         xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
                                               nullptr, xa, plan_tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
                                               wtab_all[wv], lane, wv);
@@ -1872,6 +1874,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             if (d.kind == 0 && g_knob_x && d.pa.kind == kPlanLut && ph->xdom && d.vpr >= 256) {
                 d.kind = 2;
                 memcpy(&d.pad[0], &ph->xlim, 4);
+                memcpy(&d.pad[1], &ph->vout, 4);
             }
         }
         if (total_blocks + blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;

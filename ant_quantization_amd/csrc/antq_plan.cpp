@@ -283,6 +283,16 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         h.xlim = (float)xl;
         if ((double)h.xlim > xl) h.xlim = next_dn(h.xlim);
         if (!(fabsf(T[0]) < h.xlim) || !(fabsf(T[k - 2]) < h.xlim)) ok = false;
+        // outlier test on the pre-multiplied outputs: |v| > 32  <=>  |fl(v*s)| >= fl(vout*s) needs the largest
+        // normal magnitude and the smallest outlier magnitude to stay distinct after the multiply
+        float vout = INFINITY, vnorm = 0.0f;
+        for (int i = 0; i < k; i++) {
+            const float a = fabsf(dv[i].v);
+            if (a > 32.0f) vout = std::min(vout, a);
+            else vnorm = std::max(vnorm, a);
+        }
+        if (vout < INFINITY && !((double)vout >= (double)vnorm * (1.0 + 0x1p-20))) ok = false;
+        h.vout = vout;
         h.xdom = ok ? 1u : 0u;
     }
 

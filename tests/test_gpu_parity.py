@@ -750,3 +750,36 @@ def test_x_domain_thresholds_dense_sweep(antq_lib, oracle, dev, gname):
         x = np.abs(x)
     run_case(antq_lib, oracle, dev, x, alpha, g, gmax, True, ovp, False)
     run_case(antq_lib, oracle, dev, x, alpha, g, gmax, True, ovp, True)
+
+
+def test_c4_llama70b_sized_tensor_sampled_rows(antq_lib, oracle, dev):
+    """C4: the largest tensor of the synthetic 70B stack, [28672, 8192] bf16 (470 MB in, 470 MB out),
+    OliVe flint-4 with outlier-victim pairs.  The oracle checks 96 rows drawn from the whole height (values and
+    indices, bit-exact); the pair invariant and the one-launch batch path are checked on every element."""
+    import torch
+    O = golden("olive_grids.npz")
+    gn, go = O["flint_b4_s"], O["outlier_b4_s"]
+    grid = np.concatenate([gn, go])
+    plan = antq_lib.plan_for(grid)
+    R, K = 28672, 8192
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(R, K, device=dev, generator=gen) * 0.02
+    m = torch.rand(x.shape, device=dev, generator=gen) < 0.001
+    x[m] *= torch.empty(int(m.sum()), device=dev).uniform_(8, 64, generator=gen)
+    xb = x.bfloat16()
+    alpha = (3 * x.std(1)).contiguous()
+    del x, m
+    out, idx = antq_lib.fakequant(xb, alpha, plan, 32.0, R, K, True, ovp=True, want_idx=True)
+    rows = np.unique(np.concatenate([np.arange(16), np.arange(R - 16, R), np.random.default_rng(5).integers(0, R, 64)]))
+    rt = torch.from_numpy(rows).to(dev)
+    ref, ridx = oracle.forward(bf16_bits(xb[rt]), alpha[rt].cpu().numpy(), grid, 32.0, True)
+    assert bf16_same(bf16_bits(out[rt]), ref, oracle)
+    assert np.array_equal(idx[rt].cpu().numpy().astype(np.int32), ridx)
+    pairs = idx.view(-1, 2)
+    is_out, is_vic = pairs >= gn.size, pairs == antq_lib.IDX_VICTIM
+    assert is_out.any() and not (is_out[:, 0] & is_out[:, 1]).any()
+    assert (is_vic.any(1) == is_out.any(1)).all() and (out.view(-1, 2)[is_vic] == 0).all()
+    del pairs, is_out, is_vic, idx
+    ob = torch.empty_like(xb)
+    antq_lib.Batch([(xb, ob, alpha, plan, 32.0, R, K, True)], ovp=True).run()
+    assert torch.equal(ob.view(torch.int16), out.view(torch.int16))

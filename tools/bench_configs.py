@@ -49,6 +49,14 @@ def opt67_shapes(layers=32):
     return s
 
 
+def llama70b_shapes(layers=80):
+    """C4: synthetic 70B-parameter Linear stack: 80 x {[8192,8192] x2, [1024,8192] x2, [28672,8192] x2, [8192,28672]}."""
+    s = []
+    for _ in range(layers):
+        s += [(8192, 8192)] * 2 + [(1024, 8192)] * 2 + [(28672, 8192)] * 2 + [(8192, 28672)]
+    return s
+
+
 def timed(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -162,6 +170,29 @@ def main():
         report("C3 OPT-6.7B W (%d tensors), OliVe flint4 OVP, %s, BATCHED" % (len(ws), str(dt)[6:]), elems, bpe,
                timed(bt.run, 5), 1)
         del ws, outs, al, bt
+
+    # ---------------- C4: 70B-parameter bf16 Linear stack, OliVe flint4 OVP: this rank's 1/8 share (LPT by bytes)
+    from ant_quantization_amd import sharding
+    shapes = llama70b_shapes()
+    share = sharding.lpt_assign([2 * a * b for a, b in shapes], 8)[0]
+    gen = torch.Generator(device=dev).manual_seed(5)
+    ws = []
+    for i in share:
+        w = torch.randn(*shapes[i], device=dev, generator=gen) * 0.02
+        m = torch.rand(w.shape, device=dev, generator=gen) < 0.001
+        w[m] *= torch.empty(int(m.sum()), device=dev).uniform_(8, 64, generator=gen)
+        ws.append(w.to(torch.bfloat16))
+        del w, m
+    elems = sum(w.numel() for w in ws)
+    al = [(3 * w.float().std(1)).contiguous() for w in ws]
+    outs = [torch.empty_like(w) for w in ws]
+    bt = _lib.Batch([(w, o, a, pol, 32.0, w.shape[0], w.shape[1], True) for w, a, o in zip(ws, al, outs)], ovp=True)
+    report("C4 70B bf16 W, rank 0 of 8 (%d tensors, %.1f GB in), OliVe flint4 OVP, BATCHED" % (len(ws), elems * 2 / 1e9),
+           elems, 4, timed(bt.run, 5), 1)
+    report("C4 same share, one launch per tensor", elems, 4,
+           timed(lambda: [_lib.fakequant(w, a, pol, 32.0, w.shape[0], w.shape[1], True, ovp=True, out=o) for w, a, o in zip(ws, al, outs)], 3), len(ws))
+    del ws, outs, al, bt
+    torch.cuda.empty_cache()
 
     # ---------------- headline variants
     for dt, bpe in ((torch.bfloat16, 4), (torch.float32, 8)):
