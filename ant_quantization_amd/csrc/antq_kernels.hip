@@ -535,20 +535,21 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
         fast = fast && (fabsf(dt[e]) < xa.xlim);
     }
     if (fast) {
-        const int32_t sh4 = (int32_t)xa.shift - 4;
-        const int32_t km16 = (int32_t)(xa.keymask << 4);
-        const int32_t lo16 = (int32_t)(xa.kmin << 4), hi16 = (int32_t)(xa.kmax << 4);
-        const uint32_t neg16 = xa.nbneg << 4;
-        const char *t0 = reinterpret_cast<const char *>(wtab) - lo16;
+        // slot = 2 * clamp(key) + sign: positive and negative buckets interleaved, so that the sign costs one
+        // v_alignbit and the clamp one v_med3 (an unsigned grid keeps a negative key: it clamps to kmin, slot 1)
+        const int32_t sh = (int32_t)xa.shift, km = (int32_t)xa.keymask;
+        const int32_t lo = (int32_t)xa.kmin, hi = (int32_t)xa.kmax;
+        const char *t0 = reinterpret_cast<const char *>(wtab) - (lo << 5);
         bool isout[EPL];
         const float othr = xa.vout * sc.s;
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
             const int32_t u = (int32_t)f2u(dt[e]);
-            const int32_t t = (u >> sh4) & km16;
-            const int32_t c16 = min(max(t, lo16), hi16);
-            const uint32_t sg = (uint32_t)(u >> 31) & neg16;
-            uint4 ent = *reinterpret_cast<const uint4 *>(t0 + c16 + sg);
+            const int32_t t = (u >> sh) & km;
+            int32_t ck;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+            const uint32_t slot = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);
+            uint4 ent = *reinterpret_cast<const uint4 *>(t0 + (slot << 4));
             if (!IDX) asm volatile("" : "+v"(ent.w));
             const bool c = x[e] >= u2f(ent.x);
             o[e] = c ? u2f(ent.z) : u2f(ent.y);
@@ -651,13 +652,20 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
         if (rowfast && lane < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
         rowfast = rowfast && __all(ok);
         // (v + 0) * s: a -0.0 grid entry must come out as +0.0, like the reference's (q - d) + d
-        wtab[lane] = make_uint4(f2u(Ux), f2u((u2f(ent.y) + 0.0f) * sc.s), f2u((u2f(ent.z) + 0.0f) * sc.s), ent.w);
+        // entry i is positive bucket i (slot 2i) or negative bucket i - nb (slot 2(i - nb) + 1)
+        const uint32_t nbp = xa.n_entries - xa.nbneg;
+        const uint4 w0 = make_uint4(f2u(Ux), f2u((u2f(ent.y) + 0.0f) * sc.s), f2u((u2f(ent.z) + 0.0f) * sc.s), ent.w);
+        if (lane < xa.n_entries) wtab[lane < nbp ? 2u * lane : 2u * (lane - nbp) + 1u] = w0;
+        if (xa.nbneg == 0u && lane == 0u) wtab[1] = w0;     // unsigned grid: every negative x lands in slot 1
         if (two) {
             bool ok2 = true;
             float U2 = u2f(ent2.x);
-            if (rowfast && lane + 64u < xa.n_entries && U2 < __builtin_inff()) U2 = x_threshold(U2, sc.s, sc.rs, ok2);
+            const uint32_t i2 = lane + 64u;
+            if (rowfast && i2 < xa.n_entries && U2 < __builtin_inff()) U2 = x_threshold(U2, sc.s, sc.rs, ok2);
             rowfast = rowfast && __all(ok2);
-            wtab[lane + 64u] = make_uint4(f2u(U2), f2u((u2f(ent2.y) + 0.0f) * sc.s), f2u((u2f(ent2.z) + 0.0f) * sc.s), ent2.w);
+            if (i2 < xa.n_entries)
+                wtab[i2 < nbp ? 2u * i2 : 2u * (i2 - nbp) + 1u] =
+                    make_uint4(f2u(U2), f2u((u2f(ent2.y) + 0.0f) * sc.s), f2u((u2f(ent2.z) + 0.0f) * sc.s), ent2.w);
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
@@ -684,7 +692,7 @@ k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
           float *__restrict__ alpha_out, XArgs xa, const uint4 *__restrict__ entries,
           const float *__restrict__ grid)
 {
-    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][128];
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
@@ -1748,7 +1756,7 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
 
     if (D.kind == 2) {
         // x-domain rows: wave-private table, no workgroup barrier
-        __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][128];
+        __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
         const uint32_t wv = threadIdx.x >> 6;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
         if (task >= D.total_tasks) return;
