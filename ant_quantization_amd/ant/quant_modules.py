@@ -92,6 +92,7 @@ class Quantizer(nn.Module):
         self._plan = None         # _lib.Plan of the installed grid
         self._gmax = 10.0
         self._grid_key = None
+        self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
 
     # ---------------------------------------------------------------- bookkeeping
     def disable_input_quantization(self):
@@ -306,6 +307,11 @@ class Quantizer(nn.Module):
 
         with torch.no_grad():
             self._init_quant_para(tensor, input_tensor)
+
+        if self._bank is not None:
+            hit = self._bank.lookup(self, tensor)
+            if hit is not None:
+                return hit
 
         if self.mode == 'outlier':
             q_tensor = self.outlier_quant(tensor)

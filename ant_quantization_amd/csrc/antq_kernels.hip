@@ -1087,21 +1087,34 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
             if (lane == 0) amax[r] = u2f(m);
         }
     } else {
+        // one scale for the whole tensor: block-strided, four independent 16-byte loads in flight per lane, one
+        // atomicMax per workgroup (plain loads: the clip search reads the same bytes next, out of the Infinity Cache)
         const size_t n = rows * row_len;
+        const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, stride = (size_t)gridDim.x * 256u;
         uint32_t m = 0;
         if (vec_ok) {
             const uint4 *p = static_cast<const uint4 *>(x);
             const size_t nv = n / EPL;
             uint32_t mp = 0;
-            for (size_t i = wave * 64 + lane; i < nv; i += nwaves * 64) mp = IO<T>::amax_acc(mp, p[i]);
+            size_t i = tid;
+            for (; i + 3 * stride < nv; i += 4 * stride) {
+                const uint4 a0 = p[i], a1 = p[i + stride], a2 = p[i + 2 * stride], a3 = p[i + 3 * stride];
+                mp = IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(mp, a0), a1), a2), a3);
+            }
+            for (; i < nv; i += stride) mp = IO<T>::amax_acc(mp, p[i]);
             m = IO<T>::amax_bits(mp);
-            for (size_t i = nv * EPL + wave * 64 + lane; i < n; i += nwaves * 64)
-                m = max(m, f2u(IO<T>::load1(x, i)) & 0x7fffffffu);
+            for (size_t k = nv * EPL + tid; k < n; k += stride) m = max(m, f2u(IO<T>::load1(x, k)) & 0x7fffffffu);
         } else {
-            for (size_t i = wave * 64 + lane; i < n; i += nwaves * 64) m = max(m, f2u(IO<T>::load1(x, i)) & 0x7fffffffu);
+            for (size_t k = tid; k < n; k += stride) m = max(m, f2u(IO<T>::load1(x, k)) & 0x7fffffffu);
         }
         m = wave_max_u32(m);
-        if (lane == 0 && m) atomicMax(reinterpret_cast<unsigned int *>(amax), m);
+        __shared__ uint32_t wm[4];
+        if (lane == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+            if (m) atomicMax(reinterpret_cast<unsigned int *>(amax), m);
+        }
     }
 }
 
@@ -1113,7 +1126,9 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
 // Same task decomposition as K1a (U*64 vectors of one row per task); tasks of one row add
 // their partial sums with a double atomicAdd.
 // ------------------------------------------------------------------------------------
-template <typename T, bool OVP, int U>
+constexpr int kPtCand = 128;   // candidates per workgroup in the one-scale-per-tensor mode (LDS accumulators)
+
+template <typename T, bool OVP, int U, bool PT>
 __global__ void __launch_bounds__(256)
 k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
              const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand, float gmax,
@@ -1128,6 +1143,12 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    // PT (one scale for the whole tensor): every task adds to the same ncand sums.  Global atomics on 75 addresses
+    // from every task serialise in L2 (measured: 4x the arithmetic), so each wavefront keeps its sums in LDS and the
+    // workgroup issues one atomic per candidate at the end.
+    __shared__ double wacc[PT ? 4 : 1][PT ? kPtCand : 1];
+    if (PT)
+        for (int c = (int)lane; c < kPtCand; c += 64) wacc[threadIdx.x >> 6][c] = 0.0;
     __syncthreads();
     const size_t na = per_row ? rows : 1;
     for (uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6); task < total_tasks; task += gridDim.x * 4u) {
@@ -1159,11 +1180,18 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-            if (lane == 0) {
+            if (PT) {
+                if (lane == 0) wacc[threadIdx.x >> 6][c - c_begin] += acc;
+            } else if (lane == 0) {
                 double *dst = sse + (size_t)c * na + (per_row ? row : 0);
                 if (per_row && tpr == 1) *dst = acc; else atomicAdd(dst, acc);
             }
         }
+    }
+    if (PT) {
+        __syncthreads();
+        for (int c = (int)threadIdx.x; c < c_end - c_begin; c += 256)
+            atomicAdd(sse + (size_t)(c_begin + c), (wacc[0][c] + wacc[1][c]) + (wacc[2][c] + wacc[3][c]));
     }
 }
 
@@ -1552,9 +1580,9 @@ static int launch_absmax(const void *x, float *amax, size_t rows, size_t row_len
     constexpr int EPL = IO<T>::EPL;
     const bool al = reinterpret_cast<uintptr_t>(x) % 16 == 0;
     const int vec_ok = per_row ? (al && row_len % EPL == 0) : al;
-    size_t waves = per_row ? rows : (rows * row_len + 64 * EPL * 8 - 1) / (64 * EPL * 8);
+    size_t waves = per_row ? rows : (rows * row_len + 64 * EPL * 4 - 1) / (64 * EPL * 4);
     size_t blocks = (waves + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > (per_row ? 4096u : 1024u)) blocks = per_row ? 4096 : 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((k_absmax<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, amax, rows, row_len, per_row, vec_ok);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
@@ -1638,15 +1666,23 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+    const bool pt = rows == 1;
     size_t blocks = (total + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    const size_t cap = pt ? 256 * 4 : 256 * 8;
+    if (blocks > cap) blocks = cap;
     // enough wavefronts to fill 256 CUs x 8 waves/SIMD: split the candidates when there are few rows
     int chunks = (int)std::min<size_t>((size_t)ncand, std::max<size_t>(1, (size_t)2048 / blocks));
+    if (pt) chunks = std::max(chunks, (ncand + kPtCand - 1) / kPtCand);
     const int cand_chunk = (ncand + chunks - 1) / chunks;
     chunks = (ncand + cand_chunk - 1) / cand_chunk;
-    hipLaunchKernelGGL((k_search_sse<T, OVP, U>), dim3((unsigned)blocks, (unsigned)chunks), dim3(256), lds, st,
-                       static_cast<const uint4 *>(x), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row,
-                       ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev), cand_chunk);
+    if (pt)
+        hipLaunchKernelGGL((k_search_sse<T, OVP, U, true>), dim3((unsigned)blocks, (unsigned)chunks), dim3(256), lds, st,
+                           static_cast<const uint4 *>(x), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax,
+                           per_row, ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev), cand_chunk);
+    else
+        hipLaunchKernelGGL((k_search_sse<T, OVP, U, false>), dim3((unsigned)blocks, (unsigned)chunks), dim3(256), lds, st,
+                           static_cast<const uint4 *>(x), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax,
+                           per_row, ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev), cand_chunk);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 

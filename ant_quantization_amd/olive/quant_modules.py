@@ -71,6 +71,7 @@ class Quantizer(nn.Module):
         self._steady = False
         self._plan = None
         self._gmax = 32.0
+        self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
 
     # ---------------------------------------------------------------- bookkeeping
     def disable_input_quantization(self):
@@ -247,6 +248,10 @@ class Quantizer(nn.Module):
             if not self.is_enable_weight:
                 return tensor
         self._init_quant_para(tensor, input_tensor)
+        if self._bank is not None:
+            hit = self._bank.lookup(self, tensor)
+            if hit is not None:
+                return hit
         return self._forward(tensor)
 
 

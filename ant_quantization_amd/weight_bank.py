@@ -1,0 +1,134 @@
+"""One launch for every calibrated weight quantiser of a model.
+
+The reference re-quantises each layer's weight on every forward, one small kernel sequence per layer
+(AQ:608-611, :641-644; OQ:413-416, :443-446).  For ResNet-50 that is 54 launches of a few tens of KB to
+a few MB each -- launch-bound, 7 % of the HBM roofline here -- while the same bytes through ONE
+multi-tensor launch (`antq_fakequant_batch`) reach 65 %, and 79 % for LLM-sized tensors.
+
+`WeightBank(model)` collects the steady-state weight quantisers of the wrapper layers, quantises all
+their weights in one launch into resident buffers, and hands each layer its buffer on forward.  The
+result is the same tensor the per-layer kernel would have produced (same kernels underneath, parity
+tested bit-exact); what changes is WHEN the work happens:
+
+  * weights and alphas are stamped by (`data_ptr`, `_version`); a layer whose stamp is stale triggers one
+    refresh of the whole bank (so a QAT-style optimiser step costs one launch per step, not one per layer);
+  * a forward that needs gradients through the quantiser bypasses the bank (autograd path, AQ:544-549);
+  * in-place edits through `.data` do not bump `_version` -- call `bank.invalidate()` after those.
+
+Opt-in: nothing in `quantize_model` attaches a bank by itself.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["WeightBank"]
+
+
+def _weight_layers(model):
+    for name, mod in model.named_modules():
+        q = getattr(mod, "quant_weight", None)
+        w = getattr(mod, "weight", None)
+        if q is not None and isinstance(w, torch.Tensor) and hasattr(q, "tensor_forward"):
+            yield name, mod, q, w
+
+
+class WeightBank:
+    def __init__(self, model):
+        self.model = model
+        self.entries = {}          # id(quantiser) -> dict
+        self._batches = []
+        self._ptr_key = None
+        self.launches = 0          # refreshes run so far (for tests / logging)
+        self.skipped = []          # (layer name, reason) of layers the bank leaves to the per-layer path
+        for name, mod, q, w in _weight_layers(model):
+            reason = self._unsuitable(q, w)
+            if reason:
+                self.skipped.append((name, reason))
+                continue
+            rows, row_len = (w.shape[0], w.numel() // w.shape[0]) if q.is_perchannel else (1, w.numel())
+            self.entries[id(q)] = dict(name=name, q=q, mod=mod, rows=rows, row_len=row_len,
+                                       out=torch.empty_like(w, memory_format=torch.contiguous_format), stamp=None)
+            q._bank = self
+        if not self.entries:
+            raise _lib.AntqError("WeightBank: no calibrated weight quantiser found (run one forward to calibrate first)")
+
+    @staticmethod
+    def _unsuitable(q, w):
+        if q.mode in ("base", "outlier"):
+            return "mode %s" % q.mode
+        if not (q.is_enable and q.is_enable_weight):
+            return "quantisation disabled"
+        if not q._steady:
+            return "not calibrated yet"
+        if not w.is_cuda or not w.is_contiguous():
+            return "weight not resident / not contiguous"
+        if w.dtype not in _lib._DTYPES or w.dtype == torch.float64:
+            return "dtype %s" % w.dtype
+        return None
+
+    # ------------------------------------------------------------------ bookkeeping
+    @staticmethod
+    def _stamp(q, w):
+        a = q.alpha
+        return (w.data_ptr(), w._version, a.data_ptr(), a._version, id(q._plan), q._gmax)
+
+    def invalidate(self):
+        for e in self.entries.values():
+            e["stamp"] = None
+
+    def detach(self):
+        for e in self.entries.values():
+            e["q"]._bank = None
+        self.entries.clear()
+        self._batches = []
+
+    def _build(self):
+        """(Re)build the descriptor tables: one batch per (dtype, victim-pairs on/off)."""
+        groups = {}
+        keep = []
+        for e in self.entries.values():
+            q, w = e["q"], e["mod"].weight
+            plan = q._ensure_plan()
+            alpha = q.alpha.detach().reshape(-1)
+            if alpha.dtype != torch.float32 or not alpha.is_contiguous():
+                alpha = alpha.to(torch.float32).contiguous()
+                e["alpha_copy"] = True       # stamps then also cover the copy: rebuilt whenever alpha changes
+            else:
+                e["alpha_copy"] = False
+            keep.append(alpha)
+            ovp = bool(getattr(q, "_no_outlier", True) is False)
+            groups.setdefault((w.device, w.dtype, ovp), []).append(
+                (w.detach(), e["out"], alpha, plan, q._gmax, e["rows"], e["row_len"], bool(q.is_perchannel)))
+        self._batches = [_lib.Batch(jobs, ovp=ovp) for (_, _, ovp), jobs in groups.items()]
+        self._keep = keep
+        self._ptr_key = self._pointers()
+
+    def _pointers(self):
+        return tuple((e["mod"].weight.data_ptr(), e["q"].alpha.data_ptr(), id(e["q"]._plan), e["q"]._gmax)
+                     for e in self.entries.values())
+
+    # ------------------------------------------------------------------ the one launch
+    @torch.no_grad()
+    def refresh(self):
+        need_build = self._ptr_key != self._pointers() or any(e.get("alpha_copy") for e in self.entries.values())
+        if need_build or not self._batches:
+            self._build()
+        for b in self._batches:
+            b.run()
+        self.launches += 1
+        for e in self.entries.values():
+            e["stamp"] = self._stamp(e["q"], e["mod"].weight)
+
+    def lookup(self, q, tensor):
+        """Called from TensorQuantizer.tensor_forward in steady state.  Returns the resident fake-quantised
+        weight, or None when this forward has to take the per-layer path."""
+        e = self.entries.get(id(q))
+        if e is None or tensor is not e["mod"].weight:
+            return None
+        if torch.is_grad_enabled() and (tensor.requires_grad or q.alpha.requires_grad):
+            return None
+        if not q._steady or not (q.is_enable and q.is_enable_weight):
+            return None
+        if e["stamp"] != self._stamp(q, tensor):
+            self.refresh()
+        return e["out"]

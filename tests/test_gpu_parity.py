@@ -783,3 +783,60 @@ def test_c4_llama70b_sized_tensor_sampled_rows(antq_lib, oracle, dev):
     ob = torch.empty_like(xb)
     antq_lib.Batch([(xb, ob, alpha, plan, 32.0, R, K, True)], ovp=True).run()
     assert torch.equal(ob.view(torch.int16), out.view(torch.int16))
+
+
+def test_weight_bank_one_launch_for_all_layers(antq_lib, dev):
+    """WeightBank: every calibrated weight quantiser of a model served from ONE batched launch -- same bits as the
+    per-layer path, refreshed when a weight or alpha changes, bypassed when gradients are wanted."""
+    import torch
+    from ant_quantization_amd.weight_bank import WeightBank
+    from ant_quantization_amd.ant import quant_model as aqm, quant_utils as aqu
+    from ant_quantization_amd.olive import quant_model as oqm, quant_utils as oqu
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = torch.nn.Conv2d(3, 16, 3, padding=1)        # K = 27: ragged, stays a single launch in the batch
+            self.c2 = torch.nn.Conv2d(16, 32, 3, padding=1)       # K = 144
+            self.f1 = torch.nn.Linear(32, 512)
+            self.f2 = torch.nn.Linear(512, 10)
+
+        def forward(self, x):
+            x = torch.relu(self.c2(torch.relu(self.c1(x)))).mean((2, 3))
+            return self.f2(torch.relu(self.f1(x)))
+
+    for qmod, qutil, mode in ((aqm, aqu, "ant-int-flint"), (oqm, oqu, "ant-int-flint")):
+        qutil.set_quantizer(_args(mode=mode, wbit=4, abit=4))
+        torch.manual_seed(3)
+        model = qmod.quantize_model(Net()).to(dev).eval()
+        qutil.enable_quantization(model)
+        x = torch.randn(8, 3, 16, 16, device=dev)
+        with torch.no_grad():
+            model(x)                       # calibrate
+            y_ref = model(x)               # per-layer launches
+        bank = WeightBank(model)
+        assert len(bank.entries) == 4 and not bank.skipped
+        with torch.no_grad():
+            y1 = model(x)
+            y2 = model(x)
+        assert torch.equal(y1, y_ref) and torch.equal(y2, y_ref) and bank.launches == 1
+        for e in bank.entries.values():    # each resident buffer == what the quantiser produces on its own
+            e["q"]._bank = None
+            with torch.no_grad():
+                assert torch.equal(e["q"](e["mod"].weight), e["out"])
+            e["q"]._bank = bank
+        # an optimiser-style in-place update of one weight refreshes the bank once, at the first stale layer
+        with torch.no_grad():
+            model.f1.weight.mul_(1.01)
+            y3 = model(x)
+        assert bank.launches == 2
+        bank.detach()
+        with torch.no_grad():
+            assert torch.equal(model(x), y3)
+        assert not torch.equal(y3, y_ref)
+        # with gradients wanted (ANT QAT) the bank steps aside
+        bank = WeightBank(model)
+        model(x).sum().backward() if qmod is aqm else None
+        assert bank.launches == 0
+        if qmod is aqm:
+            assert model.f1.weight.grad is not None and model.f1.quant_weight.alpha.grad is not None
