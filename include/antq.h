@@ -18,7 +18,8 @@
  *     never allocates, frees or synchronises; all work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream);
  *   - return 0 on success, a negative ANTQ_ERR_* otherwise; no exceptions;
- *   - re-entrant and thread-safe (no global mutable state).
+ *   - re-entrant and thread-safe: no global mutable state (the antq_debug_set development knobs aside);
+ *     nothing here allocates or synchronises, so every entry point can be captured into a hipGraph;
  *   - results: grid index bit-exact with the reference scan; dequantised floats
  *     bit-identical to the reference's fp32 op sequence (bf16/f16 outputs are the
  *     fp32 result rounded to nearest-even).
@@ -222,7 +223,9 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
 
 /* Development / benchmark tuning knobs (process-global; not part of the stable surface):
  *   key 0: force the per-task unroll U of the row kernels (0 = heuristic)
- *   key 1: force the persistent grid size in workgroups   (0 = heuristic) */
+ *   key 1: unused
+ *   key 2: 0 disables the per-row (x-domain) table kernels, the d-domain kernels run instead (A/B measurements)
+ *   key 3: 0 disables the binary-search path of antq_nearest (literal scan only) */
 int antq_debug_set(int key, int value);
 
 #ifdef __cplusplus

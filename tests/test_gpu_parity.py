@@ -840,3 +840,39 @@ def test_weight_bank_one_launch_for_all_layers(antq_lib, dev):
         assert bank.launches == 0
         if qmod is aqm:
             assert model.f1.weight.grad is not None and model.f1.quant_weight.alpha.grad is not None
+
+
+def test_entry_points_capture_into_a_hip_graph(antq_lib, dev):
+    """The C ABI neither allocates nor synchronises: a per-tensor launch and a batched launch captured into a
+    hipGraph replay to the same bits on fresh data in the captured buffers."""
+    import torch
+    g = golden("ant_grids.npz")["flint_b4_s"]
+    plan = antq_lib.plan_for(g)
+    plan.dev(dev)                                     # table upload happens outside the capture
+    torch.manual_seed(11)
+    xs = [torch.randn(256, 1024, device=dev) * 0.02 for _ in range(3)]
+    al = [x.abs().amax(1).contiguous() for x in xs]
+    outs = [torch.empty_like(x) for x in xs]
+    one = torch.empty_like(xs[0])
+    bt = antq_lib.Batch([(x, o, a, plan, 10.0, 256, 1024, True) for x, a, o in zip(xs, al, outs)])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                        # warm-up on the side stream, as graph capture wants
+        bt.run()
+        antq_lib.fakequant(xs[0], al[0], plan, 10.0, 256, 1024, True, out=one)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        bt.run()
+        antq_lib.fakequant(xs[0], al[0], plan, 10.0, 256, 1024, True, out=one)
+    for x in xs:                                      # new data, same buffers
+        x.mul_(1.7).add_(0.003)
+    for x, a in zip(xs, al):
+        a.copy_(x.abs().amax(1))
+    for o in outs + [one]:
+        o.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for x, a, o in zip(xs, al, outs):
+        assert torch.equal(o, antq_lib.fakequant(x, a, plan, 10.0, 256, 1024, True))
+    assert torch.equal(one, outs[0])
