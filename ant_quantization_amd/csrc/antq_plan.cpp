@@ -278,11 +278,29 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
                 else if (nb->T != t) ok = false;
             }
         }
-        const double stelim = 2.0 * vabs;   // (q-d)+d == q whenever |q-d| <= |d| <= 2|q| (Sterbenz) or q == 0
-        double xl = std::min((double)h.fastlim, stelim) * (1.0 - 0x1p-18);
+        // The table stores fl(v*s) in place of ((q - d) + d) * s, which is only the same number when the
+        // straight-through step is exact.  q - d is exact (Sterbenz) when q/2 <= d <= 2q, and then (q - d) + d == q;
+        // q == 0 is always exact.  Every region of the step function has to satisfy this for all of its d:
+        // true of every ANT / OliVe codebook (adjacent magnitudes within a factor of two, zero included), not of
+        // arbitrary value lists -- those keep the d-domain kernels, which do the arithmetic literally.
+        auto limit_of = [](float v_edge) -> double {      // how far the outermost region may extend
+            if (v_edge == 0.0f) return INFINITY;
+            return 2.0 * fabs((double)v_edge);
+        };
+        if (dv[k - 1].v < 0.0f || dv[0].v > 0.0f) ok = false;     // a one-signed grid without zero: d of the other sign
+        double xl = std::min({(double)h.fastlim, limit_of(dv[k - 1].v), limit_of(dv[0].v)}) * (1.0 - 0x1p-18);
         h.xlim = (float)xl;
         if ((double)h.xlim > xl) h.xlim = next_dn(h.xlim);
         if (!(fabsf(T[0]) < h.xlim) || !(fabsf(T[k - 2]) < h.xlim)) ok = false;
+        for (int i = 0; i < k && ok; i++) {
+            const float v = dv[i].v;
+            if (v == 0.0f) continue;
+            // region of v: [T[i-1], T[i]) clipped to (-xlim, xlim)
+            const double lo = i > 0 ? (double)T[i - 1] : -(double)h.xlim;
+            const double hi = i + 1 < k ? (double)T[i] : (double)h.xlim;
+            if (v > 0.0f) { if (!(lo >= 0.5 * v && hi <= 2.0 * v)) ok = false; }
+            else          { if (!(hi <= 0.5 * v && lo >= 2.0 * v)) ok = false; }
+        }
         // outlier test on the pre-multiplied outputs: |v| > 32  <=>  |fl(v*s)| >= fl(vout*s) needs the largest
         // normal magnitude and the smallest outlier magnitude to stay distinct after the multiply
         float vout = INFINITY, vnorm = 0.0f;

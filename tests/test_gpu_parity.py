@@ -876,3 +876,41 @@ def test_entry_points_capture_into_a_hip_graph(antq_lib, dev):
     for x, a, o in zip(xs, al, outs):
         assert torch.equal(o, antq_lib.fakequant(x, a, plan, 10.0, 256, 1024, True))
     assert torch.equal(one, outs[0])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_grids_fuzz(antq_lib, oracle, dev, seed):
+    """Arbitrary codebooks, not just the reference's generators: random size, order, duplicates, signed zeros,
+    near-ties, geometric or uniform spacing, with and without entries beyond 32 (OliVe's outlier test).  Whatever
+    plan the builder picks (x-domain table, d-domain table, literal scan), values and indices match the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(6):
+        m = int(rng.choice([2, 3, 5, 8, 15, 16, 29, 31, 64, 200]))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            g = rng.uniform(-40, 40, m)
+        elif kind == 1:
+            g = np.sign(rng.standard_normal(m)) * np.exp(rng.uniform(np.log(0.05), np.log(400), m))
+        elif kind == 2:
+            g = np.arange(m) * rng.uniform(0.1, 3.0) + rng.uniform(-20, 0)
+        else:
+            g = np.round(rng.uniform(-12, 12, m) * 4) / 4
+        g = g.astype(np.float32)
+        if rng.random() < 0.5:
+            g = np.sort(g)
+        if rng.random() < 0.4 and m > 3:
+            g[rng.integers(0, m)] = g[rng.integers(0, m)]          # duplicate
+        if rng.random() < 0.3:
+            g[rng.integers(0, m)] = -0.0
+        if rng.random() < 0.2 and m > 2:
+            i = rng.integers(0, m - 1)
+            g[i + 1] = np.nextafter(g[i], np.float32(np.inf))       # two entries one ulp apart
+        gmax = float(np.abs(g).max()) if rng.random() < 0.5 else float(max(g.max(), 0.5))
+        rows, K = [(8, 1024), (3, 4096), (16, 200), (5, 33), (64, 16), (2, 8192)][case]
+        x = make_x(rng, rows, K, specials=bool(case % 2))
+        x *= np.float32(rng.uniform(0.5, 60))
+        alpha = (safe_absmax(x).max(1) * rng.uniform(0.3, 1.2, rows) + 1e-6).astype(np.float32)
+        ovp = bool(rng.random() < 0.5)
+        bf16 = bool(rng.random() < 0.5)
+        run_case(antq_lib, oracle, dev, x, alpha, g, gmax, True, ovp, bf16)
+        run_case(antq_lib, oracle, dev, x, np.float32(alpha.mean()), g, gmax, False, ovp, not bf16)
