@@ -3,6 +3,7 @@
 Bar: grid indices bit-exact; dequantised floats bit-identical to the fp32 op sequence of the
 reference (bf16 outputs = that result rounded to nearest-even; NaN matches NaN).
 """
+import os
 import types
 
 import numpy as np
@@ -878,7 +879,7 @@ def test_entry_points_capture_into_a_hip_graph(antq_lib, dev):
     assert torch.equal(one, outs[0])
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ANTQ_FUZZ_SEEDS", 12))))
 def test_random_grids_fuzz(antq_lib, oracle, dev, seed):
     """Arbitrary codebooks, not just the reference's generators: random size, order, duplicates, signed zeros,
     near-ties, geometric or uniform spacing, with and without entries beyond 32 (OliVe's outlier test).  Whatever
@@ -914,3 +915,84 @@ def test_random_grids_fuzz(antq_lib, oracle, dev, seed):
         bf16 = bool(rng.random() < 0.5)
         run_case(antq_lib, oracle, dev, x, alpha, g, gmax, True, ovp, bf16)
         run_case(antq_lib, oracle, dev, x, np.float32(alpha.mean()), g, gmax, False, ovp, not bf16)
+
+
+def _random_grid(rng, m):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        g = rng.uniform(-40, 40, m)
+    elif kind == 1:
+        g = np.sign(rng.standard_normal(m)) * np.exp(rng.uniform(np.log(0.05), np.log(400), m))
+    elif kind == 2:
+        g = np.arange(m) * rng.uniform(0.1, 3.0) + rng.uniform(-20, 0)
+    else:
+        g = np.round(rng.uniform(-12, 12, m) * 4) / 4
+    g = g.astype(np.float32)
+    if rng.random() < 0.6:
+        g = np.sort(g)
+    if rng.random() < 0.4 and m > 3:
+        g[rng.integers(0, m)] = g[rng.integers(0, m)]
+    if rng.random() < 0.3:
+        g[rng.integers(0, m)] = -0.0
+    return g
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ANTQ_FUZZ_SEEDS", 8))))
+def test_random_grids_fuzz_other_entry_points(antq_lib, oracle, dev, seed):
+    """The same arbitrary codebooks through the remaining entry points: antq_nearest (fp32 / fp64 / bf16, up to 1024
+    entries), antq_fakequant_dynamic, antq_search_sse + antq_search_pick, antq_fakequant_batch."""
+    import torch
+    from ant_quantization_amd import core
+    rng = np.random.default_rng(5000 + seed)
+    # --- nearest
+    for m in (int(rng.choice([2, 7, 16, 31, 33, 100, 256, 509, 1024])) for _ in range(4)):
+        g = _random_grid(rng, m)
+        hi = float(np.abs(g).max()) + 1.0
+        x = np.concatenate([rng.standard_normal(6000).astype(np.float32) * np.float32(hi / 2),
+                            rng.integers(0, 2 ** 32, 3000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                            np.repeat(g, 2) + np.tile(np.float32([1e-6, -1e-6]), g.size),
+                            ((g[:-1].astype(np.float64) + g[1:]) / 2).astype(np.float32)])
+        with np.errstate(all="ignore"):
+            zr, jr = oracle.nearest(x, g)
+            z, j = antq_lib.nearest(to_dev(x, dev), to_dev(g, dev), want_idx=True)
+            assert f32_same(z.cpu().numpy(), zr) and np.array_equal(j.cpu().numpy().astype(np.int32), jr), (m, "f32")
+            z64 = antq_lib.nearest(to_dev(x.astype(np.float64), dev), to_dev(g.astype(np.float64), dev))
+            assert f32_same(z64.cpu().numpy().astype(np.float32), zr), (m, "f64")
+            xb = oracle.f32_to_bf16(x)
+            zb_ref, _ = oracle.nearest(oracle.bf16_to_f32(xb), g)
+            zb = antq_lib.nearest(to_dev(xb, dev, True), to_dev(g, dev))
+            assert bf16_same(bf16_bits(zb), oracle.f32_to_bf16(zb_ref), oracle), (m, "bf16")
+    # --- dynamic abs-max, clip search, batch
+    jobs, refs = [], []
+    for case in range(4):
+        g = _random_grid(rng, int(rng.choice([3, 8, 15, 16, 29, 64])))
+        if not (g.max() > 0):
+            g[-1] = 1.5
+        gmax = float(g.max())
+        plan = antq_lib.plan_for(g)
+        rows, K = [(16, 1024), (64, 64), (6, 4096), (33, 200)][case]
+        x = make_x(rng, rows, K, specials=False) * np.float32(rng.uniform(0.5, 30))
+        ratio = float(np.float32(rng.uniform(0.5, 1.1)))
+        alpha = oracle.absmax(x, True, ratio)
+        ref, ridx = oracle.forward(x, alpha, g, gmax)
+        xt = to_dev(x, dev)
+        out, a_dev, idx = antq_lib.fakequant_dynamic(xt, plan, gmax, rows, K, ratio=ratio, want_idx=True)
+        assert np.array_equal(a_dev.cpu().numpy(), alpha) and f32_same(out.cpu().numpy(), ref), ("dynamic", case)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int32), ridx)
+        for per_row in (True, False):
+            xmax = core.row_absmax(xt, per_row)
+            best, al, ratios = core.clip_search(xt, xmax, per_row, 60, 130, 3, plan, gmax)
+            rb, ra, trace = oracle.search_mse(x, xmax.cpu().numpy(), 60, 130, 3, g, gmax, False, per_row)
+            r_, k_ = (rows, K) if per_row else (1, rows * K)
+            sse = antq_lib.search_sse(xt, r_, k_, xmax, per_row, ratios, plan, gmax)
+            np.testing.assert_allclose((sse / k_).float().cpu().numpy(), trace, rtol=3e-5, atol=1e-12)
+            close = np.isclose(al.cpu().numpy(), ra, rtol=1e-6)
+            if not close.all():           # only near-ties may pick a different candidate
+                srt = np.sort(trace, axis=0)
+                assert ((srt[1] - srt[0]) <= 1e-4 * srt[0])[~close].all(), ("search", case, per_row)
+        a_t = torch.from_numpy(alpha).to(dev)
+        jobs.append((xt, torch.empty_like(xt), a_t, plan, gmax, rows, K, True))
+        refs.append(ref)
+    antq_lib.Batch(jobs).run()
+    for j, ref in zip(jobs, refs):
+        assert f32_same(j[1].cpu().numpy(), ref)
