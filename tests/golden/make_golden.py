@@ -450,21 +450,75 @@ def gen_olive(outdir):
     np.savez_compressed(os.path.join(outdir, "olive_search.npz"), **srch)
 
 
+# ----------------------------------------------------------------------------
+# Wider end-to-end calibrations (one file of its own so the other fixtures stay byte-identical): the remaining modes
+# (pot, float, float1..4, apot, type lists containing them -- incl. the AQ:370-397 quirk that every -floatN search
+# runs on float_value(1) while the installed grid is float_value(N)), bit widths 2..7, narrower search windows.
+# ----------------------------------------------------------------------------
+def gen_ant_wide(outdir):
+    import torch
+    import torch.distributed as dist
+
+    _install_shim()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    sys.path.insert(0, os.path.join(REF, "ant_quantization", "antquant"))
+    import quant_modules as qm
+
+    torch.manual_seed(21)
+    w = torch.distributions.Laplace(0.0, 0.03).sample((24, 96))
+    w[::5] *= 0.3
+    xa = torch.nn.functional.gelu(torch.randn(8, 192) * 1.5)
+    xr = torch.relu(torch.randn(8, 192))
+    sel = {"w__x": w.numpy(), "xa__x": xa.numpy(), "xr__x": xr.numpy()}
+    combos = [("pot", 4), ("float", 4), ("apot", 4), ("float1", 5), ("float2", 5), ("float3", 6), ("float4", 6),
+              ("flint", 3), ("flint", 5), ("flint", 6), ("int", 2), ("int", 3), ("int", 6), ("pot", 3), ("pot", 6),
+              ("apot", 6), ("int", 7), ("flint", 7),
+              ("ant-int-pot-flint-float", 4), ("ant-float1-float2-flint", 4), ("ant-pot-float-apot", 4),
+              ("ant-int-pot-flint", 3), ("ant-int-pot-flint", 5), ("ant-int-flint-float3-apot", 6)]
+    keys = []
+    for name, x, is_input in (("w", w, False), ("xa", xa, True), ("xr", xr, True)):
+        for mode, bit in combos:
+            for lo, up in ((75, 150), (90, 110)):
+                if (lo, up) != (75, 150) and not mode.startswith("ant-"):
+                    continue
+                q = qm.TensorQuantizer(mode=mode, bit=bit, is_signed=not is_input, is_enable=True, is_input=is_input,
+                                       args=_args(w_low=lo, a_low=lo, w_up=up, a_up=up))
+                q.name = "golden"
+                if not is_input:
+                    q.alpha.data = torch.ones(x.shape[0], 1)
+                out = q(x)
+                k = "%s__%s__b%d__%d_%d" % (name, mode, bit, lo, up)
+                keys.append(k)
+                sel[k + "__mode"] = np.array(q.mode)
+                sel[k + "__signed"] = np.array(bool(q.is_signed))
+                sel[k + "__alpha"] = q.alpha.data.numpy().reshape(-1)
+                sel[k + "__grid"] = q.quant_grid.data.numpy()
+                sel[k + "__out"] = out.detach().numpy()
+                sel[k + "__mse"] = np.float32(q.mse.item())
+    sel["keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(outdir, "ant_select_wide.npz"), **sel)
+    dist.destroy_process_group()
+
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["ant", "olive", "all"], default="all")
+    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "all"], default="all")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
     if a.tree == "all":
-        for t in ("ant", "olive"):
+        for t in ("ant", "ant_wide", "olive"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", t, "--out", a.out])
         return
     import torch
     torch.set_num_threads(1)   # deterministic reductions for the recorded MSE traces
     if a.tree == "ant":
         gen_ant(a.out)
+    elif a.tree == "ant_wide":
+        gen_ant_wide(a.out)
     else:
         gen_olive(a.out)
 

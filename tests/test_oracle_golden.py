@@ -225,6 +225,62 @@ def test_search_mse_traces(oracle, tree):
             assert near_tie[~close].all(), key
 
 
+_TYPE_ORDER = ("int", "flint", "pot", "float", "float1", "float2", "float3", "float4", "apot")
+
+
+def test_full_calibration_wide_fixture_set(oracle):
+    """a11 + a12 on the CPU: type selection (AQ:328-415, incl. the -floatN searches on float_value(1)), the final clip
+    search and the forward, against 90 calibrations recorded from the reference (ant_select_wide.npz)."""
+    sel = golden("ant_select_wide.npz")
+    n_alpha = n_same = 0
+    for k in [str(v) for v in sel["keys"]]:
+        name, mode, b, win = k.split("__")
+        bit, (lo, up) = int(b[1:]), map(int, win.split("_"))
+        x = sel[name + "__x"]
+        per_row = name == "w"
+        signed = True if per_row else bool(x.min() < 0)                    # update_signed, AQ:72
+        assert signed == bool(sel[k + "__signed"]), k
+        xmax = (np.abs(x).max(1) if per_row else np.abs(x).max(keepdims=True).reshape(1)).astype(np.float32)
+        if bit > 6:
+            mode, lo = "int", 95                                              # AQ:482-483, :296-297
+        elif mode.startswith("ant-"):
+            scores = []
+            for t in _TYPE_ORDER:
+                if ("-" + t) not in mode:
+                    continue
+                g = oracle.ant_float_value(bit, signed, 1) if (t.startswith("float") and t != "float") else oracle.ant_grid(t, bit, signed)
+                best, _, _ = oracle.search_mse(x, xmax, lo, up, 1, g, float(np.max(g)), False, per_row)
+                scores.append((float(best.astype(np.float32).sum()), t))
+            srt = sorted(s_ for s_, _ in scores)
+            mode = min(scores, key=lambda st: st[0])[1]            # first smallest, like argsort(mse)[0] (AQ:411-412)
+            if mode != str(sel[k + "__mode"]):
+                assert (srt[1] - srt[0]) <= 1e-4 * srt[0], (k, scores)           # only a near-tie may flip the winner
+                continue
+        assert mode == str(sel[k + "__mode"]), k
+        grid = oracle.ant_grid(mode, bit, signed)
+        g_ref = sel[k + "__grid"]
+        assert np.array_equal(grid, g_ref), k                                  # (-0 == +0: apot order, DESIGN 2)
+        best, alpha, trace = oracle.search_mse(x, xmax, lo, up, 1, grid, float(np.max(grid)), False, per_row)
+        ref_alpha = sel[k + "__alpha"].reshape(-1)
+        close = np.isclose(alpha, ref_alpha, rtol=1e-6)
+        n_alpha += close.size
+        n_same += int(close.sum())
+        if not close.all():
+            srt = np.sort(trace, axis=0)
+            assert ((srt[1] - srt[0]) <= 1e-4 * srt[0])[~close].all(), k
+        out, _ = oracle.forward(x, alpha, grid, float(np.max(grid)), False)
+        ref_out = sel[k + "__out"].reshape(x.shape)
+        rows = close if per_row else np.full(x.shape[0], bool(close.all()))
+        assert f32_same_rows(out[rows], ref_out[rows]), k
+    assert n_same >= 0.97 * n_alpha
+
+
+def f32_same_rows(a, b):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1)
+    b = np.ascontiguousarray(b, np.float32).reshape(-1)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
 # ---------------------------------------------------------------- a14: quant_affine (configs[0])
 def test_affine(oracle):
     a = golden("affine.npz")
