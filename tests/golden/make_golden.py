@@ -502,15 +502,61 @@ def gen_ant_wide(outdir):
 
 
 
+def gen_olive_wide(outdir):
+    """OliVe end to end beyond the 4-bit signed cases of olive_search.npz: bit widths 3..8, no_outlier on / off, two
+    search windows, weights with planted outliers (per channel, 3-sigma rule) and activations (per tensor), an
+    odd-numel activation (the roll wrap-around of OQ:311-320)."""
+    import torch
+
+    _install_shim()
+    sys.path.insert(0, os.path.join(REF, "olive_quantization", "antquant"))
+    import quant_modules as qm
+
+    torch.manual_seed(31)
+    w = torch.randn(24, 96) * 0.02
+    m = torch.rand(24, 96) < 0.02
+    w[m] *= torch.empty(int(m.sum())).uniform_(6, 40)
+    xa = torch.nn.functional.gelu(torch.randn(8, 192) * 1.5)
+    xa.view(-1)[::37] *= 9
+    xo = torch.randn(7, 33)                    # 231 elements: odd
+    xo.view(-1)[::29] *= 15
+    sel = {"w__x": w.numpy(), "xa__x": xa.numpy(), "xo__x": xo.numpy()}
+    keys = []
+    for name, x, is_input in (("w", w, False), ("xa", xa, True), ("xo", xo, True)):
+        for mode, bit in (("int", 3), ("flint", 3), ("int", 4), ("flint", 4), ("ant-int-flint", 4), ("int", 5), ("flint", 5),
+                          ("ant-int-flint", 5), ("flint", 6), ("ant-int-flint", 6), ("int", 8), ("ant-int-flint", 8)):
+            for no_outlier in (False, True):
+                for lo, up in ((75, 250), (90, 150)):
+                    if (lo, up) != (75, 250) and bit != 4:
+                        continue
+                    q = qm.TensorQuantizer(mode=mode, bit=bit, is_signed=not is_input, is_enable=True, is_input=is_input,
+                                           args=_args(w_low=lo, a_low=lo, w_up=up, a_up=up, no_outlier=no_outlier))
+                    q.name = "golden"
+                    if not is_input:
+                        q.alpha.data = torch.ones(x.shape[0], 1)
+                    out = q(x)
+                    k = "%s__%s__b%d__%d_%d__%s" % (name, mode, bit, lo, up, "noout" if no_outlier else "ovp")
+                    keys.append(k)
+                    sel[k + "__mode"] = np.array(q.mode)
+                    sel[k + "__signed"] = np.array(bool(q.is_signed))
+                    sel[k + "__alpha"] = q.alpha.data.numpy().reshape(-1)
+                    sel[k + "__grid"] = q.quant_grid.data.numpy()
+                    sel[k + "__outliers"] = q.outliers.data.numpy()
+                    sel[k + "__out"] = out.detach().numpy()
+                    sel[k + "__mse"] = np.float32(q.mse.item())
+    sel["keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(outdir, "olive_select_wide.npz"), **sel)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "all"], default="all")
+    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "olive_wide", "all"], default="all")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
     if a.tree == "all":
-        for t in ("ant", "ant_wide", "olive"):
+        for t in ("ant", "ant_wide", "olive", "olive_wide"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", t, "--out", a.out])
         return
     import torch
@@ -519,6 +565,8 @@ def main():
         gen_ant(a.out)
     elif a.tree == "ant_wide":
         gen_ant_wide(a.out)
+    elif a.tree == "olive_wide":
+        gen_olive_wide(a.out)
     else:
         gen_olive(a.out)
 

@@ -1046,3 +1046,44 @@ def test_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
         assert q._steady and torch.equal(q(x), out)
     assert n_checked > 700
     capsys.readouterr()
+
+
+def test_olive_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
+    """olive_select_wide.npz: OliVe calibrations recorded from the reference's Python -- bit widths 3..8, outliers on
+    and off (`no_outlier`), two search windows, per-channel weights, per-tensor activations, an odd-numel tensor."""
+    import torch
+    from ant_quantization_amd.olive import quant_modules as qm
+    sel = golden("olive_select_wide.npz")
+    n_rows = n_same = 0
+    for k in [str(v) for v in sel["keys"]]:
+        name, mode, b, win, om = k.split("__")
+        bit, (lo, up) = int(b[1:]), map(int, win.split("_"))
+        x_np = sel[name + "__x"]
+        is_input = name != "w"
+        q = qm.TensorQuantizer(mode=mode, bit=bit, is_signed=not is_input, is_enable=True, is_input=is_input,
+                               args=_args(w_low=lo, a_low=lo, w_up=up, a_up=up, no_outlier=(om == "noout"))).to(dev)
+        q.name = "golden"
+        x = to_dev(np.ascontiguousarray(x_np), dev)
+        if not is_input:
+            q.alpha.data = torch.ones(x.shape[0], 1, device=dev)
+        out = q(x)
+        assert q.mode == str(sel[k + "__mode"]), k
+        assert bool(q.is_signed) == bool(sel[k + "__signed"]), k
+        assert f32_same(q.quant_grid.cpu().numpy(), sel[k + "__grid"]), k
+        assert f32_same(q.outliers.cpu().numpy(), sel[k + "__outliers"]), k
+        ref_alpha = sel[k + "__alpha"].reshape(-1)
+        got_alpha = q.alpha.detach().cpu().numpy().reshape(-1)
+        rel = np.abs(got_alpha - ref_alpha) / np.abs(ref_alpha)
+        assert rel.max() < 0.08, (k, rel.max())
+        same = rel < 2e-6
+        n_rows += same.size
+        n_same += int(same.sum())
+        got = out.detach().cpu().numpy()
+        ref_out = sel[k + "__out"]
+        if same.all():
+            # victims depend on the partner's row too, so compare whole tensors only when every alpha agrees
+            np.testing.assert_allclose(got, ref_out, rtol=2e-6, atol=0, err_msg=k)
+        np.testing.assert_allclose(q.mse.item(), sel[k + "__mse"], rtol=5e-3, err_msg=k)
+        assert q._steady and torch.equal(q(x), out)
+    assert n_same >= 0.9 * n_rows, (n_same, n_rows)
+    capsys.readouterr()

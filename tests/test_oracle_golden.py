@@ -275,6 +275,66 @@ def test_full_calibration_wide_fixture_set(oracle):
     assert n_same >= 0.97 * n_alpha
 
 
+def test_olive_full_calibration_wide_fixture_set(oracle):
+    """OliVe a10-a12 on the CPU (OQ:189-292): 3-sigma x_max, step-2 clip search with the victim rule inside the loss,
+    int / flint selection, final forward -- against olive_select_wide.npz (bits 3..8, outliers on / off, odd numel)."""
+    sel = golden("olive_select_wide.npz")
+    n_alpha = n_same = n_full = 0
+    for k in [str(v) for v in sel["keys"]]:
+        name, mode, b, win, om = k.split("__")
+        bit, (lo, up) = int(b[1:]), map(int, win.split("_"))
+        ovp = om == "ovp"
+        x = sel[name + "__x"]
+        per_row = name == "w"
+        signed = True if per_row else bool(x.min() < 0)
+        assert signed == bool(sel[k + "__signed"]), k
+        if ovp:
+            xd = x.astype(np.float64)
+            if per_row:
+                mean, std = xd.mean(1), xd.std(1, ddof=1)
+            else:
+                mean, std = xd.mean(keepdims=True).reshape(1), np.array([xd.std(ddof=1)])
+            xmax = np.maximum(np.abs(mean + 3 * std), np.abs(mean - 3 * std)).astype(np.float32)
+        else:
+            xmax = (np.abs(x).max(1) if per_row else np.abs(x).max(keepdims=True).reshape(1)).astype(np.float32)
+        outl = oracle.olive_outlier_value(bit, signed)
+        assert np.array_equal(outl, sel[k + "__outliers"]), k
+
+        def full(t):
+            n = oracle.olive_grid(t, bit, signed)
+            return n, (np.concatenate([n, outl]) if ovp else n)
+
+        if bit > 6:
+            mode = "int"
+        elif mode.startswith("ant-"):
+            scores = []
+            for t in ("int", "flint"):
+                n, g = full(t)
+                best, _, _ = oracle.search_mse(x, xmax, lo, up, 2, g, float(n.max()), ovp, per_row)
+                scores.append((float(best.astype(np.float32).sum()), t))
+            mode = min(scores, key=lambda st: st[0])[1]
+            if mode != str(sel[k + "__mode"]):
+                srt = sorted(s_ for s_, _ in scores)
+                assert (srt[1] - srt[0]) <= 1e-4 * srt[0], (k, scores)
+                continue
+        assert mode == str(sel[k + "__mode"]), k
+        normal, grid = full(mode)
+        assert np.array_equal(normal, sel[k + "__grid"]), k
+        best, alpha, trace = oracle.search_mse(x, xmax, lo, up, 2, grid, float(normal.max()), ovp, per_row)
+        ref_alpha = sel[k + "__alpha"].reshape(-1)
+        close = np.isclose(alpha, ref_alpha, rtol=2e-6)
+        n_alpha += close.size
+        n_same += int(close.sum())
+        if not close.all():
+            srt = np.sort(trace, axis=0)
+            assert ((srt[1] - srt[0]) <= 2e-4 * srt[0])[~close].all(), k
+            continue
+        out, _ = oracle.forward(x, ref_alpha if per_row else ref_alpha[:1], grid, float(normal.max()), ovp)
+        assert f32_same_rows(out, sel[k + "__out"]), k
+        n_full += 1
+    assert n_same >= 0.9 * n_alpha and n_full >= 60, (n_same, n_alpha, n_full)
+
+
 def f32_same_rows(a, b):
     a = np.ascontiguousarray(a, np.float32).reshape(-1)
     b = np.ascontiguousarray(b, np.float32).reshape(-1)
