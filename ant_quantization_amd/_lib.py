@@ -20,7 +20,7 @@ FLAG_OVP = 1
 IDX_NONE = -1
 IDX_VICTIM = -2
 MAX_GRID = 1024
-PLAN_MAX_BYTES = 80 + 4 * MAX_GRID + 16 * 3072
+PLAN_MAX_BYTES = 96 + 4 * MAX_GRID + 16 * 3072
 
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.float64: F64}
 

@@ -5,7 +5,7 @@
 namespace antq {
 
 constexpr uint32_t kPlanMagic = 0x51544E41u;  // "ANTQ"
-constexpr uint32_t kPlanVersion = 5;
+constexpr uint32_t kPlanVersion = 6;
 
 constexpr uint32_t kPlanScan = 0;  // kernels run the literal scan for every element
 constexpr uint32_t kPlanLut = 1;   // table plan: one LDS lookup + one compare per element
@@ -44,9 +44,15 @@ struct PlanHeader {      // 80 bytes
     float xlim;          // |x*rcp(s)| < xlim  ->  x-domain table path
     float vout;          // smallest |v| > 32 in the grid (+inf if none): in the x-domain table an output o = fl(v*s)
                          // belongs to an OliVe outlier (|v| > 32, OQ:314) iff |o| >= fl(vout*s)
-    uint32_t reserved;
+    // linear key (uniformly spaced thresholds, e.g. the int grids of 8-bit layers: 255 buckets instead of the 2048
+    // an exponent/mantissa key needs): bucket = trunc(clamp(fma(d, lin_scale, lin_bias), 0, kmax)); every bucket
+    // holds exactly one threshold; no sign half (nbneg = 0), no x-domain variant.
+    uint32_t linear;
+    float lin_scale;
+    float lin_bias;
+    uint32_t reserved[2];
 };
-static_assert(sizeof(PlanHeader) == 80, "PlanHeader must be 80 bytes");
+static_assert(sizeof(PlanHeader) == 96, "PlanHeader must be 96 bytes");
 
 // bits 15 / 31 of LutEntry::idx flag |v_lo| > 32 / |v_hi| > 32 (OliVe outlier test, OQ:314)
 constexpr uint32_t kIdxMask = 0x7fffu;

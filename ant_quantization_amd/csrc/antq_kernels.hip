@@ -187,6 +187,9 @@ struct PlanArgs {
     float fastlim;
     uint32_t n_entries;
     uint32_t tab_units;  // 16-byte units to stage into LDS: n_entries + m_pad/4
+    uint32_t linear;     // PlanHeader::linear: bucket from fma(d, lin_scale, lin_bias) instead of the float's bits
+    float lin_scale;
+    float lin_bias;
 };
 
 // LDS view of the plan: [entries | grid]
@@ -281,7 +284,20 @@ __device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, 
             fast = fast && (fabsf(d[e]) < pa.fastlim);  // false for NaN / Inf / huge
         }
     }
-    if (fast) {
+    if (fast && pa.linear) {
+        // uniformly spaced thresholds: one bucket per threshold, bucket = trunc(clamp(d * scale + bias))
+        const float khi = (float)pa.kmax;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const float kf = __builtin_amdgcn_fmed3f(__builtin_fmaf(d[e], pa.lin_scale, pa.lin_bias), 0.0f, khi);
+            const uint32_t k16 = (uint32_t)kf << 4;
+            uint4 ent = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(L.lut) + k16);
+            if (!IDX) asm volatile("" : "+v"(ent.w));
+            const bool c = d[e] >= u2f(ent.x);
+            q[e] = c ? u2f(ent.z) : u2f(ent.y);
+            if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
+        }
+    } else if (fast) {
         // byte offset of the bucket: key*16 straight from the float's bits (exponent + top
         // mantissa bits, shifted so the key lands on bit 4), clamped, plus the negative half.
         const int32_t sh4 = (int32_t)pa.shift - 4;                 // shift >= 13 always
@@ -1277,6 +1293,9 @@ static bool plan_args_from_host(const void *plan_host, PlanArgs &pa)
     pa.fastlim = h->fastlim;
     pa.n_entries = (h->kind == kPlanLut) ? h->n_entries : 0;
     pa.tab_units = pa.n_entries + (pa.m_pad >> 2);
+    pa.linear = h->linear;
+    pa.lin_scale = h->lin_scale;
+    pa.lin_bias = h->lin_bias;
     return true;
 }
 
@@ -1752,7 +1771,7 @@ namespace antq {
 constexpr uint32_t kBatchMagic = 0x42544E41u;  // "ANTB"
 constexpr int kBatchU = 4;                      // vectors per lane per task (4 KiB per wavefront: best measured)
 
-struct BatchDesc {   // 128 bytes, device-visible
+struct BatchDesc {   // 144 bytes, device-visible
     const uint4 *x;
     uint4 *out;
     const float *alpha;
@@ -1768,9 +1787,9 @@ struct BatchDesc {   // 128 bytes, device-visible
     int32_t per_row;
     float gmax;
     PlanArgs pa;
-    uint32_t pad[3];
+    uint32_t pad[4];
 };
-static_assert(sizeof(BatchDesc) == 128, "BatchDesc must be 128 bytes");
+static_assert(sizeof(BatchDesc) == 144, "BatchDesc must be 144 bytes");
 
 struct BatchHeader {   // 32 bytes
     uint32_t magic, n, total_blocks, dtype, flags, lds_bytes, map_offset, bytes;

@@ -93,6 +93,14 @@ inline float eval_lut(const PlanHeader &h, const float *grid, const LutEntry *en
 {
     uint32_t u = f2u(d);
     if (!(fabsf(d) < h.fastlim)) return scan_one(d, grid, (int)h.m, idx);  // slow path (also NaN)
+    if (h.linear) {
+        float kf = fmaf(d, h.lin_scale, h.lin_bias);
+        kf = fminf(fmaxf(kf, 0.0f), (float)h.kmax);      // v_med3_f32 on the device (no NaN here)
+        const LutEntry &e = ent[(uint32_t)kf];
+        bool c = d >= e.T;
+        *idx = (int)((c ? (e.idx >> 16) : e.idx) & kIdxMask);
+        return c ? e.v_hi : e.v_lo;
+    }
     int32_t ks = (int32_t)(((uint32_t)((int32_t)u >> h.shift)) & h.keymask);
     uint32_t k = (uint32_t)(std::min(std::max(ks, (int32_t)h.kmin), (int32_t)h.kmax) - (int32_t)h.kmin);
     const LutEntry &e = ent[k + ((u >> 31) ? h.nbneg : 0u)];
@@ -204,9 +212,32 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         h.shift = shift; h.kmin = kmin; h.kmax = kmax; h.nb = nb;
         found = true;
     }
+    // Uniformly spaced thresholds (int grids): a linear key needs one bucket per threshold where the float-bits key
+    // needs 2^mb per octave (int-8: 255 instead of 2048 buckets, 4 KiB instead of 32 KiB of LDS per workgroup).  Used
+    // when the float-bits table is too big for the per-row (x-domain) kernels anyway.  bucket(d) =
+    // trunc(clamp(fma(d, scale, bias), 0, k-2)) is monotone in d, so "bucket(T[i]) == i for every i" is all it takes:
+    // a d in bucket i then lies strictly between T[i-1] and T[i+1].
+    bool linear = false;
+    if (k >= 4 && (!found || h.nb * (has_neg ? 2u : 1u) > 128u)) {
+        const double w = ((double)T[k - 2] - (double)T[0]) / (double)(k - 2);
+        const float scale = (float)(1.0 / w);
+        const float bias = (float)(0.5 - (double)T[0] * (double)scale);
+        bool ok = w > 0.0 && isfinite(scale) && isfinite(bias);
+        for (int i = 0; i + 1 < k && ok; i++) {
+            float kf = fmaf(T[i], scale, bias);
+            kf = fminf(fmaxf(kf, 0.0f), (float)(k - 2));
+            if ((int)kf != i) ok = false;
+        }
+        if (ok) {
+            linear = true;
+            h.linear = 1u; h.lin_scale = scale; h.lin_bias = bias;
+            h.shift = 0; h.kmin = 0; h.kmax = (uint32_t)(k - 2); h.nb = (uint32_t)(k - 1);
+            found = true;
+        }
+    }
     if (!found) return scan_bytes;
-    h.keymask = has_neg ? ((1u << (31 - h.shift)) - 1u) : 0xffffffffu;
-    h.nbneg = has_neg ? h.nb : 0u;
+    h.keymask = (has_neg && !linear) ? ((1u << (31 - h.shift)) - 1u) : 0xffffffffu;
+    h.nbneg = (has_neg && !linear) ? h.nb : 0u;
     h.magic = kPlanMagic;
     h.version = kPlanVersion;
     h.kind = kPlanLut;
@@ -240,7 +271,8 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         if (fabsf(e.v_hi) > 32.0f) e.idx |= 0x80000000u;
         return e;
     };
-    for (uint32_t b = 0; b < h.nb; b++) {
+    for (uint32_t b = 0; linear && b < h.nb; b++) ent[b] = mk((int)b, (int)b + 1, T[b]);
+    for (uint32_t b = 0; !linear && b < h.nb; b++) {
         uint32_t key = h.kmin + b;
         float edge = u2f(key << h.shift);  // smallest magnitude of the bucket
         int tp = -1, tn = -1;
@@ -262,7 +294,7 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
     // neighbour when the neighbour has no threshold of its own (harmless for the exact d-domain path:
     // every d of the neighbour lies on one side of it).  If the neighbour is taken, no x-domain path.
     {
-        bool ok = h.n_entries <= 128;     // wave-private table: up to two entries per lane
+        bool ok = h.n_entries <= 128 && !linear;     // wave-private table: up to two entries per lane
         auto entry_of = [&](float t) -> LutEntry * {
             const uint32_t key = mag_key(t, h.shift);
             if (key < h.kmin || key > h.kmax) return nullptr;       // clamped region: same bucket as the edge one
