@@ -211,7 +211,7 @@ def main():
                    "io_dtype": "bf16", "elements_per_step_per_gpu": args.nbuf * ROWS * COLS,
                    "sharding": "independent tensors per rank, no data-path collective",
                    "idempotence_check": ok,
-                   "per_tensor_launches": {"kernel": "antq::k_fq_xrow<bf16,...,U=8> (antq_fakequant, one launch per tensor)",
+                   "per_tensor_launches": {"kernel": "antq::k_fq_xrow<bf16,...,U=4> (antq_fakequant, one launch per tensor)",
                                            "launch_us": round(pt_launch_s * 1e6, 2),
                                            "gelem_per_s": round(ROWS * COLS / pt_launch_s / 1e9, 1),
                                            "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9, 1),

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ on a GPU box.  Run from the repo root through gpurun:
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01'
+# Everything is written under gpurun_out/<tag>/ (small text files only); copy what should be judged into profiles/.
+set -u
+TAG=${1:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+PY="python"
+
+$PY bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"
+tail -1 "$OUT/${TAG}_bench.json"
+
+# kernel trace of the same command (no PMC in this pass)
+( cd /tmp && rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- \
+    $PY "$REPO/bench.py" --no-cpu-baseline > "$OUT/bench_profiled.json" 2> /tmp/prof_kt.err )
+KS=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)
+[ -n "$KS" ] && cp "$KS" "$OUT/${TAG}_bench_kernel_stats.csv"
+tail -1 "$OUT/bench_profiled.json"
+
+# HBM traffic: one counter per pass, kernel trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section)
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rm -rf /tmp/prof_$C && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -- \
+      $PY "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/prof_$C.err )
+done
+$PY tools/pmc_summary.py $(find /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE -name '*counter_collection.csv') \
+    > "$OUT/${TAG}_pmc_summary.txt" 2>&1
+
+$PY tools/bench_configs.py       > "$OUT/${TAG}_configs.log" 2>&1
+$PY tools/probe_grid_types.py    > "$OUT/${TAG}_grid_types.log" 2>&1
+$PY tools/probe_operator_level.py > "$OUT/${TAG}_operator_level.log" 2>&1
+$PY tools/probe_weight_bank.py 2>&1 | grep -v "golden,\|bit \s" > "$OUT/${TAG}_weight_bank.log"
+ls -la "$OUT"
