@@ -1087,3 +1087,33 @@ def test_olive_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
         assert q._steady and torch.equal(q(x), out)
     assert n_same >= 0.9 * n_rows, (n_same, n_rows)
     capsys.readouterr()
+
+
+def test_calibration_collectives_single_rank_group(antq_lib, dev, capsys):
+    """The reference's DDP syncs inside _init_quant_para (broadcast(mse), all_reduce(alpha)/world, broadcast(grid),
+    AQ:520-531) run when a process group exists: with a one-rank RCCL group they must leave the result unchanged."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from ant_quantization_amd.ant import quant_modules as qm
+    sel = golden("ant_select.npz")
+    x = to_dev(np.ascontiguousarray(sel["w_laplace__x"]), dev)
+
+    def calibrate(mode):
+        q = qm.TensorQuantizer(mode=mode, bit=4, is_signed=True, is_enable=True, args=_args()).to(dev)
+        q.name = "golden"
+        q.alpha.data = torch.ones(x.shape[0], 1, device=dev)
+        return q, q(x)
+
+    ref = {m: calibrate(m) for m in ("ant-int-pot-flint", "outlier")}
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        for m, (q0, y0) in ref.items():
+            q1, y1 = calibrate(m)
+            assert q1.mode == q0.mode and torch.equal(y1, y0)
+            assert torch.equal(q1.alpha.data, q0.alpha.data) and torch.equal(q1.quant_grid, q0.quant_grid)
+    finally:
+        dist.destroy_process_group()
+    capsys.readouterr()
