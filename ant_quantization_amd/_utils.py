@@ -29,53 +29,41 @@ def _dist_on():
 def get_ckpt_path(args):
     """output/<model>_<dataset>/<mode>_W<w>A<a>_<run id>/gpu_<rank>; the run id is drawn on rank 0 and
     broadcast (over RCCL when a process group exists) so that all ranks agree (quant_utils.py:34-60)."""
-    rank = dist.get_rank() if _dist_on() else 0
-
-    def mk(p):
-        if rank == 0 and not os.path.isdir(p):
-            os.mkdir(p)
-
-    path = 'output'
-    mk(path)
-    path = os.path.join(path, args.model + "_" + args.dataset)
-    mk(path)
-    num = int(uuid.uuid4().hex[0:4], 16)
-    if _dist_on():
-        t = torch.tensor(num, device="cuda" if torch.cuda.is_available() else "cpu")
+    multi = _dist_on()
+    rank = dist.get_rank() if multi else 0
+    run_id = int(uuid.uuid4().hex[:4], 16)
+    if multi:
+        t = torch.tensor(run_id, device="cuda" if torch.cuda.is_available() else "cpu")
         dist.broadcast(t, 0)
-        num = int(t.item())
-    path = os.path.join(path, args.mode + '_W' + str(args.wbit) + 'A' + str(args.abit) + '_' + str(num))
-    mk(path)
+        run_id = int(t.item())
+    run_dir = os.path.join("output", f"{args.model}_{args.dataset}", f"{args.mode}_W{args.wbit}A{args.abit}_{run_id}")
+    if rank == 0:
+        os.makedirs(run_dir, exist_ok=True)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    if _dist_on():
+    if multi:
         dist.barrier()
-    path = os.path.join(path, "gpu_" + str(rank))
-    os.makedirs(path, exist_ok=True)
-    return path
+    mine = os.path.join(run_dir, f"gpu_{rank}")
+    os.makedirs(mine, exist_ok=True)
+    return mine
 
 
 def get_ckpt_filename(path, epoch):
-    return os.path.join(path, 'ckpt_' + str(epoch) + '.pth')
+    return os.path.join(path, f"ckpt_{epoch}.pth")
 
 
 def make_walkers(Q):
-    def disable_input_quantization(model):
-        for _, module in model.named_modules():
-            if isinstance(module, Q):
-                module.disable_input_quantization()
+    """The three model walkers of quant_utils.py:62-78 for quantiser class Q."""
+    def walker(method, with_name):
+        def walk(model):
+            for name, module in model.named_modules():
+                if isinstance(module, Q):
+                    getattr(module, method)(*((name,) if with_name else ()))
+        walk.__name__ = method
+        return walk
 
-    def enable_quantization(model):
-        for name, module in model.named_modules():
-            if isinstance(module, Q):
-                module.enable_quantization(name)
-
-    def disable_quantization(model):
-        for name, module in model.named_modules():
-            if isinstance(module, Q):
-                module.disable_quantization(name)
-
-    return disable_input_quantization, enable_quantization, disable_quantization
+    return (walker("disable_input_quantization", False), walker("enable_quantization", True),
+            walker("disable_quantization", True))
 
 
 def get_model(args):
