@@ -1,0 +1,203 @@
+// A torch-free consumer of the C ABI (include/antq.h): plain HIP runtime + libantq.so, checked against the CPU oracle
+// (oracle/libantq_oracle.so -- test infrastructure, linked here as the checker only).
+//
+// This is what a C/C++ host of the reference's path would do: build a plan on the host,
+// upload it, call the fused entry points on its own stream and buffers.  Covers antq_nearest (the quant_cuda.quant
+// replacement, KQ/quant_kernel.cu:11-62), antq_fakequant (AQ:535-551), the OliVe victim rule (OQ:311-320),
+// antq_fakequant_dynamic + antq_absmax, antq_fakequant_batch and the packed 4-bit codec.
+// Exit code 0 = every comparison bit-exact; prints one line per check.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../include/antq.h"
+
+extern "C" {
+void antq_oracle_nearest_f32(const float *x, float *z, int32_t *idx, size_t n, const float *grid, int m);
+void antq_oracle_forward_f32(const float *x, float *out, int32_t *idx, size_t rows, size_t row_len, const float *alpha,
+                             int alpha_per_row, const float *grid, int m, float gmax, int ovp);
+void antq_oracle_absmax_f32(const float *x, float *alpha, size_t rows, size_t row_len, int per_row, float ratio);
+}
+
+#define HIP_OK(e)                                                                                          \
+    do {                                                                                                   \
+        hipError_t err_ = (e);                                                                             \
+        if (err_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(err_), __LINE__); return 2; } \
+    } while (0)
+#define ANTQ_OK_(e)                                                                                        \
+    do {                                                                                                   \
+        int rc_ = (e);                                                                                     \
+        if (rc_ != ANTQ_OK) { printf("antq error %s (%d) at line %d\n", antq_strerror(rc_), rc_, __LINE__); return 3; } \
+    } while (0)
+
+static int failures = 0;
+
+static void same_bits(const char *what, const std::vector<float> &got, const std::vector<float> &ref)
+{
+    size_t bad = 0;
+    for (size_t i = 0; i < ref.size(); i++) {
+        uint32_t a, b;
+        memcpy(&a, &got[i], 4);
+        memcpy(&b, &ref[i], 4);
+        if (a != b && !(std::isnan(got[i]) && std::isnan(ref[i]))) bad++;
+    }
+    printf("%-58s %s (%zu / %zu differ)\n", what, bad ? "FAIL" : "ok", bad, ref.size());
+    if (bad) failures++;
+}
+
+static void same_idx(const char *what, const std::vector<int16_t> &got, const std::vector<int32_t> &ref)
+{
+    size_t bad = 0;
+    for (size_t i = 0; i < ref.size(); i++) bad += ((int32_t)got[i] != ref[i]);
+    printf("%-58s %s (%zu / %zu differ)\n", what, bad ? "FAIL" : "ok", bad, ref.size());
+    if (bad) failures++;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    explicit DevBuf(size_t n_) : n(n_) { if (hipMalloc(&p, n * sizeof(T) + 16) != hipSuccess) p = nullptr; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void up(const std::vector<T> &h, hipStream_t s) { (void)hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s); }
+    std::vector<T> down(hipStream_t s) const
+    {
+        std::vector<T> h(n);
+        (void)hipMemcpyAsync(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        return h;
+    }
+};
+
+int main()
+{
+    if (antq_abi_version() != ANTQ_ABI_VERSION) { printf("ABI version mismatch\n"); return 4; }
+    hipStream_t st;
+    HIP_OK(hipSetDevice(0));
+    HIP_OK(hipStreamCreate(&st));
+
+    // ANT 4-bit signed flint (AQ:223-278, values scaled to max 10) and OliVe flint + outliers (OQ:93-179)
+    const std::vector<float> flint = {-10.f, -5.f, -3.75f, -2.5f, -1.875f, -1.25f, -0.625f, 0.f, 0.f,
+                                      0.625f, 1.25f, 1.875f, 2.5f, 3.75f, 5.f, 10.f};
+    std::vector<float> olive = {-32, -16, -12, -8, -6, -4, -2, 0, 2, 4, 6, 8, 12, 16, 32};
+    const int n_normal = (int)olive.size();
+    for (float o : {-384.f, -256.f, -192.f, -128.f, -96.f, -64.f, -48.f, 48.f, 64.f, 96.f, 128.f, 192.f, 256.f, 384.f}) olive.push_back(o);
+
+    const size_t rows = 96, K = 4096, n = rows * K;
+    std::mt19937 rng(7);
+    std::normal_distribution<float> nd(0.f, 0.02f);
+    std::vector<float> x(n), alpha(rows), alpha3(rows);
+    for (auto &v : x) v = nd(rng);
+    for (size_t i = 0; i < n; i += 211) x[i] *= 25.f;                       // planted outliers
+    x[5] = NAN; x[7] = INFINITY; x[9] = -3e30f; x[11] = 0.f; x[13] = -0.f; x[15] = 1e-41f;
+    antq_oracle_absmax_f32(x.data(), alpha.data(), rows, K, 1, 1.0f);
+    for (size_t r = 0; r < rows; r++) {                                      // rows with NaN/Inf: pick a sane alpha
+        if (!(alpha[r] < 1e10f)) alpha[r] = 0.08f;
+        alpha[r] *= 0.9f;
+        alpha3[r] = 0.06f + 0.001f * (float)r;
+    }
+
+    DevBuf<float> dx(n), dout(n), dalpha(rows), dalpha3(rows), dgrid(64), damax(rows);
+    DevBuf<int16_t> didx(n);
+    DevBuf<uint8_t> dplan(ANTQ_PLAN_MAX_BYTES), dplan2(ANTQ_PLAN_MAX_BYTES), dcodes(n / 2);
+    dx.up(x, st); dalpha.up(alpha, st); dalpha3.up(alpha3, st);
+
+    std::vector<uint8_t> plan(ANTQ_PLAN_MAX_BYTES), plan2(ANTQ_PLAN_MAX_BYTES);
+    int pb = antq_plan_build(flint.data(), (int)flint.size(), plan.data(), plan.size());
+    int pb2 = antq_plan_build(olive.data(), (int)olive.size(), plan2.data(), plan2.size());
+    if (pb <= 0 || pb2 <= 0 || antq_plan_kind(plan.data()) != 1 || antq_plan_kind(plan2.data()) != 1) { printf("plan build failed\n"); return 5; }
+    HIP_OK(hipMemcpyAsync(dplan.p, plan.data(), pb, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(dplan2.p, plan2.data(), pb2, hipMemcpyHostToDevice, st));
+
+    std::vector<float> ref(n);
+    std::vector<int32_t> ridx(n);
+
+    // 1. quant_cuda.quant replacement
+    HIP_OK(hipMemcpyAsync(dgrid.p, flint.data(), flint.size() * 4, hipMemcpyHostToDevice, st));
+    ANTQ_OK_(antq_nearest(dx.p, dout.p, didx.p, n, dgrid.p, (int)flint.size(), ANTQ_F32, st));
+    antq_oracle_nearest_f32(x.data(), ref.data(), ridx.data(), n, flint.data(), (int)flint.size());
+    same_bits("antq_nearest values (flint-4)", dout.down(st), ref);
+    same_idx("antq_nearest indices", didx.down(st), ridx);
+
+    // 2. fused Quantizer._forward, per-row alpha
+    ANTQ_OK_(antq_fakequant(dx.p, dout.p, didx.p, rows, K, dalpha.p, 1, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
+    antq_oracle_forward_f32(x.data(), ref.data(), ridx.data(), rows, K, alpha.data(), 1, flint.data(), (int)flint.size(), 10.0f, 0);
+    same_bits("antq_fakequant ANT flint-4 per-row", dout.down(st), ref);
+    same_idx("antq_fakequant indices", didx.down(st), ridx);
+
+    // 3. the whole buffer as one quant group: one alpha per tensor (activations, AQ:477)
+    std::vector<float> a1 = {0.07f};
+    DevBuf<float> da1(1);
+    da1.up(a1, st);
+    ANTQ_OK_(antq_fakequant(dx.p, dout.p, nullptr, 1, n, da1.p, 0, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
+    antq_oracle_forward_f32(x.data(), ref.data(), ridx.data(), 1, n, a1.data(), 0, flint.data(), (int)flint.size(), 10.0f, 0);
+    same_bits("antq_fakequant per-tensor alpha", dout.down(st), ref);
+
+    // 4. OliVe outlier-victim pairs
+    ANTQ_OK_(antq_fakequant(dx.p, dout.p, didx.p, rows, K, dalpha3.p, 1, 32.0f, plan2.data(), dplan2.p, ANTQ_FLAG_OVP, ANTQ_F32, st));
+    antq_oracle_forward_f32(x.data(), ref.data(), ridx.data(), rows, K, alpha3.data(), 1, olive.data(), (int)olive.size(), 32.0f, 1);
+    same_bits("antq_fakequant OliVe flint-4 + outlier-victim pairs", dout.down(st), ref);
+    same_idx("antq_fakequant OliVe indices (victims = -2)", didx.down(st), ridx);
+    size_t victims = 0;
+    for (int32_t v : ridx) victims += (v == ANTQ_IDX_VICTIM);
+    if (!victims) { printf("no victims in the OliVe case\n"); failures++; }
+
+    // 5. dynamic alpha (finite data only: the row abs-max must be meaningful)
+    std::vector<float> xf = x;
+    xf[5] = 0.3f; xf[7] = -0.2f; xf[9] = 0.1f;
+    DevBuf<float> dxf(n);
+    dxf.up(xf, st);
+    std::vector<float> adyn(rows);
+    antq_oracle_absmax_f32(xf.data(), adyn.data(), rows, K, 1, 0.85f);
+    ANTQ_OK_(antq_fakequant_dynamic(dxf.p, dout.p, nullptr, damax.p, rows, K, 0.85f, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
+    antq_oracle_forward_f32(xf.data(), ref.data(), ridx.data(), rows, K, adyn.data(), 1, flint.data(), (int)flint.size(), 10.0f, 0);
+    same_bits("antq_fakequant_dynamic alpha", damax.down(st), adyn);
+    same_bits("antq_fakequant_dynamic values", dout.down(st), ref);
+    HIP_OK(hipMemsetAsync(damax.p, 0, 4, st));
+    ANTQ_OK_(antq_absmax(dxf.p, damax.p, rows, K, 0, ANTQ_F32, st));
+    std::vector<float> amax_t(1);
+    antq_oracle_absmax_f32(xf.data(), amax_t.data(), rows, K, 0, 1.0f);
+    {
+        std::vector<float> got = damax.down(st);
+        got.resize(1);
+        same_bits("antq_absmax per tensor", got, amax_t);
+    }
+
+    // 6. two jobs (ANT per-row + the per-tensor view) in one batched launch
+    DevBuf<float> dout2(n);
+    antq_job jobs[2] = {{dxf.p, dout.p, dalpha.p, rows, K, 1, 10.0f, plan.data(), dplan.p},
+                        {dxf.p, dout2.p, da1.p, 1, n, 0, 10.0f, plan.data(), dplan.p}};
+    size_t cap = antq_batch_capacity(jobs, 2, ANTQ_F32);
+    std::vector<uint8_t> batch(cap);
+    int bb = antq_batch_build(jobs, 2, ANTQ_F32, 0, batch.data(), cap);
+    if (bb <= 0) { printf("antq_batch_build failed: %d\n", bb); return 6; }
+    DevBuf<uint8_t> dbatch((size_t)bb);
+    HIP_OK(hipMemcpyAsync(dbatch.p, batch.data(), bb, hipMemcpyHostToDevice, st));
+    ANTQ_OK_(antq_fakequant_batch(batch.data(), dbatch.p, st));
+    antq_oracle_forward_f32(xf.data(), ref.data(), ridx.data(), rows, K, alpha.data(), 1, flint.data(), (int)flint.size(), 10.0f, 0);
+    same_bits("antq_fakequant_batch job 0 (per-row)", dout.down(st), ref);
+    antq_oracle_forward_f32(xf.data(), ref.data(), ridx.data(), 1, n, a1.data(), 0, flint.data(), (int)flint.size(), 10.0f, 0);
+    same_bits("antq_fakequant_batch job 1 (per-tensor)", dout2.down(st), ref);
+
+    // 7. packed 4-bit codec: decode(encode(x)) == fake-quant(x), OliVe pairs with the outlier identifier
+    ANTQ_OK_(antq_encode4(dxf.p, dcodes.p, rows, K, dalpha3.p, 1, 32.0f, plan2.data(), dplan2.p, n_normal, ANTQ_FLAG_OVP, ANTQ_F32, st));
+    ANTQ_OK_(antq_decode4(dcodes.p, dout.p, rows, K, dalpha3.p, 1, 32.0f, plan2.data(), dplan2.p, n_normal, ANTQ_FLAG_OVP, ANTQ_F32, st));
+    antq_oracle_forward_f32(xf.data(), ref.data(), ridx.data(), rows, K, alpha3.data(), 1, olive.data(), (int)olive.size(), 32.0f, 1);
+    same_bits("antq_decode4(antq_encode4(x)) OliVe, 0.5 B/elem", dout.down(st), ref);
+
+    // 8. error behaviour: codes, not exceptions
+    if (antq_fakequant(nullptr, dout.p, nullptr, rows, K, dalpha.p, 1, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st) != ANTQ_ERR_ARG) { printf("null x not rejected\n"); failures++; }
+    if (antq_fakequant(dx.p, dout.p, nullptr, rows, K, dalpha.p, 1, 10.0f, plan.data(), dplan.p, 0, 99, st) != ANTQ_ERR_UNSUPPORTED) { printf("bad dtype not rejected\n"); failures++; }
+    plan[0] ^= 0xff;
+    if (antq_fakequant(dx.p, dout.p, nullptr, rows, K, dalpha.p, 1, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st) != ANTQ_ERR_PLAN) { printf("corrupt plan not rejected\n"); failures++; }
+    printf("error codes: ok\n");
+
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipStreamDestroy(st));
+    printf(failures ? "CABI CHECK FAILED (%d)\n" : "CABI CHECK OK\n", failures);
+    return failures ? 1 : 0;
+}

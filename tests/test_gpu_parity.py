@@ -1117,3 +1117,17 @@ def test_calibration_collectives_single_rank_group(antq_lib, dev, capsys):
     finally:
         dist.destroy_process_group()
     capsys.readouterr()
+
+
+def test_c_abi_from_a_torch_free_cpp_host(antq_lib):
+    """tests/cabi/cabi_check.cpp: a plain HIP-runtime C++ program (no torch, no Python) drives the C ABI on its own
+    stream and buffers -- nearest, fused fake-quant (ANT, per-tensor, OliVe pairs), dynamic alpha, abs-max, the batched
+    launch, the 4-bit codec, error codes -- and compares every result bit for bit with the oracle library."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cabi", "cabi_check")
+    if not os.path.exists(exe):          # normally built by __graft_entry__.build() and shipped with the snapshot
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "ARCH=gfx950"], check=False, timeout=600)
+    assert os.path.exists(exe), "tests/cabi/cabi_check not built (run __graft_entry__.build())"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "CABI CHECK OK" in r.stdout, r.stdout + r.stderr
