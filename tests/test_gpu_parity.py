@@ -1131,3 +1131,33 @@ def test_c_abi_from_a_torch_free_cpp_host(antq_lib):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "CABI CHECK OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ANTQ_FUZZ_SEEDS", 4))))
+def test_random_shapes_fuzz(antq_lib, oracle, dev, seed):
+    """Every reference codebook x random shapes (1-element rows, odd K, K = 147, rows that straddle every kernel's
+    vector width, odd numel with outlier-victim pairs wrapping to element 0) x per-row / per-tensor x fp32 / bf16."""
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    rng = np.random.default_rng(9000 + seed)
+    names = [k for k in G.files if not k.startswith("INVALID")]
+    for _ in range(25):
+        if rng.random() < 0.5:
+            gname = names[rng.integers(0, len(names))]
+            g, ovp = G[gname], False
+            gmax = float(g.max())
+        else:
+            t, b, s = ["int", "flint"][rng.integers(0, 2)], int(rng.choice([3, 4, 4, 4, 5, 8])), "su"[rng.integers(0, 2)]
+            gn = O["%s_b%d_%s" % (t, b, s)]
+            g, gmax, ovp, gname = np.concatenate([gn, O["outlier_b%d_%s" % (b, s)]]), float(gn.max()), bool(rng.random() < 0.8), "olive_" + s
+        rows = int(rng.choice([1, 2, 3, 5, 8, 17, 64, 130]))
+        K = int(rng.choice([1, 2, 3, 7, 8, 15, 16, 27, 32, 64, 100, 147, 256, 257, 512, 1000, 1024, 2048, 4096, 4100, 8192]))
+        rows = min(rows, max(1, 1_000_000 // K))
+        x = make_x(rng, rows, K, unsigned=gname.endswith("_u"), specials=bool(rng.random() < 0.5)) * np.float32(rng.uniform(0.2, 40))
+        if ovp:
+            m = rng.random((rows, K)) < 0.03
+            x[m] *= rng.uniform(8, 64, m.sum()).astype(np.float32)
+        alpha = (safe_absmax(x).max(1) * rng.uniform(0.3, 1.2, rows) + 1e-6).astype(np.float32)
+        per_row = bool(rng.random() < 0.7)
+        with np.errstate(all="ignore"):
+            run_case(antq_lib, oracle, dev, x, alpha if per_row else np.float32(alpha.mean()), g, gmax, per_row, ovp,
+                     bool(rng.random() < 0.5))
