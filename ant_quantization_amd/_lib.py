@@ -48,7 +48,7 @@ def lib():
                              "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
-                             "antq_search_pick"):
+                             "antq_search_pick", "antq_alpha_grad"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
@@ -256,6 +256,21 @@ def absmax(x, rows, row_len, per_row=True):
                                  ctypes.c_int(1 if per_row else 0), ctypes.c_int(dt), _stream(x.device)),
                "antq_absmax")
     return amax
+
+
+def alpha_grad(x, out, gout, rows, row_len, per_row=True):
+    """sum over each row (or the tensor) of gout * (out - x), float64: the alpha gradient of fakequant times alpha."""
+    for name, t in (("x", x), ("out", out), ("gout", gout)):
+        _require_gpu(t, name)
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64 or out.dtype != x.dtype or gout.dtype != x.dtype:
+        raise AntqError("alpha_grad: x / out / gout must share one of float32 / bfloat16 / float16")
+    gsum = torch.zeros(rows if per_row else 1, dtype=torch.float64, device=x.device)
+    with _on_device(x.device):
+        _check(lib().antq_alpha_grad(_vp(x), _vp(out), _vp(gout), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
+                                     ctypes.c_int(1 if per_row else 0), _vp(gsum), ctypes.c_int(dt), _stream(x.device)),
+               "antq_alpha_grad")
+    return gsum
 
 
 def search_sse(x, rows, row_len, xmax, per_row, ratios, plan, gmax, ovp=False):

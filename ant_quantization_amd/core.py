@@ -24,8 +24,9 @@ class FakeQuantSTE(torch.autograd.Function):
     """out = ((q - d).detach() + d) * s with d = x / s, s = alpha / gmax  (AQ:535-551).
 
     Forward: one fused kernel.  Backward (QAT, ANT only): the straight-through estimator
-    the reference's autograd graph yields -- d out/d x = 1 (no clip mask), and
-    d out/d alpha = sum_row g * (q - d) / gmax = sum_row g * (out - x) / alpha.
+    the reference's autograd graph yields -- d out/d x = 1 (no clip mask, so the incoming gradient
+    is passed through untouched), and d out/d alpha = sum_row g * (q - d) / gmax
+    = sum_row g * (out - x) / alpha: one fused reduction kernel (`antq_alpha_grad`).
     """
 
     @staticmethod
@@ -44,12 +45,12 @@ class FakeQuantSTE(torch.autograd.Function):
         gx = g if ctx.needs_input_grad[0] else None
         ga = None
         if ctx.needs_input_grad[1]:
-            diff = (out.float() - x.float()) * g.float()
-            if ctx.per_channel:
-                ga = diff.reshape(x.shape[0], -1).sum(1).reshape(alpha.shape) / alpha
-            else:
-                ga = (diff.sum() / alpha).reshape(alpha.shape)
-            ga = ga.to(alpha.dtype)
+            rows, row_len = view_rows(x, ctx.per_channel)
+            gc = g.contiguous()
+            if gc.dtype != x.dtype:
+                gc = gc.to(x.dtype)
+            gsum = _lib.alpha_grad(x, out, gc, rows, row_len, ctx.per_channel)       # one fused reduction kernel
+            ga = (gsum.reshape(alpha.shape) / alpha.detach().double()).to(alpha.dtype)
         return gx, ga, None, None, None, None
 
 

@@ -1135,6 +1135,80 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
 }
 
 // ------------------------------------------------------------------------------------
+// Backward of the fused fake-quant w.r.t. alpha (QAT, AQ:39 alpha is a Parameter; AQ:544-549 straight-through
+// graph): d out / d alpha = (q - d) / gmax = (out - x) / alpha, so
+//     gsum[r] = sum_c fl32( gout[r,c] * fl32(out[r,c] - x[r,c]) )          (the caller divides by alpha[r])
+// fp32 terms, fp64 accumulation.  One wavefront per row; one scale per tensor: block-strided with one atomic per
+// workgroup.  d out / d x is the identity (no clip mask in the reference), so there is no kernel for it.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_alpha_grad(const void *__restrict__ x, const void *__restrict__ out, const void *__restrict__ gout,
+             double *__restrict__ gsum, size_t rows, size_t row_len, int per_row, int vec_ok)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const uint32_t lane = threadIdx.x & 63u;
+    auto vec_term = [](const uint4 &xv, const uint4 &ov, const uint4 &gv) -> float {
+        float xf[EPL], of[EPL], gf[EPL];
+        IO<T>::unpack(xv, xf);
+        IO<T>::unpack(ov, of);
+        IO<T>::unpack(gv, gf);
+        float part = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) part += gf[e] * (of[e] - xf[e]);
+        return part;
+    };
+    auto one_term = [&](size_t i) -> float {
+        return IO<T>::load1(gout, i) * (IO<T>::load1(out, i) - IO<T>::load1(x, i));
+    };
+    if (per_row) {
+        const size_t wave = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+        const size_t nwaves = (size_t)gridDim.x * 4u;
+        for (size_t r = wave; r < rows; r += nwaves) {
+            double acc = 0.0;
+            if (vec_ok) {
+                const size_t vpr = row_len / EPL;
+                const uint4 *px = static_cast<const uint4 *>(x) + r * vpr;
+                const uint4 *po = static_cast<const uint4 *>(out) + r * vpr;
+                const uint4 *pg = static_cast<const uint4 *>(gout) + r * vpr;
+                for (size_t i = lane; i < vpr; i += 64) acc += (double)vec_term(px[i], po[i], pg[i]);
+            } else {
+                for (size_t i = lane; i < row_len; i += 64) acc += (double)one_term(r * row_len + i);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) gsum[r] = acc;
+        }
+    } else {
+        const size_t n = rows * row_len;
+        const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, stride = (size_t)gridDim.x * 256u;
+        double acc = 0.0;
+        if (vec_ok) {
+            const size_t nv = n / EPL;
+            const uint4 *px = static_cast<const uint4 *>(x), *po = static_cast<const uint4 *>(out);
+            const uint4 *pg = static_cast<const uint4 *>(gout);
+            size_t i = tid;
+            for (; i + stride < nv; i += 2 * stride) {
+                const uint4 x0 = px[i], o0 = po[i], g0 = pg[i];
+                const uint4 x1 = px[i + stride], o1 = po[i + stride], g1 = pg[i + stride];
+                acc += (double)vec_term(x0, o0, g0);
+                acc += (double)vec_term(x1, o1, g1);
+            }
+            for (; i < nv; i += stride) acc += (double)vec_term(px[i], po[i], pg[i]);
+            for (size_t k = nv * EPL + tid; k < n; k += stride) acc += (double)one_term(k);
+        } else {
+            for (size_t k = tid; k < n; k += stride) acc += (double)one_term(k);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        __shared__ double wsum[4];
+        if (lane == 0) wsum[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(gsum, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Clip search (search_mse, AQ:287-326): for every candidate ratio the squared error of the
 // fake-quantised row against the row itself, WITHOUT writing the quantised tensor: x is
 // read once into registers and all `ncand` candidates are evaluated on it.
@@ -1720,6 +1794,39 @@ extern "C" int antq_fakequant_dynamic(const void *x, void *out, int16_t *idx, fl
     case ANTQ_F32: return launch_dynamic_flags<float>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, flags, st);
     case ANTQ_BF16: return launch_dynamic_flags<bf16_tag>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, flags, st);
     case ANTQ_F16: return launch_dynamic_flags<f16_tag>(x, out, idx, alpha_out, rows, row_len, ratio, gmax, pa, plan_host, plan_dev, flags, st);
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+}
+
+namespace antq {
+template <typename T>
+static int launch_alpha_grad(const void *x, const void *out, const void *gout, double *gsum, size_t rows, size_t row_len,
+                             int per_row, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const bool al = (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gout)) % 16 == 0;
+    const int vec_ok = per_row ? (al && row_len % EPL == 0) : al;
+    size_t waves = per_row ? rows : (rows * row_len + 64 * EPL * 2 - 1) / (64 * EPL * 2);
+    size_t blocks = (waves + 3) / 4;
+    const size_t cap = per_row ? 4096 : 1024;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_alpha_grad<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, out, gout, gsum, rows, row_len, per_row,
+                       vec_ok);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+}  // namespace antq
+
+extern "C" int antq_alpha_grad(const void *x, const void *out, const void *gout, size_t rows, size_t row_len, int per_row,
+                               double *gsum, int dtype, void *stream)
+{
+    if (rows == 0 || row_len == 0) return ANTQ_OK;
+    if (!x || !out || !gout || !gsum) return ANTQ_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case ANTQ_F32: return launch_alpha_grad<float>(x, out, gout, gsum, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_BF16: return launch_alpha_grad<bf16_tag>(x, out, gout, gsum, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_F16: return launch_alpha_grad<f16_tag>(x, out, gout, gsum, rows, row_len, per_row ? 1 : 0, st);
     default: return ANTQ_ERR_UNSUPPORTED;
     }
 }

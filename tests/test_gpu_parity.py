@@ -1161,3 +1161,47 @@ def test_random_shapes_fuzz(antq_lib, oracle, dev, seed):
         with np.errstate(all="ignore"):
             run_case(antq_lib, oracle, dev, x, alpha if per_row else np.float32(alpha.mean()), g, gmax, per_row, ovp,
                      bool(rng.random() < 0.5))
+
+
+def test_alpha_grad_kernel_vs_autograd_of_the_reference_graph(antq_lib, dev):
+    """antq_alpha_grad (the fused backward w.r.t. alpha) against torch autograd on the reference's op sequence
+    (AQ:535-551), per channel and per tensor, vector and ragged rows, fp32 / bf16 / fp16."""
+    import torch
+    from ant_quantization_amd import core
+    from ant_quantization_amd.ant import quant_modules as qm
+    g_np = golden("ant_grids.npz")["flint_b4_s"]
+    plan = antq_lib.plan_for(g_np)
+    grid = torch.from_numpy(g_np).to(dev)
+    torch.manual_seed(5)
+    for shape, per_channel in (((64, 1024), True), ((8, 3, 3, 3), True), ((300, 16), True), ((5, 4100), True),
+                               ((16, 64, 96), False), ((7, 33), False), ((2048, 4096), False)):
+        x = (torch.randn(*shape, device=dev) * 0.05)
+        if per_channel:
+            alpha = (x.reshape(shape[0], -1).abs().amax(1) * 0.9).reshape(shape[0], *([1] * (len(shape) - 1)))
+        else:
+            alpha = x.abs().max() * 0.8
+        go = torch.randn_like(x)
+        # the reference graph in double precision is the yardstick for both
+        xd, ad = x.double().requires_grad_(True), alpha.double().clone().requires_grad_(True)
+        scale = ad / grid.double().max()
+        d = xd / scale
+        q = qm.QuantBase.forward((x / (alpha / grid.max())).detach(), grid).double()
+        out_ref = ((q - d).detach() + d) * scale
+        out_ref.backward(go.double())
+        xi = x.detach().clone().requires_grad_(True)
+        al = alpha.clone().requires_grad_(True)
+        out = core.fake_quant(xi, al, plan, 10.0, per_channel)
+        out.backward(go)
+        assert torch.equal(xi.grad, go)                                  # d out / d x = 1, no clip mask
+        torch.testing.assert_close(al.grad.double().reshape(-1), ad.grad.reshape(-1), rtol=2e-3, atol=2e-4)
+        # the kernel alone against the same reduction done by torch in float64
+        rows, row_len = core.view_rows(x, per_channel)
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            xt, gt = x.to(dt), go.to(dt)
+            outf = antq_lib.fakequant(xt, alpha.reshape(-1).float().contiguous(), plan, 10.0, rows, row_len, per_channel)
+            gsum = antq_lib.alpha_grad(xt, outf, gt, rows, row_len, per_channel)
+            term = (gt.float() * (outf.float() - xt.float())).double()
+            ref = term.reshape(rows, row_len).sum(1) if per_channel else term.sum().reshape(1)
+            mag = term.abs().reshape(rows, row_len).sum(1) if per_channel else term.abs().sum().reshape(1)
+            # fp32 partial sums over the 4 / 8 elements of a lane's vector, float64 beyond that
+            assert ((gsum - ref).abs() <= 3e-7 * mag + 1e-12).all(), (shape, dt)
