@@ -213,9 +213,11 @@ int antq_fakequant_batch(const void *batch_host, const void *batch_dev, void *st
  *   victim        -> 15, the outlier identifier (the paper's reserved code)
  *   outlier       -> index INTO THE OUTLIER LIST; the partner nibble of the pair is 15,
  *                    which is what tells the decoder to use the outlier codebook.
- * antq_decode4(antq_encode4(x)) is bit-identical to antq_fakequant(x) for finite inputs whose
- * quotient x/scale stays within 2 max|grid| (where the straight-through step is exact);
- * elements outside the scan's validity range (code would be ANTQ_IDX_NONE) encode as the
+ * antq_decode4 writes fl(v * scale) for the decoded grid value v.  That is bit-identical to antq_fakequant(x) whenever
+ * the reference's straight-through step ((q - d) + d) is exact, which holds for every ANT / OliVe 4-bit codebook
+ * (adjacent magnitudes within a factor of two: the condition the plan builder records as its x-domain eligibility)
+ * and finite inputs within twice the outermost grid values; for arbitrary value lists the two may differ by one ulp.
+ * Elements outside the scan's validity range (code would be ANTQ_IDX_NONE) encode as the
  * grid entry holding 0.0.  row_len must be a multiple of 8; x: F32 / BF16 / F16; codes: rows*row_len/2 bytes.
  * ------------------------------------------------------------------------- */
 int antq_encode4(const void *x_dev, uint8_t *codes_dev, size_t rows, size_t row_len,
