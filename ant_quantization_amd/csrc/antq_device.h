@@ -1,0 +1,349 @@
+// antq_device.h -- element I/O traits, the plan in LDS, exact division, the per-lane quantiser core (d-domain)
+// Part of libantq's single device translation unit (antq_kernels.hip includes it); gfx950 only.
+#ifndef ANTQ_DEVICE_H
+#define ANTQ_DEVICE_H
+
+namespace antq {
+
+// ------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// Streaming (nontemporal) 16-byte accesses: x is read once and out written once, so the
+// lines are marked evict-first instead of thrashing L2 / MALL.  Measured on MI355X
+// (tools/ubench.hip): a 4 KiB-per-wave copy runs 5.4 TB/s with nt, 2.9 TB/s without.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p)
+{
+    u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v)
+{
+    u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
+}
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2_t as_u16x2(uint32_t u) { return *reinterpret_cast<u16x2_t *>(&u); }
+__device__ __forceinline__ uint32_t as_u32(u16x2_t v) { return *reinterpret_cast<uint32_t *>(&v); }
+
+struct bf16_tag {};
+struct f16_tag {};
+
+// 16-byte vector <-> EPL floats.  Conversions to the storage type round to nearest-even
+// (v_cvt_pk_bf16_f32 / v_cvt_f16_f32), which is what `tensor.to(dtype)` does.
+template <typename T> struct IO;
+template <> struct IO<float> {
+    static constexpr int EPL = 4;
+    static constexpr int ESIZE = 4;
+    __device__ __forceinline__ static void unpack(const uint4 &v, float (&f)[4])
+    {
+        f[0] = u2f(v.x); f[1] = u2f(v.y); f[2] = u2f(v.z); f[3] = u2f(v.w);
+    }
+    __device__ __forceinline__ static uint4 pack(const float (&f)[4])
+    {
+        return make_uint4(f2u(f[0]), f2u(f[1]), f2u(f[2]), f2u(f[3]));
+    }
+    __device__ __forceinline__ static float load1(const void *p, size_t i) { return static_cast<const float *>(p)[i]; }
+    __device__ __forceinline__ static void store1(void *p, size_t i, float v) { static_cast<float *>(p)[i] = v; }
+    // running |x| maximum kept as fp32 magnitude bits (order like unsigned ints; NaN on top)
+    __device__ __forceinline__ static uint32_t amax_acc(uint32_t m, const uint4 &v)
+    {
+        return max(max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, v.z & 0x7fffffffu)), v.w & 0x7fffffffu);
+    }
+    __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return m; }
+};
+template <> struct IO<bf16_tag> {
+    static constexpr int EPL = 8;
+    static constexpr int ESIZE = 2;
+    __device__ __forceinline__ static void unpack(const uint4 &v, float (&f)[8])
+    {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f[2 * i] = u2f(w[i] << 16);
+            f[2 * i + 1] = u2f(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ static uint32_t pk(float a, float b)
+    {
+        floatx2_t f = {a, b};
+        bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+        return *reinterpret_cast<uint32_t *>(&h);
+    }
+    __device__ __forceinline__ static uint4 pack(const float (&f)[8])
+    {
+        return make_uint4(pk(f[0], f[1]), pk(f[2], f[3]), pk(f[4], f[5]), pk(f[6], f[7]));
+    }
+    __device__ __forceinline__ static float load1(const void *p, size_t i)
+    {
+        return u2f((uint32_t) static_cast<const uint16_t *>(p)[i] << 16);
+    }
+    __device__ __forceinline__ static void store1(void *p, size_t i, float v)
+    {
+        static_cast<uint16_t *>(p)[i] = (uint16_t)(pk(v, 0.0f) & 0xffffu);
+    }
+    // running |x| maximum on the packed 16-bit magnitudes (v_pk_max_u16: 2 elements per op)
+    __device__ __forceinline__ static uint32_t amax_acc(uint32_t m, const uint4 &v)
+    {
+        u16x2_t a = as_u16x2(m);
+        a = __builtin_elementwise_max(a, as_u16x2(v.x & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.y & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.z & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.w & 0x7fff7fffu));
+        return as_u32(a);
+    }
+    __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return max(m & 0xffffu, m >> 16) << 16; }
+};
+template <> struct IO<f16_tag> {
+    static constexpr int EPL = 8;
+    static constexpr int ESIZE = 2;
+    __device__ __forceinline__ static float h2f(uint32_t bits16)
+    {
+        uint16_t b = (uint16_t)bits16;
+        _Float16 h = *reinterpret_cast<_Float16 *>(&b);
+        return (float)h;
+    }
+    __device__ __forceinline__ static uint32_t f2h(float f)
+    {
+        _Float16 h = (_Float16)f;
+        return (uint32_t) * reinterpret_cast<uint16_t *>(&h);
+    }
+    __device__ __forceinline__ static void unpack(const uint4 &v, float (&f)[8])
+    {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f[2 * i] = h2f(w[i] & 0xffffu);
+            f[2 * i + 1] = h2f(w[i] >> 16);
+        }
+    }
+    __device__ __forceinline__ static uint4 pack(const float (&f)[8])
+    {
+        return make_uint4(f2h(f[0]) | (f2h(f[1]) << 16), f2h(f[2]) | (f2h(f[3]) << 16),
+                          f2h(f[4]) | (f2h(f[5]) << 16), f2h(f[6]) | (f2h(f[7]) << 16));
+    }
+    __device__ __forceinline__ static float load1(const void *p, size_t i)
+    {
+        return h2f(static_cast<const uint16_t *>(p)[i]);
+    }
+    __device__ __forceinline__ static void store1(void *p, size_t i, float v)
+    {
+        static_cast<uint16_t *>(p)[i] = (uint16_t)f2h(v);
+    }
+    __device__ __forceinline__ static uint32_t amax_acc(uint32_t m, const uint4 &v)
+    {
+        u16x2_t a = as_u16x2(m);
+        a = __builtin_elementwise_max(a, as_u16x2(v.x & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.y & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.z & 0x7fff7fffu));
+        a = __builtin_elementwise_max(a, as_u16x2(v.w & 0x7fff7fffu));
+        return as_u32(a);
+    }
+    // half magnitude bits -> fp32 magnitude bits (exact widening)
+    __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return f2u(h2f(max(m & 0xffffu, m >> 16))); }
+};
+
+// Plan fields the kernels need, passed by value (lands in SGPRs).
+struct PlanArgs {
+    uint32_t kind;
+    uint32_t m;
+    uint32_t m_pad;
+    uint32_t shift;
+    uint32_t kmin;
+    uint32_t kmax;
+    uint32_t keymask;
+    uint32_t nbneg;
+    float fastlim;
+    uint32_t n_entries;
+    uint32_t tab_units;  // 16-byte units to stage into LDS: n_entries + m_pad/4
+    uint32_t linear;     // PlanHeader::linear: bucket from fma(d, lin_scale, lin_bias) instead of the float's bits
+    float lin_scale;
+    float lin_bias;
+};
+
+// LDS view of the plan: [entries | grid]
+struct PlanLds {
+    const LutEntry *lut;
+    const float *grid;
+};
+
+// Stage the table into LDS.  plan_tab points at the blob's grid area; the blob stores
+// grid first, entries second, LDS wants entries first (16-byte aligned reads).
+__device__ __forceinline__ PlanLds stage_plan(const PlanArgs &pa, const uint4 *__restrict__ plan_tab, uint4 *smem,
+                                              uint4 first)
+{
+    // `first` = plan_tab[threadIdx.x], fetched by the caller ahead of its HBM loads so that
+    // the (in-order) wait for it does not cover them.  Source unit i: [0, grid_units) is the
+    // grid, the rest are table entries; LDS wants entries first (16-byte aligned b128 reads).
+    const uint32_t grid_units = pa.m_pad >> 2;
+    if (threadIdx.x < pa.tab_units) {
+        const uint32_t i = threadIdx.x;
+        smem[(i < grid_units) ? (pa.n_entries + i) : (i - grid_units)] = first;
+    }
+    for (uint32_t i = threadIdx.x + blockDim.x; i < pa.tab_units; i += blockDim.x)
+        smem[(i < grid_units) ? (pa.n_entries + i) : (i - grid_units)] = plan_tab[i];
+    PlanLds L;
+    L.lut = reinterpret_cast<const LutEntry *>(smem);
+    L.grid = reinterpret_cast<const float *>(smem + pa.n_entries);
+    return L;
+}
+
+// ------------------------------------------------------------------------------------
+// Scale of one quant group.  AQ/quant_modules.py:536: scale = alpha / max(grid)  (true
+// fp32 division); rs = RN(1/scale) feeds the exact fast division below.
+// ------------------------------------------------------------------------------------
+struct Scale {
+    float s;
+    float rs;
+    bool ok;  // |s| within [2^-40, 2^40]: div_fast is exact
+};
+__device__ __forceinline__ Scale make_scale(float alpha, float gmax)
+{
+    Scale sc;
+    sc.s = alpha / gmax;
+    float a = fabsf(sc.s);
+    sc.ok = (a >= kScaleLo) && (a <= kScaleHi);
+    sc.rs = 1.0f / sc.s;
+    return sc;
+}
+
+// Correctly rounded x/s from rs = RN(1/s) with 1 mul + 4 fma (Markstein): q1 is a
+// faithful quotient, the exact residual x - q1*s (one fma) times rs corrects it to
+// RN(x/s).  Exact provided no intermediate under/overflows: |s| in [2^-40, 2^40] and
+// x == 0 or |x| in [2^-78, 2^60]; callers guarantee that through Scale::ok and the
+// kfast / kSmallD plan conditions (antq_internal.h).
+__device__ __forceinline__ float div_fast(float x, float s, float rs)
+{
+    float q0 = x * rs;
+    float e0 = __builtin_fmaf(-q0, s, x);
+    float q1 = __builtin_fmaf(e0, rs, q0);
+    float e1 = __builtin_fmaf(-q1, s, x);
+    return __builtin_fmaf(e1, rs, q1);
+}
+
+// literal scan, quant_kernel.cu:25-37 (grid in LDS: every lane reads the same address,
+// a broadcast).  Used for scan plans and for the rare lanes outside the table's domain.
+__device__ __forceinline__ float scan_lds(float d, const float *grid, int m, int &j)
+{
+    float sub_min = 102400.0f, z_min = 0.0f;
+    j = ANTQ_IDX_NONE;
+#pragma unroll 1
+    for (int i = 0; i < m; i++) {
+        float g = grid[i];
+        float sub_v = fabsf(d - g);
+        if (sub_v <= sub_min) { sub_min = sub_v; z_min = g; j = i; }
+    }
+    return z_min;
+}
+
+// ------------------------------------------------------------------------------------
+// Core: EPL elements of one lane, all from the same quant group.
+//   in : x[e]           out: o[e] = fl(fl(fl(q-d)+d)*s), j[e] (if IDX)
+// ------------------------------------------------------------------------------------
+template <int EPL, bool OVP, bool IDX>
+__device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, const Scale &sc,
+                                          const float (&x)[EPL], float (&o)[EPL], int (&j)[EPL])
+{
+    float d[EPL], q[EPL];
+    bool fast = (pa.kind == kPlanLut) && sc.ok;
+    if (fast) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            d[e] = div_fast(x[e], sc.s, sc.rs);
+            fast = fast && (fabsf(d[e]) < pa.fastlim);  // false for NaN / Inf / huge
+        }
+    }
+    if (fast && pa.linear) {
+        // uniformly spaced thresholds: one bucket per threshold, bucket = trunc(clamp(d * scale + bias))
+        const float khi = (float)pa.kmax;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const float kf = __builtin_amdgcn_fmed3f(__builtin_fmaf(d[e], pa.lin_scale, pa.lin_bias), 0.0f, khi);
+            const uint32_t k16 = (uint32_t)kf << 4;
+            uint4 ent = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(L.lut) + k16);
+            if (!IDX) asm volatile("" : "+v"(ent.w));
+            const bool c = d[e] >= u2f(ent.x);
+            q[e] = c ? u2f(ent.z) : u2f(ent.y);
+            if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
+        }
+    } else if (fast) {
+        // byte offset of the bucket: key*16 straight from the float's bits (exponent + top
+        // mantissa bits, shifted so the key lands on bit 4), clamped, plus the negative half.
+        const int32_t sh4 = (int32_t)pa.shift - 4;                 // shift >= 13 always
+        const int32_t km16 = (int32_t)(pa.keymask << 4);
+        const int32_t lo16 = (int32_t)(pa.kmin << 4), hi16 = (int32_t)(pa.kmax << 4);
+        const uint32_t neg16 = pa.nbneg << 4;
+        const char *lut0 = reinterpret_cast<const char *>(L.lut) - lo16;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int32_t u = (int32_t)f2u(d[e]);
+            const int32_t t = (u >> sh4) & km16;
+            const int32_t c16 = min(max(t, lo16), hi16);
+            const uint32_t sg = (uint32_t)(u >> 31) & neg16;
+            uint4 ent = *reinterpret_cast<const uint4 *>(lut0 + c16 + sg);
+            if (!IDX) asm volatile("" : "+v"(ent.w));  // keep the read a single ds_read_b128 (b96 is 2x slower)
+            const bool c = d[e] >= u2f(ent.x);
+            q[e] = c ? u2f(ent.z) : u2f(ent.y);
+            if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
+        }
+    } else {
+        // exact slow path: true division + literal scan (scan plans, odd scales, huge/NaN/Inf)
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            d[e] = x[e] / sc.s;
+            int jj;
+            q[e] = scan_lds(d[e], L.grid, (int)pa.m, jj);
+            if (IDX) j[e] = jj;
+        }
+    }
+    if (OVP) {
+        // OQ/quant_modules.py:313-320 on pairs (2p, 2p+1): the odd element is a victim when
+        // its even partner is an outlier; the even one when its odd partner is an outlier and
+        // it is not one itself.  q * (~victim) keeps the sign of zero, as float*bool does.
+#pragma unroll
+        for (int p = 0; p < EPL / 2; p++) {
+            const bool me = fabsf(q[2 * p]) > 32.0f;
+            const bool mo = fabsf(q[2 * p + 1]) > 32.0f;
+            const bool ve = mo && !me;
+            q[2 * p] = q[2 * p] * (ve ? 0.0f : 1.0f);
+            q[2 * p + 1] = q[2 * p + 1] * (me ? 0.0f : 1.0f);
+            if (IDX) {
+                if (ve) j[2 * p] = ANTQ_IDX_VICTIM;
+                if (me) j[2 * p + 1] = ANTQ_IDX_VICTIM;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        float t = (q[e] - d[e]) + d[e];  // AQ:544 / OQ:323 straight-through form
+        o[e] = t * sc.s;                 // AQ:546-549
+    }
+}
+
+template <int EPL>
+__device__ __forceinline__ void store_idx(int16_t *idx, size_t vec, const int (&j)[EPL])
+{
+    // EPL int16 = 8 or 16 bytes, naturally aligned at vec*EPL
+    if (EPL == 8) {
+        uint4 v = make_uint4(((uint32_t)j[0] & 0xffffu) | ((uint32_t)j[1] << 16),
+                             ((uint32_t)j[2] & 0xffffu) | ((uint32_t)j[3] << 16),
+                             ((uint32_t)j[4 % EPL] & 0xffffu) | ((uint32_t)j[5 % EPL] << 16),
+                             ((uint32_t)j[6 % EPL] & 0xffffu) | ((uint32_t)j[7 % EPL] << 16));
+        reinterpret_cast<uint4 *>(idx)[vec] = v;
+    } else {
+        uint2 v = make_uint2(((uint32_t)j[0] & 0xffffu) | ((uint32_t)j[1] << 16),
+                             ((uint32_t)j[2] & 0xffffu) | ((uint32_t)j[3] << 16));
+        reinterpret_cast<uint2 *>(idx)[vec] = v;
+    }
+}
+
+}  // namespace antq
+
+#endif  // ANTQ_DEVICE_H

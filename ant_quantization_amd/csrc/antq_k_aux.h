@@ -1,0 +1,198 @@
+// antq_k_aux.h -- quant_affine, copy, abs-max, alpha gradient
+// Part of libantq's single device translation unit (antq_kernels.hip includes it); gfx950 only.
+#ifndef ANTQ_K_AUX_H
+#define ANTQ_K_AUX_H
+
+#include "antq_device.h"
+
+namespace antq {
+
+// ------------------------------------------------------------------------------------
+// AsymmetricQuantFunction.forward, quant_affine.py:95-115.  fp32, element-wise; rintf is
+// round-half-to-even like torch.round.  Expression order follows the reference exactly:
+//   scale*x - zp  (linear_quantize :39), (q + zp) / scale  (linear_dequantize :62).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_affine(const float *__restrict__ x, float *__restrict__ out, int32_t *__restrict__ qout,
+         size_t n, size_t row_len, int k,
+         const float *__restrict__ xmin, const float *__restrict__ xmax, int per_row)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = per_row ? i / row_len : 0;
+    const float nlev = (float)((1 << k) - 1);
+    const float half = (float)(1 << (k - 1));
+    float range = xmax[r] - xmin[r];
+    if (range < 1e-8f) range = 1e-8f;   // torch.clamp(min=1e-8): NaN stays NaN
+    const float scale = (1.0f / range) * nlev;  // `n / tensor` is reciprocal(tensor) * n in torch (__rtruediv__)
+    float zp = rintf(scale * xmin[r]);
+    zp = zp + half;
+    float q = rintf(scale * x[i] - zp);
+    if (q < -half) q = -half;           // torch.clamp(q, -n, n-1): NaN stays NaN
+    if (q > half - 1.0f) q = half - 1.0f;
+    if (qout) qout[i] = (int32_t)q;
+    out[i] = (q + zp) / scale;
+}
+
+// 16 B per lane streaming copy: the empirical HBM ceiling for this access pattern.
+__global__ void __launch_bounds__(256)
+k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec)
+{
+    const size_t first = ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 256u + (threadIdx.x & 63u);
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const size_t i = first + 64u * u;
+        if (i < n_vec) v[u] = ld_stream(src + i);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const size_t i = first + 64u * u;
+        if (i < n_vec) st_stream(dst + i, v[u]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale_inplace(float *__restrict__ a, size_t n, float ratio)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) a[i] = a[i] * ratio;
+}
+
+// ------------------------------------------------------------------------------------
+// Row abs-max (the x_max of search_mse, AQ:289 / AQ:308).  One wavefront per row; rows
+// with row_len % EPL == 0 and 16-byte alignment use vector loads, anything else element
+// loads.  per_row == 0: every wavefront folds its strip into amax[0] with atomicMax on the
+// float's bit pattern (non-negative floats order like unsigned ints; NaN sorts above Inf,
+// so a NaN anywhere yields NaN like torch.max).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size_t row_len, int per_row, int vec_ok)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t wave = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4u;
+    if (per_row) {
+        for (size_t r = wave; r < rows; r += nwaves) {
+            uint32_t m = 0;
+            if (vec_ok) {
+                const uint4 *p = static_cast<const uint4 *>(x) + r * (row_len / EPL);
+                uint32_t mp = 0;
+                for (size_t i = lane; i < row_len / EPL; i += 64) mp = IO<T>::amax_acc(mp, p[i]);
+                m = IO<T>::amax_bits(mp);
+            } else {
+                for (size_t i = lane; i < row_len; i += 64) m = max(m, f2u(IO<T>::load1(x, r * row_len + i)) & 0x7fffffffu);
+            }
+            m = wave_max_u32(m);
+            if (lane == 0) amax[r] = u2f(m);
+        }
+    } else {
+        // one scale for the whole tensor: block-strided, four independent 16-byte loads in flight per lane, one
+        // atomicMax per workgroup (plain loads: the clip search reads the same bytes next, out of the Infinity Cache)
+        const size_t n = rows * row_len;
+        const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, stride = (size_t)gridDim.x * 256u;
+        uint32_t m = 0;
+        if (vec_ok) {
+            const uint4 *p = static_cast<const uint4 *>(x);
+            const size_t nv = n / EPL;
+            uint32_t mp = 0;
+            size_t i = tid;
+            for (; i + 3 * stride < nv; i += 4 * stride) {
+                const uint4 a0 = p[i], a1 = p[i + stride], a2 = p[i + 2 * stride], a3 = p[i + 3 * stride];
+                mp = IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(mp, a0), a1), a2), a3);
+            }
+            for (; i < nv; i += stride) mp = IO<T>::amax_acc(mp, p[i]);
+            m = IO<T>::amax_bits(mp);
+            for (size_t k = nv * EPL + tid; k < n; k += stride) m = max(m, f2u(IO<T>::load1(x, k)) & 0x7fffffffu);
+        } else {
+            for (size_t k = tid; k < n; k += stride) m = max(m, f2u(IO<T>::load1(x, k)) & 0x7fffffffu);
+        }
+        m = wave_max_u32(m);
+        __shared__ uint32_t wm[4];
+        if (lane == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+            if (m) atomicMax(reinterpret_cast<unsigned int *>(amax), m);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Backward of the fused fake-quant w.r.t. alpha (QAT, AQ:39 alpha is a Parameter; AQ:544-549 straight-through
+// graph): d out / d alpha = (q - d) / gmax = (out - x) / alpha, so
+//     gsum[r] = sum_c fl32( gout[r,c] * fl32(out[r,c] - x[r,c]) )          (the caller divides by alpha[r])
+// fp32 terms, fp64 accumulation.  One wavefront per row; one scale per tensor: block-strided with one atomic per
+// workgroup.  d out / d x is the identity (no clip mask in the reference), so there is no kernel for it.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_alpha_grad(const void *__restrict__ x, const void *__restrict__ out, const void *__restrict__ gout,
+             double *__restrict__ gsum, size_t rows, size_t row_len, int per_row, int vec_ok)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const uint32_t lane = threadIdx.x & 63u;
+    auto vec_term = [](const uint4 &xv, const uint4 &ov, const uint4 &gv) -> float {
+        float xf[EPL], of[EPL], gf[EPL];
+        IO<T>::unpack(xv, xf);
+        IO<T>::unpack(ov, of);
+        IO<T>::unpack(gv, gf);
+        float part = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) part += gf[e] * (of[e] - xf[e]);
+        return part;
+    };
+    auto one_term = [&](size_t i) -> float {
+        return IO<T>::load1(gout, i) * (IO<T>::load1(out, i) - IO<T>::load1(x, i));
+    };
+    if (per_row) {
+        const size_t wave = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+        const size_t nwaves = (size_t)gridDim.x * 4u;
+        for (size_t r = wave; r < rows; r += nwaves) {
+            double acc = 0.0;
+            if (vec_ok) {
+                const size_t vpr = row_len / EPL;
+                const uint4 *px = static_cast<const uint4 *>(x) + r * vpr;
+                const uint4 *po = static_cast<const uint4 *>(out) + r * vpr;
+                const uint4 *pg = static_cast<const uint4 *>(gout) + r * vpr;
+                for (size_t i = lane; i < vpr; i += 64) acc += (double)vec_term(px[i], po[i], pg[i]);
+            } else {
+                for (size_t i = lane; i < row_len; i += 64) acc += (double)one_term(r * row_len + i);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) gsum[r] = acc;
+        }
+    } else {
+        const size_t n = rows * row_len;
+        const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, stride = (size_t)gridDim.x * 256u;
+        double acc = 0.0;
+        if (vec_ok) {
+            const size_t nv = n / EPL;
+            const uint4 *px = static_cast<const uint4 *>(x), *po = static_cast<const uint4 *>(out);
+            const uint4 *pg = static_cast<const uint4 *>(gout);
+            size_t i = tid;
+            for (; i + stride < nv; i += 2 * stride) {
+                const uint4 x0 = px[i], o0 = po[i], g0 = pg[i];
+                const uint4 x1 = px[i + stride], o1 = po[i + stride], g1 = pg[i + stride];
+                acc += (double)vec_term(x0, o0, g0);
+                acc += (double)vec_term(x1, o1, g1);
+            }
+            for (; i < nv; i += stride) acc += (double)vec_term(px[i], po[i], pg[i]);
+            for (size_t k = nv * EPL + tid; k < n; k += stride) acc += (double)one_term(k);
+        } else {
+            for (size_t k = tid; k < n; k += stride) acc += (double)one_term(k);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        __shared__ double wsum[4];
+        if (lane == 0) wsum[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(gsum, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+    }
+}
+
+}  // namespace antq
+
+#endif  // ANTQ_K_AUX_H

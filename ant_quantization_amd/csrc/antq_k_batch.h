@@ -1,0 +1,143 @@
+// antq_k_batch.h -- batched launch: descriptor table, block -> job map, the multi-tensor kernel
+// Part of libantq's single device translation unit (antq_kernels.hip includes it); gfx950 only.
+#ifndef ANTQ_K_BATCH_H
+#define ANTQ_K_BATCH_H
+
+#include "antq_k_fakequant.h"
+
+namespace antq {
+
+constexpr uint32_t kBatchMagic = 0x42544E41u;  // "ANTB"
+constexpr int kBatchU = 4;                      // vectors per lane per task (4 KiB per wavefront: best measured)
+
+struct BatchDesc {   // 144 bytes, device-visible
+    const uint4 *x;
+    uint4 *out;
+    const float *alpha;
+    const uint4 *plan_tab;
+    uint64_t n_vec;        // lane kind: number of 16-byte vectors
+    uint32_t total_tasks;  // row kind: wavefront tasks
+    uint32_t vpr;
+    uint32_t tpr;
+    int32_t vshift;
+    uint32_t first_block;
+    uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < 64);
+                           // 2 = row-run per wavefront, x-domain table (pad[] = xlim bits, grid offset)
+    int32_t per_row;
+    float gmax;
+    PlanArgs pa;
+    uint32_t pad[4];
+};
+static_assert(sizeof(BatchDesc) == 144, "BatchDesc must be 144 bytes");
+
+struct BatchHeader {   // 32 bytes
+    uint32_t magic, n, total_blocks, dtype, flags, lds_bytes, map_offset, bytes;
+};
+
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(256)
+k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
+{
+    constexpr int EPL = IO<T>::EPL;
+    constexpr int U = kBatchU;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t j = block_map[blockIdx.x];
+    const BatchDesc &D = descs[j];
+    const PlanArgs pa = D.pa;
+    const uint32_t lb = blockIdx.x - D.first_block;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint4 *plan_tab = D.plan_tab;
+
+    if (D.kind == 2) {
+        // x-domain rows: wave-private table, no workgroup barrier
+        __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
+        const uint32_t wv = threadIdx.x >> 6;
+        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
+        if (task >= D.total_tasks) return;
+        XArgs xa;
+        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]); xa.vout = u2f(D.pad[1]);
+        xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
+                                              nullptr, xa, plan_tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
+                                              wtab_all[wv], lane, wv);
+        return;
+    }
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    if (D.kind == 0) {
+        const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
+        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+        const bool active = task < total;
+        uint4 v[U];
+        float a;
+        task_load<T, U>(D.x, D.alpha, D.per_row, active ? task : total - 1u, vpr, tpr, lane, false, v, a);
+        const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+        __syncthreads();
+        if (active)
+            task_run<T, OVP, false, U, false>(D.out, nullptr, nullptr, 1.0f, task, vpr, tpr, lane, D.gmax, pa, L, v, a);
+    } else {
+        const size_t n_vec = D.n_vec;
+        const size_t first = ((size_t)lb * U) * 256u + threadIdx.x;
+        uint4 v[U];
+        float a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t vi = first + (size_t)u * 256u;
+            v[u] = make_uint4(0, 0, 0, 0);
+            a[u] = 1.0f;
+            if (vi < n_vec) {
+                v[u] = ld_stream(D.x + vi);
+                size_t row = 0;
+                if (D.per_row) row = (D.vshift >= 0) ? (vi >> D.vshift) : (vi / D.vpr);
+                a[u] = D.alpha[row];
+            }
+        }
+        const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t vi = first + (size_t)u * 256u;
+            if (vi < n_vec) {
+                const Scale sc = make_scale(a[u], D.gmax);
+                float xf[EPL], of[EPL];
+                int jj[EPL];
+                IO<T>::unpack(v[u], xf);
+                quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, jj);
+                st_stream(D.out + vi, IO<T>::pack(of));
+            }
+        }
+    }
+}
+
+static int epl_of(int dtype) { return dtype == ANTQ_F32 ? 4 : (dtype == ANTQ_BF16 || dtype == ANTQ_F16) ? 8 : 0; }
+
+// blocks a job needs, or 0 if it cannot be expressed (ragged / unaligned)
+static size_t job_blocks(const antq_job &J, int epl, BatchDesc *d)
+{
+    size_t rows = J.rows, row_len = J.row_len;
+    const size_t n = rows * row_len;
+    if (!J.alpha_per_row) { rows = 1; row_len = n; }
+    if (n == 0 || row_len % epl != 0) return 0;
+    if (reinterpret_cast<uintptr_t>(J.x_dev) % 16 || reinterpret_cast<uintptr_t>(J.out_dev) % 16) return 0;
+    const size_t vpr = row_len / epl;
+    if (vpr > 0xffffffffull) return 0;
+    size_t blocks;
+    if (vpr >= 64) {
+        const size_t tpr = (vpr + 64 * kBatchU - 1) / (64 * kBatchU);
+        const size_t total = rows * tpr;
+        if (total > 0xfffffff0ull) return 0;
+        blocks = (total + 3) / 4;
+        if (d) { d->kind = 0; d->total_tasks = (uint32_t)total; d->vpr = (uint32_t)vpr; d->tpr = (uint32_t)tpr; d->vshift = -1; d->n_vec = n / epl; }
+    } else {
+        const size_t n_vec = n / epl;
+        blocks = (n_vec + 256 * kBatchU - 1) / (256 * kBatchU);
+        int vshift = -1;
+        if ((vpr & (vpr - 1)) == 0) { vshift = 0; while (((size_t)1 << vshift) < vpr) vshift++; }
+        if (d) { d->kind = 1; d->total_tasks = 0; d->vpr = (uint32_t)vpr; d->tpr = 1; d->vshift = vshift; d->n_vec = n_vec; }
+    }
+    return blocks;
+}
+
+}  // namespace antq
+
+#endif  // ANTQ_K_BATCH_H

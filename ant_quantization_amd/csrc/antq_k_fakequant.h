@@ -1,0 +1,486 @@
+// antq_k_fakequant.h -- fused Quantizer._forward kernels: K1a rows (d-domain table), K1x rows (per-row x-domain table), K1b lane groups, K1c element-granular
+// Part of libantq's single device translation unit (antq_kernels.hip includes it); gfx950 only.
+#ifndef ANTQ_K_FAKEQUANT_H
+#define ANTQ_K_FAKEQUANT_H
+
+#include "antq_device.h"
+
+namespace antq {
+
+// ------------------------------------------------------------------------------------
+// K1a  wave-uniform scale.  A task = up to U*64 consecutive 16-byte vectors of ONE row
+// (quant group) = one wavefront; the row's alpha is a scalar load and scale / reciprocal
+// are wave-uniform.  All U loads of the task are issued before anything else; with 6-8
+// resident wavefronts per SIMD that keeps > 100 KiB per CU in flight, which is what hides
+// HBM latency (a persistent ping-pong variant measured slower: it doubles the registers).
+// Rows need row_len % EPL == 0; lanes past the row end are masked.
+//   vpr = vectors per row, tpr = tasks per row = ceil(vpr / (64*U)).
+// DYN: alpha is not read but computed: alpha = max|row| * ratio (requires tpr == 1, the
+// whole row sits in this wave's registers; one HBM read of x in total).
+// Launch: 256 threads (4 wavefronts); grid = ceil(total_tasks / 4).
+// ------------------------------------------------------------------------------------
+template <typename T, int U>
+__device__ __forceinline__ void task_load(const uint4 *__restrict__ x, const float *__restrict__ alpha, int per_row,
+                                          uint32_t task, uint32_t vpr, uint32_t tpr, uint32_t lane, bool dyn,
+                                          uint4 (&v)[U], float &a)
+{
+    uint32_t row = task, g = 0;
+    if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+    const uint32_t v0 = g * (64u * U) + lane;
+    const uint4 *p = x + (size_t)row * vpr;
+    // Unconditional loads (lanes past the row end re-read the row's last vector and are
+    // masked at the store): no exec-mask branches between the loads, so all U of them are
+    // in flight together.
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = ld_stream(p + min(v0 + 64u * u, vpr - 1u));
+    a = 1.0f;
+    if (!dyn) a = alpha[per_row ? row : 0];
+}
+
+// wave-wide max of a non-negative float (bit patterns order like integers); NaN propagates
+// as in torch.max because a NaN's magnitude bits exceed every finite value's.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    return m;
+}
+
+template <typename T, bool OVP, bool IDX, int U, bool DYN>
+__device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__restrict__ idx,
+                                         float *__restrict__ alpha_out, float ratio,
+                                         uint32_t task, uint32_t vpr, uint32_t tpr, uint32_t lane, float gmax,
+                                         const PlanArgs &pa, const PlanLds &L, const uint4 (&v)[U], float a)
+{
+    constexpr int EPL = IO<T>::EPL;
+    uint32_t row = task, g = 0;
+    if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+    const uint32_t v0 = g * (64u * U) + lane;
+    const size_t base = (size_t)row * vpr + v0;
+    if (DYN) {
+        // alpha = fl32(max|x| * ratio): AQ/quant_modules.py:474 (x_max) and :300 (x_max * ratio)
+        uint32_t m = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t mu = IO<T>::amax_acc(0u, v[u]);
+            if (v0 + 64u * u < vpr) m = IO<T>::amax_acc(m, v[u]);  // lanes past the row end hold a duplicate
+            (void)mu;
+        }
+        m = IO<T>::amax_bits(m);
+        m = wave_max_u32(m);
+        a = u2f(m) * ratio;
+        if (alpha_out && lane == 0) alpha_out[row] = a;
+    }
+    const Scale sc = make_scale(a, gmax);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (v0 + 64u * u < vpr) {
+            float xf[EPL], of[EPL];
+            int j[EPL];
+            IO<T>::unpack(v[u], xf);
+            quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
+            st_stream(out + base + 64u * u, IO<T>::pack(of));
+            if (IDX) store_idx<EPL>(idx, base + 64u * u, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep one vector's working set live at a time
+    }
+}
+
+template <typename T, bool OVP, bool IDX, int U, bool DYN, bool LOOP = false>
+__global__ void __launch_bounds__(256)
+k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+             uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
+             const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+             float *__restrict__ alpha_out, PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t stride = gridDim.x * 4u;   // one-shot launch: stride >= total_tasks, the loop runs once
+
+    // table fetch is issued FIRST (L2 hit) so that its wait (vmcnt is in-order) does not
+    // also wait for the HBM loads of the task, which are issued right behind it
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+
+    uint4 v[U];
+    float a;
+    bool active = task < total_tasks;
+    task_load<T, U>(x, alpha, per_row, active ? task : total_tasks - 1u, vpr, tpr, lane, DYN, v, a);
+
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+    // Big tables (8-bit grids: up to 48 KiB) are staged once per workgroup and amortised over a
+    // grid-stride loop of tasks; small tables use a one-shot grid (loop runs once).
+    if (!LOOP) {
+        if (active) task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
+        return;
+    }
+    while (active) {
+        task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
+        task += stride;
+        active = task < total_tasks;
+        if (active) task_load<T, U>(x, alpha, per_row, task, vpr, tpr, lane, DYN, v, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1x  x-domain row kernel: the fast path for rows of >= 256 vectors (the headline shape).
+//
+// K1a spends most of its VALU time on per-element work that only depends on the ROW:
+// dividing by the row's scale, and mapping the quotient back (straight-through add,
+// multiply by the scale).  Here each wavefront first rebuilds the grid's bucket table for
+// ITS row -- lane b owns bucket b:
+//     U_b   = min { x : fl(x / s) >= T_b }       (threshold moved into the x domain, exact)
+//     O_lo  = fl(v_lo * s),  O_hi = fl(v_hi * s)  (= the reference's output: (q-d)+d == q
+//                                                  for |d| <= 2 max|v|, see antq_plan.cpp)
+// into a wave-private 1 KiB LDS table (no workgroup barrier), then per element does
+//     bucket from x * rcp(s)  (approximate quotient: only picks the bucket; thresholds keep
+//                              2^-20 clear of bucket edges, so a 2-ulp error cannot matter)
+//     out = (x >= U_b) ? O_hi : O_lo
+// i.e. 1 mul + 5 integer ops + 1 LDS read + compare/select: ~10 VALU ops per element instead
+// of ~18.  Lanes whose |x * rcp(s)| >= xlim (clipped far beyond the grid, Inf, NaN) and rows
+// with an odd scale take the exact reference sequence (true division, literal scan).
+// ------------------------------------------------------------------------------------
+struct XArgs {
+    uint32_t m;
+    uint32_t shift;
+    uint32_t kmin;
+    uint32_t kmax;
+    uint32_t keymask;
+    uint32_t nbneg;
+    uint32_t n_entries;
+    float xlim;
+    float vout;
+};
+
+__device__ __forceinline__ float f_up(float c)   // next float towards +inf (c != 0)
+{
+    const uint32_t u = f2u(c);
+    return u2f((int32_t)u >= 0 ? u + 1u : u - 1u);
+}
+__device__ __forceinline__ float f_dn(float c)   // next float towards -inf (c != 0)
+{
+    const uint32_t u = f2u(c);
+    return u2f((int32_t)u >= 0 ? u - 1u : u + 1u);
+}
+
+// U = min { x : RN(x / s) >= T } for a scale inside div_fast's domain, s > 0, T finite, non-zero.
+__device__ __forceinline__ float x_threshold(float T, float s, float rs, bool &ok)
+{
+    float c = T * s;   // within an ulp or two of the boundary
+#pragma unroll
+    for (int it = 0; it < 2; it++) { const float p = f_dn(c); if (div_fast(p, s, rs) >= T) c = p; }
+#pragma unroll
+    for (int it = 0; it < 2; it++) { if (!(div_fast(c, s, rs) >= T)) c = f_up(c); }
+    ok = (div_fast(c, s, rs) >= T) && !(div_fast(f_dn(c), s, rs) >= T);
+    return c;
+}
+
+template <int EPL, bool OVP, bool IDX>
+__device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, const float *__restrict__ grid,
+                                            const Scale &sc, bool rowfast, const float (&x)[EPL], float (&o)[EPL],
+                                            int (&j)[EPL])
+{
+    bool fast = rowfast;
+    float dt[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        dt[e] = x[e] * sc.rs;
+        fast = fast && (fabsf(dt[e]) < xa.xlim);
+    }
+    if (fast) {
+        // slot = 2 * clamp(key) + sign: positive and negative buckets interleaved, so that the sign costs one
+        // v_alignbit and the clamp one v_med3 (an unsigned grid keeps a negative key: it clamps to kmin, slot 1)
+        const int32_t sh = (int32_t)xa.shift, km = (int32_t)xa.keymask;
+        const int32_t lo = (int32_t)xa.kmin, hi = (int32_t)xa.kmax;
+        const char *t0 = reinterpret_cast<const char *>(wtab) - (lo << 5);
+        bool isout[EPL];
+        const float othr = xa.vout * sc.s;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int32_t u = (int32_t)f2u(dt[e]);
+            const int32_t t = (u >> sh) & km;
+            int32_t ck;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+            const uint32_t slot = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);
+            uint4 ent = *reinterpret_cast<const uint4 *>(t0 + (slot << 4));
+            if (!IDX) asm volatile("" : "+v"(ent.w));
+            const bool c = x[e] >= u2f(ent.x);
+            o[e] = c ? u2f(ent.z) : u2f(ent.y);
+            if (OVP) isout[e] = fabsf(o[e]) >= othr;      // |v| > 32 (PlanHeader::vout)
+            if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
+        }
+        if (OVP) {
+#pragma unroll
+            for (int p = 0; p < EPL / 2; p++) {
+                const bool me = isout[2 * p], mo = isout[2 * p + 1];
+                const bool ve = mo && !me;
+                o[2 * p] = ve ? 0.0f : o[2 * p];          // ((q*0 - d) + d) * s == +0 for s > 0
+                o[2 * p + 1] = me ? 0.0f : o[2 * p + 1];
+                if (IDX) {
+                    if (ve) j[2 * p] = ANTQ_IDX_VICTIM;
+                    if (me) j[2 * p + 1] = ANTQ_IDX_VICTIM;
+                }
+            }
+        }
+    } else {
+        // exact reference sequence for this lane's EPL elements
+        float d[EPL], q[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            d[e] = x[e] / sc.s;
+            int jj;
+            q[e] = scan_lds(d[e], grid, (int)xa.m, jj);
+            if (IDX) j[e] = jj;
+        }
+        if (OVP) {
+#pragma unroll
+            for (int p = 0; p < EPL / 2; p++) {
+                const bool me = fabsf(q[2 * p]) > 32.0f;
+                const bool mo = fabsf(q[2 * p + 1]) > 32.0f;
+                const bool ve = mo && !me;
+                q[2 * p] = q[2 * p] * (ve ? 0.0f : 1.0f);
+                q[2 * p + 1] = q[2 * p + 1] * (me ? 0.0f : 1.0f);
+                if (IDX) {
+                    if (ve) j[2 * p] = ANTQ_IDX_VICTIM;
+                    if (me) j[2 * p + 1] = ANTQ_IDX_VICTIM;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const float t = (q[e] - d[e]) + d[e];
+            o[e] = t * sc.s;
+        }
+    }
+}
+
+// Body of the x-domain row kernel for one wavefront task (shared by k_fq_xrow and k_fq_batch).
+template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR>
+__device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+                                          uint32_t task, uint32_t vpr, uint32_t tpr,
+                                          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+                                          float *__restrict__ alpha_out, const XArgs &xa,
+                                          const uint4 *__restrict__ entries, const float *__restrict__ grid,
+                                          uint4 *wtab, uint32_t lane, uint32_t wv)
+{
+    constexpr int EPL = IO<T>::EPL;
+    // static bucket entries of this lane (L2 hits), issued ahead of the HBM loads; tables of
+    // 65..128 buckets (e.g. unsigned int-4) give every lane a second entry
+    uint4 ent = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u), ent2 = ent;
+    if (lane < xa.n_entries) ent = entries[lane];
+    const bool two = xa.n_entries > 64u;
+    if (two && lane + 64u < xa.n_entries) ent2 = entries[lane + 64u];
+
+    uint4 v[U];
+    float a;
+    task_load<T, U>(x, alpha, per_row, task, vpr, tpr, lane, DYN, v, a);
+
+    uint32_t row = task, g = 0;
+    if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+    const uint32_t v0 = g * (64u * U) + lane;
+    const size_t base = (size_t)row * vpr + v0;
+    if (DYN) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (v0 + 64u * u < vpr) m = IO<T>::amax_acc(m, v[u]);
+        m = wave_max_u32(IO<T>::amax_bits(m));
+        if (WPR == 4) {
+            // the row spans the 4 wavefronts of this workgroup (tpr == 4): combine their maxima
+            __shared__ uint32_t wmax[4];
+            if (lane == 0) wmax[wv] = m;
+            __syncthreads();
+            m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        }
+        a = u2f(m) * ratio;
+        if (alpha_out && lane == 0 && (WPR == 1 || wv == 0)) alpha_out[row] = a;
+    }
+    const Scale sc = make_scale(a, gmax);
+
+    // per-row table: thresholds into the x domain, outputs pre-multiplied by the scale
+    bool rowfast = sc.ok && (sc.s > 0.0f);
+    {
+        bool ok = true;
+        float Ux = u2f(ent.x);
+        if (rowfast && lane < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
+        rowfast = rowfast && __all(ok);
+        // (v + 0) * s: a -0.0 grid entry must come out as +0.0, like the reference's (q - d) + d
+        // entry i is positive bucket i (slot 2i) or negative bucket i - nb (slot 2(i - nb) + 1)
+        const uint32_t nbp = xa.n_entries - xa.nbneg;
+        const uint4 w0 = make_uint4(f2u(Ux), f2u((u2f(ent.y) + 0.0f) * sc.s), f2u((u2f(ent.z) + 0.0f) * sc.s), ent.w);
+        if (lane < xa.n_entries) wtab[lane < nbp ? 2u * lane : 2u * (lane - nbp) + 1u] = w0;
+        if (xa.nbneg == 0u && lane == 0u) wtab[1] = w0;     // unsigned grid: every negative x lands in slot 1
+        if (two) {
+            bool ok2 = true;
+            float U2 = u2f(ent2.x);
+            const uint32_t i2 = lane + 64u;
+            if (rowfast && i2 < xa.n_entries && U2 < __builtin_inff()) U2 = x_threshold(U2, sc.s, sc.rs, ok2);
+            rowfast = rowfast && __all(ok2);
+            if (i2 < xa.n_entries)
+                wtab[i2 < nbp ? 2u * i2 : 2u * (i2 - nbp) + 1u] =
+                    make_uint4(f2u(U2), f2u((u2f(ent2.y) + 0.0f) * sc.s), f2u((u2f(ent2.z) + 0.0f) * sc.s), ent2.w);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (v0 + 64u * u < vpr) {
+            float xf[EPL], of[EPL];
+            int j[EPL];
+            IO<T>::unpack(v[u], xf);
+            quant_vec_x<EPL, OVP, IDX>(xa, wtab, grid, sc, rowfast, xf, of, j);
+            st_stream(out + base + 64u * u, IO<T>::pack(of));
+            if (IDX) store_idx<EPL>(idx, base + 64u * u, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR = 1>
+__global__ void __launch_bounds__(256)
+k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+          uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
+          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+          float *__restrict__ alpha_out, XArgs xa, const uint4 *__restrict__ entries,
+          const float *__restrict__ grid)
+{
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    if (task >= total_tasks) return;   // no workgroup barrier in this kernel (WPR == 4: whole workgroups exit)
+    xrow_task<T, OVP, IDX, U, DYN, WPR>(x, out, idx, task, vpr, tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries,
+                                        grid, wtab_all[wv], lane, wv);
+}
+
+// ------------------------------------------------------------------------------------
+// K1b  per-lane scale: small rows / small groups (vpr < 64: several quant groups share a
+// wavefront, e.g. group-16 = 2 bf16 lanes or 4 fp32 lanes per group).  Each lane gathers
+// its own alpha and builds its own scale.  vshift >= 0 when vpr is a power of two.
+// ------------------------------------------------------------------------------------
+template <typename T, bool OVP, bool IDX, int U, bool DYN>
+__global__ void __launch_bounds__(256)
+k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+          size_t n_vec, uint32_t vpr, int vshift,
+          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+          float *__restrict__ alpha_out, PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    constexpr int EPL = IO<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
+    uint4 v[U];
+    float a[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t vi = first + (size_t)u * 256u;
+        v[u] = make_uint4(0, 0, 0, 0);
+        a[u] = 1.0f;
+        if (vi < n_vec) {
+            v[u] = ld_stream(x + vi);
+            if (!DYN) {
+                size_t row = 0;
+                if (per_row) row = (vshift >= 0) ? (vi >> vshift) : (vi / vpr);
+                a[u] = alpha[row];
+            }
+        }
+    }
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t vi = first + (size_t)u * 256u;
+        float xf[EPL];
+        IO<T>::unpack(v[u], xf);
+        if (DYN) {
+            // group = vpr (power of two <= 32) adjacent lanes; butterfly max inside the group.
+            // Lanes past n_vec hold zeros and belong to no real group (n_vec % vpr == 0).
+            uint32_t m = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
+            for (uint32_t off = 1; off < vpr; off <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, (int)off, 64));
+            a[u] = u2f(m) * ratio;
+            if (alpha_out && vi < n_vec && (vi & (vpr - 1)) == 0) alpha_out[vi >> vshift] = a[u];
+        }
+        if (vi < n_vec) {
+            const Scale sc = make_scale(a[u], gmax);
+            float of[EPL];
+            int j[EPL];
+            quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
+            st_stream(out + vi, IO<T>::pack(of));
+            if (IDX) store_idx<EPL>(idx, vi, j);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1c  element-granular fallback: any row_len (e.g. conv1's K = 147), any alignment,
+// and the < EPL tail of a per-tensor launch.  One thread per PAIR (2p, 2p+1) of the flat
+// tensor so the OliVe victim rule stays inside a thread; with an odd element count the
+// last element's "partner" is element 0 (torch.roll wrap-around, OQ:315-318).
+//   elements [e0, e0 + n_here) of a tensor with n_total elements, e0 even.
+// ------------------------------------------------------------------------------------
+template <typename T, bool OVP, bool IDX>
+__global__ void __launch_bounds__(256)
+k_fq_scalar(const void *__restrict__ x, void *__restrict__ out, int16_t *__restrict__ idx,
+            size_t e0, size_t n_here, size_t n_total, size_t row_len,
+            const float *__restrict__ alpha, int per_row, float gmax,
+            PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+    const size_t p = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const size_t i0 = e0 + 2 * p;
+    if (2 * p >= n_here) return;
+    const bool has_odd = (2 * p + 1 < n_here);
+    const size_t i1 = has_odd ? i0 + 1 : 0;  // wrap partner (only read when !has_odd && OVP)
+    const bool need1 = has_odd || (OVP && i0 + 1 == n_total);
+
+    float xs[2] = {IO<T>::load1(x, i0), need1 ? IO<T>::load1(x, i1) : 0.0f};
+    float d[2], q[2];
+    float s[2];
+    int j[2] = {ANTQ_IDX_NONE, ANTQ_IDX_NONE};
+    for (int e = 0; e < 2; e++) {
+        const size_t ii = e ? i1 : i0;
+        const float a = alpha[per_row ? (ii / row_len) : 0];
+        s[e] = a / gmax;
+        d[e] = xs[e] / s[e];
+        int jj;
+        q[e] = scan_lds(d[e], L.grid, (int)pa.m, jj);
+        j[e] = jj;
+    }
+    if (OVP && need1) {
+        const bool me = fabsf(q[0]) > 32.0f;
+        const bool mo = fabsf(q[1]) > 32.0f;
+        if (has_odd) {
+            const bool ve = mo && !me;
+            q[0] = q[0] * (ve ? 0.0f : 1.0f);
+            q[1] = q[1] * (me ? 0.0f : 1.0f);
+            if (ve) j[0] = ANTQ_IDX_VICTIM;
+            if (me) j[1] = ANTQ_IDX_VICTIM;
+        } else {
+            // odd numel: the last (even-indexed) element is zeroed iff element 0 is an outlier
+            q[0] = q[0] * (mo ? 0.0f : 1.0f);
+            if (mo) j[0] = ANTQ_IDX_VICTIM;
+        }
+    }
+    {
+        float t = (q[0] - d[0]) + d[0];
+        IO<T>::store1(out, i0, t * s[0]);
+        if (IDX) idx[i0] = (int16_t)j[0];
+    }
+    if (has_odd) {
+        float t = (q[1] - d[1]) + d[1];
+        IO<T>::store1(out, i1, t * s[1]);
+        if (IDX) idx[i1] = (int16_t)j[1];
+    }
+}
+
+}  // namespace antq
+
+#endif  // ANTQ_K_FAKEQUANT_H

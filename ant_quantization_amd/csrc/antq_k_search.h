@@ -1,0 +1,170 @@
+// antq_k_search.h -- clip search (search_mse): SSE of every candidate on one read, and the selection step
+// Part of libantq's single device translation unit (antq_kernels.hip includes it); gfx950 only.
+#ifndef ANTQ_K_SEARCH_H
+#define ANTQ_K_SEARCH_H
+
+#include "antq_device.h"
+
+namespace antq {
+
+// ------------------------------------------------------------------------------------
+// Clip search (search_mse, AQ:287-326): for every candidate ratio the squared error of the
+// fake-quantised row against the row itself, WITHOUT writing the quantised tensor: x is
+// read once into registers and all `ncand` candidates are evaluated on it.
+//   sse[c, r] += sum_col fl32( fl32|out - x| ^ 2 )      (fp32 terms, fp64 accumulation)
+// Same task decomposition as K1a (U*64 vectors of one row per task); tasks of one row add
+// their partial sums with a double atomicAdd.
+// ------------------------------------------------------------------------------------
+constexpr int kPtCand = 128;   // candidates per workgroup in the one-scale-per-tensor mode (LDS accumulators)
+
+template <typename T, bool OVP, int U, bool PT>
+__global__ void __launch_bounds__(256)
+k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
+             const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand, float gmax,
+             double *__restrict__ sse, PlanArgs pa, const uint4 *__restrict__ plan_tab, int cand_chunk)
+{
+    constexpr int EPL = IO<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    // small tensors do not have enough rows to fill the chip: blockIdx.y splits the candidate list
+    const int c_begin = (int)blockIdx.y * cand_chunk;
+    const int c_end = min(ncand, c_begin + cand_chunk);
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    // PT (one scale for the whole tensor): every task adds to the same ncand sums.  Global atomics on 75 addresses
+    // from every task serialise in L2 (measured: 4x the arithmetic), so each wavefront keeps its sums in LDS and the
+    // workgroup issues one atomic per candidate at the end.
+    __shared__ double wacc[PT ? 4 : 1][PT ? kPtCand : 1];
+    if (PT)
+        for (int c = (int)lane; c < kPtCand; c += 64) wacc[threadIdx.x >> 6][c] = 0.0;
+    __syncthreads();
+    const size_t na = per_row ? rows : 1;
+    for (uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6); task < total_tasks; task += gridDim.x * 4u) {
+        uint4 v[U];
+        float xm;
+        task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
+        uint32_t row = task, g = 0;
+        if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+        const uint32_t v0 = g * (64u * U) + lane;
+        for (int c = c_begin; c < c_end; c++) {
+            const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
+            const Scale sc = make_scale(a, gmax);
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (v0 + 64u * u < vpr) {
+                    float xf[EPL], of[EPL];
+                    int j[EPL];
+                    IO<T>::unpack(v[u], xf);
+                    quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
+                    float part = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) {
+                        const float df = fabsf(of[e] - xf[e]);  // AQ:282 (q - x).abs().pow(2)
+                        part += df * df;
+                    }
+                    acc += (double)part;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (PT) {
+                if (lane == 0) wacc[threadIdx.x >> 6][c - c_begin] += acc;
+            } else if (lane == 0) {
+                double *dst = sse + (size_t)c * na + (per_row ? row : 0);
+                if (per_row && tpr == 1) *dst = acc; else atomicAdd(dst, acc);
+            }
+        }
+    }
+    if (PT) {
+        __syncthreads();
+        for (int c = (int)threadIdx.x; c < c_end - c_begin; c += 256)
+            atomicAdd(sse + (size_t)(c_begin + c), (wacc[0][c] + wacc[1][c]) + (wacc[2][c] + wacc[3][c]));
+    }
+}
+
+// Element-granular clip search for ragged rows (row_len % EPL != 0, e.g. 3x3x3 conv rows) or
+// unaligned buffers: one wavefront per row (per strip of 16 Ki elements for a per-tensor
+// scale), exact slow-path arithmetic (true division + literal scan).  With OVP the partner
+// element (i ^ 1, or element 0 for the last element of an odd-sized tensor) is quantised
+// with ITS row's candidate alpha, as the reference does when it quantises the whole tensor.
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(256)
+k_search_sse_scalar(const void *__restrict__ x, size_t rows, size_t row_len, const float *__restrict__ xmax,
+                    int per_row, const float *__restrict__ ratios, int ncand, float gmax, double *__restrict__ sse,
+                    PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t n = rows * row_len;
+    const size_t strip = per_row ? row_len : (size_t)16384;
+    const size_t nstrips = per_row ? rows : (n + strip - 1) / strip;
+    const size_t na = per_row ? rows : 1;
+    for (size_t st = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6); st < nstrips; st += (size_t)gridDim.x * 4u) {
+        const size_t b = st * strip;
+        const size_t e = per_row ? b + row_len : (b + strip < n ? b + strip : n);
+        for (int c = 0; c < ncand; c++) {
+            const float r = ratios[c];
+            double acc = 0.0;
+            for (size_t i = b + lane; i < e; i += 64) {
+                const float xv = IO<T>::load1(x, i);
+                const float s0 = (xmax[per_row ? i / row_len : 0] * r) / gmax;
+                const float d = xv / s0;
+                int j;
+                float q = scan_lds(d, L.grid, (int)pa.m, j);
+                if (OVP) {
+                    size_t ip = i ^ (size_t)1;
+                    if (ip >= n) ip = 0;                       // odd numel: torch.roll wrap-around
+                    const bool has_partner = (ip != i);
+                    if (has_partner) {
+                        const float s1 = (xmax[per_row ? ip / row_len : 0] * r) / gmax;
+                        int jp;
+                        const float qp = scan_lds(IO<T>::load1(x, ip) / s1, L.grid, (int)pa.m, jp);
+                        const bool me = fabsf(q) > 32.0f, mp = fabsf(qp) > 32.0f;
+                        bool victim;
+                        if (i & 1) victim = mp;                 // odd element: victim iff its even partner is an outlier
+                        else if ((i ^ 1) < n) victim = mp && !me;  // even element with a real odd partner
+                        else victim = mp;                       // last element of an odd-sized tensor
+                        q = q * (victim ? 0.0f : 1.0f);
+                    }
+                }
+                const float t = (q - d) + d;
+                const float df = fabsf(t * s0 - xv);
+                acc += (double)(df * df);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) {
+                double *dst = sse + (size_t)c * na + (per_row ? st : 0);
+                if (per_row) *dst = acc; else atomicAdd(dst, acc);
+            }
+        }
+    }
+}
+
+// search_mse's selection loop, one thread per row (AQ:299-306): strict '<' keeps the earliest best.
+__global__ void __launch_bounds__(256)
+k_search_pick(const double *__restrict__ sse, const float *__restrict__ xmax, const float *__restrict__ ratios,
+              int ncand, size_t na, double row_len, float *__restrict__ best_score, float *__restrict__ best_alpha)
+{
+    const size_t r = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= na) return;
+    float best = 1e10f;
+    const float xm = xmax[r];
+    float alpha = xm;
+    for (int c = 0; c < ncand; c++) {
+        const float score = (float)(sse[(size_t)c * na + r] / row_len);
+        if (score < best) { best = score; alpha = xm * ratios[c]; }
+    }
+    best_score[r] = best;
+    best_alpha[r] = alpha;
+}
+
+}  // namespace antq
+
+#endif  // ANTQ_K_SEARCH_H
