@@ -65,6 +65,8 @@ def _quantizers(model, cls, rearm=True):
 
 def _to_8bit(m):
     m.bit.data = torch.tensor(8, device=m.bit.device)
+    if hasattr(m, "_hm_known"):
+        m._hm_known("bit", 8)       # the host just wrote it: no read-back later
     m.rearm()
 
 

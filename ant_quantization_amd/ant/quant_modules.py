@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, core, grids
+from .._mirror import HostMirrorMixin
 from .quant_affine import *  # noqa: F401,F403  (the reference star-imports it, AQ:9)
 
 _TYPE_ORDER = ("int", "flint", "pot", "float", "float1", "float2", "float3", "float4", "apot")
@@ -53,7 +54,7 @@ class QuantBase():
             return QuantBase._quantization(real_val, quant_grid)
 
 
-class Quantizer(nn.Module):
+class Quantizer(HostMirrorMixin, nn.Module):
     def __init__(self, mode="base", bit=8, is_signed=True, is_enable=False, is_input=False, args=None, operator=None):
         super(Quantizer, self).__init__()
         self.mode = mode
@@ -70,6 +71,7 @@ class Quantizer(nn.Module):
         self.register_buffer('bit', torch.tensor(bit))
         self.register_buffer('has_inited_quant_para', torch.tensor(0.0))
         self.register_buffer('quant_grid', torch.ones(2 ** bit))
+        self._hm_setup(bit=int(bit), has_inited_quant_para=0.0)
 
         self.w_up = self.args.w_up
         self.a_up = self.args.a_up
@@ -92,6 +94,7 @@ class Quantizer(nn.Module):
         self._plan = None         # _lib.Plan of the installed grid
         self._gmax = 10.0
         self._grid_key = None
+        self._searched = False    # the last search_mse had at least one candidate
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
 
     # ---------------------------------------------------------------- bookkeeping
@@ -107,7 +110,7 @@ class Quantizer(nn.Module):
         self.is_enable = False
 
     def update_signed(self, tensor):
-        if tensor.min() < 0:
+        if not self.is_signed and tensor.min() < 0:      # already signed (weights): nothing to learn, no sync
             self.is_signed = True
 
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
@@ -122,7 +125,7 @@ class Quantizer(nn.Module):
 
     # ---------------------------------------------------------------- grids (AQ:75-278)
     def _bits(self):
-        return int(self.bit.item())
+        return int(self._hm_get('bit'))
 
     def _to_grid(self, values):
         return torch.from_numpy(np.ascontiguousarray(values)).to(self.quant_grid.device)
@@ -174,8 +177,9 @@ class Quantizer(nn.Module):
         if self._bits() > 6:
             lb = int(95)
         plan = self._ensure_plan()
-        best_score, alpha, _ = core.clip_search(tensor, x_max, per_channel, lb, ub, 1, plan, self._gmax)
-        ratio = (alpha / x_max).mean().item()
+        best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 1, plan, self._gmax)
+        self._searched = ratios is not None
+        ratio = (alpha / x_max).mean()        # 0-dim tensor: the reference's float, without the sync
         if per_channel:
             return best_score.sum(), alpha.unsqueeze(1), ratio
         return best_score.sum(), alpha.reshape(()), ratio
@@ -197,8 +201,8 @@ class Quantizer(nn.Module):
             self._install_grid(g)
             best, _, _ = self.search_mse(data)
             modes.append(t)
-            mse_list.append(best.item())
-        mse_idx = np.argsort(np.array(mse_list))
+            mse_list.append(best.reshape(()))
+        mse_idx = np.argsort(torch.stack(mse_list).cpu().numpy())     # one read-back for all types
         self.mode = modes[mse_idx[0]]
 
     def outlier_set(self, data):
@@ -217,6 +221,7 @@ class Quantizer(nn.Module):
         self.is_perchannel = False
         self._install_grid(grids.ant_int(self._bits(), self.is_signed))
         self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
+        self._hm_known('has_inited_quant_para', 1.0)
         self._steady = True
 
     def outlier_quant(self, data):
@@ -240,10 +245,11 @@ class Quantizer(nn.Module):
     def _init_quant_para(self, data, data_b):
         """AQ:468-533.  The device read of `has_inited_quant_para` happens once; afterwards the
         host flag `_steady` short-circuits (the reference syncs on it every forward)."""
-        if self._steady:
+        if self._steady and self._hm_fresh():
             return
         with torch.no_grad():
-            if self.has_inited_quant_para.item() != 0:
+            self._hm_get('bit')                      # (re-keys the mirror if the buffer was edited or rebound)
+            if self._hm_get('has_inited_quant_para') != 0:
                 self._ensure_plan()
                 self._steady = True
                 return
@@ -268,15 +274,19 @@ class Quantizer(nn.Module):
                 raise RuntimeError("Unsupported mode: " + self.mode)
             self._install_grid(grids.ant_grid(self.mode, self._bits(), self.is_signed))
 
-            _, self.alpha.data, alpha_ratio = self.search_mse(data)
+            best_sum, self.alpha.data, alpha_ratio = self.search_mse(data)
 
-            quant_data = self._forward(data)
-            self.mse = self.mse_loss(quant_data, data, 2, is_perchannel=self.is_perchannel).mean()
+            # AQ:519-520 runs _forward + mse_loss once more for the log value `mse`; that MSE is the winning
+            # candidate's score, which the search already holds (mean over rows of the per-row best).
+            if self._searched:
+                self.mse = best_sum / (self.alpha.numel() if self.is_perchannel else 1)
+            else:
+                self.mse = self.mse_loss(self._forward(data), data, 2, is_perchannel=self.is_perchannel).mean()
             if _dist_on():
                 dist.broadcast(self.mse, 0)
             if _rank() == 0:
                 print(self.mode, end="\t")
-                print("%d-bit \t %s," % (self.bit.item(), self.name))
+                print("%d-bit \t %s," % (self._bits(), self.name))
             if _dist_on():
                 rt = self.alpha.data.clone()
                 dist.all_reduce(rt, op=dist.ReduceOp.SUM)
@@ -285,6 +295,7 @@ class Quantizer(nn.Module):
                 dist.broadcast(self.quant_grid, 0)
 
             self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
+            self._hm_known('has_inited_quant_para', 1.0)
             self._steady = True
 
     # ---------------------------------------------------------------- steady state

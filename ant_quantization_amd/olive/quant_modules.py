@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, core, grids
+from .._mirror import HostMirrorMixin
 
 
 class QuantBase():
@@ -37,7 +38,7 @@ class QuantBase():
             return QuantBase._quantization(real_val, quant_grid)
 
 
-class Quantizer(nn.Module):
+class Quantizer(HostMirrorMixin, nn.Module):
     def __init__(self, mode="base", bit=8, is_signed=True, is_enable=False, is_input=False, args=None, operator=None):
         super(Quantizer, self).__init__()
         self.mode = mode
@@ -60,6 +61,7 @@ class Quantizer(nn.Module):
         self.register_buffer('has_inited_quant_para', torch.tensor(0.0))
         self.register_buffer('quant_grid', torch.ones(2 ** bit))
         self.register_buffer('outliers', torch.ones(2 ** bit))
+        self._hm_setup(bit=int(bit), has_inited_quant_para=0.0)
         self.percent = self.args.percent / 100
         self.is_perchannel = True
         if is_input:
@@ -71,6 +73,7 @@ class Quantizer(nn.Module):
         self._steady = False
         self._plan = None
         self._gmax = 32.0
+        self._searched = False
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
 
     # ---------------------------------------------------------------- bookkeeping
@@ -86,7 +89,7 @@ class Quantizer(nn.Module):
         self.is_enable = False
 
     def update_signed(self, tensor):
-        if tensor.min() < 0:
+        if not self.is_signed and tensor.min() < 0:      # already signed (weights): nothing to learn, no sync
             self.is_signed = True
 
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
@@ -104,7 +107,7 @@ class Quantizer(nn.Module):
 
     # ---------------------------------------------------------------- codebooks (OQ:72-179)
     def _bits(self):
-        return int(self.bit.item())
+        return int(self._hm_get('bit'))
 
     def _to_grid(self, values):
         return torch.from_numpy(np.ascontiguousarray(values)).to(self.quant_grid.device)
@@ -168,9 +171,10 @@ class Quantizer(nn.Module):
         lb = int(self.w_low) if per_channel else int(self.a_low)
         ub = int(self.w_up) if per_channel else int(self.a_up)
         plan = self._ensure_plan()
-        best_score, alpha, _ = core.clip_search(tensor, x_max, per_channel, lb, ub, 2, plan, self._gmax,
-                                                ovp=not self._no_outlier)
-        ratio = (alpha / x_max).mean().item()
+        best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 2, plan, self._gmax,
+                                                     ovp=not self._no_outlier)
+        self._searched = ratios is not None
+        ratio = (alpha / x_max).mean()        # 0-dim tensor: the reference's float, without the sync
         if per_channel:
             return best_score.sum(), alpha.unsqueeze(1), ratio
         return best_score.sum(), alpha.reshape(()), ratio
@@ -188,15 +192,16 @@ class Quantizer(nn.Module):
             self._install(grids.olive_grid(t, self._bits(), self.is_signed), outl)
             best, _, _ = self.search_mse(data)
             modes.append(t)
-            mse_list.append(best.item())
-        self.mode = modes[np.argsort(np.array(mse_list))[0]]
+            mse_list.append(best.reshape(()))
+        self.mode = modes[np.argsort(torch.stack(mse_list).cpu().numpy())[0]]   # one read-back for both types
 
     @torch.no_grad()
     def _init_quant_para(self, data, data_b):
         """OQ:258-292."""
-        if self._steady:
+        if self._steady and self._hm_fresh():
             return
-        if self.has_inited_quant_para.item() != 0:
+        self._hm_get('bit')
+        if self._hm_get('has_inited_quant_para') != 0:
             self._ensure_plan()
             self._steady = True
             return
@@ -218,14 +223,18 @@ class Quantizer(nn.Module):
             raise RuntimeError("Unsupported mode: " + self.mode)
         self._install(grids.olive_grid(self.mode, self._bits(), self.is_signed), outl)
 
-        _, self.alpha.data, alpha_ratio = self.search_mse(data)
+        best_sum, self.alpha.data, alpha_ratio = self.search_mse(data)
 
-        quant_data = self._forward(data)
-        self.mse = self.mse_loss(quant_data, data, 2, is_perchannel=self.is_perchannel).mean()
+        # OQ:283-284 runs _forward + mse_loss once more for the log value `mse`: it is the winning candidate's score
+        if self._searched:
+            self.mse = best_sum / (self.alpha.numel() if self.is_perchannel else 1)
+        else:
+            self.mse = self.mse_loss(self._forward(data), data, 2, is_perchannel=self.is_perchannel).mean()
         print(self.mode, end="\t")
-        print("%d-bit \t %s," % (self.bit.item(), self.name))
+        print("%d-bit \t %s," % (self._bits(), self.name))
 
         self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
+        self._hm_known('has_inited_quant_para', 1.0)
         self._steady = True
 
     # ---------------------------------------------------------------- steady state

@@ -291,3 +291,32 @@ def test_quantize_model_on_hf_structures():
     assert type(q.lm_head) is torch.nn.Linear                 # OliVe never quantises lm_head
     oqu.disable_quantization(q)
     assert q(torch.randint(0, 100, (2, 8))).logits.shape == (2, 8, 100)
+
+
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_host_mirror_of_bit_and_inited_buffers(tree, monkeypatch):
+    """`bit` / `has_inited_quant_para` are mirrored on the host (no device read per forward) but any edit of the
+    buffers -- in place, by rebinding `.data` as set_8_bit_layer_* does (AQ/quant_model.py:83), through
+    load_state_dict -- is noticed, and read back exactly once."""
+    import importlib
+    import torch
+    qm = importlib.import_module("ant_quantization_amd.%s.quant_modules" % tree)
+    q = qm.TensorQuantizer(mode="flint", bit=4, is_signed=True, is_enable=True, args=_args())
+    reads = []
+    real_item = torch.Tensor.item
+    monkeypatch.setattr(torch.Tensor, "item", lambda self: (reads.append(1), real_item(self))[1])
+    assert q._bits() == 4 and q._hm_get("has_inited_quant_para") == 0 and not reads      # known from construction
+    q.double()                                                   # _apply re-keys, values survive: still no read
+    assert q._bits() == 4 and not reads and q._hm_fresh()
+    q.bit.data = torch.tensor(8)                                  # the reference's way of switching a layer to 8 bit
+    assert not q._hm_fresh() and q._bits() == 8 and len(reads) == 1
+    assert q._bits() == 8 and len(reads) == 1                     # ... read back once
+    q.bit.fill_(6)
+    assert q._bits() == 6 and len(reads) == 2
+    sd = {k: v.clone() for k, v in q.state_dict().items()}
+    sd["bit"] = torch.tensor(5)
+    sd["has_inited_quant_para"] = torch.tensor(1.0)
+    q.load_state_dict(sd)
+    assert q._bits() == 5 and q._hm_get("has_inited_quant_para") == 1 and len(reads) == 4
+    q._hm_known("bit", 3)                                         # what the host writes itself needs no read
+    assert q._bits() == 3 and len(reads) == 4
