@@ -128,7 +128,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         return int(self._hm_get('bit'))
 
     def _to_grid(self, values):
-        return torch.from_numpy(np.ascontiguousarray(values)).to(self.quant_grid.device)
+        return core.device_grid(values, self.quant_grid.device)
 
     def int_value(self, q_type="int"):
         return self._to_grid(grids.ant_int(self._bits(), self.is_signed))

@@ -101,6 +101,22 @@ def _ratios(lo, hi, step, device):
     return t
 
 
+_grid_cache = {}
+
+
+def device_grid(values, device):
+    """A fresh device tensor holding `values` (host float32 array) without a host->device copy per call: one resident
+    master per (bytes, device), cloned on the device.  Calibration installs 2-5 codebooks per quantiser; a pageable
+    H2D copy each would serialise the host with whatever the GPU is still doing."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    key = (v.tobytes(), device.type, device.index)
+    t = _grid_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(v.copy()).to(device)
+        _grid_cache[key] = t
+    return t.clone()
+
+
 def row_absmax(x, per_channel):
     xc = x.detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)

@@ -110,7 +110,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         return int(self._hm_get('bit'))
 
     def _to_grid(self, values):
-        return torch.from_numpy(np.ascontiguousarray(values)).to(self.quant_grid.device)
+        return core.device_grid(values, self.quant_grid.device)
 
     @torch.no_grad()
     def int_value(self):
