@@ -132,9 +132,11 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
 // multiply by the scale).  Here each wavefront first rebuilds the grid's bucket table for
 // ITS row -- lane b owns bucket b:
 //     U_b   = min { x : fl(x / s) >= T_b }       (threshold moved into the x domain, exact)
-//     O_lo  = fl(v_lo * s),  O_hi = fl(v_hi * s)  (= the reference's output: (q-d)+d == q
-//                                                  for |d| <= 2 max|v|, see antq_plan.cpp)
-// into a wave-private 1 KiB LDS table (no workgroup barrier), then per element does
+//     O_lo  = fl(v_lo * s),  O_hi = fl(v_hi * s)  (= the reference's output when the straight-through step
+//                                                  (q-d)+d is exact in every region: PlanHeader::xdom,
+//                                                  checked per region in antq_plan.cpp)
+// into a wave-private LDS table of up to 256 sign-interleaved 16-byte slots (no workgroup
+// barrier), then per element does
 //     bucket from x * rcp(s)  (approximate quotient: only picks the bucket; thresholds keep
 //                              2^-20 clear of bucket edges, so a 2-ulp error cannot matter)
 //     out = (x >= U_b) ? O_hi : O_lo
