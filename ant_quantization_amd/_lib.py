@@ -371,10 +371,11 @@ class _Job(ctypes.Structure):
 class Batch:
     """Fake-quant of many (static-alpha) tensors in ONE launch (antq_fakequant_batch).
 
-    jobs: iterable of dicts / tuples (x, out, alpha, plan, gmax, rows, row_len, per_row); all tensors on
-    one device with one dtype.  Jobs the batch kernel cannot express (row_len not a multiple of 16 bytes,
-    e.g. conv1's K = 147) are kept aside and launched one by one by run().  The descriptor table is
-    built once and stays resident: weights and calibrated alphas do not move between forwards."""
+    jobs: iterable of tuples (x, out, alpha, plan, gmax, rows, row_len, per_row); all tensors on one device.
+    Ragged rows (conv1's K = 147) and unaligned buffers ride in the same launch (element-granular blocks); only
+    a job whose dtype differs from the first one's is kept aside and launched on its own by run().  The
+    descriptor table is built once and stays resident: weights and calibrated alphas do not move between
+    forwards."""
 
     def __init__(self, jobs, ovp=False):
         jobs = [tuple(j) for j in jobs]
@@ -384,12 +385,10 @@ class Batch:
         _require_gpu(x0, "x")
         self.device, self.dtype, self.ovp = x0.device, _DTYPES[x0.dtype], ovp
         self._keep = jobs                       # keeps tensors and plans alive
-        epl = 4 if self.dtype == F32 else 8
         self.singles, batched = [], []
         for j in jobs:
             x, out, alpha, plan, gmax, rows, row_len, per_row = j
-            rl = row_len if per_row else rows * row_len
-            if rl % epl or x.data_ptr() % 16 or out.data_ptr() % 16 or x.dtype != x0.dtype:
+            if x.dtype != x0.dtype:
                 self.singles.append(j)
             else:
                 batched.append(j)

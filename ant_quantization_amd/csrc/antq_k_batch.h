@@ -23,6 +23,7 @@ struct BatchDesc {   // 144 bytes, device-visible
     uint32_t first_block;
     uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < 64);
                            // 2 = row-run per wavefront, x-domain table (pad[] = xlim bits, grid offset)
+                           // 3 = element-granular (ragged rows / unaligned buffers): n_vec = elements, vpr = row_len
     int32_t per_row;
     float gmax;
     PlanArgs pa;
@@ -64,7 +65,12 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
     }
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
-    if (D.kind == 0) {
+    if (D.kind == 3) {
+        const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+        __syncthreads();
+        scalar_pair<T, OVP, false>(D.x, D.out, nullptr, (size_t)lb * 256u + threadIdx.x, 0, (size_t)D.n_vec, (size_t)D.n_vec,
+                                   (size_t)D.vpr, D.alpha, D.per_row, D.gmax, pa, L);
+    } else if (D.kind == 0) {
         const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
         const bool active = task < total;
@@ -111,14 +117,19 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
 
 static int epl_of(int dtype) { return dtype == ANTQ_F32 ? 4 : (dtype == ANTQ_BF16 || dtype == ANTQ_F16) ? 8 : 0; }
 
-// blocks a job needs, or 0 if it cannot be expressed (ragged / unaligned)
+// blocks a job needs, or 0 if it cannot be expressed
 static size_t job_blocks(const antq_job &J, int epl, BatchDesc *d)
 {
     size_t rows = J.rows, row_len = J.row_len;
     const size_t n = rows * row_len;
     if (!J.alpha_per_row) { rows = 1; row_len = n; }
-    if (n == 0 || row_len % epl != 0) return 0;
-    if (reinterpret_cast<uintptr_t>(J.x_dev) % 16 || reinterpret_cast<uintptr_t>(J.out_dev) % 16) return 0;
+    if (n == 0) return 0;
+    if (row_len % epl != 0 || reinterpret_cast<uintptr_t>(J.x_dev) % 16 || reinterpret_cast<uintptr_t>(J.out_dev) % 16) {
+        // ragged rows (conv1: K = 147) or unaligned buffers: one thread per flat pair, exact reference arithmetic
+        if (row_len > 0xffffffffull) return 0;
+        if (d) { d->kind = 3; d->total_tasks = 0; d->vpr = (uint32_t)row_len; d->tpr = 1; d->vshift = -1; d->n_vec = n; }
+        return ((n + 1) / 2 + 255) / 256;
+    }
     const size_t vpr = row_len / epl;
     if (vpr > 0xffffffffull) return 0;
     size_t blocks;

@@ -424,19 +424,13 @@ k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
 // last element's "partner" is element 0 (torch.roll wrap-around, OQ:315-318).
 //   elements [e0, e0 + n_here) of a tensor with n_total elements, e0 even.
 // ------------------------------------------------------------------------------------
+// pair p of the range: elements e0 + 2p, e0 + 2p + 1 (shared by k_fq_scalar and the batched kernel's ragged jobs)
 template <typename T, bool OVP, bool IDX>
-__global__ void __launch_bounds__(256)
-k_fq_scalar(const void *__restrict__ x, void *__restrict__ out, int16_t *__restrict__ idx,
-            size_t e0, size_t n_here, size_t n_total, size_t row_len,
-            const float *__restrict__ alpha, int per_row, float gmax,
-            PlanArgs pa, const uint4 *__restrict__ plan_tab)
+__device__ __forceinline__ void scalar_pair(const void *__restrict__ x, void *__restrict__ out, int16_t *__restrict__ idx,
+                                            size_t p, size_t e0, size_t n_here, size_t n_total, size_t row_len,
+                                            const float *__restrict__ alpha, int per_row, float gmax,
+                                            const PlanArgs &pa, const PlanLds &L)
 {
-    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-    uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
-    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
-    __syncthreads();
-    const size_t p = (size_t)blockIdx.x * 256u + threadIdx.x;
     const size_t i0 = e0 + 2 * p;
     if (2 * p >= n_here) return;
     const bool has_odd = (2 * p + 1 < n_here);
@@ -481,6 +475,22 @@ k_fq_scalar(const void *__restrict__ x, void *__restrict__ out, int16_t *__restr
         IO<T>::store1(out, i1, t * s[1]);
         if (IDX) idx[i1] = (int16_t)j[1];
     }
+}
+
+template <typename T, bool OVP, bool IDX>
+__global__ void __launch_bounds__(256)
+k_fq_scalar(const void *__restrict__ x, void *__restrict__ out, int16_t *__restrict__ idx,
+            size_t e0, size_t n_here, size_t n_total, size_t row_len,
+            const float *__restrict__ alpha, int per_row, float gmax,
+            PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+    scalar_pair<T, OVP, IDX>(x, out, idx, (size_t)blockIdx.x * 256u + threadIdx.x, e0, n_here, n_total, row_len, alpha,
+                             per_row, gmax, pa, L);
 }
 
 }  // namespace antq

@@ -588,6 +588,8 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     for (int i = 0; i < n; i++) {
         const antq_job &J = jobs[i];
         if (!J.x_dev || !J.out_dev || !J.alpha_dev || !J.plan_host || !J.plan_dev) return ANTQ_ERR_ARG;
+        const uintptr_t esz = (dtype == ANTQ_F32) ? 4 : 2;
+        if (reinterpret_cast<uintptr_t>(J.x_dev) % esz || reinterpret_cast<uintptr_t>(J.out_dev) % esz) return ANTQ_ERR_ALIGN;
         BatchDesc d;
         memset(&d, 0, sizeof(d));
         const size_t blocks = job_blocks(J, epl, &d);

@@ -182,10 +182,9 @@ int antq_affine(const float *x_dev, float *out_dev, int32_t *q_dev,
  * (~6 us of host time each vs < 1 us of HBM time); here every workgroup looks up its job in a
  * descriptor table that the caller builds once (weights and alphas are static between
  * forwards) and keeps resident on the device.
- *   antq_batch_build : pure host code; writes the descriptor blob (returns its size in bytes,
- *                      or ANTQ_ERR_UNSUPPORTED if some job needs the element-granular kernel:
- *                      row_len not a multiple of 16 bytes, or unaligned pointers -- launch
- *                      those with antq_fakequant).  All jobs share dtype and flags.
+ *   antq_batch_build : pure host code; writes the descriptor blob (returns its size in bytes).  All jobs share dtype
+ *                      and flags.  Jobs whose rows are not a multiple of 16 bytes (conv1: K = 147) or whose
+ *                      buffers are not 16-byte aligned run element-granular inside the same launch.
  *   antq_fakequant_batch : one launch for all jobs; batch_dev is the caller's device copy.
  * ------------------------------------------------------------------------- */
 typedef struct antq_job {
