@@ -78,7 +78,11 @@ def cpu_baseline(seconds_budget=12.0):
         best = min(best, dt)
         spent += dt
         passes += 1
+    t0 = time.perf_counter()
+    work(0, 64)                                                  # the same oracle on ONE host thread, 64 rows
+    one_thread = 64 * COLS / (time.perf_counter() - t0) / 1e9
     return {"value": round(rows * COLS / best / 1e9, 5), "unit": "Gelem/s", "cores": cores, "kind": "port",
+            "single_thread_gelem_per_s": round(one_thread, 6),
             "sample": "%d rows x %d cols bf16 (1/4 of one headline tensor), flint 4-bit per-row alpha, "
                       "best of %d passes, %d threads" % (rows, COLS, passes, cores)}
 
