@@ -58,9 +58,20 @@ def llama70b_shapes(layers=80):
 
 
 def timed(fn, reps):
+    """Seconds per call at steady clocks: warm up for >= 60 ms of GPU time first (an idle MI355X ramps for ~50 ms,
+    tools/probe_clock_ramp.py), then time max(reps, enough calls for >= 40 ms) back-to-back calls with HIP events."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    once = max(e0.elapsed_time(e1) * 1e-3, 1e-6)
+    for _ in range(min(20000, int(0.06 / once) + 1)):
+        fn()
+    reps = max(reps, min(20000, int(0.04 / once) + 1))
+    torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
         fn()
