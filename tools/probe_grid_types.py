@@ -3,14 +3,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ant_quantization_amd import _lib, grids
 dev = torch.device("cuda:0")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_configs import timed as _timed   # steady-clock timing (warm-up >= 60 ms, >= 40 ms measured)
+
+
 def timed(fn, reps=10):
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps
+    return _timed(fn, reps)
+
+
 nb = 8
 for dt, bpe in ((torch.float32, 8), (torch.bfloat16, 4)):
     xs = [(torch.randn(4096, 4096, device=dev) * 0.02).to(dt) for _ in range(nb)]

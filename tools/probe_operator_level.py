@@ -3,14 +3,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ant_quantization_amd import _lib, grids, quant_cuda
 dev = torch.device("cuda:0")
-def timed(fn, reps=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_configs import timed as _timed   # steady-clock timing (warm-up >= 60 ms, >= 40 ms measured)
+
+
+def timed(fn, reps=10):
+    return _timed(fn, reps)
+
+
 xs = [torch.randn(4096 * 4096, device=dev) * 4 for _ in range(8)]
 for name, g in (("flint4 (16)", grids.ant_flint(4, True)), ("olive flint4+outliers (29)", np.concatenate([grids.olive_flint(4, True), grids.olive_outliers(4, True)])),
                 ("int6 (64)", grids.ant_int(6, True)), ("int8 (256)", grids.ant_int(8, True))):
