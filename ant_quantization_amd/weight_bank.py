@@ -88,6 +88,8 @@ class WeightBank:
         keep = []
         for e in self.entries.values():
             q, w = e["q"], e["mod"].weight
+            if e["out"].dtype != w.dtype or e["out"].device != w.device or e["out"].shape != w.shape:
+                e["out"] = torch.empty_like(w, memory_format=torch.contiguous_format)   # .half() / .to(device) since
             plan = q._ensure_plan()
             alpha = q.alpha.detach().reshape(-1)
             if alpha.dtype != torch.float32 or not alpha.is_contiguous():
@@ -104,8 +106,8 @@ class WeightBank:
         self._ptr_key = self._pointers()
 
     def _pointers(self):
-        return tuple((e["mod"].weight.data_ptr(), e["q"].alpha.data_ptr(), id(e["q"]._plan), e["q"]._gmax)
-                     for e in self.entries.values())
+        return tuple((e["mod"].weight.data_ptr(), e["mod"].weight.dtype, e["q"].alpha.data_ptr(), id(e["q"]._plan),
+                      e["q"]._gmax) for e in self.entries.values())
 
     # ------------------------------------------------------------------ the one launch
     @torch.no_grad()

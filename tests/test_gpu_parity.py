@@ -1218,3 +1218,37 @@ def test_alpha_grad_kernel_vs_autograd_of_the_reference_graph(antq_lib, dev):
             mag = term.abs().reshape(rows, row_len).sum(1) if per_channel else term.abs().sum().reshape(1)
             # fp32 partial sums over the 4 / 8 elements of a lane's vector, float64 beyond that
             assert ((gsum - ref).abs() <= 3e-7 * mag + 1e-12).all(), (shape, dt)
+
+
+def test_weight_bank_mixed_precision_layers_and_dtype_moves(antq_lib, dev):
+    """WeightBank on a model with an 8-bit first layer (set_8_bit_layer_n), then moved to bf16: buffers are rebuilt,
+    the two dtypes / grids ride in their own batches, results still equal the per-layer path."""
+    import torch
+    from ant_quantization_amd.weight_bank import WeightBank
+    from ant_quantization_amd.ant import quant_model as aqm, quant_utils as aqu
+    aqu.set_quantizer(_args(mode="ant-int-flint", wbit=4, abit=4))
+    torch.manual_seed(8)
+    net = torch.nn.Sequential(torch.nn.Linear(96, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256), torch.nn.ReLU(),
+                              torch.nn.Linear(256, 10))
+    model = aqm.quantize_model(net).to(dev).eval()
+    aqu.enable_quantization(model)
+    aqm.set_8_bit_layer_n(model, 1)                      # some layers' quantisers -> 8 bit (forces 'int', AQ:482)
+    x = torch.randn(32, 96, device=dev)
+    with torch.no_grad():
+        model(x)
+        y_ref = model(x)
+    eight = [m for m in model.modules() if hasattr(m, "quant_weight") and int(m.quant_weight.bit) == 8]
+    four = [m for m in model.modules() if hasattr(m, "quant_weight") and int(m.quant_weight.bit) == 4]
+    assert eight and four and all(m.quant_weight.mode == "int" and m.quant_weight.quant_grid.numel() == 256 for m in eight)
+    bank = WeightBank(model)
+    with torch.no_grad():
+        assert torch.equal(model(x), y_ref) and bank.launches == 1
+    # a dtype move re-creates every parameter: stamps go stale, the bank rebuilds its descriptors once
+    model.to(torch.bfloat16)
+    xb = x.bfloat16()
+    with torch.no_grad():
+        yb = model(xb)
+        assert bank.launches == 2 and torch.equal(model(xb), yb) and bank.launches == 2
+    bank.detach()
+    with torch.no_grad():
+        assert torch.equal(model(xb), yb)
