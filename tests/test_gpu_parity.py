@@ -1252,3 +1252,44 @@ def test_weight_bank_mixed_precision_layers_and_dtype_moves(antq_lib, dev):
     bank.detach()
     with torch.no_grad():
         assert torch.equal(model(xb), yb)
+
+
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_steady_state_forward_is_sync_free_and_graph_capturable(antq_lib, dev, tree):
+    """After calibration a quantised model's forward does no device->host read (the reference syncs several times
+    per quantiser per forward, AQ:470 / :482): the whole forward -- activation quantisers, weight quantisers with and
+    without a WeightBank -- captures into a hipGraph (capture would fail on any sync) and replays on new inputs."""
+    import importlib
+    import torch
+    from ant_quantization_amd.weight_bank import WeightBank
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qutil.set_quantizer(_args(mode="ant-int-flint", wbit=4, abit=4))
+    torch.manual_seed(12)
+    net = torch.nn.Sequential(torch.nn.Linear(128, 512), torch.nn.GELU(), torch.nn.Linear(512, 512), torch.nn.GELU(),
+                              torch.nn.Linear(512, 64))
+    model = qmod.quantize_model(net).to(dev).eval()
+    qutil.enable_quantization(model)
+    static_x = torch.randn(64, 128, device=dev)
+    with torch.no_grad():
+        model(static_x)                                  # calibration (this one does read back)
+    for use_bank in (False, True):
+        bank = WeightBank(model) if use_bank else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                model(static_x)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            static_y = model(static_x)
+        for seed in (1, 2):
+            xn = torch.randn(64, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+            static_x.copy_(xn)
+            graph.replay()
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                assert torch.equal(static_y, model(xn)), (tree, use_bank, seed)
+        if bank is not None:
+            bank.detach()
