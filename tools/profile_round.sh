@@ -32,4 +32,6 @@ $PY tools/bench_configs.py       > "$OUT/${TAG}_configs.log" 2>&1
 $PY tools/probe_grid_types.py    > "$OUT/${TAG}_grid_types.log" 2>&1
 $PY tools/probe_operator_level.py > "$OUT/${TAG}_operator_level.log" 2>&1
 $PY tools/probe_weight_bank.py 2>&1 | grep -v "golden,\|bit \s" > "$OUT/${TAG}_weight_bank.log"
+$PY tools/probe_graph_forward.py 2>&1 | grep -v "bit \s\|amdgpu" > "$OUT/${TAG}_graph_forward.log"
+$PY tools/probe_size_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_size_sweep.log"
 ls -la "$OUT"
