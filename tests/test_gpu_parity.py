@@ -1293,3 +1293,37 @@ def test_steady_state_forward_is_sync_free_and_graph_capturable(antq_lib, dev, t
                 assert torch.equal(static_y, model(xn)), (tree, use_bank, seed)
         if bank is not None:
             bank.detach()
+
+
+def test_qat_training_loop_updates_weights_and_alpha(antq_lib, dev):
+    """ANT QAT (IMG/main.py:197-202): a few optimiser steps through the fused forward + fused alpha gradient -- the loss
+    goes down, weights and the per-channel alphas move, and evaluation afterwards uses the updated parameters."""
+    import torch
+    from ant_quantization_amd.ant import quant_model as aqm, quant_utils as aqu
+    aqu.set_quantizer(_args(mode="ant-int-flint", wbit=4, abit=4))
+    torch.manual_seed(21)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.ReLU(), torch.nn.Linear(128, 16))
+    teacher = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.ReLU(), torch.nn.Linear(128, 16)).to(dev)
+    model = aqm.quantize_model(net).to(dev)
+    aqu.enable_quantization(model)
+    x = torch.randn(512, 64, device=dev)
+    with torch.no_grad():
+        y = teacher(x)
+        model(x)                                                       # calibrate
+    w0 = model[0].weight.detach().clone()
+    a0 = model[0].quant_weight.alpha.detach().clone()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    losses = []
+    model.train()
+    for _ in range(40):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(model(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    assert not torch.equal(model[0].weight, w0) and not torch.equal(model[0].quant_weight.alpha, a0)
+    assert torch.isfinite(model[0].quant_weight.alpha).all() and model[0].quant_weight.alpha.grad is not None
+    model.eval()
+    with torch.no_grad():
+        assert float(torch.nn.functional.mse_loss(model(x), y)) < 0.6 * losses[0]
