@@ -152,12 +152,20 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._plan = _lib.plan_for(v)
         with np.errstate(all="ignore"):
             self._gmax = float(np.max(v))
+        self._grid_key = self._grid_now()
+
+    def _grid_now(self):
+        g = self.quant_grid
+        return (g.data_ptr(), g._version)
 
     def _ensure_plan(self):
-        if self._plan is None:
-            v = self.quant_grid.detach().float().cpu().numpy()   # once after a checkpoint load
+        """The plan of the grid currently in `quant_grid`.  The buffer is watched by (data_ptr, _version): a checkpoint
+        load, the DDP broadcast of AQ:531 or a user's edit replaces the plan (one read-back), nothing else costs a sync."""
+        if self._plan is None or self._grid_key != self._grid_now():
+            v = self.quant_grid.detach().float().cpu().numpy()
             self._plan = _lib.plan_for(v)
             self._gmax = float(np.max(v))
+            self._grid_key = self._grid_now()
         return self._plan
 
     # ---------------------------------------------------------------- calibration

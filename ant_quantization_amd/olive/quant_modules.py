@@ -73,6 +73,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._steady = False
         self._plan = None
         self._gmax = 32.0
+        self._grid_key = None
         self._searched = False
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
 
@@ -131,6 +132,11 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self.quant_grid.data = self._to_grid(normal)
         self.outliers.data = self._to_grid(outl)
         self._set_plan(normal, outl)
+        self._grid_key = self._grid_now()
+
+    def _grid_now(self):
+        g, o = self.quant_grid, self.outliers
+        return (g.data_ptr(), g._version, o.data_ptr(), o._version)
 
     def _set_plan(self, normal, outl):
         full = normal if self._no_outlier else np.concatenate([normal, outl])
@@ -138,9 +144,11 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._gmax = float(np.max(normal))
 
     def _ensure_plan(self):
-        if self._plan is None:
+        """Plan of cat(quant_grid, outliers) as they are NOW: the buffers are watched by (data_ptr, _version)."""
+        if self._plan is None or self._grid_key != self._grid_now():
             self._set_plan(self.quant_grid.detach().float().cpu().numpy(),
                            self.outliers.detach().float().cpu().numpy())
+            self._grid_key = self._grid_now()
         return self._plan
 
     # ---------------------------------------------------------------- calibration

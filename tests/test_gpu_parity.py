@@ -1327,3 +1327,21 @@ def test_qat_training_loop_updates_weights_and_alpha(antq_lib, dev):
     model.eval()
     with torch.no_grad():
         assert float(torch.nn.functional.mse_loss(model(x), y)) < 0.6 * losses[0]
+
+
+def test_quantizer_follows_external_grid_edits(antq_lib, oracle, dev, capsys):
+    """The plan follows the `quant_grid` buffer: an in-place edit after calibration (what the DDP broadcast of AQ:531
+    does on the non-zero ranks, or a user patching a codebook) is picked up on the next forward."""
+    import torch
+    from ant_quantization_amd.ant import quant_modules as qm
+    g = golden("ant_grids.npz")
+    q = qm.TensorQuantizer(mode="flint", bit=4, is_signed=True, is_enable=True, args=_args()).to(dev)
+    x = torch.randn(16, 256, device=dev) * 0.03
+    q.alpha.data = torch.ones(16, 1, device=dev)
+    q(x)
+    assert f32_same(q.quant_grid.cpu().numpy(), g["flint_b4_s"])
+    q.quant_grid.copy_(torch.from_numpy(g["int_b4_s"]).to(dev))          # in place, same buffer
+    out = q(x)
+    ref, _ = oracle.forward(x.cpu().numpy(), q.alpha.detach().cpu().numpy().reshape(-1), g["int_b4_s"])
+    assert f32_same(out.cpu().numpy(), ref)
+    capsys.readouterr()
