@@ -1343,5 +1343,5 @@ def test_quantizer_follows_external_grid_edits(antq_lib, oracle, dev, capsys):
     q.quant_grid.copy_(torch.from_numpy(g["int_b4_s"]).to(dev))          # in place, same buffer
     out = q(x)
     ref, _ = oracle.forward(x.cpu().numpy(), q.alpha.detach().cpu().numpy().reshape(-1), g["int_b4_s"])
-    assert f32_same(out.cpu().numpy(), ref)
+    assert f32_same(out.detach().cpu().numpy(), ref)
     capsys.readouterr()
