@@ -35,8 +35,10 @@ struct BatchHeader {   // 32 bytes
     uint32_t magic, n, total_blocks, dtype, flags, lds_bytes, map_offset, bytes;
 };
 
+// Occupancy (measured): the plain kernel is best at the 6 wavefronts per SIMD its 80 VGPRs give it (8 loses
+// 1.3 points); with the outlier-victim rule the extra VALU work per element wants 8 (64 VGPRs): +1 to +1.5 points.
 template <typename T, bool OVP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, OVP ? 8 : 1)
 k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
 {
     constexpr int EPL = IO<T>::EPL;
