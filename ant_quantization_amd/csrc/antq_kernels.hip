@@ -80,7 +80,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const uint4 *tab = plan_tab_ptr(plan_dev);
     const uint4 *xv = static_cast<const uint4 *>(x);
     uint4 *ov = static_cast<uint4 *>(out);
-    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 256 && (!DYN || vpr <= 2048);
+    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 64 && (!DYN || vpr <= 2048);
     if (use_x) {
         // x-domain row kernel: 4 or 8 KiB of one row per wavefront (the per-row table is rebuilt per task)
         int U = 4;   // 4 KiB of the row per wavefront measured best at steady clocks (79 % of 8 TB/s on 1 GiB)
@@ -597,7 +597,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         if (!plan_args_from_host(J.plan_host, d.pa)) return ANTQ_ERR_PLAN;
         {
             const PlanHeader *ph = static_cast<const PlanHeader *>(J.plan_host);
-            if (d.kind == 0 && g_knob_x && d.pa.kind == kPlanLut && ph->xdom && d.vpr >= 256) {
+            if (d.kind == 0 && g_knob_x && d.pa.kind == kPlanLut && ph->xdom && d.vpr >= 64) {
                 d.kind = 2;
                 memcpy(&d.pad[0], &ph->xlim, 4);
                 memcpy(&d.pad[1], &ph->vout, 4);
