@@ -264,6 +264,37 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
     }
 }
 
+// The wave-private table of one (row, scale): lane b moves the threshold of its bucket(s) into the x domain and
+// pre-multiplies the two outputs.  `ent` / `ent2` are the lane's static plan entries (bucket b and b + 64).  Returns
+// whether the table path may be used for this scale (Scale::ok and s > 0).  Ends with the wave's LDS writes landed.
+__device__ __forceinline__ bool build_row_table(const XArgs &xa, const uint4 &ent, const uint4 &ent2, const Scale &sc,
+                                                uint4 *wtab, uint32_t lane)
+{
+    bool rowfast = sc.ok && (sc.s > 0.0f);
+    bool ok = true;
+    float Ux = u2f(ent.x);
+    if (rowfast && lane < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
+    rowfast = rowfast && __all(ok);
+    // (v + 0) * s: a -0.0 grid entry must come out as +0.0, like the reference's (q - d) + d
+    // entry i is positive bucket i (slot 2i) or negative bucket i - nb (slot 2(i - nb) + 1)
+    const uint32_t nbp = xa.n_entries - xa.nbneg;
+    const uint4 w0 = make_uint4(f2u(Ux), f2u((u2f(ent.y) + 0.0f) * sc.s), f2u((u2f(ent.z) + 0.0f) * sc.s), ent.w);
+    if (lane < xa.n_entries) wtab[lane < nbp ? 2u * lane : 2u * (lane - nbp) + 1u] = w0;
+    if (xa.nbneg == 0u && lane == 0u) wtab[1] = w0;     // unsigned grid: every negative x lands in slot 1
+    if (xa.n_entries > 64u) {
+        bool ok2 = true;
+        float U2 = u2f(ent2.x);
+        const uint32_t i2 = lane + 64u;
+        if (rowfast && i2 < xa.n_entries && U2 < __builtin_inff()) U2 = x_threshold(U2, sc.s, sc.rs, ok2);
+        rowfast = rowfast && __all(ok2);
+        if (i2 < xa.n_entries)
+            wtab[i2 < nbp ? 2u * i2 : 2u * (i2 - nbp) + 1u] =
+                make_uint4(f2u(U2), f2u((u2f(ent2.y) + 0.0f) * sc.s), f2u((u2f(ent2.z) + 0.0f) * sc.s), ent2.w);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+    return rowfast;
+}
+
 // Body of the x-domain row kernel for one wavefront task (shared by k_fq_xrow and k_fq_batch).
 template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR>
 __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
@@ -308,30 +339,7 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
     const Scale sc = make_scale(a, gmax);
 
     // per-row table: thresholds into the x domain, outputs pre-multiplied by the scale
-    bool rowfast = sc.ok && (sc.s > 0.0f);
-    {
-        bool ok = true;
-        float Ux = u2f(ent.x);
-        if (rowfast && lane < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
-        rowfast = rowfast && __all(ok);
-        // (v + 0) * s: a -0.0 grid entry must come out as +0.0, like the reference's (q - d) + d
-        // entry i is positive bucket i (slot 2i) or negative bucket i - nb (slot 2(i - nb) + 1)
-        const uint32_t nbp = xa.n_entries - xa.nbneg;
-        const uint4 w0 = make_uint4(f2u(Ux), f2u((u2f(ent.y) + 0.0f) * sc.s), f2u((u2f(ent.z) + 0.0f) * sc.s), ent.w);
-        if (lane < xa.n_entries) wtab[lane < nbp ? 2u * lane : 2u * (lane - nbp) + 1u] = w0;
-        if (xa.nbneg == 0u && lane == 0u) wtab[1] = w0;     // unsigned grid: every negative x lands in slot 1
-        if (two) {
-            bool ok2 = true;
-            float U2 = u2f(ent2.x);
-            const uint32_t i2 = lane + 64u;
-            if (rowfast && i2 < xa.n_entries && U2 < __builtin_inff()) U2 = x_threshold(U2, sc.s, sc.rs, ok2);
-            rowfast = rowfast && __all(ok2);
-            if (i2 < xa.n_entries)
-                wtab[i2 < nbp ? 2u * i2 : 2u * (i2 - nbp) + 1u] =
-                    make_uint4(f2u(U2), f2u((u2f(ent2.y) + 0.0f) * sc.s), f2u((u2f(ent2.z) + 0.0f) * sc.s), ent2.w);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+    const bool rowfast = build_row_table(xa, ent, ent2, sc, wtab, lane);
 
 #pragma unroll
     for (int u = 0; u < U; u++) {

@@ -4,6 +4,7 @@
 #define ANTQ_K_SEARCH_H
 
 #include "antq_device.h"
+#include "antq_k_fakequant.h"
 
 namespace antq {
 
@@ -17,21 +18,38 @@ namespace antq {
 // ------------------------------------------------------------------------------------
 constexpr int kPtCand = 128;   // candidates per workgroup in the one-scale-per-tensor mode (LDS accumulators)
 
-template <typename T, bool OVP, int U, bool PT>
+// XD: grids with an x-domain plan (PlanHeader::xdom: every ANT / OliVe 4-bit codebook).  For every candidate the
+// wavefront rebuilds its row table for THAT scale (closed-form thresholds, ~14 ops per lane) and the element loop is
+// the one of k_fq_xrow -- no division, no straight-through arithmetic, no multiply: ~12 instead of ~20 VALU ops per
+// candidate evaluation.
+template <typename T, bool OVP, int U, bool PT, bool XD>
 __global__ void __launch_bounds__(256)
 k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
              const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand, float gmax,
-             double *__restrict__ sse, PlanArgs pa, const uint4 *__restrict__ plan_tab, int cand_chunk)
+             double *__restrict__ sse, PlanArgs pa, const uint4 *__restrict__ plan_tab, int cand_chunk, XArgs xa)
 {
     constexpr int EPL = IO<T>::EPL;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[XD ? 4 : 1][XD ? 256 : 1];
     const uint32_t lane = threadIdx.x & 63u;
     // small tensors do not have enough rows to fill the chip: blockIdx.y splits the candidate list
     const int c_begin = (int)blockIdx.y * cand_chunk;
     const int c_end = min(ncand, c_begin + cand_chunk);
-    uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
-    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    PlanLds L;
+    L.lut = nullptr;
+    L.grid = nullptr;
+    uint4 ent = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u), ent2 = ent;
+    uint4 *wtab = wtab_all[XD ? (threadIdx.x >> 6) : 0];
+    const float *grid_g = reinterpret_cast<const float *>(plan_tab);
+    if (XD) {
+        const uint4 *entries = plan_tab + (pa.m_pad >> 2);
+        if (lane < xa.n_entries) ent = entries[lane];
+        if (xa.n_entries > 64u && lane + 64u < xa.n_entries) ent2 = entries[lane + 64u];
+    } else {
+        uint4 tab0 = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+        L = stage_plan(pa, plan_tab, smem, tab0);
+    }
     // PT (one scale for the whole tensor): every task adds to the same ncand sums.  Global atomics on 75 addresses
     // from every task serialise in L2 (measured: 4x the arithmetic), so each wavefront keeps its sums in LDS and the
     // workgroup issues one atomic per candidate at the end.
@@ -50,6 +68,8 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
         for (int c = c_begin; c < c_end; c++) {
             const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
             const Scale sc = make_scale(a, gmax);
+            bool rowfast = false;
+            if (XD) rowfast = build_row_table(xa, ent, ent2, sc, wtab, lane);
             double acc = 0.0;
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -57,7 +77,8 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
                     float xf[EPL], of[EPL];
                     int j[EPL];
                     IO<T>::unpack(v[u], xf);
-                    quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
+                    if (XD) quant_vec_x<EPL, OVP, false>(xa, wtab, grid_g, sc, rowfast, xf, of, j);
+                    else quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
                     float part = 0.0f;
 #pragma unroll
                     for (int e = 0; e < EPL; e++) {

@@ -426,8 +426,8 @@ static int launch_dynamic_flags(const void *x, void *out, int16_t *idx, float *a
 
 template <typename T, bool OVP>
 static int launch_search(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
-                         const float *ratios, int ncand, float gmax, const PlanArgs &pa, const void *plan_dev,
-                         double *sse, hipStream_t st)
+                         const float *ratios, int ncand, float gmax, const PlanArgs &pa, const void *plan_host,
+                         const void *plan_dev, double *sse, hipStream_t st)
 {
     constexpr int EPL = IO<T>::EPL;
     const size_t lds = (size_t)pa.tab_units * 16;
@@ -455,14 +455,20 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     if (pt) chunks = std::max(chunks, (ncand + kPtCand - 1) / kPtCand);
     const int cand_chunk = (ncand + chunks - 1) / chunks;
     chunks = (ncand + cand_chunk - 1) / cand_chunk;
-    if (pt)
-        hipLaunchKernelGGL((k_search_sse<T, OVP, U, true>), dim3((unsigned)blocks, (unsigned)chunks), dim3(256), lds, st,
-                           static_cast<const uint4 *>(x), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax,
-                           per_row, ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev), cand_chunk);
-    else
-        hipLaunchKernelGGL((k_search_sse<T, OVP, U, false>), dim3((unsigned)blocks, (unsigned)chunks), dim3(256), lds, st,
-                           static_cast<const uint4 *>(x), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax,
-                           per_row, ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev), cand_chunk);
+    const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
+    const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 64;
+    XArgs xa;
+    xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+    xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
+    const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
+    const uint4 *xv = static_cast<const uint4 *>(x);
+#define ANTQ_LAUNCH_S(PT_, XD_)                                                                                    \
+    hipLaunchKernelGGL((k_search_sse<T, OVP, U, PT_, XD_>), gdim, bdim, (XD_) ? 0 : lds, st, xv, (uint32_t)total,    \
+                       (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, gmax, sse, pa,              \
+                       plan_tab_ptr(plan_dev), cand_chunk, xa)
+    if (pt) { if (xd) ANTQ_LAUNCH_S(true, true); else ANTQ_LAUNCH_S(true, false); }
+    else    { if (xd) ANTQ_LAUNCH_S(false, true); else ANTQ_LAUNCH_S(false, false); }
+#undef ANTQ_LAUNCH_S
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
@@ -544,14 +550,14 @@ extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const
     const int pr = per_row ? 1 : 0;
     switch (dtype) {
     case ANTQ_F32:
-        return ovp ? launch_search<float, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st)
-                   : launch_search<float, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st);
+        return ovp ? launch_search<float, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st)
+                   : launch_search<float, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st);
     case ANTQ_BF16:
-        return ovp ? launch_search<bf16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st)
-                   : launch_search<bf16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st);
+        return ovp ? launch_search<bf16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st)
+                   : launch_search<bf16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st);
     case ANTQ_F16:
-        return ovp ? launch_search<f16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st)
-                   : launch_search<f16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_dev, sse, st);
+        return ovp ? launch_search<f16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st)
+                   : launch_search<f16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st);
     default:
         return ANTQ_ERR_UNSUPPORTED;
     }
