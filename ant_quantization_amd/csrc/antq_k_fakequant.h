@@ -155,6 +155,9 @@ struct XArgs {
     uint32_t n_entries;
     float xlim;
     float vout;
+    uint32_t linear;     // PlanHeader::linear: slot = trunc(clamp(fma(x * rcp(s), lin_scale, lin_bias), 0, kmax)), no sign slots
+    float lin_scale;
+    float lin_bias;
 };
 
 __device__ __forceinline__ float f_up(float c)   // next float towards +inf (c != 0)
@@ -202,16 +205,29 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
         // v_alignbit and the clamp one v_med3 (an unsigned grid keeps a negative key: it clamps to kmin, slot 1)
         const int32_t sh = (int32_t)xa.shift, km = (int32_t)xa.keymask;
         const int32_t lo = (int32_t)xa.kmin, hi = (int32_t)xa.kmax;
-        const char *t0 = reinterpret_cast<const char *>(wtab) - (lo << 5);
+        const bool lin = xa.linear != 0u;               // wave-uniform
+        const char *t0 = reinterpret_cast<const char *>(wtab) - (lin ? 0 : (lo << 5));
+        const float khi = (float)xa.kmax;
         bool isout[EPL];
         const float othr = xa.vout * sc.s;
+        uint32_t slots[EPL];
+        if (lin) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++)
+                slots[e] = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(dt[e], xa.lin_scale, xa.lin_bias), 0.0f, khi);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int32_t u = (int32_t)f2u(dt[e]);
+                const int32_t t = (u >> sh) & km;
+                int32_t ck;
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+                slots[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
-            const int32_t u = (int32_t)f2u(dt[e]);
-            const int32_t t = (u >> sh) & km;
-            int32_t ck;
-            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
-            const uint32_t slot = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);
+            const uint32_t slot = slots[e];
             uint4 ent = *reinterpret_cast<const uint4 *>(t0 + (slot << 4));
             if (!IDX) asm volatile("" : "+v"(ent.w));
             const bool c = x[e] >= u2f(ent.x);
@@ -267,30 +283,26 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
 // The wave-private table of one (row, scale): lane b moves the threshold of its bucket(s) into the x domain and
 // pre-multiplies the two outputs.  `ent` / `ent2` are the lane's static plan entries (bucket b and b + 64).  Returns
 // whether the table path may be used for this scale (Scale::ok and s > 0).  Ends with the wave's LDS writes landed.
-__device__ __forceinline__ bool build_row_table(const XArgs &xa, const uint4 &ent, const uint4 &ent2, const Scale &sc,
-                                                uint4 *wtab, uint32_t lane)
+__device__ __forceinline__ bool build_row_table(const XArgs &xa, const uint4 &ent, const uint4 &ent2,
+                                                const Scale &sc, uint4 *wtab, uint32_t lane)
 {
     bool rowfast = sc.ok && (sc.s > 0.0f);
-    bool ok = true;
-    float Ux = u2f(ent.x);
-    if (rowfast && lane < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
-    rowfast = rowfast && __all(ok);
-    // (v + 0) * s: a -0.0 grid entry must come out as +0.0, like the reference's (q - d) + d
-    // entry i is positive bucket i (slot 2i) or negative bucket i - nb (slot 2(i - nb) + 1)
+    // entry i of a float-bits table is positive bucket i (slot 2i) or negative bucket i - nb (slot 2(i - nb) + 1);
+    // a linear table has one bucket per threshold and no sign slots (slot i)
     const uint32_t nbp = xa.n_entries - xa.nbneg;
-    const uint4 w0 = make_uint4(f2u(Ux), f2u((u2f(ent.y) + 0.0f) * sc.s), f2u((u2f(ent.z) + 0.0f) * sc.s), ent.w);
-    if (lane < xa.n_entries) wtab[lane < nbp ? 2u * lane : 2u * (lane - nbp) + 1u] = w0;
-    if (xa.nbneg == 0u && lane == 0u) wtab[1] = w0;     // unsigned grid: every negative x lands in slot 1
-    if (xa.n_entries > 64u) {
-        bool ok2 = true;
-        float U2 = u2f(ent2.x);
-        const uint32_t i2 = lane + 64u;
-        if (rowfast && i2 < xa.n_entries && U2 < __builtin_inff()) U2 = x_threshold(U2, sc.s, sc.rs, ok2);
-        rowfast = rowfast && __all(ok2);
-        if (i2 < xa.n_entries)
-            wtab[i2 < nbp ? 2u * i2 : 2u * (i2 - nbp) + 1u] =
-                make_uint4(f2u(U2), f2u((u2f(ent2.y) + 0.0f) * sc.s), f2u((u2f(ent2.z) + 0.0f) * sc.s), ent2.w);
-    }
+    const bool lin = xa.linear != 0u;
+    auto put = [&](uint32_t i, const uint4 &e) {
+        bool ok = true;
+        float Ux = u2f(e.x);
+        if (rowfast && i < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
+        // (v + 0) * s: a -0.0 grid entry must come out as +0.0, like the reference's (q - d) + d
+        const uint4 w = make_uint4(f2u(Ux), f2u((u2f(e.y) + 0.0f) * sc.s), f2u((u2f(e.z) + 0.0f) * sc.s), e.w);
+        if (i < xa.n_entries) wtab[lin ? i : (i < nbp ? 2u * i : 2u * (i - nbp) + 1u)] = w;
+        return w;
+    };
+    const uint4 w0 = put(lane, ent);
+    if (!lin && xa.nbneg == 0u && lane == 0u) wtab[1] = w0;     // unsigned grid: every negative x lands in slot 1
+    if (xa.n_entries > 64u) put(lane + 64u, ent2);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
     return rowfast;
 }

@@ -41,8 +41,8 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
     uint4 ent = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u), ent2 = ent;
     uint4 *wtab = wtab_all[XD ? (threadIdx.x >> 6) : 0];
     const float *grid_g = reinterpret_cast<const float *>(plan_tab);
+    const uint4 *entries = plan_tab + (pa.m_pad >> 2);
     if (XD) {
-        const uint4 *entries = plan_tab + (pa.m_pad >> 2);
         if (lane < xa.n_entries) ent = entries[lane];
         if (xa.n_entries > 64u && lane + 64u < xa.n_entries) ent2 = entries[lane + 64u];
     } else {

@@ -93,6 +93,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
         XArgs xa;
         xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
         xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
+        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
         const uint4 *entries = tab + (pa.m_pad >> 2);
         const float *grid = reinterpret_cast<const float *>(tab);
         const dim3 grid_dim((unsigned)((total + 3) / 4)), block(256);
@@ -460,6 +461,7 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     XArgs xa;
     xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
     xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
+        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
     const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
     const uint4 *xv = static_cast<const uint4 *>(x);
 #define ANTQ_LAUNCH_S(PT_, XD_)                                                                                    \

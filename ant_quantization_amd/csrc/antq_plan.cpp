@@ -294,13 +294,26 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
     // neighbour when the neighbour has no threshold of its own (harmless for the exact d-domain path:
     // every d of the neighbour lies on one side of it).  If the neighbour is taken, no x-domain path.
     {
-        bool ok = h.n_entries <= 128 && !linear;     // wave-private table: up to two entries per lane
+        // wave-private table: at most two entries per lane (128), sign-interleaved for float-bits keys.  Measured: a
+        // 255-bucket linear table (int-8, four entries per lane and task) is SLOWER per-row than the d-domain path
+        // (67 vs 72 % batched bf16), the 63 / 127-bucket ones of int-6 / int-7 are faster (81 vs 75 %).
+        bool ok = h.n_entries <= 128;
+        if (linear) {
+            // linear buckets have a threshold each, half a bucket away from both edges: a 2-ulp error of the approximate
+            // quotient must not carry a d that is within 2^-20 of a threshold into another bucket
+            for (int i = 0; i + 1 < k && ok; i++)
+                for (float t : {T[i] * (1.0f + 0x1p-20f), T[i] * (1.0f - 0x1p-20f)}) {
+                    float kf = fmaf(t, h.lin_scale, h.lin_bias);
+                    kf = fminf(fmaxf(kf, 0.0f), (float)h.kmax);
+                    if ((int)kf != i) ok = false;
+                }
+        }
         auto entry_of = [&](float t) -> LutEntry * {
             const uint32_t key = mag_key(t, h.shift);
             if (key < h.kmin || key > h.kmax) return nullptr;       // clamped region: same bucket as the edge one
             return &ent[(key - h.kmin) + ((t < 0.0f && has_neg) ? h.nb : 0u)];
         };
-        for (int i = 0; i + 1 < k && ok; i++) {
+        for (int i = 0; i + 1 < k && ok && !linear; i++) {
             const float t = T[i];
             LutEntry *own = entry_of(t);
             for (float nb_t : {t * (1.0f + 0x1p-20f), t * (1.0f - 0x1p-20f)}) {
