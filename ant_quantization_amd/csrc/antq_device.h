@@ -5,6 +5,12 @@
 
 namespace antq {
 
+// Rows of at least this many 16-byte vectors get a wavefront (or several) to themselves: wave-uniform scale, per-row
+// x-domain table.  Shorter rows / groups share a wavefront with a per-lane scale (k_fq_lane).  Measured on batches of
+// 16 x 4096^2: at 64 vectors per row the row kernels reach 47-55 % (bf16) / 56-70 % (fp32) because a wavefront then has
+// one vector per lane in flight, the lane kernel 60 / 79 %; from 128 vectors up the row-table kernel wins (73-80 %).
+constexpr unsigned kRowKernelMinVpr = 128;
+
 // ------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ struct BatchDesc {   // 144 bytes, device-visible
     uint32_t tpr;
     int32_t vshift;
     uint32_t first_block;
-    uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < 64);
+    uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < kRowKernelMinVpr);
                            // 2 = row-run per wavefront, x-domain table (pad[] = xlim bits, grid offset)
                            // 3 = element-granular (ragged rows / unaligned buffers): n_vec = elements, vpr = row_len
     int32_t per_row;
@@ -136,7 +136,7 @@ static size_t job_blocks(const antq_job &J, int epl, BatchDesc *d)
     const size_t vpr = row_len / epl;
     if (vpr > 0xffffffffull) return 0;
     size_t blocks;
-    if (vpr >= 64) {
+    if (vpr >= kRowKernelMinVpr) {
         const size_t tpr = (vpr + 64 * kBatchU - 1) / (64 * kBatchU);
         const size_t total = rows * tpr;
         if (total > 0xfffffff0ull) return 0;

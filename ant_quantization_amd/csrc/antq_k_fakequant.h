@@ -125,8 +125,8 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
 }
 
 // ------------------------------------------------------------------------------------
-// K1x  x-domain row kernel: the fast path for rows of >= 64 vectors (the headline shape and every Linear / conv row
-// of 256 fp32 or 512 bf16 elements and up; the closed-form threshold makes the per-task table cheap enough).
+// K1x  x-domain row kernel: the fast path for rows of >= kRowKernelMinVpr (128) vectors: the headline shape and every
+// Linear / conv row of 512 fp32 or 1024 bf16 elements and up; the closed-form threshold keeps the per-task table cheap.
 //
 // K1a spends most of its VALU time on per-element work that only depends on the ROW:
 // dividing by the row's scale, and mapping the quotient back (straight-through add,

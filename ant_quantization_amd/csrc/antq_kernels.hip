@@ -80,7 +80,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const uint4 *tab = plan_tab_ptr(plan_dev);
     const uint4 *xv = static_cast<const uint4 *>(x);
     uint4 *ov = static_cast<uint4 *>(out);
-    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 64 && (!DYN || vpr <= 2048);
+    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr && (!DYN || vpr <= 2048);
     if (use_x) {
         // x-domain row kernel: 4 or 8 KiB of one row per wavefront (the per-row table is rebuilt per task)
         int U = 4;   // 4 KiB of the row per wavefront measured best at steady clocks (79 % of 8 TB/s on 1 GiB)
@@ -178,7 +178,7 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
 
     if (aligned && row_len % EPL == 0) {
         const size_t vpr = row_len / EPL;
-        if (vpr >= 64) {
+        if (vpr >= kRowKernelMinVpr) {
             if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
             return launch_uniform<T, OVP, IDX, false>(x, out, idx, rows, vpr, alpha, per_row, gmax, 1.0f, nullptr, pa,
                                                       plan_host, plan_dev, lds, st);
@@ -457,7 +457,7 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     const int cand_chunk = (ncand + chunks - 1) / chunks;
     chunks = (ncand + cand_chunk - 1) / cand_chunk;
     const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
-    const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= 64;
+    const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr;
     XArgs xa;
     xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
     xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
@@ -605,7 +605,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         if (!plan_args_from_host(J.plan_host, d.pa)) return ANTQ_ERR_PLAN;
         {
             const PlanHeader *ph = static_cast<const PlanHeader *>(J.plan_host);
-            if (d.kind == 0 && g_knob_x && d.pa.kind == kPlanLut && ph->xdom && d.vpr >= 64) {
+            if (d.kind == 0 && g_knob_x && d.pa.kind == kPlanLut && ph->xdom && d.vpr >= kRowKernelMinVpr) {
                 d.kind = 2;
                 memcpy(&d.pad[0], &ph->xlim, 4);
                 memcpy(&d.pad[1], &ph->vout, 4);
