@@ -34,4 +34,5 @@ $PY tools/probe_operator_level.py > "$OUT/${TAG}_operator_level.log" 2>&1
 $PY tools/probe_weight_bank.py 2>&1 | grep -v "golden,\|bit \s" > "$OUT/${TAG}_weight_bank.log"
 $PY tools/probe_graph_forward.py 2>&1 | grep -v "bit \s\|amdgpu" > "$OUT/${TAG}_graph_forward.log"
 $PY tools/probe_size_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_size_sweep.log"
+$PY tools/probe_group_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_group_sweep.log"
 ls -la "$OUT"
