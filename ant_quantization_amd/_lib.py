@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("ANTQ_LIB") or os.path.join(_HERE, "libantq.so")   # A
 
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_OVP = 1
+FLAG_DYNAMIC = 2
 IDX_NONE = -1
 IDX_VICTIM = -2
 MAX_GRID = 1024
@@ -377,7 +378,9 @@ class Batch:
     descriptor table is built once and stays resident: weights and calibrated alphas do not move between
     forwards."""
 
-    def __init__(self, jobs, ovp=False):
+    def __init__(self, jobs, ovp=False, dynamic=False):
+        """dynamic=True: every job's alpha tensor is an OUTPUT (row abs-max computed in the kernel); rows must be
+        2 KiB..32 KiB long, per_row, and the grid's plan x-domain eligible -- otherwise AntqError."""
         jobs = [tuple(j) for j in jobs]
         if not jobs:
             raise AntqError("empty batch")
@@ -401,7 +404,8 @@ class Batch:
                               plan.host_addr, plan.dev(self.device).data_ptr())
             cap = lib().antq_batch_capacity(arr, len(batched), self.dtype)
             host = np.zeros(cap, dtype=np.uint8)
-            n = lib().antq_batch_build(arr, len(batched), self.dtype, FLAG_OVP if ovp else 0,
+            n = lib().antq_batch_build(arr, len(batched), self.dtype,
+                                       (FLAG_OVP if ovp else 0) | (FLAG_DYNAMIC if dynamic else 0),
                                        host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
             if n <= 0:
                 _check(n, "antq_batch_build")

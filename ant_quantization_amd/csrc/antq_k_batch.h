@@ -24,6 +24,10 @@ struct BatchDesc {   // 144 bytes, device-visible
     uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < kRowKernelMinVpr);
                            // 2 = row-run per wavefront, x-domain table (pad[] = xlim bits, grid offset)
                            // 3 = element-granular (ragged rows / unaligned buffers): n_vec = elements, vpr = row_len
+                           // 4..7 = kind 2 with the alpha computed in the kernel (ANTQ_FLAG_DYNAMIC, k_fq_batch_dyn): the row in
+                           //         one wavefront, 4 / 8 vectors per lane (<= 256 / <= 512 vectors: kinds 4 / 6), or spread
+                           //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7); `alpha` is
+                           //         then an OUTPUT, pad[2] = clip ratio bits
     int32_t per_row;
     float gmax;
     PlanArgs pa;
@@ -51,9 +55,9 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
     const uint32_t lane = threadIdx.x & 63u;
     const uint4 *plan_tab = D.plan_tab;
 
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];     // wave-private row tables (kinds 2, 4, 5)
     if (D.kind == 2) {
         // x-domain rows: wave-private table, no workgroup barrier
-        __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
         const uint32_t wv = threadIdx.x >> 6;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
         if (task >= D.total_tasks) return;
@@ -115,6 +119,47 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
                 st_stream(D.out + vi, IO<T>::pack(of));
             }
         }
+    }
+}
+
+// ANTQ_FLAG_DYNAMIC batches: alpha = row abs-max (x ratio) computed from the registers that hold the row -- one HBM
+// read -- for every tensor of the batch in one launch.  A kernel of its own so that the 8-vectors-per-lane variants do
+// not raise the register count (and lower the occupancy) of the static kernel above.
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(256)
+k_fq_batch_dyn(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
+{
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
+    const uint32_t j = block_map[blockIdx.x];
+    const BatchDesc &D = descs[j];
+    const PlanArgs pa = D.pa;
+    const uint32_t lb = blockIdx.x - D.first_block;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint4 *plan_tab = D.plan_tab;
+    const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
+    XArgs xa;
+    xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+    xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]); xa.vout = u2f(D.pad[1]);
+    xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+    float *alpha_out = const_cast<float *>(D.alpha);
+    const uint4 *entries = plan_tab + (pa.m_pad >> 2);
+    const float *grid = reinterpret_cast<const float *>(plan_tab);
+    const float ratio = u2f(D.pad[2]);
+    if (D.kind == 4) {
+        if (task < D.total_tasks)
+            xrow_task<T, OVP, false, 4, true, 1>(D.x, D.out, nullptr, task, D.vpr, 1u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
+                                                 entries, grid, wtab_all[wv], lane, wv);
+    } else if (D.kind == 6) {
+        if (task < D.total_tasks)
+            xrow_task<T, OVP, false, 8, true, 1>(D.x, D.out, nullptr, task, D.vpr, 1u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
+                                                 entries, grid, wtab_all[wv], lane, wv);
+    } else if (D.kind == 5) {
+        xrow_task<T, OVP, false, 4, true, 4>(D.x, D.out, nullptr, task, D.vpr, 4u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
+                                             entries, grid, wtab_all[wv], lane, wv);
+    } else {
+        xrow_task<T, OVP, false, 8, true, 4>(D.x, D.out, nullptr, task, D.vpr, 4u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
+                                             entries, grid, wtab_all[wv], lane, wv);
     }
 }
 

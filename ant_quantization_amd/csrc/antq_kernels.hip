@@ -575,7 +575,8 @@ extern "C" size_t antq_batch_capacity(const antq_job *jobs, int n, int dtype)
     const int epl = epl_of(dtype);
     if (!jobs || n < 1 || !epl) return 0;
     size_t blocks = 0;
-    for (int i = 0; i < n; i++) blocks += job_blocks(jobs[i], epl, nullptr);
+    // (the dynamic variant gives rows of 257..1024 vectors a workgroup each: never more than max(static, rows))
+    for (int i = 0; i < n; i++) blocks += std::max(job_blocks(jobs[i], epl, nullptr), jobs[i].rows);
     return sizeof(BatchHeader) + sizeof(BatchDesc) * (size_t)n + 4 * blocks;
 }
 
@@ -600,7 +601,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         if (reinterpret_cast<uintptr_t>(J.x_dev) % esz || reinterpret_cast<uintptr_t>(J.out_dev) % esz) return ANTQ_ERR_ALIGN;
         BatchDesc d;
         memset(&d, 0, sizeof(d));
-        const size_t blocks = job_blocks(J, epl, &d);
+        size_t blocks = job_blocks(J, epl, &d);
         if (blocks == 0) return ANTQ_ERR_UNSUPPORTED;
         if (!plan_args_from_host(J.plan_host, d.pa)) return ANTQ_ERR_PLAN;
         {
@@ -609,6 +610,16 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                 d.kind = 2;
                 memcpy(&d.pad[0], &ph->xlim, 4);
                 memcpy(&d.pad[1], &ph->vout, 4);
+            }
+            if (flags & ANTQ_FLAG_DYNAMIC) {
+                // alpha computed in the kernel: the row has to live in the registers of one wavefront / workgroup
+                if (d.kind != 2 || !J.alpha_per_row || d.vpr > 2048u) return ANTQ_ERR_UNSUPPORTED;
+                const float one = 1.0f;
+                memcpy(&d.pad[2], &one, 4);
+                if (J.rows > 0x3ffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+                // one wavefront per row up to 512 vectors (4 or 8 per lane), one workgroup per row beyond
+                if (d.vpr <= 512u) { d.kind = d.vpr <= 256u ? 4 : 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4; }
+                else { d.kind = d.vpr <= 1024u ? 5 : 7; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
             }
         }
         if (total_blocks + blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
@@ -644,9 +655,13 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(h->total_blocks), block(256);
     const bool ovp = (h->flags & ANTQ_FLAG_OVP) != 0;
+    const bool dyn = (h->flags & ANTQ_FLAG_DYNAMIC) != 0;
 #define ANTQ_LAUNCH_B(TT)                                                                                         \
     do {                                                                                                          \
-        if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true>), grid, block, h->lds_bytes, st, descs, map);           \
+        if (dyn) {                                                                                                \
+            if (ovp) hipLaunchKernelGGL((k_fq_batch_dyn<TT, true>), grid, block, 0, st, descs, map);              \
+            else hipLaunchKernelGGL((k_fq_batch_dyn<TT, false>), grid, block, 0, st, descs, map);                 \
+        } else if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true>), grid, block, h->lds_bytes, st, descs, map);    \
         else hipLaunchKernelGGL((k_fq_batch<TT, false>), grid, block, h->lds_bytes, st, descs, map);              \
     } while (0)
     switch (h->dtype) {

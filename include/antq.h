@@ -52,6 +52,7 @@ extern "C" {
 
 /* flags of antq_fakequant* */
 #define ANTQ_FLAG_OVP        1u    /* OliVe outlier-victim pair masking (OQ:311-320) */
+#define ANTQ_FLAG_DYNAMIC    2u    /* antq_batch_build only: alpha computed in the kernel */
 
 /* values written to the optional int16 index output */
 #define ANTQ_IDX_NONE    (-1)      /* no grid entry within 102400 (NaN/Inf/huge)     */
@@ -185,6 +186,10 @@ int antq_affine(const float *x_dev, float *out_dev, int32_t *q_dev,
  *   antq_batch_build : pure host code; writes the descriptor blob (returns its size in bytes).  All jobs share dtype
  *                      and flags.  Jobs whose rows are not a multiple of 16 bytes (conv1: K = 147) or whose
  *                      buffers are not 16-byte aligned run element-granular inside the same launch.
+ *                      With ANTQ_FLAG_DYNAMIC every job's alpha_dev is an OUTPUT: alpha[r] = max_c |x[r,c]| is computed
+ *                      in the kernel from the registers holding the row (antq_fakequant_dynamic with ratio 1, many
+ *                      tensors, one launch); rows must be per-row, 2 KiB..32 KiB long and the plan x-domain
+ *                      eligible (every ANT / OliVe 4-bit codebook), otherwise ANTQ_ERR_UNSUPPORTED.
  *   antq_fakequant_batch : one launch for all jobs; batch_dev is the caller's device copy.
  * ------------------------------------------------------------------------- */
 typedef struct antq_job {

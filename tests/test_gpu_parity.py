@@ -1345,3 +1345,36 @@ def test_quantizer_follows_external_grid_edits(antq_lib, oracle, dev, capsys):
     ref, _ = oracle.forward(x.cpu().numpy(), q.alpha.detach().cpu().numpy().reshape(-1), g["int_b4_s"])
     assert f32_same(out.detach().cpu().numpy(), ref)
     capsys.readouterr()
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+def test_dynamic_batched_launch_equals_per_tensor_dynamic(antq_lib, dev, dtype_name):
+    """ANTQ_FLAG_DYNAMIC: many tensors, alpha = row abs-max computed in the kernel, ONE launch -- same alphas and the
+    same bits as antq_fakequant_dynamic per tensor (itself oracle-checked), ANT and OliVe pairs; rows outside the
+    register-resident range are refused."""
+    import torch
+    dtype = getattr(torch, dtype_name)
+    epl = 4 if dtype == torch.float32 else 8
+    g = golden("ant_grids.npz")["flint_b4_s"]
+    O = golden("olive_grids.npz")
+    pol = antq_lib.plan_for(np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]]))
+    plan = antq_lib.plan_for(g)
+    torch.manual_seed(14)
+    shapes = [(64, 128 * epl), (33, 256 * epl), (17, 384 * epl), (9, 1024 * epl), (40, 200 * epl), (5, 777 * epl),
+              (6, 512 * epl), (3, 2048 * epl), (4, 1500 * epl)]
+    for p, gmax, ovp in ((plan, 10.0, False), (pol, 32.0, True)):
+        xs = [(torch.randn(*s, device=dev) * 0.03).to(dtype) for s in shapes]
+        for x in xs:
+            x.view(-1)[::97] *= 25
+        refs = [antq_lib.fakequant_dynamic(x, p, gmax, x.shape[0], x.shape[1], ovp=ovp) for x in xs]
+        outs = [torch.zeros_like(x) for x in xs]
+        alphas = [torch.zeros(x.shape[0], dtype=torch.float32, device=dev) for x in xs]
+        bt = antq_lib.Batch([(x, o, a, p, gmax, x.shape[0], x.shape[1], True) for x, o, a in zip(xs, outs, alphas)],
+                            ovp=ovp, dynamic=True)
+        bt.run()
+        for (ro, ra, _), o, a, s in zip(refs, outs, alphas, shapes):
+            assert torch.equal(a, ra) and torch.equal(o, ro), (s, ovp)
+    for bad in [(8, 64 * epl), (8, 2049 * epl)]:                      # too short for a row kernel / too long for registers
+        x = torch.randn(*bad, device=dev).to(dtype)
+        with pytest.raises(antq_lib.AntqError):
+            antq_lib.Batch([(x, torch.empty_like(x), torch.zeros(8, device=dev), plan, 10.0, bad[0], bad[1], True)], dynamic=True)

@@ -28,8 +28,14 @@ def main():
             tp = timed(lambda: [_lib.fakequant(x, a, plan, 10.0, n // G, G, True, out=o) for x, a, o in zip(xs, al, outs)], 5)
             td = timed(lambda: [_lib.fakequant_dynamic(x, plan, 10.0, n // G, G, out=o, want_alpha=False)
                                 for x, o in zip(xs, outs)], 5)
-            print("%-9s group-%-5d static: batched %5.1f%%  per tensor %5.1f%%   dynamic, per tensor %5.1f%%  of 8 TB/s" % (
-                str(dt)[6:], G, 16 * n * bpe / tb / 8e10, 16 * n * bpe / tp / 8e10, 16 * n * bpe / td / 8e10), flush=True)
+            try:                                   # rows of 2..16 KiB: alpha in the kernel, all tensors in one launch
+                bd = _lib.Batch([(x, o, torch.empty_like(a), plan, 10.0, n // G, G, True) for x, a, o in zip(xs, al, outs)],
+                                dynamic=True)
+                tdb = "%5.1f%%" % (16 * n * bpe / timed(bd.run, 20) / 8e10)
+            except _lib.AntqError:
+                tdb = "   n/a"
+            print("%-9s group-%-5d static: batched %5.1f%%  per tensor %5.1f%%   dynamic: batched %s  per tensor %5.1f%%  of 8 TB/s" % (
+                str(dt)[6:], G, 16 * n * bpe / tb / 8e10, 16 * n * bpe / tp / 8e10, tdb, 16 * n * bpe / td / 8e10), flush=True)
         del xs, outs
 
 
