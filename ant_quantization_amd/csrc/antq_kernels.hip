@@ -323,9 +323,21 @@ extern "C" int antq_affine(const float *x, float *out, int32_t *q, size_t rows, 
     if (rows == 0 || row_len == 0) return ANTQ_OK;
     if (!x || !out || !xmin || !xmax || k < 1 || k > 24) return ANTQ_ERR_ARG;
     const size_t n = rows * row_len;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = (per_row ? row_len : n) % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(out) % 16 == 0 && (!q || reinterpret_cast<uintptr_t>(q) % 16 == 0);
+    if (vec) {
+        const size_t n_vec = n / 4, vpr = (per_row ? row_len : n) / 4;
+        const size_t blocks = (n_vec + 1023) / 1024;
+        if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(k_affine_vec, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint4 *>(x),
+                           reinterpret_cast<uint4 *>(out), reinterpret_cast<int4 *>(q), n_vec, vpr, k, xmin, xmax,
+                           per_row ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+    }
     const size_t blocks = (n + 255) / 256;
     if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_affine, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, q, n,
+    hipLaunchKernelGGL(k_affine, dim3((unsigned)blocks), dim3(256), 0, st, x, out, q, n,
                        row_len, k, xmin, xmax, per_row ? 1 : 0);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }

@@ -1378,3 +1378,32 @@ def test_dynamic_batched_launch_equals_per_tensor_dynamic(antq_lib, dev, dtype_n
         x = torch.randn(*bad, device=dev).to(dtype)
         with pytest.raises(antq_lib.AntqError):
             antq_lib.Batch([(x, torch.empty_like(x), torch.zeros(8, device=dev), plan, 10.0, bad[0], bad[1], True)], dynamic=True)
+
+
+def test_affine_vector_kernel_equals_element_kernel(antq_lib, oracle, dev):
+    """antq_affine picks a 16-byte vector kernel (exact 5-FMA division) for aligned inputs and an element kernel (IEEE
+    division) otherwise: same bits on the same data, across benign and hostile (min, max) ranges, and both equal the
+    oracle's restatement of quant_affine.py:95-115."""
+    import torch
+    torch.manual_seed(17)
+    rows, K = 96, 1024
+    base = torch.randn(rows * K + 4, device=dev)
+    base[::311] *= 50
+    for k in (4, 8):
+        for scale_x, shift in ((1.0, 0.0), (1e-6, 0.0), (1e4, 3e4), (1e-9, 1.0), (3e18, 0.0)):
+            buf = base * scale_x + shift
+            xa = buf[:rows * K].view(rows, K)                       # 16-byte aligned -> vector kernel
+            xu = buf[1:rows * K + 1]                                # 4-byte offset   -> element kernel
+            xu.copy_(xa.reshape(-1).clone())
+            xa = xu.clone().view(rows, K)
+            for per_row in (False, True):
+                if per_row:
+                    mn, mx = xa.min(1).values.contiguous(), xa.max(1).values.contiguous()
+                else:
+                    mn, mx = xa.min().reshape(1), xa.max().reshape(1)
+                ov, qv = antq_lib.affine(xa, k, mn, mx, rows, K, per_row, want_q=True)
+                oe = antq_lib.affine(xu, k, mn, mx, rows, K, per_row)
+                assert torch.equal(ov.view(-1).view(torch.int32), oe.view(torch.int32)), (k, scale_x, shift, per_row)
+                ref = oracle.affine(xa.cpu().numpy(), k, mn.cpu().numpy(), mx.cpu().numpy())
+                ref_out = ref[0] if isinstance(ref, tuple) else ref
+                assert f32_same(ov.cpu().numpy(), ref_out), (k, scale_x, shift, per_row)
