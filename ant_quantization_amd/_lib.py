@@ -49,7 +49,7 @@ def lib():
                              "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
-                             "antq_search_pick", "antq_alpha_grad"):
+                             "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
@@ -194,6 +194,27 @@ def nearest(x, grid, want_idx=False):
     with torch.cuda.device(x.device):
         _check(lib().antq_nearest(_vp(x), _vp(z), _vp(idx), ctypes.c_size_t(x.numel()), _vp(grid),
                                   ctypes.c_int(grid.numel()), ctypes.c_int(dt), _stream(x.device)), "antq_nearest")
+    return (z, idx) if want_idx else z
+
+
+def nearest_plan(x, plan, want_idx=False):
+    """quant_cuda.quant body through a plan (the grid is known on the host): table lookup instead of the scan.
+    Falls back to nearest() (the literal scan on the plan's grid) for ragged / unaligned / float64 inputs."""
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    epl = 4 if dt == F32 else 8
+    if dt == F64 or x.numel() % epl or x.data_ptr() % 16:
+        g = torch.from_numpy(plan.grid).to(x.device)
+        return nearest(x, g.to(x.dtype) if dt in (F32, F64) else g, want_idx)
+    z = torch.empty_like(x)
+    idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
+    pd = plan.dev(x.device)
+    with _on_device(x.device):
+        _check(lib().antq_nearest_plan(_vp(x), _vp(z), _vp(idx), ctypes.c_size_t(x.numel()),
+                                       ctypes.c_void_p(plan.host_addr), _vp(pd), ctypes.c_int(dt), _stream(x.device)),
+               "antq_nearest_plan")
     return (z, idx) if want_idx else z
 
 

@@ -253,20 +253,13 @@ __device__ __forceinline__ float scan_lds(float d, const float *grid, int m, int
 // Core: EPL elements of one lane, all from the same quant group.
 //   in : x[e]           out: o[e] = fl(fl(fl(q-d)+d)*s), j[e] (if IDX)
 // ------------------------------------------------------------------------------------
-template <int EPL, bool OVP, bool IDX>
-__device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, const Scale &sc,
-                                          const float (&x)[EPL], float (&o)[EPL], int (&j)[EPL])
+// Table lookup for EPL grid-domain values d (all inside the table's domain, |d| < fastlim): q = nearest grid value of
+// the reference scan, j = its scan-order index.  One ds_read_b128 and one compare per element.
+template <int EPL, bool IDX>
+__device__ __forceinline__ void lut_lookup(const PlanArgs &pa, const PlanLds &L, const float (&d)[EPL], float (&q)[EPL],
+                                           int (&j)[EPL])
 {
-    float d[EPL], q[EPL];
-    bool fast = (pa.kind == kPlanLut) && sc.ok;
-    if (fast) {
-#pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            d[e] = div_fast(x[e], sc.s, sc.rs);
-            fast = fast && (fabsf(d[e]) < pa.fastlim);  // false for NaN / Inf / huge
-        }
-    }
-    if (fast && pa.linear) {
+    if (pa.linear) {
         // uniformly spaced thresholds: one bucket per threshold, bucket = trunc(clamp(d * scale + bias))
         const float khi = (float)pa.kmax;
 #pragma unroll
@@ -279,7 +272,7 @@ __device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, 
             q[e] = c ? u2f(ent.z) : u2f(ent.y);
             if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
         }
-    } else if (fast) {
+    } else {
         // byte offset of the bucket: key*16 straight from the float's bits (exponent + top
         // mantissa bits, shifted so the key lands on bit 4), clamped, plus the negative half.
         const int32_t sh4 = (int32_t)pa.shift - 4;                 // shift >= 13 always
@@ -299,6 +292,24 @@ __device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, 
             q[e] = c ? u2f(ent.z) : u2f(ent.y);
             if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
         }
+    }
+}
+
+template <int EPL, bool OVP, bool IDX>
+__device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, const Scale &sc,
+                                          const float (&x)[EPL], float (&o)[EPL], int (&j)[EPL])
+{
+    float d[EPL], q[EPL];
+    bool fast = (pa.kind == kPlanLut) && sc.ok;
+    if (fast) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            d[e] = div_fast(x[e], sc.s, sc.rs);
+            fast = fast && (fabsf(d[e]) < pa.fastlim);  // false for NaN / Inf / huge
+        }
+    }
+    if (fast) {
+        lut_lookup<EPL, IDX>(pa, L, d, q, j);
     } else {
         // exact slow path: true division + literal scan (scan plans, odd scales, huge/NaN/Inf)
 #pragma unroll

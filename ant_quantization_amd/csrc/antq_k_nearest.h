@@ -187,6 +187,56 @@ k_nearest16(const void *__restrict__ x, void *__restrict__ z, int16_t *__restric
     if (idx) idx[i] = (int16_t)j;
 }
 
+// ------------------------------------------------------------------------------------
+// Nearest value through a plan (antq_nearest_plan): when the caller knows the grid on the host (a quantiser's static
+// codebook), the M-step scan is the same one-LDS-read lookup the fused kernels use, on d = x itself.  16 bytes per lane,
+// 4 vectors in flight; elements beyond the table's domain (|x| >= fastlim, NaN, Inf) and scan plans run the literal scan.
+// ------------------------------------------------------------------------------------
+template <typename T, bool IDX>
+__global__ void __launch_bounds__(256)
+k_nearest_plan(const uint4 *__restrict__ x, uint4 *__restrict__ z, int16_t *__restrict__ idx, size_t n_vec,
+               PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    constexpr int EPL = IO<T>::EPL;
+    constexpr int U = 4;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t vi = first + (size_t)u * 256u;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (vi < n_vec) v[u] = ld_stream(x + vi);
+    }
+    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t vi = first + (size_t)u * 256u;
+        if (vi >= n_vec) continue;
+        float d[EPL], q[EPL];
+        int j[EPL];
+        IO<T>::unpack(v[u], d);
+        bool fast = pa.kind == kPlanLut;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) fast = fast && (fabsf(d[e]) < pa.fastlim);
+        if (fast) {
+            lut_lookup<EPL, IDX>(pa, L, d, q, j);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                int jj;
+                q[e] = scan_lds(d[e], L.grid, (int)pa.m, jj);
+                j[e] = jj;
+            }
+        }
+        st_stream(z + vi, IO<T>::pack(q));
+        if (IDX) store_idx<EPL>(idx, vi, j);
+    }
+}
+
 }  // namespace antq
 
 #endif  // ANTQ_K_NEAREST_H

@@ -292,6 +292,40 @@ extern "C" int antq_nearest(const void *x, void *z, int16_t *idx, size_t n, cons
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+// quant_cuda.quant for a grid the caller has a plan for (quantisers' static codebooks): table lookup instead of the scan.
+extern "C" int antq_nearest_plan(const void *x, void *z, int16_t *idx, size_t n, const void *plan_host, const void *plan_dev,
+                                 int dtype, void *stream)
+{
+    if (n == 0) return ANTQ_OK;
+    if (!x || !z || !plan_host || !plan_dev) return ANTQ_ERR_ARG;
+    PlanArgs pa;
+    if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
+    const int epl = dtype == ANTQ_F32 ? 4 : (dtype == ANTQ_BF16 || dtype == ANTQ_F16) ? 8 : 0;
+    if (!epl) return ANTQ_ERR_UNSUPPORTED;
+    if (n % epl || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(z) % 16 ||
+        (idx && reinterpret_cast<uintptr_t>(idx) % 16))
+        return ANTQ_ERR_UNSUPPORTED;                     // ragged / unaligned: use antq_nearest (the literal scan)
+    const size_t n_vec = n / epl;
+    const size_t blocks = (n_vec + 1023) / 1024;
+    if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)pa.tab_units * 16;
+    const uint4 *xv = static_cast<const uint4 *>(x);
+    uint4 *zv = static_cast<uint4 *>(z);
+#define ANTQ_LAUNCH_N(TT)                                                                                          \
+    do {                                                                                                           \
+        if (idx) hipLaunchKernelGGL((k_nearest_plan<TT, true>), dim3((unsigned)blocks), dim3(256), lds, st, xv, zv, idx, n_vec, pa, plan_tab_ptr(plan_dev)); \
+        else hipLaunchKernelGGL((k_nearest_plan<TT, false>), dim3((unsigned)blocks), dim3(256), lds, st, xv, zv, idx, n_vec, pa, plan_tab_ptr(plan_dev));    \
+    } while (0)
+    switch (dtype) {
+    case ANTQ_F32: ANTQ_LAUNCH_N(float); break;
+    case ANTQ_BF16: ANTQ_LAUNCH_N(bf16_tag); break;
+    default: ANTQ_LAUNCH_N(f16_tag); break;
+    }
+#undef ANTQ_LAUNCH_N
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
 extern "C" int antq_fakequant(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,
                               const float *alpha, int alpha_per_row, float gmax, const void *plan_host,
                               const void *plan_dev, unsigned flags, int dtype, void *stream)

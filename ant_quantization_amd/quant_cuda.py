@@ -17,9 +17,31 @@ import torch
 
 from . import _lib
 
+# The reference calls quant(x, self.quant_grid) with the SAME grid buffer on every forward.  The first call with a
+# given buffer state reads the grid back once and builds its plan; later calls go through the table kernel
+# (antq_nearest_plan) -- about twice as fast as scanning.  Keyed by (data_ptr, _version, numel, dtype, device); the
+# entry keeps the grid tensor alive, so its address cannot be recycled for another grid while the entry exists.
+# (An edit through `.data` does not bump `_version`: PyTorch's own staleness rule applies.)
+_plans = {}
+
+
+def _plan_of(grid):
+    key = (grid.data_ptr(), grid._version, grid.numel(), grid.dtype, grid.device)
+    hit = _plans.get(key)
+    if hit is None:
+        if len(_plans) > 256:
+            _plans.clear()
+        hit = (_lib.plan_for(grid.detach().float().cpu().numpy()), grid)
+        _plans[key] = hit
+    return hit[0]
+
 
 def quant(x, y):
     if x.dim() != 1:
         raise RuntimeError("quant_cuda.quant: x must be 1-D (got %d-D)" % x.dim())
-    z = _lib.nearest(x.contiguous(), y.contiguous())
+    x = x.contiguous()
+    if x.dtype == torch.float32 and y.numel() <= _lib.MAX_GRID:
+        z = _lib.nearest_plan(x, _plan_of(y))
+    else:
+        z = _lib.nearest(x, y.contiguous())
     return z, torch.zeros_like(x)

@@ -76,6 +76,12 @@ const char *antq_strerror(int code);
 int antq_nearest(const void *x_dev, void *z_dev, int16_t *idx_dev, size_t n,
                  const void *grid_dev, int m, int dtype, void *stream);
 
+/* The same operator for a grid the caller knows on the host (a quantiser's static codebook: build the plan once, see
+ * below): one table lookup per element instead of the m-step scan -- same z, same j*.  x, z: n elements of F32 / BF16 /
+ * F16, 16-byte aligned, n a multiple of 4 (F32) or 8; anything else: ANTQ_ERR_UNSUPPORTED, use antq_nearest. */
+int antq_nearest_plan(const void *x_dev, void *z_dev, int16_t *idx_dev, size_t n,
+                      const void *plan_host, const void *plan_dev, int dtype, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Plan: host-side, exact pre-computation of the decision thresholds of the
  * reference scan for one grid (pure CPU, no HIP calls).  The caller keeps the
