@@ -1407,3 +1407,42 @@ def test_affine_vector_kernel_equals_element_kernel(antq_lib, oracle, dev):
                 ref = oracle.affine(xa.cpu().numpy(), k, mn.cpu().numpy(), mx.cpu().numpy())
                 ref_out = ref[0] if isinstance(ref, tuple) else ref
                 assert f32_same(ov.cpu().numpy(), ref_out), (k, scale_x, shift, per_row)
+
+
+def test_nearest_plan_equals_scan_and_cache_follows_grid_edits(antq_lib, oracle, dev):
+    """antq_nearest_plan (table lookup on d = x) == the reference scan, fp32 / bf16 / fp16, aligned and ragged; and
+    quant_cuda.quant's per-buffer plan cache notices an in-place edit of the grid."""
+    import torch
+    from ant_quantization_amd import quant_cuda
+    rng = np.random.default_rng(31)
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    grids_ = [G["flint_b4_s"], G["int_b8_u"], G["pot_b6_u"], G["apot_b4_s"], np.float32([3, 1, 2, 1, 3, -7]),
+              np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])]
+    for g in grids_:
+        plan = antq_lib.plan_for(g)
+        hi = float(np.abs(g).max()) + 1
+        for n in (8192, 8191, 33):
+            x = np.concatenate([rng.standard_normal(n - 12).astype(np.float32) * np.float32(hi / 2),
+                                np.float32([0.0, -0.0, 1e5, -1e5, 102400.0, 2e5, np.inf, -np.inf, np.nan, 36000.0, 1e-30, 65535.0])])
+            with np.errstate(all="ignore"):
+                zr, jr = oracle.nearest(x, g)
+            z, j = antq_lib.nearest_plan(to_dev(x, dev), plan, want_idx=True)
+            assert f32_same(z.cpu().numpy(), zr) and np.array_equal(j.cpu().numpy().astype(np.int32), jr), (g[:4], n)
+            xb = oracle.f32_to_bf16(x)
+            with np.errstate(all="ignore"):
+                zb_ref, _ = oracle.nearest(oracle.bf16_to_f32(xb), g)
+            zb = antq_lib.nearest_plan(to_dev(xb, dev, True), plan)
+            assert bf16_same(bf16_bits(zb), oracle.f32_to_bf16(zb_ref), oracle), (g[:4], n, "bf16")
+            xh = torch.from_numpy(x).to(dev).half()
+            with np.errstate(all="ignore"):
+                zh_ref, _ = oracle.nearest(xh.float().cpu().numpy(), g)
+            zh = antq_lib.nearest_plan(xh, plan)
+            assert f32_same(zh.float().cpu().numpy(), torch.from_numpy(zh_ref).half().float().numpy()), (g[:4], n, "f16")
+    # the drop-in's plan cache: same buffer, new contents
+    gt = torch.from_numpy(G["flint_b4_s"].copy()).to(dev)
+    x = torch.randn(4096, device=dev) * 4
+    z1, zero = quant_cuda.quant(x, gt)
+    assert not zero.any() and f32_same(z1.cpu().numpy(), oracle.nearest(x.cpu().numpy(), G["flint_b4_s"])[0])
+    gt.copy_(torch.from_numpy(G["int_b4_s"]).to(dev))
+    z2, _ = quant_cuda.quant(x, gt)
+    assert f32_same(z2.cpu().numpy(), oracle.nearest(x.cpu().numpy(), G["int_b4_s"])[0])
