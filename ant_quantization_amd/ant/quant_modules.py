@@ -41,12 +41,16 @@ class QuantBase():
     dtype, nearest-value kernel, reshape."""
 
     def _quantization(x, quant_grid):
-        shape = x.shape
-        quant_array = x.view(-1)
-        quant_grid = quant_grid.type_as(quant_array) if quant_array.dtype in (torch.float32, torch.float64) \
-            else quant_grid.float()
-        quant_array = _lib.nearest(quant_array, quant_grid.contiguous())
-        return quant_array.view(shape)
+        """The operator boundary (AQ:12-18 / OQ:9-15): flat view, the nearest-value operator, reshape back -- what
+        `quant_cuda.quant` does, minus the all-zero index tensor the reference allocates and throws away."""
+        from .. import quant_cuda
+        flat = x.view(-1).contiguous()
+        if flat.dtype == torch.float32 and quant_grid.dtype == torch.float32:
+            z = _lib.nearest_plan(flat, quant_cuda._plan_of(quant_grid))      # plan cached per grid buffer state
+        else:
+            g = quant_grid.type_as(flat) if flat.dtype in (torch.float32, torch.float64) else quant_grid.float()
+            z = _lib.nearest(flat, g.contiguous())
+        return z.view(x.shape)
 
     @staticmethod
     def forward(real_val, quant_grid):
