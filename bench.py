@@ -24,8 +24,8 @@ Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes of one lau
 read bf16 + write bf16, x nbuf x 16.7 M elements) / average duration of that launch, measured
 here with HIP events recorded on the launch stream around the timed region (which consists of
 exactly `steps` launches of that kernel).  `cpu_baseline` times the CPU
-oracle (oracle/antq_oracle.c, a literal restatement of the reference's op sequence: "port") on the
-host cores for one tensor of the same workload.
+oracle (oracle/antq_oracle.c, a literal restatement of the reference's op sequence: "port") on all
+host cores (and on one) on rows of the same workload.
 """
 import argparse
 import json
@@ -44,47 +44,40 @@ BYTES_PER_ELEM = 4               # algorithmic: read one bf16 + write one bf16 (
 
 
 def cpu_baseline(seconds_budget=12.0):
-    """Oracle (port of the reference op sequence) on the host cores, one 4096x4096 bf16 tensor
-    split by rows over all cores; repeated until ~seconds_budget of CPU work is done."""
+    """Oracle (port of the reference op sequence) on the host cores: 64 rows of 4096 bf16 elements per hardware thread
+    (16384 rows = four headline tensors on a 256-thread host), every thread sweeping its rows `reps` times so that
+    thread start-up does not count; about `seconds_budget` CPU-seconds in total.  Plus the same oracle on one thread."""
     import numpy as np
     from oracle import antq_oracle as orc
     from ant_quantization_amd import grids
     orc.build()
     cores = os.cpu_count() or 1
     rng = np.random.default_rng(6)
-    rows = 1024                                                   # bounded sample: 1/4 of one tensor
+    rows = 64 * cores
     x = orc.f32_to_bf16((rng.standard_normal((rows, COLS)) * 0.02).astype(np.float32))
     out = np.empty_like(x)
     g = grids.ant_flint(4, True)
     alpha = orc.absmax(orc.bf16_to_f32(x), True, 1.0)
-    bounds = [(rows * t // cores, rows * (t + 1) // cores) for t in range(cores)]
+    t0 = time.perf_counter()
+    orc.forward_rows(x, out, 0, 64, alpha, g, 10.0)               # ONE host thread, 64 rows
+    one_thread = 64 * COLS / (time.perf_counter() - t0)           # elements / s
+    reps = max(1, int(seconds_budget * one_thread / (rows * COLS)))
 
     def work(b, e):
-        orc.forward_rows(x, out, b, e, alpha, g, 10.0)           # ctypes call: releases the GIL
+        for _ in range(reps):
+            orc.forward_rows(x, out, b, e, alpha, g, 10.0)        # ctypes call: releases the GIL
 
-    def one_pass():
-        ts = [threading.Thread(target=work, args=be) for be in bounds]
-        t0 = time.perf_counter()
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        return time.perf_counter() - t0
-
-    one_pass()
-    best, spent, passes = 1e30, 0.0, 0
-    while spent * cores < seconds_budget and passes < 50:
-        dt = one_pass()
-        best = min(best, dt)
-        spent += dt
-        passes += 1
+    ts = [threading.Thread(target=work, args=(64 * t, 64 * (t + 1))) for t in range(cores)]
     t0 = time.perf_counter()
-    work(0, 64)                                                  # the same oracle on ONE host thread, 64 rows
-    one_thread = 64 * COLS / (time.perf_counter() - t0) / 1e9
-    return {"value": round(rows * COLS / best / 1e9, 5), "unit": "Gelem/s", "cores": cores, "kind": "port",
-            "single_thread_gelem_per_s": round(one_thread, 6),
-            "sample": "%d rows x %d cols bf16 (1/4 of one headline tensor), flint 4-bit per-row alpha, "
-                      "best of %d passes, %d threads" % (rows, COLS, passes, cores)}
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": round(rows * COLS * reps / dt / 1e9, 5), "unit": "Gelem/s", "cores": cores, "kind": "port",
+            "single_thread_gelem_per_s": round(one_thread / 1e9, 6),
+            "sample": "%d rows x %d cols bf16 (64 rows per thread), flint 4-bit per-row alpha, %d sweeps, %d threads, "
+                      "%.1f s wall" % (rows, COLS, reps, cores, dt)}
 
 
 def main():
