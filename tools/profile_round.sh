@@ -35,4 +35,5 @@ $PY tools/probe_weight_bank.py 2>&1 | grep -v "golden,\|bit \s" > "$OUT/${TAG}_w
 $PY tools/probe_graph_forward.py 2>&1 | grep -v "bit \s\|amdgpu" > "$OUT/${TAG}_graph_forward.log"
 $PY tools/probe_size_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_size_sweep.log"
 $PY tools/probe_group_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_group_sweep.log"
+( $PY tools/bench_sharded.py --model opt6.7b; $PY tools/bench_sharded.py --model llama70b --inplace ) 2>&1 | grep "^{" > "$OUT/${TAG}_sharded.log"
 ls -la "$OUT"
