@@ -24,6 +24,7 @@ struct BatchDesc {   // 144 bytes, device-visible
     uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < kRowKernelMinVpr);
                            // 2 = row-run per wavefront, x-domain table (pad[] = xlim bits, grid offset)
                            // 3 = element-granular (ragged rows / unaligned buffers): n_vec = elements, vpr = row_len
+                           // 8 = groups of 16 / 32 / 64 vectors, a per-group x-domain table in a slice of the wavefront's area
                            // 4..7 = kind 2 with the alpha computed in the kernel (ANTQ_FLAG_DYNAMIC, k_fq_batch_dyn): the row in
                            //         one wavefront, 4 / 8 vectors per lane (<= 256 / <= 512 vectors: kinds 4 / 6), or spread
                            //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7); `alpha` is
@@ -42,7 +43,7 @@ struct BatchHeader {   // 32 bytes
 // Occupancy (measured): the plain kernel is best at the 6 wavefronts per SIMD its 80 VGPRs give it (8 loses
 // 1.3 points); with the outlier-victim rule the extra VALU work per element wants 8 (64 VGPRs): +1 to +1.5 points.
 template <typename T, bool OVP>
-__global__ void __launch_bounds__(256, OVP ? 8 : 1)
+__global__ void __launch_bounds__(256, OVP ? 8 : 6)
 k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
 {
     constexpr int EPL = IO<T>::EPL;
@@ -68,6 +69,17 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
         xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
                                               nullptr, xa, plan_tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
                                               wtab_all[wv], lane, wv);
+        return;
+    }
+    if (D.kind == 8) {
+        // groups of 16 / 32 / 64 vectors with an x-domain plan: a table per group in a slice of the wavefront's area
+        XArgs xa;
+        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]); xa.vout = u2f(D.pad[1]);
+        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+        lane_xs_task<T, OVP, false, U>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
+                                       ((size_t)lb * U) * 256u + threadIdx.x, xa, plan_tab + (pa.m_pad >> 2),
+                                       reinterpret_cast<const float *>(plan_tab), wtab_all[threadIdx.x >> 6], lane);
         return;
     }
     uint4 tab0 = make_uint4(0, 0, 0, 0);

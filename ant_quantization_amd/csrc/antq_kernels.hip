@@ -189,6 +189,8 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
             constexpr int U = 2;
             const size_t blocks = (n_vec + 256 * U - 1) / (256 * U);
             if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+            // (the per-group table variant, lane_xs_task, is used by the batched launch only: as a single-round launch per
+            //  tensor it measured slower than this kernel, 47 vs 52 % for bf16 group-128)
             hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, false>), dim3((unsigned)blocks), dim3(256), lds, st,
                                static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
                                vshift, alpha, per_row, gmax, 1.0f, (float *)nullptr, pa, tab);
@@ -654,6 +656,12 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             const PlanHeader *ph = static_cast<const PlanHeader *>(J.plan_host);
             if (d.kind == 0 && g_knob_x && d.pa.kind == kPlanLut && ph->xdom && d.vpr >= kRowKernelMinVpr) {
                 d.kind = 2;
+                memcpy(&d.pad[0], &ph->xlim, 4);
+                memcpy(&d.pad[1], &ph->vout, 4);
+            }
+            if (d.kind == 1 && g_knob_x && J.alpha_per_row && d.pa.kind == kPlanLut && ph->xdom &&
+                xs_eligible(d.vpr, d.pa.n_entries, d.pa.nbneg, d.pa.linear)) {
+                d.kind = 8;
                 memcpy(&d.pad[0], &ph->xlim, 4);
                 memcpy(&d.pad[1], &ph->vout, 4);
             }
