@@ -511,6 +511,17 @@ def test_batched_launch_equals_individual_launches(antq_lib, dev):
     antq_lib.Batch(jobs, ovp=True).run()
     assert all(torch.equal(j[1], r) for j, r in zip(jobs, refs))
     # ragged and odd-numel jobs with outlier-victim pairs (the wrap-around partner) next to vector jobs, one launch
+    # (per-group tables of the batched kernel with victim pairs: rows of 16 / 32 / 64 vectors, fp32 and bf16)
+    for dt in (torch.float32, torch.bfloat16):
+        epl = 4 if dt == torch.float32 else 8
+        ws = [(torch.randn(r, v * epl, device=dev) * 0.02).to(dt) for r, v in ((96, 16), (40, 32), (33, 64), (8, 128))]
+        for w in ws:
+            w.view(-1)[::23] *= 30
+        al = [(3 * w.float().std(1)).contiguous() for w in ws]
+        refs = [antq_lib.fakequant(w, a, pol, 32.0, w.shape[0], w.shape[1], True, ovp=True) for w, a in zip(ws, al)]
+        jobs = [(w, torch.zeros_like(w), a, pol, 32.0, w.shape[0], w.shape[1], True) for w, a in zip(ws, al)]
+        antq_lib.Batch(jobs, ovp=True).run()
+        assert all(torch.equal(j[1], r) for j, r in zip(jobs, refs)), dt
     shapes2 = [(7, 33), (64, 147), (256, 512), (5, 27), (1, 4099)]
     ws = [torch.randn(*sh, device=dev) * 0.02 for sh in shapes2]
     for w in ws:
