@@ -165,16 +165,18 @@ class Quantizer(HostMirrorMixin, nn.Module):
     def _three_sigma(self, tensor, per_channel):
         """OQ:193-197 / :213-218: x_max = max(|mean + 3 std|, |mean - 3 std|) (unbiased std), or the
         abs-max when outliers are disabled.  O(N) statistics stay in torch (mean / std are the
-        reference's own reductions; they run once per calibration)."""
+        reference's own reductions; they run once per calibration), in the TENSOR'S OWN dtype as the reference
+        computes them (fp16 for its LLM scripts: torch accumulates in fp32 and rounds mean / std to the dtype),
+        without a full-size fp32 copy; only the `rows` results are widened for the kernels."""
         if self._no_outlier:
             return core.row_absmax(tensor, per_channel)
-        t = tensor.detach().float()
+        t = tensor.detach()
         if per_channel:
             t2 = t.reshape(t.shape[0], -1)
             mean, std = t2.mean(dim=-1), t2.std(dim=-1)
         else:
             mean, std = t.mean(), t.std()
-        return torch.maximum((mean + 3 * std).abs(), (mean - 3 * std).abs()).reshape(-1)
+        return torch.maximum((mean + 3 * std).abs(), (mean - 3 * std).abs()).reshape(-1).float()
 
     @torch.no_grad()
     def search_mse(self, tensor):

@@ -49,6 +49,42 @@ def _install_shim():
     return shim
 
 
+TRACES_ONLY = False      # --traces-only: regenerate nothing but the *_traces.npz files (added in round 2)
+
+
+def _save(outdir, name, arrays):
+    """np.savez_compressed, skipped for the round-1 files under --traces-only (they stay byte-identical)."""
+    if TRACES_ONLY and not name.endswith("_traces.npz"):
+        return
+    np.savez_compressed(os.path.join(outdir, name), **arrays)
+
+
+def _calibration_trace(scores, ncand):
+    """What a complete `TensorQuantizer(x)` calibration leaves in the mse_loss recorder: for every type of an
+    `ant-...` list one search (ncand calls), then the search on the installed grid (ncand calls), then the one call
+    for the log value (AQ:519-520 / OQ:286-287).  Returns (final search [ncand, rows], per-type sum of the per-row
+    minima [ntypes] float64) -- the numbers the clip pick and the type pick were made from."""
+    assert ncand > 0 and (len(scores) - 1) % ncand == 0, (len(scores), ncand)
+    blocks = (len(scores) - 1) // ncand
+    st = [np.stack(scores[b * ncand:(b + 1) * ncand]).astype(np.float32) for b in range(blocks)]
+    sums = np.array([blk.min(axis=0).astype(np.float64).sum() for blk in st[:-1]], dtype=np.float64)
+    return st[-1], sums
+
+
+def _record_mse_loss(qm):
+    """Wrap the reference's Quantizer.mse_loss so that every score it returns is appended to the returned list."""
+    scores = []
+    orig = qm.Quantizer.mse_loss
+
+    def rec_mse(self, qt, st, p=2.0, is_perchannel=True):
+        r = orig(self, qt, st, p, is_perchannel)
+        scores.append(r.detach().reshape(-1).clone().numpy())
+        return r
+
+    qm.Quantizer.mse_loss = rec_mse
+    return scores
+
+
 def _args(**kw):
     d = dict(w_up=150, a_up=150, w_low=75, a_low=75, percent=100, search=False, no_outlier=False)
     d.update(kw)
@@ -117,7 +153,7 @@ def gen_ant(outdir):
                     grids[key] = g.numpy().astype(np.float32)
                 except Exception as e:  # assertion in convert_tensor, etc.
                     grids["INVALID_" + key] = np.array([0], dtype=np.int8)
-    np.savez_compressed(os.path.join(outdir, "ant_grids.npz"), **grids)
+    _save(outdir, "ant_grids.npz", grids)
 
     # ---- (2) nearest: literal scan on adversarial inputs -------------------
     rng = np.random.default_rng(20240601)
@@ -137,7 +173,7 @@ def gen_ant(outdir):
     near["f64_flint_b4_s_x"] = x64
     near["f64_flint_b4_s_z"] = z64.numpy()
     near["f64_flint_b4_s_idx"] = shim.last_idx.astype(np.int16)
-    np.savez_compressed(os.path.join(outdir, "ant_nearest.npz"), **near)
+    _save(outdir, "ant_nearest.npz", near)
 
     # ---- (3) _forward with fixed alpha --------------------------------------
     fwd = {}
@@ -190,7 +226,7 @@ def gen_ant(outdir):
     fwd["g16_flint_alpha"] = q.alpha.data.numpy().reshape(-1)
     fwd["g16_flint_out"] = out.numpy().reshape(32, 64)
     fwd["g16_flint_idx"] = shim.last_idx.reshape(-1).astype(np.int16)
-    np.savez_compressed(os.path.join(outdir, "ant_forward.npz"), **fwd)
+    _save(outdir, "ant_forward.npz", fwd)
 
     # ---- (5) search_mse traces ----------------------------------------------
     srch = {}
@@ -220,10 +256,10 @@ def gen_ant(outdir):
             srch[k + "_ratio"] = np.float32(ratio)
     srch["w_x"] = w.numpy()
     srch["a_x"] = a.numpy()
-    np.savez_compressed(os.path.join(outdir, "ant_search.npz"), **srch)
+    _save(outdir, "ant_search.npz", srch)
 
     # ---- (6) full TensorQuantizer: type select + calibration + forward ------
-    sel = {}
+    sel, tr = {}, {}
     torch.manual_seed(7)
     cases = {
         "w_gauss": (torch.randn(32, 128) * 0.02, False),
@@ -247,6 +283,7 @@ def gen_ant(outdir):
             sel[k + "__out"] = out.detach().numpy()
             sel[k + "__mse"] = np.float32(q.mse.item())
             sel[k + "__ncand"] = np.int32(len(scores))
+            tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, 75)
         sel[name + "__x"] = x.numpy()
     # 8-bit forces int (AQ:482-483) with lb=95 (AQ:296-297)
     x = cases["w_gauss"][0]
@@ -256,7 +293,8 @@ def gen_ant(outdir):
     sel["w_gauss__b8__mode"] = np.array(q.mode)
     sel["w_gauss__b8__alpha"] = q.alpha.data.numpy().reshape(-1)
     sel["w_gauss__b8__out"] = out.detach().numpy()
-    np.savez_compressed(os.path.join(outdir, "ant_select.npz"), **sel)
+    _save(outdir, "ant_select.npz", sel)
+    _save(outdir, "ant_select_traces.npz", tr)
     qm.Quantizer.mse_loss = orig_mse
 
     # ---- (6b) 'outlier' baseline mode (int4 body + int16 outliers by percentile, AQ:417-465) ----
@@ -275,7 +313,7 @@ def gen_ant(outdir):
             outl[k + "_p4"] = np.float32(q.percent_value_int4.item())
             outl[k + "_p16"] = np.float32(q.percent_value_int16.item())
             outl[k + "_out2"] = q(xx * 0.5).detach().numpy()      # second call: steady state on new data
-    np.savez_compressed(os.path.join(outdir, "ant_outlier.npz"), **outl)
+    _save(outdir, "ant_outlier.npz", outl)
 
     # ---- (7) quant_affine -----------------------------------------------------
     import quant_affine as qa
@@ -293,7 +331,7 @@ def gen_ant(outdir):
     aff["lin_x"] = l.numpy()
     aff["lin_k4_pc_out"] = qa.AsymmetricQuantFunction.apply(l, 4, l.min(1).values, l.max(1).values).numpy()
     aff["lin_k8_pt_out"] = qa.AsymmetricQuantFunction.apply(l, 8, l.min(), l.max()).numpy()
-    np.savez_compressed(os.path.join(outdir, "affine.npz"), **aff)
+    _save(outdir, "affine.npz", aff)
     dist.destroy_process_group()
 
 
@@ -324,7 +362,7 @@ def gen_olive(outdir):
                     grids["%s_b%d_%s" % (t, bit, s)] = fn().numpy().astype(np.float32)
                 except Exception:
                     grids["INVALID_%s_b%d_%s" % (t, bit, s)] = np.array([0], dtype=np.int8)
-    np.savez_compressed(os.path.join(outdir, "olive_grids.npz"), **grids)
+    _save(outdir, "olive_grids.npz", grids)
 
     rng = np.random.default_rng(20240602)
     near = {}
@@ -339,7 +377,7 @@ def gen_olive(outdir):
             near[k + "_x"] = x
             near[k + "_z"] = z.numpy()
             near[k + "_idx"] = shim.last_idx.astype(np.int16)
-    np.savez_compressed(os.path.join(outdir, "olive_nearest.npz"), **near)
+    _save(outdir, "olive_nearest.npz", near)
 
     # ---- _forward with OVP ------------------------------------------------------
     fwd = {}
@@ -399,7 +437,7 @@ def gen_olive(outdir):
         fwd["a6x50_%s_pt_ovp_alpha" % t] = q.alpha.data.numpy().reshape(-1)
         fwd["a6x50_%s_pt_ovp_out" % t] = out.numpy()
         fwd["a6x50_%s_pt_ovp_idx" % t] = shim.last_idx.reshape(-1).astype(np.int16)
-    np.savez_compressed(os.path.join(outdir, "olive_forward.npz"), **fwd)
+    _save(outdir, "olive_forward.npz", fwd)
 
     # ---- search_mse + full quantiser ---------------------------------------------
     srch = {}
@@ -430,6 +468,7 @@ def gen_olive(outdir):
                 srch[k + "_best_sum"] = np.float32(best.item() if hasattr(best, "item") else best)
                 srch[k + "_alpha"] = alpha.numpy().reshape(-1)
                 srch[k + "_ratio"] = np.float32(ratio)
+    tr = {}
     for name, x, is_input in (("w", w, False), ("a", a, True)):
         for mode in ("ant-int-flint", "flint", "int"):
             q = mk(mode, 4, not is_input, is_input=is_input)
@@ -446,8 +485,10 @@ def gen_olive(outdir):
             srch[k + "__out"] = out.numpy()
             srch[k + "__mse"] = np.float32(q.mse.item())
             srch[k + "__ncand"] = np.int32(len(scores))
+            tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, len(range(75, 250, 2)))
     qm.Quantizer.mse_loss = orig_mse
-    np.savez_compressed(os.path.join(outdir, "olive_search.npz"), **srch)
+    _save(outdir, "olive_search.npz", srch)
+    _save(outdir, "olive_search_traces.npz", tr)
 
 
 # ----------------------------------------------------------------------------
@@ -465,6 +506,7 @@ def gen_ant_wide(outdir):
     sys.path.insert(0, os.path.join(REF, "ant_quantization", "antquant"))
     import quant_modules as qm
 
+    scores, tr = _record_mse_loss(qm), {}
     torch.manual_seed(21)
     w = torch.distributions.Laplace(0.0, 0.03).sample((24, 96))
     w[::5] *= 0.3
@@ -487,8 +529,10 @@ def gen_ant_wide(outdir):
                 q.name = "golden"
                 if not is_input:
                     q.alpha.data = torch.ones(x.shape[0], 1)
+                del scores[:]
                 out = q(x)
                 k = "%s__%s__b%d__%d_%d" % (name, mode, bit, lo, up)
+                tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, up - (95 if bit > 6 else lo))
                 keys.append(k)
                 sel[k + "__mode"] = np.array(q.mode)
                 sel[k + "__signed"] = np.array(bool(q.is_signed))
@@ -497,7 +541,8 @@ def gen_ant_wide(outdir):
                 sel[k + "__out"] = out.detach().numpy()
                 sel[k + "__mse"] = np.float32(q.mse.item())
     sel["keys"] = np.array(keys)
-    np.savez_compressed(os.path.join(outdir, "ant_select_wide.npz"), **sel)
+    _save(outdir, "ant_select_wide.npz", sel)
+    _save(outdir, "ant_select_wide_traces.npz", tr)
     dist.destroy_process_group()
 
 
@@ -512,6 +557,7 @@ def gen_olive_wide(outdir):
     sys.path.insert(0, os.path.join(REF, "olive_quantization", "antquant"))
     import quant_modules as qm
 
+    scores, tr = _record_mse_loss(qm), {}
     torch.manual_seed(31)
     w = torch.randn(24, 96) * 0.02
     m = torch.rand(24, 96) < 0.02
@@ -534,8 +580,10 @@ def gen_olive_wide(outdir):
                     q.name = "golden"
                     if not is_input:
                         q.alpha.data = torch.ones(x.shape[0], 1)
+                    del scores[:]
                     out = q(x)
                     k = "%s__%s__b%d__%d_%d__%s" % (name, mode, bit, lo, up, "noout" if no_outlier else "ovp")
+                    tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, len(range(lo, up, 2)))
                     keys.append(k)
                     sel[k + "__mode"] = np.array(q.mode)
                     sel[k + "__signed"] = np.array(bool(q.is_signed))
@@ -545,19 +593,25 @@ def gen_olive_wide(outdir):
                     sel[k + "__out"] = out.detach().numpy()
                     sel[k + "__mse"] = np.float32(q.mse.item())
     sel["keys"] = np.array(keys)
-    np.savez_compressed(os.path.join(outdir, "olive_select_wide.npz"), **sel)
+    _save(outdir, "olive_select_wide.npz", sel)
+    _save(outdir, "olive_select_wide_traces.npz", tr)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "olive_wide", "all"], default="all")
     ap.add_argument("--out", default=HERE)
+    ap.add_argument("--traces-only", action="store_true",
+                    help="write only the *_traces.npz files (per-candidate MSE of the complete calibrations)")
     a = ap.parse_args()
+    global TRACES_ONLY
+    TRACES_ONLY = a.traces_only
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
     if a.tree == "all":
         for t in ("ant", "ant_wide", "olive", "olive_wide"):
-            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", t, "--out", a.out])
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", t, "--out", a.out] +
+                                  (["--traces-only"] if a.traces_only else []))
         return
     import torch
     torch.set_num_threads(1)   # deterministic reductions for the recorded MSE traces
