@@ -49,7 +49,7 @@ def lib():
                              "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
-                             "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan"):
+                             "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
@@ -215,6 +215,34 @@ def nearest_plan(x, plan, want_idx=False):
         _check(lib().antq_nearest_plan(_vp(x), _vp(z), _vp(idx), ctypes.c_size_t(x.numel()),
                                        ctypes.c_void_p(plan.host_addr), _vp(pd), ctypes.c_int(dt), _stream(x.device)),
                "antq_nearest_plan")
+    return (z, idx) if want_idx else z
+
+
+def hinted_ok(x, grid, plan):
+    """Can antq_nearest_hinted take this call?  (fp32 / bf16 / fp16 x, fp32 grid of the plan's size, whole 16-byte
+    vectors.)  Everything else goes through nearest(): the literal scan."""
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64 or grid.dtype != torch.float32 or grid.numel() != plan.grid.size:
+        return False
+    return x.numel() % (4 if dt == F32 else 8) == 0 and x.data_ptr() % 16 == 0
+
+
+def nearest_hinted(x, grid, plan, stale=None, want_idx=False):
+    """quant_cuda.quant body on the DEVICE grid `grid`, with `plan` as the host's belief of its contents: the kernel
+    verifies the belief (bit compare of the m values) and scans `grid` literally when it is wrong, raising `stale`
+    (a pinned host int32 tensor, polled by the caller without a sync)."""
+    _require_gpu(x, "x")
+    _require_gpu(grid, "grid")
+    if not hinted_ok(x, grid, plan):
+        raise AntqError("nearest_hinted: unsupported dtype / size / alignment (use nearest)")
+    z = torch.empty_like(x)
+    idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
+    pd = plan.dev(x.device)
+    with _on_device(x.device):
+        _check(lib().antq_nearest_hinted(_vp(x), _vp(z), _vp(idx), ctypes.c_size_t(x.numel()), _vp(grid),
+                                         ctypes.c_int(grid.numel()), ctypes.c_void_p(plan.host_addr), _vp(pd),
+                                         _vp(stale), ctypes.c_int(_DTYPES[x.dtype]), _stream(x.device)),
+               "antq_nearest_hinted")
     return (z, idx) if want_idx else z
 
 

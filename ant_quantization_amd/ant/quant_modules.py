@@ -40,22 +40,22 @@ class QuantBase():
     """AQ:11-24.  `_quantization` is the operator boundary: flat view, grid cast to x's
     dtype, nearest-value kernel, reshape."""
 
-    def _quantization(x, quant_grid):
+    def _quantization(x, quant_grid, plan=None):
         """The operator boundary (AQ:12-18 / OQ:9-15): flat view, the nearest-value operator, reshape back -- what
-        `quant_cuda.quant` does, minus the all-zero index tensor the reference allocates and throws away."""
-        from .. import quant_cuda
+        `quant_cuda.quant` does, minus the all-zero index tensor the reference allocates and throws away.  `plan`: the
+        calling quantiser's own plan of `quant_grid`, passed to the kernel as a hint it verifies against the buffer."""
         flat = x.view(-1).contiguous()
-        if flat.dtype == torch.float32 and quant_grid.dtype == torch.float32:
-            z = _lib.nearest_plan(flat, quant_cuda._plan_of(quant_grid))      # plan cached per grid buffer state
+        if plan is not None and _lib.hinted_ok(flat, quant_grid, plan):
+            z = _lib.nearest_hinted(flat, quant_grid.contiguous(), plan)
         else:
             g = quant_grid.type_as(flat) if flat.dtype in (torch.float32, torch.float64) else quant_grid.float()
             z = _lib.nearest(flat, g.contiguous())
         return z.view(x.shape)
 
     @staticmethod
-    def forward(real_val, quant_grid):
+    def forward(real_val, quant_grid, plan=None):
         with torch.no_grad():
-            return QuantBase._quantization(real_val, quant_grid)
+            return QuantBase._quantization(real_val, quant_grid, plan)
 
 
 class Quantizer(HostMirrorMixin, nn.Module):
@@ -243,7 +243,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         p4, p16 = self.percent_value_int4, self.percent_value_int16
         if p4 > 0:
             scale = p4 / torch.max(self.quant_grid)
-            body = QuantBase.forward(data / scale, self.quant_grid).clone().detach() * scale
+            body = QuantBase.forward(data / scale, self.quant_grid, self._ensure_plan()).clone().detach() * scale
         else:
             body = data.clone().detach()
         if not (self.percent < 100):

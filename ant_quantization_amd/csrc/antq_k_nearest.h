@@ -191,17 +191,25 @@ k_nearest16(const void *__restrict__ x, void *__restrict__ z, int16_t *__restric
 // Nearest value through a plan (antq_nearest_plan): when the caller knows the grid on the host (a quantiser's static
 // codebook), the M-step scan is the same one-LDS-read lookup the fused kernels use, on d = x itself.  16 bytes per lane,
 // 4 vectors in flight; elements beyond the table's domain (|x| >= fastlim, NaN, Inf) and scan plans run the literal scan.
+//
+// HINTED (antq_nearest_hinted): the operator's contract is "nearest value of the DEVICE array `gcheck`", and the plan
+// is only what the host believes that array holds.  Every workgroup compares the m device values with the plan's own
+// copy of the grid, bit for bit (m <= 1024 L2-resident floats, fetched ahead of the HBM loads); on any difference it
+// runs the literal scan on the device values instead -- a stale plan costs time, never a wrong result -- and raises
+// *stale so that the host can drop its belief without ever synchronising.
 // ------------------------------------------------------------------------------------
-template <typename T, bool IDX>
+template <typename T, bool IDX, bool HINTED>
 __global__ void __launch_bounds__(256)
 k_nearest_plan(const uint4 *__restrict__ x, uint4 *__restrict__ z, int16_t *__restrict__ idx, size_t n_vec,
-               PlanArgs pa, const uint4 *__restrict__ plan_tab)
+               PlanArgs pa, const uint4 *__restrict__ plan_tab, const float *__restrict__ gcheck, int *__restrict__ stale)
 {
     constexpr int EPL = IO<T>::EPL;
     constexpr int U = 4;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    float g0 = 0.0f;
+    if (HINTED && threadIdx.x < pa.m) g0 = gcheck[threadIdx.x];
     const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
     uint4 v[U];
 #pragma unroll
@@ -212,6 +220,20 @@ k_nearest_plan(const uint4 *__restrict__ x, uint4 *__restrict__ z, int16_t *__re
     }
     const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
+    bool hinted_ok = true;
+    if (HINTED) {
+        int diff = 0;
+        if (threadIdx.x < pa.m) diff = f2u(g0) != f2u(L.grid[threadIdx.x]);
+        for (uint32_t i = threadIdx.x + 256u; i < pa.m; i += 256u) diff |= f2u(gcheck[i]) != f2u(L.grid[i]);
+        if (__syncthreads_or(diff)) {
+            // the plan describes another grid: literal scan on what the device array holds now
+            float *lg = const_cast<float *>(L.grid);
+            for (uint32_t i = threadIdx.x; i < pa.m; i += 256u) lg[i] = gcheck[i];
+            __syncthreads();
+            hinted_ok = false;
+            if (stale && blockIdx.x == 0 && threadIdx.x == 0) *stale = 1;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const size_t vi = first + (size_t)u * 256u;
@@ -219,7 +241,7 @@ k_nearest_plan(const uint4 *__restrict__ x, uint4 *__restrict__ z, int16_t *__re
         float d[EPL], q[EPL];
         int j[EPL];
         IO<T>::unpack(v[u], d);
-        bool fast = pa.kind == kPlanLut;
+        bool fast = pa.kind == kPlanLut && hinted_ok;
 #pragma unroll
         for (int e = 0; e < EPL; e++) fast = fast && (fabsf(d[e]) < pa.fastlim);
         if (fast) {

@@ -295,13 +295,15 @@ extern "C" int antq_nearest(const void *x, void *z, int16_t *idx, size_t n, cons
 }
 
 // quant_cuda.quant for a grid the caller has a plan for (quantisers' static codebooks): table lookup instead of the scan.
-extern "C" int antq_nearest_plan(const void *x, void *z, int16_t *idx, size_t n, const void *plan_host, const void *plan_dev,
-                                 int dtype, void *stream)
+// gcheck != nullptr: the hinted form (see k_nearest_plan).
+static int launch_nearest_plan(const void *x, void *z, int16_t *idx, size_t n, const void *plan_host, const void *plan_dev,
+                               const float *gcheck, int m_check, int *stale, int dtype, void *stream)
 {
     if (n == 0) return ANTQ_OK;
     if (!x || !z || !plan_host || !plan_dev) return ANTQ_ERR_ARG;
     PlanArgs pa;
     if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
+    if (gcheck && (uint32_t)m_check != pa.m) return ANTQ_ERR_ARG;
     const int epl = dtype == ANTQ_F32 ? 4 : (dtype == ANTQ_BF16 || dtype == ANTQ_F16) ? 8 : 0;
     if (!epl) return ANTQ_ERR_UNSUPPORTED;
     if (n % epl || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(z) % 16 ||
@@ -314,10 +316,14 @@ extern "C" int antq_nearest_plan(const void *x, void *z, int16_t *idx, size_t n,
     const size_t lds = (size_t)pa.tab_units * 16;
     const uint4 *xv = static_cast<const uint4 *>(x);
     uint4 *zv = static_cast<uint4 *>(z);
+    const uint4 *tab = plan_tab_ptr(plan_dev);
+#define ANTQ_LAUNCH_N2(TT, II, HH)                                                                                 \
+    hipLaunchKernelGGL((k_nearest_plan<TT, II, HH>), dim3((unsigned)blocks), dim3(256), lds, st, xv, zv, idx, n_vec, pa, \
+                       tab, gcheck, stale)
 #define ANTQ_LAUNCH_N(TT)                                                                                          \
     do {                                                                                                           \
-        if (idx) hipLaunchKernelGGL((k_nearest_plan<TT, true>), dim3((unsigned)blocks), dim3(256), lds, st, xv, zv, idx, n_vec, pa, plan_tab_ptr(plan_dev)); \
-        else hipLaunchKernelGGL((k_nearest_plan<TT, false>), dim3((unsigned)blocks), dim3(256), lds, st, xv, zv, idx, n_vec, pa, plan_tab_ptr(plan_dev));    \
+        if (gcheck) { if (idx) ANTQ_LAUNCH_N2(TT, true, true); else ANTQ_LAUNCH_N2(TT, false, true); }             \
+        else { if (idx) ANTQ_LAUNCH_N2(TT, true, false); else ANTQ_LAUNCH_N2(TT, false, false); }                  \
     } while (0)
     switch (dtype) {
     case ANTQ_F32: ANTQ_LAUNCH_N(float); break;
@@ -325,7 +331,21 @@ extern "C" int antq_nearest_plan(const void *x, void *z, int16_t *idx, size_t n,
     default: ANTQ_LAUNCH_N(f16_tag); break;
     }
 #undef ANTQ_LAUNCH_N
+#undef ANTQ_LAUNCH_N2
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+extern "C" int antq_nearest_plan(const void *x, void *z, int16_t *idx, size_t n, const void *plan_host, const void *plan_dev,
+                                 int dtype, void *stream)
+{
+    return launch_nearest_plan(x, z, idx, n, plan_host, plan_dev, nullptr, 0, nullptr, dtype, stream);
+}
+
+extern "C" int antq_nearest_hinted(const void *x, void *z, int16_t *idx, size_t n, const float *grid_dev, int m,
+                                   const void *plan_host, const void *plan_dev, int *stale, int dtype, void *stream)
+{
+    if (!grid_dev || m < 1) return ANTQ_ERR_ARG;
+    return launch_nearest_plan(x, z, idx, n, plan_host, plan_dev, grid_dev, m, stale, dtype, stream);
 }
 
 extern "C" int antq_fakequant(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,

@@ -1,0 +1,5 @@
+"""Stands in for the reference's antquant/quant_utils.py: `sys.path.append(<this directory>)` where the harnesses append
+"../antquant" (ImageNet/main.py:14-16, BERT/run_glue.py:45-47, llm/run_clm.py:56-59)."""
+import _path  # noqa: F401
+from ant_quantization_amd.ant.quant_utils import *  # noqa: F401,F403
+from ant_quantization_amd.ant.quant_utils import logging, quant_args  # noqa: F401  (ImageNet/main.py:91 relies on the leak)

@@ -24,22 +24,22 @@ from .._mirror import HostMirrorMixin
 class QuantBase():
     """OQ:8-21 (reshape(-1) instead of view(-1): non-contiguous inputs are accepted)."""
 
-    def _quantization(x, quant_grid):
+    def _quantization(x, quant_grid, plan=None):
         """The operator boundary (AQ:12-18 / OQ:9-15): flat view, the nearest-value operator, reshape back -- what
-        `quant_cuda.quant` does, minus the all-zero index tensor the reference allocates and throws away."""
-        from .. import quant_cuda
+        `quant_cuda.quant` does, minus the all-zero index tensor the reference allocates and throws away.  `plan`: a
+        caller's plan of `quant_grid`, passed to the kernel as a hint it verifies against the buffer."""
         flat = x.reshape(-1).contiguous()
-        if flat.dtype == torch.float32 and quant_grid.dtype == torch.float32:
-            z = _lib.nearest_plan(flat, quant_cuda._plan_of(quant_grid))      # plan cached per grid buffer state
+        if plan is not None and _lib.hinted_ok(flat, quant_grid, plan):
+            z = _lib.nearest_hinted(flat, quant_grid.contiguous(), plan)
         else:
             g = quant_grid.type_as(flat) if flat.dtype in (torch.float32, torch.float64) else quant_grid.float()
             z = _lib.nearest(flat, g.contiguous())
         return z.view(x.shape)
 
     @staticmethod
-    def forward(real_val, quant_grid):
+    def forward(real_val, quant_grid, plan=None):
         with torch.no_grad():
-            return QuantBase._quantization(real_val, quant_grid)
+            return QuantBase._quantization(real_val, quant_grid, plan)
 
 
 class Quantizer(HostMirrorMixin, nn.Module):

@@ -9,39 +9,85 @@ element under the reference scan's rule (last minimum wins, 0 beyond 102400); id
 reference's second output: a freshly allocated all-zero tensor shaped like x that its
 kernel never writes (quant_kernel.cu:18,49) and its caller discards.
 
-Put this package directory on sys.path (or `sys.modules['quant_cuda'] = this module`) and
-the reference's unmodified quant_modules.py runs on MI355X.  Launches go to the CURRENT
-torch stream of x's device (the reference used the legacy default stream).
+Importable the way the reference imports it (`import quant_cuda`, quant_modules.py:7): put
+`ant_quantization_amd/dropin/` -- or this package directory -- on sys.path; it also works as
+`ant_quantization_amd.quant_cuda`.  With it the reference's unmodified quant_modules.py runs
+on MI355X.  Launches go to the CURRENT torch stream of x's device (the reference used the
+legacy default stream).
+
+Speed without trust.  The reference passes the same `quant_grid` buffer on every forward, and a
+grid the host has seen can be served by a table lookup (24 us per 4096^2 fp32, whatever the grid
+size) instead of the m-step scan (45-71 us).  But a tensor's identity proves nothing about its
+contents: `buf.data = other` keeps the Python object and its `_version`, and the caching allocator
+hands freed addresses out again (the reference's own calibration rebinds `quant_grid.data` to
+same-sized tensors in a loop).  So a remembered plan is only ever a HINT here: the kernel
+(antq_nearest_hinted) compares the device grid with the plan's copy and scans the device values
+literally if they differ, and tells the host through a pinned flag, which then forgets the plan.
+A wrong belief costs microseconds, never a wrong result, and nothing on this path synchronises
+except the one read-back that builds a plan for a buffer seen twice.
 """
+import collections
+import os
+import sys
+
 import torch
 
-from . import _lib
+try:
+    from . import _lib
+except ImportError:                    # imported top-level, as the reference does: `import quant_cuda`
+    _pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if _pkg_parent not in sys.path:
+        sys.path.insert(0, _pkg_parent)
+    from ant_quantization_amd import _lib
 
-# The reference calls quant(x, self.quant_grid) with the SAME grid buffer on every forward.  The first call with a
-# given buffer state reads the grid back once and builds its plan; later calls go through the table kernel
-# (antq_nearest_plan) -- about twice as fast as scanning.  Keyed by (data_ptr, _version, numel, dtype, device); the
-# entry keeps the grid tensor alive, so its address cannot be recycled for another grid while the entry exists.
-# (An edit through `.data` does not bump `_version`: PyTorch's own staleness rule applies.)
-_plans = {}
+_MAX_HINTS = 64
 
 
-def _plan_of(grid):
-    key = (grid.data_ptr(), grid._version, grid.numel(), grid.dtype, grid.device)
-    hit = _plans.get(key)
-    if hit is None:
-        if len(_plans) > 256:
-            _plans.clear()
-        hit = (_lib.plan_for(grid.detach().float().cpu().numpy()), grid)
-        _plans[key] = hit
-    return hit[0]
+class _Hint:
+    __slots__ = ("plan", "seen", "need", "stale", "strikes")
+
+    def __init__(self):
+        self.plan = None          # the host's belief about the buffer's contents
+        self.seen = 0             # sightings since the belief was last dropped
+        self.need = 2             # sightings before a read-back is worth it (doubles after every wrong belief)
+        self.stale = None         # pinned int32[1], written by the kernel when the belief was wrong
+        self.strikes = 0
+
+
+_hints = collections.OrderedDict()      # (data_ptr, numel, device index) -> _Hint, LRU
+
+
+def _hint_for(grid):
+    key = (grid.data_ptr(), grid.numel(), grid.device.index)
+    h = _hints.get(key)
+    if h is None:
+        h = _hints[key] = _Hint()
+        if len(_hints) > _MAX_HINTS:
+            _hints.popitem(last=False)
+    else:
+        _hints.move_to_end(key)
+    if h.plan is not None and int(h.stale[0]) != 0:
+        # an earlier launch found other values at this address: forget, and be slower to believe again
+        h.plan, h.seen, h.strikes = None, 0, h.strikes + 1
+        h.need = min(2 << h.strikes, 256)
+    if h.plan is None:
+        h.seen += 1
+        if h.seen >= h.need:
+            h.plan = _lib.plan_for(grid.detach().float().cpu().numpy())     # the one read-back per long-lived buffer
+            h.stale = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return h
 
 
 def quant(x, y):
     if x.dim() != 1:
         raise RuntimeError("quant_cuda.quant: x must be 1-D (got %d-D)" % x.dim())
     x = x.contiguous()
-    if x.dtype == torch.float32 and y.numel() <= _lib.MAX_GRID:
-        z = _lib.nearest_plan(x, _plan_of(y))
-    else:
-        z = _lib.nearest(x, y.contiguous())
+    y = y.contiguous()
+    z = None
+    if x.dtype == torch.float32 and y.dtype == torch.float32 and 0 < y.numel() <= _lib.MAX_GRID and x.is_cuda:
+        h = _hint_for(y)
+        if h.plan is not None and _lib.hinted_ok(x, y, h.plan):
+            z = _lib.nearest_hinted(x, y, h.plan, h.stale)
+    if z is None:
+        z = _lib.nearest(x, y)
     return z, torch.zeros_like(x)

@@ -82,6 +82,17 @@ int antq_nearest(const void *x_dev, void *z_dev, int16_t *idx_dev, size_t n,
 int antq_nearest_plan(const void *x_dev, void *z_dev, int16_t *idx_dev, size_t n,
                       const void *plan_host, const void *plan_dev, int dtype, void *stream);
 
+/* quant_cuda.quant (quant_kernel.cu:11-62) with a plan as a HINT.  Contract = antq_nearest on the device array
+ * grid_dev (m floats; x of F32 / BF16 / F16): the plan is only what the host believes grid_dev holds (built from an
+ * earlier read-back of the same buffer).  Every workgroup compares the m device values with the plan's own copy of the
+ * grid bit for bit; if they differ it runs the literal scan on the device values -- a stale plan costs time, never a
+ * wrong result -- and stores 1 to *stale (nullable; device-accessible memory, e.g. a pinned host int the caller polls
+ * without synchronising).  m must equal the plan's grid size (ANTQ_ERR_ARG otherwise); size / alignment rules of
+ * antq_nearest_plan. */
+int antq_nearest_hinted(const void *x_dev, void *z_dev, int16_t *idx_dev, size_t n,
+                        const float *grid_dev, int m, const void *plan_host, const void *plan_dev,
+                        int *stale, int dtype, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Plan: host-side, exact pre-computation of the decision thresholds of the
  * reference scan for one grid (pure CPU, no HIP calls).  The caller keeps the

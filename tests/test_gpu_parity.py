@@ -1454,11 +1454,110 @@ def test_nearest_plan_equals_scan_and_cache_follows_grid_edits(antq_lib, oracle,
                 zh_ref, _ = oracle.nearest(xh.float().cpu().numpy(), g)
             zh = antq_lib.nearest_plan(xh, plan)
             assert f32_same(zh.float().cpu().numpy(), torch.from_numpy(zh_ref).half().float().numpy()), (g[:4], n, "f16")
-    # the drop-in's plan cache: same buffer, new contents
+    # the drop-in: same buffer, new contents
     gt = torch.from_numpy(G["flint_b4_s"].copy()).to(dev)
     x = torch.randn(4096, device=dev) * 4
-    z1, zero = quant_cuda.quant(x, gt)
-    assert not zero.any() and f32_same(z1.cpu().numpy(), oracle.nearest(x.cpu().numpy(), G["flint_b4_s"])[0])
+    for _ in range(3):          # (third call: through the plan learnt at the second sighting)
+        z1, zero = quant_cuda.quant(x, gt)
+        assert not zero.any() and f32_same(z1.cpu().numpy(), oracle.nearest(x.cpu().numpy(), G["flint_b4_s"])[0])
     gt.copy_(torch.from_numpy(G["int_b4_s"]).to(dev))
     z2, _ = quant_cuda.quant(x, gt)
     assert f32_same(z2.cpu().numpy(), oracle.nearest(x.cpu().numpy(), G["int_b4_s"])[0])
+
+
+def test_dropin_operator_never_trusts_a_buffer_identity(antq_lib, oracle, dev):
+    """quant_cuda.quant remembers a plan per grid ADDRESS only as a hint that the kernel verifies against the device
+    array (antq_nearest_hinted).  What the reference's own calibration does -- `quant_grid.data = int_value()`, then
+    flint, pot, the winner again: same object, same `_version`, same numel, addresses recycled by the caching
+    allocator -- and in-place edits through `.data` (no version bump either) must always quantise on the values the
+    buffer holds NOW."""
+    import torch
+    from ant_quantization_amd import quant_cuda
+    G = golden("ant_grids.npz")
+    names = ["int_b4_s", "flint_b4_s", "pot_b4_s", "float_b4_s"]
+    x = torch.randn(1 << 14, device=dev) * 4
+    xn = x.cpu().numpy()
+    refs = {k: oracle.nearest(xn, G[k])[0] for k in names}
+    buf = torch.nn.Module()
+    buf.register_buffer("quant_grid", torch.ones(16, device=dev))
+    v0 = buf.quant_grid._version
+    seen_hint = 0
+    for it in range(40):
+        k = names[(it * 7 + it // 3) % 4]
+        buf.quant_grid.data = torch.from_numpy(G[k]).to(dev)          # rebinding: same object, same version, old block freed
+        for _ in range(1 + it % 3):
+            z, _ = quant_cuda.quant(x, buf.quant_grid)
+            assert f32_same(z.cpu().numpy(), refs[k]), (it, k)
+        h = quant_cuda._hints.get((buf.quant_grid.data_ptr(), 16, dev.index))
+        seen_hint += int(h is not None and h.plan is not None)
+    assert buf.quant_grid._version == v0
+    assert seen_hint > 0                                               # the table path did engage along the way
+    # in-place through .data: same address, same version, other values -- with a plan already believed for the address
+    g = torch.from_numpy(G["flint_b4_s"].copy()).to(dev)
+    for _ in range(3):
+        quant_cuda.quant(x, g)
+    h = quant_cuda._hints[(g.data_ptr(), 16, dev.index)]
+    assert h.plan is not None
+    v = g._version
+    g.data.copy_(torch.from_numpy(G["pot_b4_s"]).to(dev))
+    assert g._version == v
+    z, _ = quant_cuda.quant(x, g)
+    assert f32_same(z.cpu().numpy(), refs["pot_b4_s"])                 # stale belief: the kernel scanned the device values
+    torch.cuda.synchronize()
+    assert int(h.stale[0]) == 1                                        # ... and told the host, without a sync on the path
+    for _ in range(6):
+        z, _ = quant_cuda.quant(x, g)
+        assert f32_same(z.cpu().numpy(), refs["pot_b4_s"])
+    assert h.plan is not None and int(h.stale[0]) == 0 and np.array_equal(h.plan.grid, G["pot_b4_s"])   # relearnt
+    # OliVe's caller passes a fresh torch.cat((quant_grid, outliers)) temporary on every call (OQ:303-306)
+    O = golden("olive_grids.npz")
+    gn, go = to_dev(O["flint_b4_s"], dev), to_dev(O["outlier_b4_s"], dev)
+    ref = oracle.nearest(xn * 20, np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]]))[0]
+    for _ in range(8):
+        z, _ = quant_cuda.quant(x * 20, torch.cat((gn, go)))
+        assert f32_same(z.cpu().numpy(), ref)
+    # ANT's `outlier` mode goes through the quantiser's OWN plan as the hint
+    from ant_quantization_amd.ant import quant_modules as qm
+    q = qm.TensorQuantizer(mode="outlier", bit=4, is_signed=True, is_enable=True, args=_args(percent=99)).to(dev)
+    q.name = "t"
+    w = torch.randn(64, 256, device=dev)
+    o1 = q(w)
+    q.quant_grid.data = (q.quant_grid * 0.5).clone()                   # rebinding behind the quantiser's back
+    q._grid_key = q._grid_now()                                        # worst case: the host watch is fooled too
+    o2 = q(w)
+    scale = q.percent_value_int4 / torch.max(q.quant_grid)
+    body = torch.from_numpy(oracle.nearest((w / scale).cpu().numpy().reshape(-1), q.quant_grid.cpu().numpy())[0]).to(dev).view_as(w) * scale
+    inl = w.abs() <= q.percent_value_int4
+    assert torch.equal(o2[inl], body[inl]) and not torch.equal(o1, o2)
+
+
+def test_quant_cuda_importable_the_reference_way(antq_lib, oracle, dev, tmp_path):
+    """The reference does `import quant_cuda` (AQ/quant_modules.py:7) and calls
+    `quant_cuda.quant(x.view(-1), grid.type_as(x))` (AQ:12-18): from a clean interpreter whose sys.path holds only the
+    drop-in directory (or the package directory itself), fp32 and fp64, against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, sys.argv[1])\n"
+        "import quant_cuda\n"
+        "g = np.load(sys.argv[2])['flint_b4_s']\n"
+        "x = np.load(sys.argv[3])\n"
+        "for dt in (torch.float32, torch.float64):\n"
+        "    xt = torch.from_numpy(x).to('cuda:0').to(dt)\n"
+        "    grid = torch.from_numpy(g).to('cuda:0')\n"
+        "    for _ in range(3):\n"
+        "        z, idx = quant_cuda.quant(xt.view(-1), grid.type_as(xt))\n"
+        "    assert z.dtype == dt and z.shape == xt.view(-1).shape and idx.shape == z.shape and not idx.any()\n"
+        "    np.save(sys.argv[4] + str(dt)[-2:] + '.npy', z.cpu().numpy())\n")
+    x = np.random.default_rng(5).standard_normal((64, 100)).astype(np.float32) * 4
+    np.save(tmp_path / "x.npy", x)
+    zr, _ = oracle.nearest(x.reshape(-1), golden("ant_grids.npz")["flint_b4_s"])
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    for d in (os.path.join(root, "ant_quantization_amd", "dropin"), os.path.join(root, "ant_quantization_amd")):
+        out = str(tmp_path / ("z_%s_" % os.path.basename(d)))
+        subprocess.check_call([sys.executable, "-c", code, d, os.path.join(root, "tests", "golden", "ant_grids.npz"),
+                               str(tmp_path / "x.npy"), out], cwd=str(tmp_path), env=env)
+        assert f32_same(np.load(out + "32.npy"), zr)
+        assert np.array_equal(np.load(out + "64.npy"), zr.astype(np.float64))

@@ -320,3 +320,28 @@ def test_host_mirror_of_bit_and_inited_buffers(tree, monkeypatch):
     assert q._bits() == 5 and q._hm_get("has_inited_quant_para") == 1 and len(reads) == 4
     q._hm_known("bit", 3)                                         # what the host writes itself needs no read
     assert q._bits() == 3 and len(reads) == 4
+
+
+def test_dropin_directories_import_the_reference_way(tmp_path):
+    """`import quant_cuda` (AQ/quant_modules.py:7) and the harnesses' `sys.path.append("../antquant"); from quant_model
+    import *; from quant_utils import *` (ImageNet/main.py:14-16, llm/run_clm.py:56-59) from a clean interpreter whose
+    sys.path only gains the drop-in directory: the imports succeed without a GPU and export the names the harnesses use."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    for d in ("dropin", ""):
+        code = "import sys; sys.path.insert(0, %r); import quant_cuda; assert callable(quant_cuda.quant)" % \
+               os.path.join(root, "ant_quantization_amd", d).rstrip("/")
+        subprocess.check_call([sys.executable, "-c", code], cwd=str(tmp_path), env=env)
+    names = ("set_quantizer quantize_model set_first_last_layer enable_quantization disable_quantization "
+             "disable_input_quantization set_8_bit_layer_n set_8_bit_layer_l load_ant_state_dict get_ckpt_path "
+             "get_ckpt_filename set_util_logging get_model logging").split()
+    for tree in ("ant", "olive"):
+        code = ("import sys; sys.path.append(%r)\n"
+                "from quant_model import *\nfrom quant_utils import *\nimport quant_modules\n"
+                "missing = [n for n in %r if n not in globals()]\nassert not missing, missing\n"
+                "assert quant_modules.QuantLinear is quant_modules.LinearQuantizer\n"
+                % (os.path.join(root, "ant_quantization_amd", "dropin", tree), names))
+        subprocess.check_call([sys.executable, "-c", code], cwd=str(tmp_path), env=env)
