@@ -41,6 +41,57 @@ def row_block(rows: int, rank: int, world: int, pair_safe_row_len: int = 0) -> T
     return b, e
 
 
+# ---- OliVe pairs on a row-sharded tensor with an ODD element count ------------------------------------------------
+# Pairs (2k, 2k+1) live on the FLAT tensor and `torch.roll` wraps (OQ:313-318): with an odd element count the last
+# element has no partner of its own and is zeroed iff element 0 is an outlier.  When rows are sharded, element 0 lives
+# on rank 0 and the last element on the last rank, whose local launch pairs it with the first element of ITS block
+# instead.  That one bit is the only thing the sharded path ever exchanges; every other pair is whole inside a block
+# because row_block() cuts at even flat offsets.
+def wrap_flag(out_block0, alpha0, plan, gmax):
+    """Rank 0: is global element 0 an outlier (|q| > 32, OQ:314)?  Read off its OUTPUT: out = fl(q * s), so
+    |q| > 32 <=> |out| >= fl(vout * s) with vout the smallest outlier magnitude of the codebook (monotone rounding;
+    32 and vout are a factor 1.5 apart, so the two sides cannot merge, in fp32 or after the bf16 / fp16 store).  An
+    element-0 victim (zeroed by an outlier at element 1) is not an outlier itself.  Returns a 1-element int32 tensor."""
+    import numpy as np
+    import torch
+    mag = np.abs(plan.grid)
+    if not (mag > 32).any():
+        return torch.zeros(1, dtype=torch.int32, device=out_block0.device)
+    vout = float(mag[mag > 32].min())
+    s0 = alpha0.reshape(-1)[:1].float() / gmax                       # fp32 division, as AQ:536 / OQ:296
+    thr = (s0 * vout).to(out_block0.dtype)
+    return (out_block0.reshape(-1)[:1].abs() >= thr).to(torch.int32)
+
+
+def apply_wrap_flag(x_block, out_block, alpha_last, plan, gmax, flag, plain_fn=None):
+    """Last rank: redo the LAST element of its block.  Zero if `flag` (element 0 is an outlier), else its plain
+    fake-quant value (the local launch may have zeroed it against the wrong partner).  No host sync.
+    plain_fn(x1, alpha1) -> fake-quant of one element without the pair rule; default: the HIP kernel."""
+    import torch
+    xl = x_block.reshape(-1)[-1:].contiguous()
+    al = alpha_last.reshape(-1)[-1:].float().contiguous()
+    if plain_fn is None:
+        from . import _lib
+        plain = _lib.fakequant(xl, al, plan, gmax, 1, 1, True, ovp=False)
+    else:
+        plain = plain_fn(xl, al)
+    out_block.reshape(-1)[-1:] = torch.where(flag.to(torch.bool), torch.zeros_like(plain), plain)
+
+
+def fix_odd_numel_wrap(x_block, out_block, alpha_block, plan, gmax, rows, row_len, rank, world, group=None, plain_fn=None):
+    """Call after the per-rank OVP launch on a row block of a [rows, row_len] tensor: a no-op unless the tensor's element
+    count is odd and it is actually sharded; then one int32 travels from rank 0 to the last rank (broadcast)."""
+    if world == 1 or (rows * row_len) % 2 == 0:
+        return
+    import torch
+    import torch.distributed as dist
+    flag = wrap_flag(out_block, alpha_block, plan, gmax) if rank == 0 else \
+        torch.zeros(1, dtype=torch.int32, device=out_block.device)
+    dist.broadcast(flag, 0, group=group)
+    if rank == world - 1:
+        apply_wrap_flag(x_block, out_block, alpha_block, plan, gmax, flag, plain_fn)
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """MAX of a python float over the process group (identity without one)."""
     import torch

@@ -23,15 +23,20 @@ bracket the timed region and at the MAX-reduction of the elapsed time.
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes of one launch (4 B/elem:
 read bf16 + write bf16, x nbuf x 16.7 M elements) / average duration of that launch, measured
 here with HIP events recorded on the launch stream around the timed region (which consists of
-exactly `steps` launches of that kernel).  `cpu_baseline` times the CPU
-oracle (oracle/antq_oracle.c, a literal restatement of the reference's op sequence: "port") on all
-host cores (and on one) on rows of the same workload.
+exactly `steps` launches of that kernel).  `roofline.copy_ceiling` is the empirical ceiling SURVEY 8d
+asks for: a plain 16-byte-per-lane nontemporal copy kernel and hipMemcpyDtoD over the same buffers,
+timed right after the timed region.  `cpu_baseline` times the CPU oracle (oracle/antq_oracle.c, a
+literal restatement of the reference's op sequence: "port") with OpenMP on all host cores (and on
+one); `cpu_baseline_torch` is the same op sequence as PyTorch CPU ops.
+
+ANTQ_BENCH_SELFTEST=1 (tests/test_sharding_gloo.py): the rank / barrier / MAX-over-ranks / report
+logic below runs unchanged on CPU over gloo with a stub in place of the GPU workload, so that the
+multi-rank harness the driver launches at N = 2, 4, 8 is executed code and not only prose.
 """
 import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,12 +46,112 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ROWS = COLS = 4096
 BYTES_PER_ELEM = 4               # algorithmic: read one bf16 + write one bf16
+METRIC = "Gelements/s quant-dequant + achieved HBM GB/s %peak, 4-bit ANT, 1/8 MI355X"
 
 
+# ------------------------------------------------------------------------------------------------
+# rank harness: one process per GPU, no data-path collective
+# ------------------------------------------------------------------------------------------------
+class Harness:
+    """What every rank does around its own, independent work: join the job `torch.distributed.run` started, meet the
+    others at a barrier on both sides of the timed region, agree on the slowest rank's time."""
+
+    def __init__(self, gpus, selftest=False):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.selftest = selftest
+        if self.world != gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch N ranks with `python -m torch.distributed.run "
+                     "--nnodes=1 --nproc-per-node N ... bench.py --gpus N` (one process per GPU); refusing to report "
+                     "a number for a job of another size" % (gpus, self.world))
+        import torch
+        self.torch = torch
+        if selftest:
+            self.dev = torch.device("cpu")
+        else:
+            if not torch.cuda.is_available():
+                sys.exit("bench.py needs an MI355X; there is no CPU fallback (the CPU oracle is only the reported baseline)")
+            if self.local_rank >= torch.cuda.device_count():
+                sys.exit("bench.py: LOCAL_RANK %d but only %d visible GPU(s)" % (self.local_rank, torch.cuda.device_count()))
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        self.dist = None
+        if self.world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):      # launched by torchrun
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo" if selftest else "nccl", rank=self.rank, world_size=self.world)   # nccl = RCCL
+            self.dist = dist
+            self.barrier()                 # builds the communicator now, so later barriers cost microseconds
+
+    def sync(self):
+        if not self.selftest:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, value):
+        if self.dist is None:
+            return float(value)
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, steps, warmup, on_start=None, on_stop=None):
+        """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both sides;
+        returns the MAX over ranks of the wall-clock time of the bracketed region."""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        if on_start:
+            on_start()
+        for _ in range(steps):
+            step()
+        if on_stop:
+            on_stop()
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        self.barrier()
+        return self.max_over_ranks(elapsed)
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def report(h, args, elems_per_step_per_gpu, elapsed, extra):
+    """The one JSON line (rank 0).  value = units ALL ranks processed / the slowest rank's time."""
+    total = h.world * elems_per_step_per_gpu * args.steps
+    res = {
+        "metric": METRIC,
+        "value": round(total / elapsed / 1e9, 3),
+        "unit": "Gelem/s",
+        "n_gpus": h.world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+    }
+    res.update(extra)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only; a bounded sample of the same workload)
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(seconds_budget=12.0):
-    """Oracle (port of the reference op sequence) on the host cores: 64 rows of 4096 bf16 elements per hardware thread
-    (16384 rows = four headline tensors on a 256-thread host), every thread sweeping its rows `reps` times so that
-    thread start-up does not count; about `seconds_budget` CPU-seconds in total.  Plus the same oracle on one thread."""
+    """Oracle (port of the reference op sequence, oracle/antq_oracle.c) with OpenMP on every host core: 64 rows of 4096
+    bf16 elements per hardware thread, swept `reps` times inside ONE parallel region (thread start-up is paid once,
+    outside the sweeps that matter); about `seconds_budget` CPU-seconds per core.  Plus the same on one thread."""
     import numpy as np
     from oracle import antq_oracle as orc
     from ant_quantization_amd import grids
@@ -59,25 +164,66 @@ def cpu_baseline(seconds_budget=12.0):
     g = grids.ant_flint(4, True)
     alpha = orc.absmax(orc.bf16_to_f32(x), True, 1.0)
     t0 = time.perf_counter()
-    orc.forward_rows(x, out, 0, 64, alpha, g, 10.0)               # ONE host thread, 64 rows
-    one_thread = 64 * COLS / (time.perf_counter() - t0)           # elements / s
-    reps = max(1, int(seconds_budget * one_thread / (rows * COLS)))
-
-    def work(b, e):
-        for _ in range(reps):
-            orc.forward_rows(x, out, b, e, alpha, g, 10.0)        # ctypes call: releases the GIL
-
-    ts = [threading.Thread(target=work, args=(64 * t, 64 * (t + 1))) for t in range(cores)]
+    orc.forward_omp(x[:64], out[:64], alpha[:64], g, 10.0, reps=1, threads=1)     # ONE host thread, 64 rows
+    one_thread = 64 * COLS / (time.perf_counter() - t0)                            # elements / s
+    reps = max(1, int(seconds_budget * one_thread / (64 * COLS)))
+    orc.forward_omp(x, out, alpha, g, 10.0, reps=1, threads=cores)                 # spawns the OpenMP team
     t0 = time.perf_counter()
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
+    used = orc.forward_omp(x, out, alpha, g, 10.0, reps=reps, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(rows * COLS * reps / dt / 1e9, 5), "unit": "Gelem/s", "cores": cores, "kind": "port",
+    return {"value": round(rows * COLS * reps / dt / 1e9, 5), "unit": "Gelem/s", "cores": used, "kind": "port",
             "single_thread_gelem_per_s": round(one_thread / 1e9, 6),
-            "sample": "%d rows x %d cols bf16 (64 rows per thread), flint 4-bit per-row alpha, %d sweeps, %d threads, "
-                      "%.1f s wall" % (rows, COLS, reps, cores, dt)}
+            "sample": "%d rows x %d cols bf16 (64 rows per thread), flint 4-bit per-row alpha, %d sweeps, %d OpenMP "
+                      "threads (static row split), %.1f s wall" % (rows, COLS, reps, used, dt)}
+
+
+def cpu_baseline_torch(seconds_budget=6.0):
+    """The reference's own op sequence as PyTorch CPU ops (SURVEY 8d baseline 2; the reference has no CPU kernel, and its
+    Python cannot travel to the GPU box): d = x / scale (row-broadcast); q = nearest grid value; t = (q - d) + d;
+    out = t * scale (AQ:535-551), fp32 arithmetic on a bf16 tensor.  `nearest` = the stand-in for quant_cuda.quant
+    written with torch ops (bucketize on the mid-points of the sorted grid: one pass, no [N, 16] distance matrix)."""
+    import numpy as np
+    import torch
+    from ant_quantization_amd import grids
+    g = torch.from_numpy(np.unique(grids.ant_flint(4, True)))
+    mids = (g[:-1] + g[1:]) / 2
+    x = (torch.randn(1024, COLS, generator=torch.Generator().manual_seed(6)) * 0.02).to(torch.bfloat16)
+    alpha = x.float().abs().amax(1, keepdim=True)
+
+    def fwd():
+        xf = x.float()
+        scale = alpha / 10.0
+        d = xf / scale
+        q = g[torch.bucketize(d, mids, right=True)]
+        return (((q - d) + d) * scale).to(torch.bfloat16)
+
+    fwd()
+    best, t_all, n = 1e30, time.perf_counter(), 0
+    while n < 5 or (time.perf_counter() - t_all < seconds_budget and n < 200):
+        t0 = time.perf_counter()
+        fwd()
+        best = min(best, time.perf_counter() - t0)
+        n += 1
+    return {"value": round(x.numel() / best / 1e9, 5), "unit": "Gelem/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "PyTorch-CPU op sequence (div, bucketize-nearest, STE add, mul) on 1024 x %d bf16, "
+                                      "best of %d, torch.get_num_threads() = %d" % (COLS, n, torch.get_num_threads())}
+
+
+# ------------------------------------------------------------------------------------------------
+def selftest_main(args):
+    """Stub workload for the CPU test of the rank harness: rank r sleeps (r + 1) ms per step."""
+    h = Harness(args.gpus, selftest=True)
+    units = 1000000
+
+    def step():
+        time.sleep(1e-3 * (h.rank + 1))
+
+    elapsed = h.timed(step, args.steps, args.warmup)
+    if h.rank == 0:
+        res = report(h, args, units, elapsed, {"data": "stub", "selftest": True,
+                                                "config": {"workload": "stub: rank r sleeps (r+1) ms per step"}})
+        print(json.dumps(res), flush=True)
+    h.finish()
 
 
 def main():
@@ -88,35 +234,26 @@ def main():
     ap.add_argument("--nbuf", type=int, default=32, help="distinct 4096x4096 bf16 tensors per GPU (one step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if os.environ.get("ANTQ_BENCH_SELFTEST") == "1":
+        return selftest_main(args)
 
-    import torch
-    import torch.distributed as dist
+    h = Harness(args.gpus)
+    torch, dev, rank = h.torch, h.dev, h.rank
     from ant_quantization_amd import _lib, grids
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X; there is no CPU fallback (the CPU oracle is only the reported baseline)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torchrun
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL; only barriers + one MAX reduce
-        dist.barrier()                      # builds the communicator now, so later barriers cost microseconds
 
     # ---- workload: resident in HBM before the timed region -----------------------------------
     gen = torch.Generator(device=dev)
     gen.manual_seed(6 + rank)
     plan = _lib.plan_for(grids.ant_flint(4, True))
+    x_slab = torch.empty(args.nbuf, ROWS, COLS, dtype=torch.bfloat16, device=dev)      # contiguous: the copy ceiling below
+    out_slab = torch.empty_like(x_slab)                                                # is measured on the very same bytes
     xs, alphas, outs = [], [], []
-    for _ in range(args.nbuf):
-        x = (torch.randn(ROWS, COLS, device=dev, generator=gen) * 0.02).to(torch.bfloat16)
-        xs.append(x)
-        alphas.append(_lib.absmax(x, ROWS, COLS, per_row=True))           # calibrated alpha = row abs-max
-        outs.append(torch.empty_like(x))
-    torch.cuda.synchronize()
+    for i in range(args.nbuf):
+        x_slab[i] = (torch.randn(ROWS, COLS, device=dev, generator=gen) * 0.02).to(torch.bfloat16)
+        xs.append(x_slab[i])
+        alphas.append(_lib.absmax(xs[i], ROWS, COLS, per_row=True))           # calibrated alpha = row abs-max
+        outs.append(out_slab[i])
+    h.sync()
 
     # One STEP = one pass of the hot path over the batch = ONE launch of the batched entry point
     # (antq_fakequant_batch: every workgroup looks its tensor up in a resident descriptor table).
@@ -130,78 +267,58 @@ def main():
         for i in range(args.nbuf):
             _lib.fakequant(xs[i], alphas[i], plan, 10.0, ROWS, COLS, True, out=outs[i])
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def event_time(fn, min_seconds, per_call):
+        """Average HIP-event duration of fn() over back-to-back calls for at least `min_seconds` (last reading)."""
+        t_all, last = time.perf_counter(), None
+        while last is None or time.perf_counter() - t_all < min_seconds:
+            ev0.record()
+            for _ in range(per_call):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            last = ev0.elapsed_time(ev1) * 1e-3 / per_call
+        return last
 
     # ---- setup pass: the same work as one launch per tensor (k_fq_xrow, the reference's granularity).
     # Reported beside the headline; it also keeps the GPU busy for >= 0.3 s before anything is timed,
     # which is what it takes for an idle MI355X to reach steady clocks (the first ~50 ms of load run
     # up to 20 % slower: tools/probe_clock_ramp.py).
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    pt_launch_s, t_setup = None, time.perf_counter()
-    while time.perf_counter() - t_setup < 0.3:
-        ev0.record()
-        for _ in range(5):
-            step_per_tensor()
-        ev1.record()
-        torch.cuda.synchronize()
-        pt_launch_s = ev0.elapsed_time(ev1) * 1e-3 / (5 * args.nbuf)      # keep the last (steady-clock) reading
+    pt_launch_s = event_time(step_per_tensor, 0.3, 5) / args.nbuf
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()                                  # HIP events on the launch stream (= torch's current stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    # ---- roofline of the dominant kernel (antq::k_fq_batch): the timed region is nothing but
-    # back-to-back launches of it on one stream, so its average launch duration = event time / launches.
+    # ---- the timed region: HIP events on the launch stream (= torch's current stream) inside the barriers
+    elapsed = h.timed(step, args.steps, args.warmup, on_start=ev0.record, on_stop=ev1.record)
+    # roofline of the dominant kernel (antq::k_fq_batch): the timed region is nothing but back-to-back
+    # launches of it on one stream, so its average launch duration = event time / launches.
     launch_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     algo_bytes = args.nbuf * ROWS * COLS * BYTES_PER_ELEM
     achieved = algo_bytes / launch_s / 1e9
 
     # ---- parity spot check of what was just measured (cheap, outside the timed region) --------
     ok = bool(torch.equal(_lib.fakequant(outs[0], alphas[0], plan, 10.0, ROWS, COLS, True), outs[0]))
 
-    if use_dist:
-        dist.barrier()
     if rank != 0:
-        dist.destroy_process_group()
+        h.finish()
         return
 
-    traffic = None
+    # ---- empirical ceiling on the same bytes (SURVEY 8d): plain copies x_slab -> out_slab, one launch each
+    copy_s = event_time(lambda: _lib.copy(x_slab, out_slab), 0.15, 10)
+    d2d_s = event_time(lambda: out_slab.copy_(x_slab), 0.15, 10)
+    ceiling = max(algo_bytes / copy_s, algo_bytes / d2d_s) / 1e9
+
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # rocprofv3 --pmc result, see profiles/README.md
     if os.path.exists(tpath):
         try:
             per_tensor = json.load(open(tpath)).get("k_fq_batch_bf16_bytes_per_tensor")
             traffic = int(per_tensor * args.nbuf) if per_tensor else None
+            traffic_note = ("from profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                            "command (FETCH_SIZE x2 per the guide's gfx950 correction), NOT measured in this run")
         except Exception:
             traffic = None
 
-    total_elems = world * args.nbuf * ROWS * COLS * args.steps
-    res = {
-        "metric": "Gelements/s quant-dequant + achieved HBM GB/s %peak, 4-bit ANT, 1/8 MI355X",
-        "value": round(total_elems / elapsed / 1e9, 3),
-        "unit": "Gelem/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
+    res = report(h, args, args.nbuf * ROWS * COLS, elapsed, {
         "config": {"workload": "headline: %d x [4096,4096] bf16 weight tensors per GPU, ANT 4-bit signed flint grid, "
                                "calibrated per-row alpha, steady-state _forward; one step = ONE batched launch "
                                "(antq_fakequant_batch) over all %d tensors" % (args.nbuf, args.nbuf),
@@ -214,15 +331,20 @@ def main():
                                            "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9, 1),
                                            "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "antq::k_fq_batch<bf16,false>", "launch_us": round(launch_s * 1e6, 2),
-                     "algorithmic_bytes_per_launch": algo_bytes},
-    }
-    if world == 1 and not args.no_cpu_baseline:      # reported baseline, N=1 only
+                     "algorithmic_bytes_per_launch": algo_bytes,
+                     "copy_ceiling": {"antq_copy_GBps": round(algo_bytes / copy_s / 1e9, 1),
+                                      "hipMemcpyDtoD_GBps": round(algo_bytes / d2d_s / 1e9, 1),
+                                      "frac_of_copy_ceiling": round(achieved / ceiling, 4),
+                                      "what": "plain copy of the same %d bytes in -> out (one launch), timed after the "
+                                              "timed region" % (algo_bytes // 2)}},
+    })
+    if h.world == 1 and not args.no_cpu_baseline:      # reported baselines, N=1 only
         res["cpu_baseline"] = cpu_baseline()
+        res["cpu_baseline_torch"] = cpu_baseline_torch()
     print(json.dumps(res), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+    h.finish()
 
 
 if __name__ == "__main__":

@@ -408,4 +408,34 @@ void antq_oracle_forward_rows_bf16(const uint16_t *x, uint16_t *out, size_t row_
     }
 }
 
+/* The timed CPU baseline of bench.py ("antq_cpu ... OpenMP, at 1 thread and at all host cores"): `reps`
+ * sweeps of forward_rows_bf16 over all rows, rows split statically over `threads` OpenMP threads (0 = the runtime's
+ * default).  Returns the number of threads that actually ran. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int antq_oracle_forward_omp_bf16(const uint16_t *x, uint16_t *out, size_t rows, size_t row_len, const float *alpha,
+                                 int alpha_per_row, const float *grid, int m, float gmax, int reps, int threads)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+        for (int rep = 0; rep < reps; rep++) {
+#pragma omp for schedule(static) nowait
+            for (long long r = 0; r < (long long)rows; r++)
+                antq_oracle_forward_rows_bf16(x, out, (size_t)r, (size_t)r + 1, row_len, alpha, alpha_per_row, grid, m, gmax);
+        }
+    }
+#else
+    (void)threads;
+    for (int rep = 0; rep < reps; rep++)
+        antq_oracle_forward_rows_bf16(x, out, 0, rows, row_len, alpha, alpha_per_row, grid, m, gmax);
+#endif
+    return used;
+}
+
 int antq_oracle_abi_version(void) { return 1; }

@@ -191,6 +191,18 @@ def forward_rows(x2d, out, row_begin, row_end, alpha, grid, gmax):
        _p(alpha), ctypes.c_int(per_row), _p(grid), ctypes.c_int(grid.size), ctypes.c_float(gmax))
 
 
+def forward_omp(x2d, out, alpha, grid, gmax, reps=1, threads=0):
+    """CPU-baseline leg (bench.py): `reps` sweeps of a4 over all rows of a bf16 tensor on `threads` OpenMP threads
+    (0: all).  Returns the number of threads used."""
+    rows, row_len = x2d.shape
+    assert x2d.dtype == np.uint16 and out.dtype == np.uint16
+    per_row = 1 if alpha.size == rows and rows > 1 else 0
+    fn = lib().antq_oracle_forward_omp_bf16
+    fn.restype = ctypes.c_int
+    return int(fn(_p(x2d), _p(out), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), _p(alpha), ctypes.c_int(per_row),
+                  _p(grid), ctypes.c_int(grid.size), ctypes.c_float(gmax), ctypes.c_int(reps), ctypes.c_int(threads)))
+
+
 # --------------------------------------------------------------------------
 # a7/a8 codebook generators (numpy restatement; float32 like torch.tensor())
 # --------------------------------------------------------------------------

@@ -1561,3 +1561,46 @@ def test_quant_cuda_importable_the_reference_way(antq_lib, oracle, dev, tmp_path
                                str(tmp_path / "x.npy"), out], cwd=str(tmp_path), env=env)
         assert f32_same(np.load(out + "32.npy"), zr)
         assert np.array_equal(np.load(out + "64.npy"), zr.astype(np.float64))
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_row_sharded_odd_numel_ovp_wrap(antq_lib, oracle, dev, bf16):
+    """A row-sharded OliVe tensor with an ODD element count: the last element's partner is global element 0
+    (torch.roll wrap, OQ:313-318), which another rank owns.  sharding.wrap_flag / apply_wrap_flag (what
+    fix_odd_numel_wrap broadcasts and applies) through the real kernels, all ranks emulated on this GPU: the
+    concatenated blocks must equal the unsharded oracle result bit for bit."""
+    import torch
+    from ant_quantization_amd import sharding
+    O = golden("olive_grids.npz")
+    gn = O["flint_b4_s"]
+    grid = np.concatenate([gn, O["outlier_b4_s"]])
+    plan = antq_lib.plan_for(grid)
+    rng = np.random.default_rng(17)
+    rows, K = 9, 33
+    for world in (2, 3):
+        for first, blk_first in ((0.9, 0.0), (0.001, 0.9), (0.9, 0.9), (0.001, 0.001), (-0.9, 0.9)):
+            x = (rng.standard_normal((rows, K)) * 0.02).astype(np.float32)
+            alpha = np.full(rows, 0.06, np.float32) + rng.random(rows).astype(np.float32) * 0.01
+            blocks = [sharding.row_block(rows, r, world, pair_safe_row_len=K) for r in range(world)]
+            x[0, 0], x[-1, -1], x[blocks[-1][0], 0] = first, 0.01, blk_first
+            if bf16:
+                xs = oracle.f32_to_bf16(x)
+                full, _ = oracle.forward(xs, alpha, grid, 32.0, True)
+            else:
+                xs = x
+                full, _ = oracle.forward(x, alpha, grid, 32.0, True)
+            outs, xts, ats = [], [], []
+            for b, e in blocks:
+                xt = to_dev(np.ascontiguousarray(xs[b:e]), dev, bf16)
+                at = to_dev(alpha[b:e].copy(), dev)
+                outs.append(antq_lib.fakequant(xt, at, plan, 32.0, e - b, K, True, ovp=True))
+                xts.append(xt)
+                ats.append(at)
+            flag = sharding.wrap_flag(outs[0], ats[0], plan, 32.0)
+            assert int(flag.item()) == int(abs(first) > 0.5)
+            sharding.apply_wrap_flag(xts[-1], outs[-1], ats[-1], plan, 32.0, flag)
+            got = torch.cat([o.reshape(-1) for o in outs])
+            if bf16:
+                assert bf16_same(bf16_bits(got), full.reshape(-1), oracle), (world, first, blk_first)
+            else:
+                assert f32_same(got.cpu().numpy(), full), (world, first, blk_first)
