@@ -65,11 +65,13 @@ static inline const uint4 *plan_tab_ptr(const void *plan_dev)
     return reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev) + sizeof(PlanHeader));
 }
 
-// tuning knobs (dev / bench only; see antq_debug_set)
-static int g_knob_u = 0;        // force U of the uniform kernel (0 = heuristic)
-static int g_knob_blocks = 0;   // (unused since the kernels are one-shot)
-static int g_knob_x = 1;        // 0 disables the x-domain row kernel (A/B measurements)
-static int g_knob_nearest_fast = 1;   // 0: antq_nearest always runs the literal scan
+// tuning knobs (dev / bench only; see antq_debug_set).  THREAD-LOCAL: they change the dispatch of the calling thread's
+// later calls only, so a probe that forgets to reset them cannot change which kernel another thread's calls run, and the
+// library keeps no process-global mutable state.
+static thread_local int g_knob_u = 0;        // force U of the uniform kernel (0 = heuristic)
+static thread_local int g_knob_blocks = 0;   // (unused since the kernels are one-shot)
+static thread_local int g_knob_x = 1;        // 0 disables the x-domain row kernel (A/B measurements)
+static thread_local int g_knob_nearest_fast = 1;   // 0: antq_nearest always runs the literal scan
 
 template <typename T, bool OVP, bool IDX, bool DYN>
 static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, size_t vpr, const float *alpha,

@@ -18,7 +18,8 @@
  *     never allocates, frees or synchronises; all work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream);
  *   - return 0 on success, a negative ANTQ_ERR_* otherwise; no exceptions;
- *   - re-entrant and thread-safe: no global mutable state (the antq_debug_set development knobs aside);
+ *   - re-entrant and thread-safe: no process-global mutable state (the antq_debug_set development knobs are
+ *     thread-local: they only steer the calling thread's own later calls);
  *     nothing here allocates or synchronises, so every entry point can be captured into a hipGraph;
  *   - results: grid index bit-exact with the reference scan; dequantised floats
  *     bit-identical to the reference's fp32 op sequence (bf16/f16 outputs are the
@@ -254,7 +255,8 @@ int antq_decode4(const uint8_t *codes_dev, void *out_dev, size_t rows, size_t ro
  * used by bench.py to measure the empirical HBM ceiling on the same buffers. */
 int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
 
-/* Development / benchmark tuning knobs (process-global; not part of the stable surface):
+/* Development / benchmark tuning knobs (thread-local: only the calling thread's later calls are affected; not part of
+ * the stable surface):
  *   key 0: force the per-task unroll U of the row kernels (0 = heuristic)
  *   key 1: unused
  *   key 2: 0 disables the per-row (x-domain) table kernels, the d-domain kernels run instead (A/B measurements)

@@ -1604,3 +1604,119 @@ def test_row_sharded_odd_numel_ovp_wrap(antq_lib, oracle, dev, bf16):
                 assert bf16_same(bf16_bits(got), full.reshape(-1), oracle), (world, first, blk_first)
             else:
                 assert f32_same(got.cpu().numpy(), full), (world, first, blk_first)
+
+
+def test_bench_workload_batched_kernel_vs_oracle(antq_lib, oracle, dev):
+    """The launch bench.py times, checked DIRECTLY: the same batch (32 x [4096, 4096] bf16, randn * 0.02 from the device
+    generator seeded 6, signed flint-4, alpha = row abs-max, one antq_fakequant_batch launch = k_fq_batch<bf16,false>),
+    72 rows of every tensor against the oracle (values), the same rows' indices through the per-tensor kernel, and every
+    element of the batched output against the per-tensor launch."""
+    import torch
+    from ant_quantization_amd import grids
+    g = grids.ant_flint(4, True)
+    assert np.array_equal(g, golden("ant_grids.npz")["flint_b4_s"])
+    plan = antq_lib.plan_for(g)
+    R = K = 4096
+    nbuf = 32
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(6)
+    xs, alphas, outs = [], [], []
+    for _ in range(nbuf):
+        x = (torch.randn(R, K, device=dev, generator=gen) * 0.02).to(torch.bfloat16)
+        xs.append(x)
+        alphas.append(antq_lib.absmax(x, R, K, per_row=True))
+        outs.append(torch.empty_like(x))
+    batch = antq_lib.Batch([(xs[i], outs[i], alphas[i], plan, 10.0, R, K, True) for i in range(nbuf)])
+    assert not batch.singles
+    batch.run()
+    rng = np.random.default_rng(6)
+    n_rows = 0
+    for i in range(nbuf):
+        rows = np.unique(np.concatenate([[0, 1, R - 2, R - 1], rng.integers(0, R, 72)]))
+        rt = torch.from_numpy(rows).to(dev)
+        xa = bf16_bits(xs[i][rt])
+        a = alphas[i][rt].cpu().numpy()
+        assert np.array_equal(a, oracle.absmax(oracle.bf16_to_f32(xa), True, 1.0))          # the calibrated alpha itself
+        ref, ridx = oracle.forward(xa, a, g, 10.0, False)
+        assert bf16_same(bf16_bits(outs[i][rt]), ref, oracle), i
+        o1, idx = antq_lib.fakequant(xs[i], alphas[i], plan, 10.0, R, K, True, want_idx=True)
+        assert np.array_equal(idx[rt].cpu().numpy().astype(np.int32), ridx), i
+        assert torch.equal(o1.view(torch.int16), outs[i].view(torch.int16)), i               # batch == per tensor, everywhere
+        n_rows += rows.size
+    assert n_rows >= 64 * nbuf
+
+
+def test_bert_base_real_shapes_weights_and_activations(antq_lib, oracle, dev, capsys):
+    """C2 at its real sizes: the 74 nn.Linear weights of BERT-base (49 x [768,768] incl. the pooler,
+    12 x [3072,768], 12 x [768,3072], the [2,768] classifier; randn * 0.02, seed 2) calibrated with `ant-int-pot-flint`
+    4-bit (w_low 80, w_up 150: ABERT/scripts/cola_ptq.sh:82-89) and the two activation shapes [64,128,768] /
+    [64,128,3072] (gelu(randn), seed 3) per tensor through the atomic `PT` search path.  Oracle checks: the clip
+    search of sampled rows (scores within reduction noise, the pick the oracle's own or a tie by the ORACLE's scores),
+    the steady-state forward of sampled rows / the whole activation bit for bit, and the batched launch over all 74
+    weights against the per-layer outputs."""
+    import torch
+    from ant_quantization_amd.ant import quant_modules as qm
+    from calib_check import NEAR_TIE_RTOL
+    shapes = [(768, 768)] * 49 + [(3072, 768)] * 12 + [(768, 3072)] * 12 + [(2, 768)]
+    gen = torch.Generator(device=dev).manual_seed(2)
+    args = _args(w_low=80, a_low=80, w_up=150, a_up=150)
+    rng = np.random.default_rng(2)
+    jobs, per_layer = [], []
+    for li, (r, k) in enumerate(shapes):
+        w = torch.randn(r, k, device=dev, generator=gen) * 0.02
+        q = qm.TensorQuantizer(mode="ant-int-pot-flint", bit=4, is_signed=True, is_enable=True, args=args).to(dev)
+        q.name = "L%d" % li
+        q.alpha.data = torch.ones(r, 1, device=dev)
+        out = q(w)
+        grid = q.quant_grid.cpu().numpy()
+        alpha = q.alpha.detach().reshape(-1)
+        if li % 6 == 0 or r == 2:             # 14 layers get the oracle's calibration on sampled rows
+            rows = np.unique(rng.integers(0, r, 3))
+            wn = w[torch.from_numpy(rows).to(dev)].cpu().numpy()
+            xmax = np.abs(wn).max(1).astype(np.float32)
+            best, oalpha, trace = oracle.search_mse(wn, xmax, 80, 150, 1, grid, 10.0, False, True)
+            got = alpha[torch.from_numpy(rows).to(dev)].cpu().numpy()
+            for j in range(rows.size):
+                if got[j] != oalpha[j]:
+                    c = int(np.argmin(np.abs(got[j] / xmax[j] - np.float32(np.arange(80, 150) * 0.01))))
+                    assert (trace[c, j] - best[j]) <= NEAR_TIE_RTOL * best[j], (li, rows[j], got[j], oalpha[j])
+        rows = np.unique(np.concatenate([[0, r - 1], rng.integers(0, r, 24)]))
+        rt = torch.from_numpy(rows).to(dev)
+        ref, _ = oracle.forward(w[rt].cpu().numpy(), alpha[rt].cpu().numpy(), grid, 10.0, False)
+        assert f32_same(out[rt].cpu().numpy(), ref), li
+        ob = torch.empty_like(w)
+        jobs.append((w, ob, alpha.contiguous(), antq_lib.plan_for(grid), 10.0, r, k, True))
+        per_layer.append(out)
+    b = antq_lib.Batch(jobs)
+    assert not b.singles
+    b.run()
+    for j, out in zip(jobs, per_layer):
+        assert torch.equal(j[1], out)
+    # activations, per tensor
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for shape in ((64, 128, 768), (64, 128, 3072)):
+        x = torch.nn.functional.gelu(torch.randn(*shape, device=dev, generator=gen))
+        q = qm.TensorQuantizer(mode="ant-int-pot-flint", bit=4, is_signed=False, is_enable=True, is_input=True, args=args).to(dev)
+        q.name = "act"
+        out = q(x)
+        assert q.is_signed                                                  # gelu output has negatives: AQ:71-73
+        grid = q.quant_grid.cpu().numpy()
+        a = q.alpha.detach().reshape(1).cpu().numpy()
+        xn = x.cpu().numpy().reshape(1, -1)
+        ref, _ = oracle.forward(xn, a, grid, 10.0, False)
+        assert f32_same(out.cpu().numpy(), ref), shape
+        # the per-tensor search (LDS accumulators + one atomic per candidate and workgroup): three candidates' scores
+        # against the oracle's forward + mse on the whole tensor, and the pick against its neighbours
+        xmax = antq_lib.absmax(x.contiguous(), 1, x.numel(), per_row=False)
+        from ant_quantization_amd import core
+        ratios = core._ratios(80, 150, 1, dev)
+        sse = antq_lib.search_sse(x.contiguous(), 1, x.numel(), xmax, False, ratios, antq_lib.plan_for(grid), 10.0)
+        mse = (sse[:, 0] / x.numel()).float().cpu().numpy()
+        c_pick = int(np.argmin(mse))
+        assert np.float32(xmax.item() * np.float32((80 + c_pick) * 0.01)) == a[0]
+        for c in sorted({0, c_pick, max(c_pick - 1, 0), min(c_pick + 1, 69), 69}):
+            ac = np.float32(xmax.item()) * np.float32((80 + c) * 0.01)
+            oq, _ = oracle.forward(xn, np.float32([ac]), grid, 10.0, False)
+            ref_mse = oracle.mse(oq, xn, per_row=False)
+            np.testing.assert_allclose(mse[c], np.asarray(ref_mse).reshape(-1)[0], rtol=2e-5, err_msg=str((shape, c)))
+    capsys.readouterr()
