@@ -5,7 +5,7 @@
 namespace antq {
 
 constexpr uint32_t kPlanMagic = 0x51544E41u;  // "ANTQ"
-constexpr uint32_t kPlanVersion = 6;
+constexpr uint32_t kPlanVersion = 7;
 
 constexpr uint32_t kPlanScan = 0;  // kernels run the literal scan for every element
 constexpr uint32_t kPlanLut = 1;   // table plan: one LDS lookup + one compare per element
@@ -50,7 +50,14 @@ struct PlanHeader {      // 80 bytes
     uint32_t linear;
     float lin_scale;
     float lin_bias;
-    uint32_t reserved[2];
+    // approximate-quotient path in the d domain (quant_vec_a: small groups, tables too big for a per-row copy).  Usable
+    // when adom != 0 -- the two conditions of `xdom` that do not depend on the table size: (1) the bucket picked from
+    // x*rcp(s) (within 2^-22 of fl(x/s)) holds the threshold that decides fl(x/s) -- thresholds within 2^-20 of a
+    // bucket edge are duplicated into the neighbour -- and (2) the straight-through step (q-d)+d is exact in every
+    // region for |d| < xlim, so out = fl((q+0)*s).  Elements whose approximate quotient lies within 2^-20 (relative)
+    // of their bucket's threshold are redone with the true division.
+    uint32_t adom;
+    uint32_t reserved[1];
 };
 static_assert(sizeof(PlanHeader) == 96, "PlanHeader must be 96 bytes");
 

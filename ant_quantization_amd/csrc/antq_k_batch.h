@@ -1,4 +1,4 @@
-// antq_k_batch.h -- batched launch: descriptor table, block -> job map, the multi-tensor kernel
+// antq_k_batch.h -- batched launch: descriptor table, block -> job map, the multi-tensor kernels
 // Part of libantq's single device translation unit (antq_kernels.hip includes it); gfx950 only.
 #ifndef ANTQ_K_BATCH_H
 #define ANTQ_K_BATCH_H
@@ -7,46 +7,97 @@
 
 namespace antq {
 
-constexpr uint32_t kBatchMagic = 0x42544E41u;  // "ANTB"
+constexpr uint32_t kBatchMagic = 0x32544E41u;  // "ANT2"
 constexpr int kBatchU = 4;                      // vectors per lane per task (4 KiB per wavefront: best measured)
 
-struct BatchDesc {   // 144 bytes, device-visible
+struct BatchDesc {   // 152 bytes, device-visible
     const uint4 *x;
     uint4 *out;
-    const float *alpha;
+    const float *alpha;    // ANTQ_FLAG_DYNAMIC: an OUTPUT
     const uint4 *plan_tab;
     uint64_t n_vec;        // lane kind: number of 16-byte vectors
     uint32_t total_tasks;  // row kind: wavefront tasks
     uint32_t vpr;
     uint32_t tpr;
     int32_t vshift;
-    uint32_t first_block;
+    uint32_t first_block;  // first block of this job INSIDE ITS FAMILY'S LAUNCH
     uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < kRowKernelMinVpr);
-                           // 2 = row-run per wavefront, x-domain table (pad[] = xlim bits, grid offset)
+                           // 2 = row-run per wavefront, x-domain table
                            // 3 = element-granular (ragged rows / unaligned buffers): n_vec = elements, vpr = row_len
                            // 8 = groups of 16 / 32 / 64 vectors, a per-group x-domain table in a slice of the wavefront's area
                            // 4..7 = kind 2 with the alpha computed in the kernel (ANTQ_FLAG_DYNAMIC, k_fq_batch_dyn): the row in
                            //         one wavefront, 4 / 8 vectors per lane (<= 256 / <= 512 vectors: kinds 4 / 6), or spread
-                           //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7); `alpha` is
-                           //         then an OUTPUT, pad[2] = clip ratio bits
+                           //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7)
     int32_t per_row;
     float gmax;
     PlanArgs pa;
-    uint32_t pad[4];
+    float vout;            // PlanHeader::vout (x-domain kinds)
+    float ratio;           // ANTQ_FLAG_DYNAMIC: alpha = max|row| * ratio
+    uint32_t pad[2];
 };
-static_assert(sizeof(BatchDesc) == 144, "BatchDesc must be 144 bytes");
+static_assert(sizeof(BatchDesc) == 152, "BatchDesc must be 152 bytes");
 
-struct BatchHeader {   // 32 bytes
-    uint32_t magic, n, total_blocks, dtype, flags, lds_bytes, map_offset, bytes;
+// A batch is up to four launches, one per kernel FAMILY, so that no kernel carries the registers of code paths its
+// jobs never take (the headline x-domain row kernel keeps its 80 VGPRs whatever else a batch may contain):
+//   family 0  k_fq_batch        x-domain tables: kinds 2, 8
+//   family 1  k_fq_batch_d<AD>  d-domain table, approximate-quotient elements (plans with adom): kinds 0, 1 (+ 3)
+//   family 2  k_fq_batch_d      d-domain table, exact division (scan plans, arbitrary value lists): kinds 0, 1, 3
+//   family 3  k_fq_batch_dyn    ANTQ_FLAG_DYNAMIC rows of >= 128 vectors with an x-domain plan: kinds 4..7
+// (with ANTQ_FLAG_DYNAMIC families 1 / 2 run their DYN instantiation: groups of <= 64 vectors, rows of <= 256 vectors)
+constexpr int kBatchFamilies = 4;
+
+struct BatchHeader {   // 48 bytes
+    uint32_t magic, n, dtype, flags, lds_bytes, map_offset, bytes, total_blocks;
+    uint32_t fam_blocks[kBatchFamilies];
 };
+static_assert(sizeof(BatchHeader) == 48, "BatchHeader must be 48 bytes");
 
-// Occupancy (measured): the plain kernel is best at the 6 wavefronts per SIMD its 80 VGPRs give it (8 loses
-// 1.3 points); with the outlier-victim rule the extra VALU work per element wants 8 (64 VGPRs): +1 to +1.5 points.
+__device__ __forceinline__ XArgs xargs_of(const BatchDesc &D)
+{
+    const PlanArgs &pa = D.pa;
+    XArgs xa;
+    xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+    xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = pa.xlim; xa.vout = D.vout;
+    xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+    return xa;
+}
+
+// Family 0.  Occupancy (measured): the plain kernel is best at the 6 wavefronts per SIMD its 80 VGPRs give it
+// (8 loses 1.3 points); with the outlier-victim rule the extra VALU work per element wants 8 (64 VGPRs): +1 to +1.5 points.
 template <typename T, bool OVP>
 __global__ void __launch_bounds__(256, OVP ? 8 : 6)
 k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
 {
-    constexpr int EPL = IO<T>::EPL;
+    constexpr int U = kBatchU;
+    const uint32_t j = block_map[blockIdx.x];
+    const BatchDesc &D = descs[j];
+    const uint32_t lb = blockIdx.x - D.first_block;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint4 *plan_tab = D.plan_tab;
+    const XArgs xa = xargs_of(D);
+
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];     // wave-private row / group tables
+    if (D.kind == 2) {
+        // x-domain rows: wave-private table, no workgroup barrier
+        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
+        if (task >= D.total_tasks) return;
+        xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
+                                              nullptr, xa, plan_tab + (D.pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
+                                              wtab_all[wv], lane, wv);
+    } else {
+        // groups of 16 / 32 / 64 vectors with an x-domain plan: a table per group in a slice of the wavefront's area
+        lane_xs_task<T, OVP, false, U>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
+                                       ((size_t)lb * U) * 256u + threadIdx.x, xa, plan_tab + (D.pa.m_pad >> 2),
+                                       reinterpret_cast<const float *>(plan_tab), wtab_all[wv], lane);
+    }
+}
+
+// Families 1 / 2: the plan's own (d-domain) table staged per workgroup.
+template <typename T, bool OVP, bool AD, bool DYN>
+__global__ void __launch_bounds__(256)
+k_fq_batch_d(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
+{
     constexpr int U = kBatchU;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     const uint32_t j = block_map[blockIdx.x];
@@ -55,88 +106,36 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
     const uint32_t lb = blockIdx.x - D.first_block;
     const uint32_t lane = threadIdx.x & 63u;
     const uint4 *plan_tab = D.plan_tab;
-
-    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];     // wave-private row tables (kinds 2, 4, 5)
-    if (D.kind == 2) {
-        // x-domain rows: wave-private table, no workgroup barrier
-        const uint32_t wv = threadIdx.x >> 6;
-        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
-        if (task >= D.total_tasks) return;
-        XArgs xa;
-        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]); xa.vout = u2f(D.pad[1]);
-        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
-        xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
-                                              nullptr, xa, plan_tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
-                                              wtab_all[wv], lane, wv);
-        return;
-    }
-    if (D.kind == 8) {
-        // groups of 16 / 32 / 64 vectors with an x-domain plan: a table per group in a slice of the wavefront's area
-        XArgs xa;
-        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]); xa.vout = u2f(D.pad[1]);
-        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
-        lane_xs_task<T, OVP, false, U>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
-                                       ((size_t)lb * U) * 256u + threadIdx.x, xa, plan_tab + (pa.m_pad >> 2),
-                                       reinterpret_cast<const float *>(plan_tab), wtab_all[threadIdx.x >> 6], lane);
+    float *alpha_out = DYN ? const_cast<float *>(D.alpha) : nullptr;
+    if (D.kind == 1) {
+        lane_task<T, OVP, false, U, DYN, AD>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
+                                             D.ratio, alpha_out, pa, plan_tab, smem, ((size_t)lb * U) * 256u + threadIdx.x);
         return;
     }
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
-    if (D.kind == 3) {
-        const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
-        __syncthreads();
-        scalar_pair<T, OVP, false>(D.x, D.out, nullptr, (size_t)lb * 256u + threadIdx.x, 0, (size_t)D.n_vec, (size_t)D.n_vec,
-                                   (size_t)D.vpr, D.alpha, D.per_row, D.gmax, pa, L);
-    } else if (D.kind == 0) {
+    if (D.kind == 0) {
         const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
         const bool active = task < total;
         uint4 v[U];
         float a;
-        task_load<T, U>(D.x, D.alpha, D.per_row, active ? task : total - 1u, vpr, tpr, lane, false, v, a);
+        task_load<T, U>(D.x, D.alpha, D.per_row, active ? task : total - 1u, vpr, tpr, lane, DYN, v, a);
         const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
         __syncthreads();
         if (active)
-            task_run<T, OVP, false, U, false>(D.out, nullptr, nullptr, 1.0f, task, vpr, tpr, lane, D.gmax, pa, L, v, a);
-    } else {
-        const size_t n_vec = D.n_vec;
-        const size_t first = ((size_t)lb * U) * 256u + threadIdx.x;
-        uint4 v[U];
-        float a[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const size_t vi = first + (size_t)u * 256u;
-            v[u] = make_uint4(0, 0, 0, 0);
-            a[u] = 1.0f;
-            if (vi < n_vec) {
-                v[u] = ld_stream(D.x + vi);
-                size_t row = 0;
-                if (D.per_row) row = (D.vshift >= 0) ? (vi >> D.vshift) : (vi / D.vpr);
-                a[u] = D.alpha[row];
-            }
-        }
+            task_run<T, OVP, false, U, DYN, AD ? 1 : 0>(D.out, nullptr, alpha_out, D.ratio, task, vpr, tpr, lane, D.gmax, pa, L, v, a);
+    } else if (!DYN) {
         const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const size_t vi = first + (size_t)u * 256u;
-            if (vi < n_vec) {
-                const Scale sc = make_scale(a[u], D.gmax);
-                float xf[EPL], of[EPL];
-                int jj[EPL];
-                IO<T>::unpack(v[u], xf);
-                quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, jj);
-                st_stream(D.out + vi, IO<T>::pack(of));
-            }
-        }
+        scalar_pair<T, OVP, false>(D.x, D.out, nullptr, (size_t)lb * 256u + threadIdx.x, 0, (size_t)D.n_vec, (size_t)D.n_vec,
+                                   (size_t)D.vpr, D.alpha, D.per_row, D.gmax, pa, L);
     }
 }
 
-// ANTQ_FLAG_DYNAMIC batches: alpha = row abs-max (x ratio) computed from the registers that hold the row -- one HBM
-// read -- for every tensor of the batch in one launch.  A kernel of its own so that the 8-vectors-per-lane variants do
-// not raise the register count (and lower the occupancy) of the static kernel above.
+// Family 3.  ANTQ_FLAG_DYNAMIC rows: alpha = row abs-max (x ratio) computed from the registers that hold the row -- one
+// HBM read -- for every tensor of the batch in one launch.  A kernel of its own so that the 8-vectors-per-lane variants
+// do not raise the register count (and lower the occupancy) of the static kernel above.
 template <typename T, bool OVP>
 __global__ void __launch_bounds__(256)
 k_fq_batch_dyn(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
@@ -150,14 +149,11 @@ k_fq_batch_dyn(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__
     const uint32_t wv = threadIdx.x >> 6;
     const uint4 *plan_tab = D.plan_tab;
     const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
-    XArgs xa;
-    xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-    xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = u2f(D.pad[0]); xa.vout = u2f(D.pad[1]);
-    xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+    const XArgs xa = xargs_of(D);
     float *alpha_out = const_cast<float *>(D.alpha);
     const uint4 *entries = plan_tab + (pa.m_pad >> 2);
     const float *grid = reinterpret_cast<const float *>(plan_tab);
-    const float ratio = u2f(D.pad[2]);
+    const float ratio = D.ratio;
     if (D.kind == 4) {
         if (task < D.total_tasks)
             xrow_task<T, OVP, false, 4, true, 1>(D.x, D.out, nullptr, task, D.vpr, 1u, nullptr, 1, D.gmax, ratio, alpha_out, xa,

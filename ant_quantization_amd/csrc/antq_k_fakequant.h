@@ -46,7 +46,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t m)
     return m;
 }
 
-template <typename T, bool OVP, bool IDX, int U, bool DYN>
+// ADM: 1 / 0 = the approximate-quotient element path is / is not compiled in; -1 = both, chosen per launch by pa.adom
+template <typename T, bool OVP, bool IDX, int U, bool DYN, int ADM = -1>
 __device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__restrict__ idx,
                                          float *__restrict__ alpha_out, float ratio,
                                          uint32_t task, uint32_t vpr, uint32_t tpr, uint32_t lane, float gmax,
@@ -71,14 +72,18 @@ __device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__res
         a = u2f(m) * ratio;
         if (alpha_out && lane == 0) alpha_out[row] = a;
     }
-    const Scale sc = make_scale(a, gmax);
+    // plans with `adom` (every ANT / OliVe codebook whose table is too big for a per-row copy: int-8, flint-5..8, ...):
+    // approximate quotient + margin test instead of the exact division per element (wave-uniform choice)
+    const bool ad = ADM < 0 ? (pa.adom != 0u) : (ADM != 0);
+    const Scale sc = ad ? make_scale_a(a, gmax) : make_scale(a, gmax);
 #pragma unroll
     for (int u = 0; u < U; u++) {
         if (v0 + 64u * u < vpr) {
             float xf[EPL], of[EPL];
             int j[EPL];
             IO<T>::unpack(v[u], xf);
-            quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
+            if (ad) quant_vec_a<EPL, OVP, IDX>(pa, L, sc, sc.ok, xf, of, j);
+            else quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
             st_stream(out + base + 64u * u, IO<T>::pack(of));
             if (IDX) store_idx<EPL>(idx, base + 64u * u, j);
         }
@@ -389,18 +394,19 @@ k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
 // wavefront, e.g. group-16 = 2 bf16 lanes or 4 fp32 lanes per group).  Each lane gathers
 // its own alpha and builds its own scale.  vshift >= 0 when vpr is a power of two.
 // ------------------------------------------------------------------------------------
-template <typename T, bool OVP, bool IDX, int U, bool DYN>
-__global__ void __launch_bounds__(256)
-k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
-          size_t n_vec, uint32_t vpr, int vshift,
-          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
-          float *__restrict__ alpha_out, PlanArgs pa, const uint4 *__restrict__ plan_tab)
+// AD: the plan allows the approximate-quotient element path (quant_vec_a): no exact division and no straight-through
+// arithmetic in the element loop -- what keeps 16-element groups of bf16 (2 lanes per group) from being VALU-bound.
+// DYN: alpha = max|group| * ratio from a butterfly over the group's lanes (vpr a power of two <= 64).
+// Body shared by k_fq_lane and the batched d-domain kernel (k_fq_batch_d).
+template <typename T, bool OVP, bool IDX, int U, bool DYN, bool AD>
+__device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+                                          size_t n_vec, uint32_t vpr, int vshift, const float *__restrict__ alpha, int per_row,
+                                          float gmax, float ratio, float *__restrict__ alpha_out, const PlanArgs &pa,
+                                          const uint4 *__restrict__ plan_tab, uint4 *smem, size_t first)
 {
     constexpr int EPL = IO<T>::EPL;
-    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
-    const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
     uint4 v[U];
     float a[U];
 #pragma unroll
@@ -425,7 +431,7 @@ k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
         float xf[EPL];
         IO<T>::unpack(v[u], xf);
         if (DYN) {
-            // group = vpr (power of two <= 32) adjacent lanes; butterfly max inside the group.
+            // group = vpr (power of two <= 64) adjacent lanes; butterfly max inside the group.
             // Lanes past n_vec hold zeros and belong to no real group (n_vec % vpr == 0).
             uint32_t m = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
             for (uint32_t off = 1; off < vpr; off <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, (int)off, 64));
@@ -433,14 +439,31 @@ k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
             if (alpha_out && vi < n_vec && (vi & (vpr - 1)) == 0) alpha_out[vi >> vshift] = a[u];
         }
         if (vi < n_vec) {
-            const Scale sc = make_scale(a[u], gmax);
             float of[EPL];
             int j[EPL];
-            quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
+            if (AD) {
+                const Scale sc = make_scale_a(a[u], gmax);
+                quant_vec_a<EPL, OVP, IDX>(pa, L, sc, sc.ok, xf, of, j);
+            } else {
+                const Scale sc = make_scale(a[u], gmax);
+                quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
+            }
             st_stream(out + vi, IO<T>::pack(of));
             if (IDX) store_idx<EPL>(idx, vi, j);
         }
     }
+}
+
+template <typename T, bool OVP, bool IDX, int U, bool DYN, bool AD>
+__global__ void __launch_bounds__(256)
+k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
+          size_t n_vec, uint32_t vpr, int vshift,
+          const float *__restrict__ alpha, int per_row, float gmax, float ratio,
+          float *__restrict__ alpha_out, PlanArgs pa, const uint4 *__restrict__ plan_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    lane_task<T, OVP, IDX, U, DYN, AD>(x, out, idx, n_vec, vpr, vshift, alpha, per_row, gmax, ratio, alpha_out, pa, plan_tab,
+                                       smem, ((size_t)blockIdx.x * U) * 256u + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------

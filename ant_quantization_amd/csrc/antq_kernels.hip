@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "../../include/antq.h"
 #include "antq_internal.h"
@@ -34,6 +35,15 @@
 #include "antq_k_search.h"
 
 namespace antq {
+
+// tuning knobs (dev / bench only; see antq_debug_set).  THREAD-LOCAL: they change the dispatch of the calling thread's
+// later calls only, so a probe that forgets to reset them cannot change which kernel another thread's calls run, and the
+// library keeps no process-global mutable state.
+static thread_local int g_knob_u = 0;        // force U of the uniform kernel (0 = heuristic)
+static thread_local int g_knob_blocks = 0;   // (unused since the kernels are one-shot)
+static thread_local int g_knob_x = 1;        // 0 disables the x-domain row kernel (A/B measurements)
+static thread_local int g_knob_nearest_fast = 1;   // 0: antq_nearest always runs the literal scan
+static thread_local int g_knob_a = 1;        // 0 disables the approximate-quotient element path (quant_vec_a): exact division
 
 // ------------------------------------------------------------------------------------
 // host-side launch helpers
@@ -57,6 +67,8 @@ static bool plan_args_from_host(const void *plan_host, PlanArgs &pa)
     pa.linear = h->linear;
     pa.lin_scale = h->lin_scale;
     pa.lin_bias = h->lin_bias;
+    pa.adom = (h->kind == kPlanLut && g_knob_a != 0) ? h->adom : 0u;
+    pa.xlim = h->xlim;
     return true;
 }
 
@@ -64,14 +76,6 @@ static inline const uint4 *plan_tab_ptr(const void *plan_dev)
 {
     return reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev) + sizeof(PlanHeader));
 }
-
-// tuning knobs (dev / bench only; see antq_debug_set).  THREAD-LOCAL: they change the dispatch of the calling thread's
-// later calls only, so a probe that forgets to reset them cannot change which kernel another thread's calls run, and the
-// library keeps no process-global mutable state.
-static thread_local int g_knob_u = 0;        // force U of the uniform kernel (0 = heuristic)
-static thread_local int g_knob_blocks = 0;   // (unused since the kernels are one-shot)
-static thread_local int g_knob_x = 1;        // 0 disables the x-domain row kernel (A/B measurements)
-static thread_local int g_knob_nearest_fast = 1;   // 0: antq_nearest always runs the literal scan
 
 template <typename T, bool OVP, bool IDX, bool DYN>
 static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, size_t vpr, const float *alpha,
@@ -193,9 +197,14 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
             if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
             // (the per-group table variant, lane_xs_task, is used by the batched launch only: as a single-round launch per
             //  tensor it measured slower than this kernel, 47 vs 52 % for bf16 group-128)
-            hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, false>), dim3((unsigned)blocks), dim3(256), lds, st,
-                               static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
-                               vshift, alpha, per_row, gmax, 1.0f, (float *)nullptr, pa, tab);
+            if (pa.adom)
+                hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, false, true>), dim3((unsigned)blocks), dim3(256), lds, st,
+                                   static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
+                                   vshift, alpha, per_row, gmax, 1.0f, (float *)nullptr, pa, tab);
+            else
+                hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, false, false>), dim3((unsigned)blocks), dim3(256), lds, st,
+                                   static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
+                                   vshift, alpha, per_row, gmax, 1.0f, (float *)nullptr, pa, tab);
         }
     } else if (aligned && !per_row && n >= (size_t)64 * EPL) {
         // per-tensor scale with a ragged tail: vector body + element tail
@@ -419,6 +428,7 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 1) g_knob_blocks = value;
     else if (key == 2) g_knob_x = value;
     else if (key == 3) g_knob_nearest_fast = value;
+    else if (key == 4) g_knob_a = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }
@@ -451,17 +461,22 @@ static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_o
     if (aligned && row_len % EPL == 0) {
         const size_t vpr = row_len / EPL;
         const bool pow2 = (vpr & (vpr - 1)) == 0;
-        if (vpr <= 32 && pow2) {
-            // several groups per wavefront: butterfly max over vpr adjacent lanes
+        if (vpr <= 64 && pow2) {
+            // several groups per wavefront (or one: 64 vectors): butterfly max over vpr adjacent lanes
             int vshift = 0;
             while (((size_t)1 << vshift) < vpr) vshift++;
             const size_t n_vec = rows * vpr;
             constexpr int U = 2;
             const size_t blocks = (n_vec + 256 * U - 1) / (256 * U);
             if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, true>), dim3((unsigned)blocks), dim3(256), lds, st,
-                               static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
-                               vshift, (const float *)nullptr, 1, gmax, ratio, alpha_out, pa, tab);
+            if (pa.adom)
+                hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, true, true>), dim3((unsigned)blocks), dim3(256), lds, st,
+                                   static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
+                                   vshift, (const float *)nullptr, 1, gmax, ratio, alpha_out, pa, tab);
+            else
+                hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, true, false>), dim3((unsigned)blocks), dim3(256), lds, st,
+                                   static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
+                                   vshift, (const float *)nullptr, 1, gmax, ratio, alpha_out, pa, tab);
             return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
         }
         if (vpr <= 2048) {
@@ -655,6 +670,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     const int epl = epl_of(dtype);
     if (!jobs || !blob || n < 1 || n > 65535) return ANTQ_ERR_ARG;
     if (!epl) return ANTQ_ERR_UNSUPPORTED;
+    const bool dyn = (flags & ANTQ_FLAG_DYNAMIC) != 0;
     char *p = static_cast<char *>(blob);
     BatchHeader h;
     memset(&h, 0, sizeof(h));
@@ -663,7 +679,10 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     if (cap < h.map_offset) return ANTQ_ERR_PLAN;
     BatchDesc *descs = reinterpret_cast<BatchDesc *>(p + sizeof(BatchHeader));
     uint32_t *map = reinterpret_cast<uint32_t *>(p + h.map_offset);
-    size_t total_blocks = 0, lds = 0;
+    std::vector<uint8_t> fam((size_t)n);
+    std::vector<size_t> nblk((size_t)n);
+    size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0}, lds = 0;
+    bool any_da = false;
     for (int i = 0; i < n; i++) {
         const antq_job &J = jobs[i];
         if (!J.x_dev || !J.out_dev || !J.alpha_dev || !J.plan_host || !J.plan_dev) return ANTQ_ERR_ARG;
@@ -674,43 +693,64 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         size_t blocks = job_blocks(J, epl, &d);
         if (blocks == 0) return ANTQ_ERR_UNSUPPORTED;
         if (!plan_args_from_host(J.plan_host, d.pa)) return ANTQ_ERR_PLAN;
-        {
-            const PlanHeader *ph = static_cast<const PlanHeader *>(J.plan_host);
-            if (d.kind == 0 && g_knob_x && d.pa.kind == kPlanLut && ph->xdom && d.vpr >= kRowKernelMinVpr) {
-                d.kind = 2;
-                memcpy(&d.pad[0], &ph->xlim, 4);
-                memcpy(&d.pad[1], &ph->vout, 4);
-            }
-            if (d.kind == 1 && g_knob_x && J.alpha_per_row && d.pa.kind == kPlanLut && ph->xdom &&
-                xs_eligible(d.vpr, d.pa.n_entries, d.pa.nbneg, d.pa.linear)) {
-                d.kind = 8;
-                memcpy(&d.pad[0], &ph->xlim, 4);
-                memcpy(&d.pad[1], &ph->vout, 4);
-            }
-            if (flags & ANTQ_FLAG_DYNAMIC) {
-                // alpha computed in the kernel: the row has to live in the registers of one wavefront / workgroup
-                if (d.kind != 2 || !J.alpha_per_row || d.vpr > 2048u) return ANTQ_ERR_UNSUPPORTED;
-                const float one = 1.0f;
-                memcpy(&d.pad[2], &one, 4);
-                if (J.rows > 0x3ffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+        const PlanHeader *ph = static_cast<const PlanHeader *>(J.plan_host);
+        const bool xdom = g_knob_x && d.pa.kind == kPlanLut && ph->xdom;
+        d.vout = ph->vout;
+        d.ratio = 1.0f;
+        int f;
+        if (!dyn) {
+            if (d.kind == 0 && xdom) d.kind = 2;
+            if (d.kind == 1 && xdom && J.alpha_per_row && !d.pa.adom &&
+                xs_eligible(d.vpr, d.pa.n_entries, d.pa.nbneg, d.pa.linear))
+                d.kind = 8;          // (plans with adom -- all that have xdom, unless the knob is off -- take the lane kernel)
+            f = (d.kind == 2 || d.kind == 8) ? 0 : (d.kind == 3 ? -1 : (d.pa.adom ? 1 : 2));
+        } else {
+            // alpha computed in the kernel: the group / row has to live in the registers of a few lanes, one wavefront
+            // or one workgroup
+            if (!J.alpha_per_row || d.kind == 3 || J.rows > 0x3ffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+            if (d.kind == 1) {
+                if (d.vshift < 0 || d.vpr > 64u) return ANTQ_ERR_UNSUPPORTED;   // butterfly over a power-of-two group
+                f = d.pa.adom ? 1 : 2;
+            } else if (xdom) {
+                if (d.vpr > 2048u) return ANTQ_ERR_UNSUPPORTED;
                 // one wavefront per row up to 512 vectors (4 or 8 per lane), one workgroup per row beyond
                 if (d.vpr <= 512u) { d.kind = d.vpr <= 256u ? 4 : 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4; }
                 else { d.kind = d.vpr <= 1024u ? 5 : 7; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
+                f = 3;
+            } else {
+                if (d.vpr > 64u * kBatchU) return ANTQ_ERR_UNSUPPORTED;         // the row in one wavefront's registers
+                d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4;
+                f = d.pa.adom ? 1 : 2;
             }
         }
-        if (total_blocks + blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
-        if (cap < h.map_offset + 4 * (total_blocks + blocks)) return ANTQ_ERR_PLAN;
+        any_da = any_da || f == 1;
         d.x = static_cast<const uint4 *>(J.x_dev);
         d.out = static_cast<uint4 *>(J.out_dev);
         d.alpha = J.alpha_dev;
         d.plan_tab = plan_tab_ptr(J.plan_dev);
-        d.first_block = (uint32_t)total_blocks;
         d.per_row = J.alpha_per_row ? 1 : 0;
         d.gmax = J.gmax;
         descs[i] = d;
-        for (size_t b = 0; b < blocks; b++) map[total_blocks + b] = (uint32_t)i;
-        total_blocks += blocks;
-        lds = std::max(lds, (size_t)d.pa.tab_units * 16);
+        fam[(size_t)i] = (uint8_t)(f < 0 ? 255 : f);
+        nblk[(size_t)i] = blocks;
+        if (f != 0 && f != 3) lds = std::max(lds, (size_t)d.pa.tab_units * 16);
+    }
+    // element-granular jobs (exact arithmetic, no table path) ride along with whichever d-domain launch exists
+    for (int i = 0; i < n; i++)
+        if (fam[(size_t)i] == 255) fam[(size_t)i] = any_da ? 1 : 2;
+    size_t total_blocks = 0;
+    for (int i = 0; i < n; i++) {
+        descs[i].first_block = (uint32_t)fam_blocks[fam[(size_t)i]];
+        fam_blocks[fam[(size_t)i]] += nblk[(size_t)i];
+        total_blocks += nblk[(size_t)i];
+    }
+    if (total_blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+    if (cap < h.map_offset + 4 * total_blocks) return ANTQ_ERR_PLAN;
+    size_t off[kBatchFamilies], acc = 0;
+    for (int f = 0; f < kBatchFamilies; f++) { off[f] = acc; acc += fam_blocks[f]; h.fam_blocks[f] = (uint32_t)fam_blocks[f]; }
+    for (int i = 0; i < n; i++) {
+        uint32_t *m = map + off[fam[(size_t)i]] + descs[i].first_block;
+        for (size_t b = 0; b < nblk[(size_t)i]; b++) m[b] = (uint32_t)i;
     }
     h.total_blocks = (uint32_t)total_blocks;
     h.lds_bytes = (uint32_t)lds;
@@ -729,16 +769,32 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
     const BatchDesc *descs = reinterpret_cast<const BatchDesc *>(pd + sizeof(BatchHeader));
     const uint32_t *map = reinterpret_cast<const uint32_t *>(pd + h->map_offset);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(h->total_blocks), block(256);
+    const dim3 block(256);
     const bool ovp = (h->flags & ANTQ_FLAG_OVP) != 0;
     const bool dyn = (h->flags & ANTQ_FLAG_DYNAMIC) != 0;
+    const uint32_t *fmap[kBatchFamilies];
+    {
+        const uint32_t *m = map;
+        for (int f = 0; f < kBatchFamilies; f++) { fmap[f] = m; m += h->fam_blocks[f]; }
+    }
+#define ANTQ_LAUNCH_D(TT, OO, AA)                                                                                   \
+    do {                                                                                                            \
+        const int f_ = (AA) ? 1 : 2;                                                                                \
+        if (dyn) hipLaunchKernelGGL((k_fq_batch_d<TT, OO, AA, true>), dim3(h->fam_blocks[f_]), block, h->lds_bytes, st, descs, fmap[f_]);  \
+        else hipLaunchKernelGGL((k_fq_batch_d<TT, OO, AA, false>), dim3(h->fam_blocks[f_]), block, h->lds_bytes, st, descs, fmap[f_]);     \
+    } while (0)
 #define ANTQ_LAUNCH_B(TT)                                                                                         \
     do {                                                                                                          \
-        if (dyn) {                                                                                                \
-            if (ovp) hipLaunchKernelGGL((k_fq_batch_dyn<TT, true>), grid, block, 0, st, descs, map);              \
-            else hipLaunchKernelGGL((k_fq_batch_dyn<TT, false>), grid, block, 0, st, descs, map);                 \
-        } else if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true>), grid, block, h->lds_bytes, st, descs, map);    \
-        else hipLaunchKernelGGL((k_fq_batch<TT, false>), grid, block, h->lds_bytes, st, descs, map);              \
+        if (h->fam_blocks[0]) {                                                                                   \
+            if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true>), dim3(h->fam_blocks[0]), block, 0, st, descs, fmap[0]);   \
+            else hipLaunchKernelGGL((k_fq_batch<TT, false>), dim3(h->fam_blocks[0]), block, 0, st, descs, fmap[0]);      \
+        }                                                                                                         \
+        if (h->fam_blocks[1]) { if (ovp) ANTQ_LAUNCH_D(TT, true, true); else ANTQ_LAUNCH_D(TT, false, true); }    \
+        if (h->fam_blocks[2]) { if (ovp) ANTQ_LAUNCH_D(TT, true, false); else ANTQ_LAUNCH_D(TT, false, false); }  \
+        if (h->fam_blocks[3]) {                                                                                   \
+            if (ovp) hipLaunchKernelGGL((k_fq_batch_dyn<TT, true>), dim3(h->fam_blocks[3]), block, 0, st, descs, fmap[3]);   \
+            else hipLaunchKernelGGL((k_fq_batch_dyn<TT, false>), dim3(h->fam_blocks[3]), block, 0, st, descs, fmap[3]);      \
+        }                                                                                                         \
     } while (0)
     switch (h->dtype) {
     case ANTQ_F32: ANTQ_LAUNCH_B(float); break;
@@ -747,6 +803,7 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
     default: return ANTQ_ERR_UNSUPPORTED;
     }
 #undef ANTQ_LAUNCH_B
+#undef ANTQ_LAUNCH_D
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 

@@ -297,7 +297,7 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         // wave-private table: at most two entries per lane (128), sign-interleaved for float-bits keys.  Measured: a
         // 255-bucket linear table (int-8, four entries per lane and task) is SLOWER per-row than the d-domain path
         // (67 vs 72 % batched bf16), the 63 / 127-bucket ones of int-6 / int-7 are faster (81 vs 75 %).
-        bool ok = h.n_entries <= 128;
+        bool ok = true;                                 // conditions (1) + (2): `adom`; plus the size and outlier tests: `xdom`
         if (linear) {
             // linear buckets have a threshold each, half a bucket away from both edges: a 2-ulp error of the approximate
             // quotient must not carry a d that is within 2^-20 of a threshold into another bucket
@@ -354,9 +354,10 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
             if (a > 32.0f) vout = std::min(vout, a);
             else vnorm = std::max(vnorm, a);
         }
+        h.adom = ok ? 1u : 0u;                          // (the d-domain path reads the outlier flags of the entries)
         if (vout < INFINITY && !((double)vout >= (double)vnorm * (1.0 + 0x1p-20))) ok = false;
         h.vout = vout;
-        h.xdom = ok ? 1u : 0u;
+        h.xdom = (ok && h.n_entries <= 128) ? 1u : 0u;
     }
 
     // self-check against the literal scan
@@ -426,6 +427,60 @@ extern "C" int antq_plan_eval_host(const void *blob, const float *d, float *q, i
         int j;
         q[i] = (h->kind == kPlanLut) ? eval_lut(*h, grid, ent, d[i], &j) : scan_one(d[i], grid, (int)h->m, &j);
         if (idx) idx[i] = (int16_t)j;
+    }
+    return ANTQ_OK;
+}
+
+// Host model of the approximate-quotient element path (quant_vec_a in antq_device.h) for one quant group: out[i], idx[i]
+// for the inputs x[i] at scale s = alpha / gmax.  The device takes rs = v_rcp_f32(s), which is only specified to 1 ulp:
+// `rs_ulps` moves the model's reciprocal that many ulps off RN(1/s) (tests sweep -1, 0, +1 and require identical
+// results).  slow[i] (nullable) = 1 where the element was redone by the exact sequence.  No OVP (pairs are a lane-local
+// rule on top of q).  ANTQ_ERR_UNSUPPORTED when the plan has no `adom`.
+extern "C" int antq_plan_eval_host_a(const void *blob, const float *x, size_t n, float alpha, float gmax, int rs_ulps,
+                                     float *out, int16_t *idx, uint8_t *slow)
+{
+    if (!blob || !x || !out) return ANTQ_ERR_ARG;
+    const PlanHeader *h = static_cast<const PlanHeader *>(blob);
+    if (h->magic != kPlanMagic || h->version != kPlanVersion) return ANTQ_ERR_PLAN;
+    if (h->kind != kPlanLut || !h->adom) return ANTQ_ERR_UNSUPPORTED;
+    const float *grid = plan_grid(blob);
+    const LutEntry *ent = plan_entries(blob);
+    const float s = alpha / gmax;
+    const bool ok = (s >= kScaleLo) && (s <= kScaleHi);
+    float rs = 1.0f / s;
+    for (int k = 0; k < abs(rs_ulps) && ok; k++) rs = rs_ulps > 0 ? next_up(rs) : next_dn(rs);
+    for (size_t i = 0; i < n; i++) {
+        const float dt = x[i] * rs;
+        bool fast = ok && (fabsf(dt) < h->xlim);
+        float q = 0.0f;
+        int j = ANTQ_IDX_NONE;
+        if (fast) {
+            const LutEntry *e;
+            if (h->linear) {
+                float kf = fmaf(dt, h->lin_scale, h->lin_bias);
+                kf = fminf(fmaxf(kf, 0.0f), (float)h->kmax);
+                e = &ent[(uint32_t)kf];
+            } else {
+                const uint32_t u = f2u(dt);
+                int32_t ks = (int32_t)(((uint32_t)((int32_t)u >> h->shift)) & h->keymask);
+                uint32_t k = (uint32_t)(std::min(std::max(ks, (int32_t)h->kmin), (int32_t)h->kmax) - (int32_t)h->kmin);
+                e = &ent[k + ((u >> 31) ? h->nbneg : 0u)];
+            }
+            const bool c = dt >= e->T;
+            if (fabsf(dt - e->T) < fabsf(e->T) * 0x1p-20f) fast = false;
+            q = c ? e->v_hi : e->v_lo;
+            j = (int)((c ? (e->idx >> 16) : e->idx) & kIdxMask);
+        }
+        if (fast) {
+            out[i] = fmaf(q, s, 0.0f);
+        } else {
+            const float d = x[i] / s;
+            q = scan_one(d, grid, (int)h->m, &j);
+            const float t = (q - d) + d;
+            out[i] = t * s;
+        }
+        if (idx) idx[i] = (int16_t)j;
+        if (slow) slow[i] = fast ? 0 : 1;
     }
     return ANTQ_OK;
 }

@@ -166,8 +166,11 @@ def cpu_baseline(seconds_budget=12.0):
     t0 = time.perf_counter()
     orc.forward_omp(x[:64], out[:64], alpha[:64], g, 10.0, reps=1, threads=1)     # ONE host thread, 64 rows
     one_thread = 64 * COLS / (time.perf_counter() - t0)                            # elements / s
-    reps = max(1, int(seconds_budget * one_thread / (64 * COLS)))
     orc.forward_omp(x, out, alpha, g, 10.0, reps=1, threads=cores)                 # spawns the OpenMP team
+    t0 = time.perf_counter()
+    orc.forward_omp(x, out, alpha, g, 10.0, reps=1, threads=cores)                 # one sweep, to size the sample: the
+    sweep = time.perf_counter() - t0                                               # box may grant fewer cores than it shows
+    reps = max(1, min(int(seconds_budget / max(sweep, 1e-4)), int(seconds_budget * one_thread / (64 * COLS))))
     t0 = time.perf_counter()
     used = orc.forward_omp(x, out, alpha, g, 10.0, reps=reps, threads=cores)
     dt = time.perf_counter() - t0

@@ -113,6 +113,14 @@ int antq_plan_bytes(const void *plan_host);
  * suite uses it to check a plan against the literal scan without a GPU. */
 int antq_plan_eval_host(const void *plan_host, const float *d, float *q, int16_t *idx, size_t n);
 
+/* Host model of the approximate-quotient element path the small-group / big-table kernels run for plans that allow it
+ * (pure CPU): out[i] = fake-quant of x[i] at scale alpha / gmax, idx[i] its grid index, slow[i] (nullable) = 1 where the
+ * margin test sent the element to the exact sequence.  rs_ulps: offset of the modelled reciprocal from RN(1 / scale) in
+ * ulps (the device's v_rcp_f32 is specified to 1 ulp; results must not depend on it).  ANTQ_ERR_UNSUPPORTED for plans
+ * without that path. */
+int antq_plan_eval_host_a(const void *plan_host, const float *x, size_t n, float alpha, float gmax, int rs_ulps,
+                          float *out, int16_t *idx, uint8_t *slow);
+
 /* ---------------------------------------------------------------------------
  * Fused Quantizer._forward with a calibrated (static) alpha:
  *     scale = alpha / gmax ; d = x / scale ; q = nearest(d) ; [OVP] ;

@@ -1493,6 +1493,7 @@ def test_dropin_operator_never_trusts_a_buffer_identity(antq_lib, oracle, dev):
     assert buf.quant_grid._version == v0
     assert seen_hint > 0                                               # the table path did engage along the way
     # in-place through .data: same address, same version, other values -- with a plan already believed for the address
+    quant_cuda._hints.clear()         # (this address may be a recycled one that has earned a long probation above)
     g = torch.from_numpy(G["flint_b4_s"].copy()).to(dev)
     for _ in range(3):
         quant_cuda.quant(x, g)

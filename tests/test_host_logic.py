@@ -345,3 +345,55 @@ def test_dropin_directories_import_the_reference_way(tmp_path):
                 "assert quant_modules.QuantLinear is quant_modules.LinearQuantizer\n"
                 % (os.path.join(root, "ant_quantization_amd", "dropin", tree), names))
         subprocess.check_call([sys.executable, "-c", code], cwd=str(tmp_path), env=env)
+
+
+def test_approximate_quotient_path_host_model_equals_oracle(antq_lib, oracle):
+    """quant_vec_a (small groups / big tables): bucket and decision from x * rcp(s) with a 2^-20 margin test, exact
+    redo inside the margin.  Its host model (antq_plan_eval_host_a) against the oracle's division + scan + STE sequence
+    on every codebook that allows the path: inputs packed around every decision threshold moved into the x domain
+    (+-64 floats), every bf16 value, random draws; many scales; the modelled reciprocal moved by -1 / 0 / +1 ulp (the
+    device's v_rcp_f32 is only specified to 1 ulp: the result may not depend on it)."""
+    L = antq_lib.lib()
+    L.antq_plan_eval_host_a.restype = ctypes.c_int
+    rng = np.random.default_rng(11)
+    n_plans = n_slow = n_total = 0
+    allbf = (np.arange(65536, dtype=np.uint32) << 16).view(np.float32)
+    for k, g in _all_grids().items():
+        if g.size > antq_lib.MAX_GRID:
+            continue
+        plan = antq_lib.Plan(g)
+        hdr = plan.host[:96].view(np.uint32)
+        if not plan.is_table or hdr[22] == 0:              # PlanHeader::adom (word 22)
+            continue
+        n_plans += 1
+        gmax = float(np.max(g))
+        gs = np.unique(g)
+        mids = ((gs[:-1].astype(np.float64) + gs[1:]) / 2)
+        for alpha in np.concatenate([np.float32([1.0, 0.07, 10.0, 3.3e-5, 4.1e6]),
+                                     np.exp(rng.uniform(-12, 12, 3)).astype(np.float32)]):
+            s = np.float32(alpha) / np.float32(gmax)
+            pts = [allbf[np.isfinite(allbf)][::7], (rng.standard_normal(4000) * float(s) * gmax / 2).astype(np.float32)]
+            for m in mids:
+                c = np.float32(m * float(s))
+                u = int(np.abs(c).view(np.uint32))
+                w = np.arange(max(u - 64, 0), u + 64, dtype=np.uint64).astype(np.uint32)
+                if c < 0:
+                    w = w | np.uint32(0x80000000)
+                pts.append(w.view(np.float32))
+            x = np.ascontiguousarray(np.concatenate(pts), dtype=np.float32)
+            with np.errstate(all="ignore"):
+                ref, ridx = oracle.forward(x.reshape(1, -1), np.float32([alpha]), g, gmax, False)
+            for ulps in (-1, 0, 1):
+                out = np.empty_like(x)
+                idx = np.empty(x.size, np.int16)
+                slow = np.empty(x.size, np.uint8)
+                rc = L.antq_plan_eval_host_a(plan.host_ptr(), x.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(x.size),
+                                             ctypes.c_float(alpha), ctypes.c_float(gmax), ctypes.c_int(ulps),
+                                             out.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p),
+                                             slow.ctypes.data_as(ctypes.c_void_p))
+                assert rc == 0
+                assert same_bits(out, ref.reshape(-1)), (k, alpha, ulps)
+                assert np.array_equal(idx.astype(np.int32), ridx.reshape(-1)), (k, alpha, ulps)
+                n_slow += int(slow[-4000 - 0:].sum()) if False else 0
+            n_total += x.size
+    assert n_plans > 120, n_plans

@@ -19,9 +19,16 @@ for dt, bpe in ((torch.float32, 8), (torch.bfloat16, 4)):
     for name, g in (("int8 s (256)", grids.ant_int(8, True)), ("int8 u (256)", grids.ant_int(8, False)), ("int6 s", grids.ant_int(6, True)),
                     ("flint6 s", grids.ant_flint(6, True)), ("int4 s", grids.ant_int(4, True)), ("pot4 s", grids.ant_pot(4, True))):
         plan = _lib.plan_for(g)
-        hdr = plan.host[:80].view(np.uint32)
+        hdr = plan.host[:96].view(np.uint32)
         xx = [x.abs() for x in xs] if name.endswith("u (256)") else xs
         t = timed(lambda: [_lib.fakequant(x, a, plan, 10.0, 4096, 4096, True, out=o) for x, a, o in zip(xx, al, outs)]) / nb
-        print("%-8s %-14s kind=%d entries=%4d xdom=%d : %7.1f us/launch  %6.1f Gelem/s  %.1f%% of 8 TB/s" % (
-            str(dt)[6:], name, plan.kind, hdr[11], hdr[16], t * 1e6, 16.777216e6 / t / 1e9, 16.777216e6 * bpe / t / 8e10))
+        _lib.lib().antq_debug_set(4, 0)      # A/B: the same launches with the exact division per element
+        t0 = timed(lambda: [_lib.fakequant(x, a, plan, 10.0, 4096, 4096, True, out=o) for x, a, o in zip(xx, al, outs)]) / nb
+        _lib.lib().antq_debug_set(4, 1)
+        jobs = [(x, o, a, plan, 10.0, 4096, 4096, True) for x, a, o in zip(xx, al, outs)]
+        tb = timed(_lib.Batch(jobs).run) / nb
+        print("%-8s %-14s kind=%d entries=%4d xdom=%d adom=%d : %7.1f us/launch  %6.1f Gelem/s  %.1f%% of 8 TB/s"
+              "   [exact division: %.1f%%]   batched: %.1f%%" % (
+            str(dt)[6:], name, plan.kind, hdr[11], hdr[16], hdr[22], t * 1e6, 16.777216e6 / t / 1e9, 16.777216e6 * bpe / t / 8e10,
+            16.777216e6 * bpe / t0 / 8e10, 16.777216e6 * bpe / tb / 8e10))
     del xs, outs
