@@ -346,134 +346,6 @@ __device__ __forceinline__ void quant_vec(const PlanArgs &pa, const PlanLds &L, 
     }
 }
 
-// ------------------------------------------------------------------------------------
-// Core, approximate-quotient form (plans with `adom`): the element loop without the exact division and without the
-// straight-through arithmetic.
-//     dt = x * rcp(s)                 within 2^-22 (relative) of d = fl(x / s): 1 ulp of v_rcp_f32, one rounding of
-//                                     the product, half an ulp of d itself
-//     bucket(dt) -> {T, v_lo, v_hi}   the plan builder guarantees that this bucket holds the threshold deciding d
-//                                     (thresholds within 2^-20 of a bucket edge are duplicated into the neighbour)
-//     q  = dt >= T ? v_hi : v_lo      the same decision as d >= T unless |dt - T| < 2^-20 |T|: such elements (about one
-//                                     in 10^5), elements with |dt| >= xlim, NaN / Inf and odd scales are redone by the
-//                                     exact reference sequence (true division, literal scan) -- per lane, rarely taken
-//     out = fl((q + 0) * s)           == ((q - d) + d) * s because the straight-through step is exact in every region
-//                                     (Sterbenz; checked per region by the plan builder), as one fma(q, s, +0)
-// ~11 VALU ops per element instead of ~18 (5-FMA division, fastlim test, STE add/sub, multiply).
-// sc.rs only needs to be rcp(s) here.
-// ------------------------------------------------------------------------------------
-template <int EPL, bool OVP, bool IDX>
-__device__ __forceinline__ void quant_vec_a(const PlanArgs &pa, const PlanLds &L, const Scale &sc, bool lanefast,
-                                            const float (&x)[EPL], float (&o)[EPL], int (&j)[EPL])
-{
-    float dt[EPL], q[EPL];
-    bool fast = lanefast;
-#pragma unroll
-    for (int e = 0; e < EPL; e++) {
-        dt[e] = x[e] * sc.rs;
-        fast = fast && (fabsf(dt[e]) < pa.xlim);  // false for NaN / Inf / far beyond the grid
-    }
-    uint32_t flags[EPL];
-    if (fast) {
-        uint4 ent[EPL];
-        if (pa.linear) {
-            const float khi = (float)pa.kmax;
-#pragma unroll
-            for (int e = 0; e < EPL; e++) {
-                const float kf = __builtin_amdgcn_fmed3f(__builtin_fmaf(dt[e], pa.lin_scale, pa.lin_bias), 0.0f, khi);
-                ent[e] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(L.lut) + ((uint32_t)kf << 4));
-            }
-        } else {
-            const int32_t sh4 = (int32_t)pa.shift - 4;                 // shift >= 13 always
-            const int32_t km16 = (int32_t)(pa.keymask << 4);
-            const int32_t lo16 = (int32_t)(pa.kmin << 4), hi16 = (int32_t)(pa.kmax << 4);
-            const uint32_t neg16 = pa.nbneg << 4;
-            const char *lut0 = reinterpret_cast<const char *>(L.lut) - lo16;
-#pragma unroll
-            for (int e = 0; e < EPL; e++) {
-                const int32_t u = (int32_t)f2u(dt[e]);
-                const int32_t t = (u >> sh4) & km16;
-                int32_t c16;
-                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c16) : "v"(t), "v"(lo16), "v"(hi16));
-                const uint32_t sg = (uint32_t)(u >> 31) & neg16;
-                ent[e] = *reinterpret_cast<const uint4 *>(lut0 + c16 + sg);
-            }
-        }
-        bool near = false;
-#pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            asm volatile("" : "+v"(ent[e].w));        // keep the read a single ds_read_b128
-            const float T = u2f(ent[e].x);
-            const bool c = dt[e] >= T;
-            // strict '<': a bucket without a threshold holds T = +inf, and inf < inf is false
-            near = near || (fabsf(dt[e] - T) < fabsf(T) * 0x1p-20f);
-            q[e] = c ? u2f(ent[e].z) : u2f(ent[e].y);
-            flags[e] = (c ? (ent[e].w >> 16) : ent[e].w) & 0xffffu;      // scan-order index, bit 15 = |v| > 32
-        }
-        fast = !near;
-    }
-    if (fast) {
-        if (IDX) {
-#pragma unroll
-            for (int e = 0; e < EPL; e++) j[e] = (int)(flags[e] & kIdxMask);
-        }
-        if (OVP) {
-#pragma unroll
-            for (int p = 0; p < EPL / 2; p++) {
-                const bool me = (flags[2 * p] & 0x8000u) != 0u, mo = (flags[2 * p + 1] & 0x8000u) != 0u;
-                const bool ve = mo && !me;
-                q[2 * p] = ve ? 0.0f : q[2 * p];          // ((q*0 - d) + d) * s == +0 for s > 0
-                q[2 * p + 1] = me ? 0.0f : q[2 * p + 1];
-                if (IDX) {
-                    if (ve) j[2 * p] = ANTQ_IDX_VICTIM;
-                    if (me) j[2 * p + 1] = ANTQ_IDX_VICTIM;
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPL; e++) o[e] = __builtin_fmaf(q[e], sc.s, 0.0f);   // (q + 0) * s in one rounding: -0.0 -> +0.0
-    } else {
-        // exact reference sequence for this lane's EPL elements
-        float d[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            d[e] = x[e] / sc.s;
-            int jj;
-            q[e] = scan_lds(d[e], L.grid, (int)pa.m, jj);
-            if (IDX) j[e] = jj;
-        }
-        if (OVP) {
-#pragma unroll
-            for (int p = 0; p < EPL / 2; p++) {
-                const bool me = fabsf(q[2 * p]) > 32.0f;
-                const bool mo = fabsf(q[2 * p + 1]) > 32.0f;
-                const bool ve = mo && !me;
-                q[2 * p] = q[2 * p] * (ve ? 0.0f : 1.0f);
-                q[2 * p + 1] = q[2 * p + 1] * (me ? 0.0f : 1.0f);
-                if (IDX) {
-                    if (ve) j[2 * p] = ANTQ_IDX_VICTIM;
-                    if (me) j[2 * p + 1] = ANTQ_IDX_VICTIM;
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            const float t = (q[e] - d[e]) + d[e];
-            o[e] = t * sc.s;
-        }
-    }
-}
-
-// Scale for quant_vec_a: s exactly as the reference divides it (AQ:536), the reciprocal only approximately.
-__device__ __forceinline__ Scale make_scale_a(float alpha, float gmax)
-{
-    Scale sc;
-    sc.s = alpha / gmax;
-    const float a = sc.s;                               // lanefast needs s > 0 and inside [2^-40, 2^40]
-    sc.ok = (a >= kScaleLo) && (a <= kScaleHi);
-    sc.rs = __builtin_amdgcn_rcpf(sc.s);
-    return sc;
-}
-
 template <int EPL>
 __device__ __forceinline__ void store_idx(int16_t *idx, size_t vec, const int (&j)[EPL])
 {

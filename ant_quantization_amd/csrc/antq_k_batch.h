@@ -113,7 +113,7 @@ k_fq_batch_d(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ b
         return;
     }
     uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    if ((!AD || D.kind == 3) && threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     if (D.kind == 0) {
         const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
@@ -121,10 +121,13 @@ k_fq_batch_d(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ b
         uint4 v[U];
         float a;
         task_load<T, U>(D.x, D.alpha, D.per_row, active ? task : total - 1u, vpr, tpr, lane, DYN, v, a);
-        const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+        PlanLds L;
+        ATab A;
+        if (AD) A = stage_atab<false>(pa, plan_tab, smem);
+        else L = stage_plan(pa, plan_tab, smem, tab0);
         __syncthreads();
         if (active)
-            task_run<T, OVP, false, U, DYN, AD ? 1 : 0>(D.out, nullptr, alpha_out, D.ratio, task, vpr, tpr, lane, D.gmax, pa, L, v, a);
+            task_run<T, OVP, false, U, DYN, AD ? 1 : 0>(D.out, nullptr, alpha_out, D.ratio, task, vpr, tpr, lane, D.gmax, pa, L, A, v, a);
     } else if (!DYN) {
         const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
         __syncthreads();

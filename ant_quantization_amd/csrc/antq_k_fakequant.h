@@ -4,6 +4,7 @@
 #define ANTQ_K_FAKEQUANT_H
 
 #include "antq_device.h"
+#include "antq_k_approx.h"
 
 namespace antq {
 
@@ -51,7 +52,7 @@ template <typename T, bool OVP, bool IDX, int U, bool DYN, int ADM = -1>
 __device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__restrict__ idx,
                                          float *__restrict__ alpha_out, float ratio,
                                          uint32_t task, uint32_t vpr, uint32_t tpr, uint32_t lane, float gmax,
-                                         const PlanArgs &pa, const PlanLds &L, const uint4 (&v)[U], float a)
+                                         const PlanArgs &pa, const PlanLds &L, const ATab &A, const uint4 (&v)[U], float a)
 {
     constexpr int EPL = IO<T>::EPL;
     uint32_t row = task, g = 0;
@@ -75,14 +76,16 @@ __device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__res
     // plans with `adom` (every ANT / OliVe codebook whose table is too big for a per-row copy: int-8, flint-5..8, ...):
     // approximate quotient + margin test instead of the exact division per element (wave-uniform choice)
     const bool ad = ADM < 0 ? (pa.adom != 0u) : (ADM != 0);
-    const Scale sc = ad ? make_scale_a(a, gmax) : make_scale(a, gmax);
+    ScaleA sa;
+    Scale sc;
+    if (ad) sa = make_scale_a(a, gmax); else sc = make_scale(a, gmax);
 #pragma unroll
     for (int u = 0; u < U; u++) {
         if (v0 + 64u * u < vpr) {
             float xf[EPL], of[EPL];
             int j[EPL];
             IO<T>::unpack(v[u], xf);
-            if (ad) quant_vec_a<EPL, OVP, IDX>(pa, L, sc, sc.ok, xf, of, j);
+            if (ad) quant_vec_a<EPL, OVP, IDX>(pa, A, sa, xf, of, j);
             else quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);
             st_stream(out + base + 64u * u, IO<T>::pack(of));
             if (IDX) store_idx<EPL>(idx, base + 64u * u, j);
@@ -106,23 +109,26 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
     // table fetch is issued FIRST (L2 hit) so that its wait (vmcnt is in-order) does not
     // also wait for the HBM loads of the task, which are issued right behind it
     uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    if (!pa.adom && threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
 
     uint4 v[U];
     float a;
     bool active = task < total_tasks;
     task_load<T, U>(x, alpha, per_row, active ? task : total_tasks - 1u, vpr, tpr, lane, DYN, v, a);
 
-    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    PlanLds L;
+    ATab A;
+    if (pa.adom) A = stage_atab<IDX>(pa, plan_tab, smem);      // (tab0 unused: the table is converted entry by entry)
+    else L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
     // Big tables (8-bit grids: up to 48 KiB) are staged once per workgroup and amortised over a
     // grid-stride loop of tasks; small tables use a one-shot grid (loop runs once).
     if (!LOOP) {
-        if (active) task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
+        if (active) task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, A, v, a);
         return;
     }
     while (active) {
-        task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, v, a);
+        task_run<T, OVP, IDX, U, DYN>(out, idx, alpha_out, ratio, task, vpr, tpr, lane, gmax, pa, L, A, v, a);
         task += stride;
         active = task < total_tasks;
         if (active) task_load<T, U>(x, alpha, per_row, task, vpr, tpr, lane, DYN, v, a);
@@ -406,7 +412,7 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
 {
     constexpr int EPL = IO<T>::EPL;
     uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    if (!AD && threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     uint4 v[U];
     float a[U];
 #pragma unroll
@@ -423,7 +429,10 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
             }
         }
     }
-    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    PlanLds L;
+    ATab A;
+    if (AD) A = stage_atab<IDX>(pa, plan_tab, smem);
+    else L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -442,8 +451,8 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
             float of[EPL];
             int j[EPL];
             if (AD) {
-                const Scale sc = make_scale_a(a[u], gmax);
-                quant_vec_a<EPL, OVP, IDX>(pa, L, sc, sc.ok, xf, of, j);
+                const ScaleA sc = make_scale_a(a[u], gmax);
+                quant_vec_a<EPL, OVP, IDX>(pa, A, sc, xf, of, j);
             } else {
                 const Scale sc = make_scale(a[u], gmax);
                 quant_vec<EPL, OVP, IDX>(pa, L, sc, xf, of, j);

@@ -77,6 +77,13 @@ static inline const uint4 *plan_tab_ptr(const void *plan_dev)
     return reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev) + sizeof(PlanHeader));
 }
 
+// dynamic LDS of a kernel that stages the plan's table (stage_plan) or, for plans with adom, its converted image (stage_atab)
+static inline size_t lds_table(const PlanArgs &pa, bool idx)
+{
+    const size_t plain = (size_t)pa.tab_units * 16;
+    return pa.adom ? std::max(plain, atab_bytes(pa.n_entries, pa.nbneg, pa.linear, pa.m_pad, idx)) : plain;
+}
+
 template <typename T, bool OVP, bool IDX, bool DYN>
 static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, size_t vpr, const float *alpha,
                           int per_row, float gmax, float ratio, float *alpha_out, const PlanArgs &pa,
@@ -176,7 +183,7 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
 {
     constexpr int EPL = IO<T>::EPL;
     const size_t n = rows * row_len;
-    const size_t lds = (size_t)pa.tab_units * 16;
+    const size_t lds = lds_table(pa, IDX);
     const uint4 *tab = plan_tab_ptr(plan_dev);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
                          (!idx || reinterpret_cast<uintptr_t>(idx) % 16 == 0);
@@ -454,7 +461,7 @@ static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_o
                           float ratio, float gmax, const PlanArgs &pa, const void *plan_host, const void *plan_dev, hipStream_t st)
 {
     constexpr int EPL = IO<T>::EPL;
-    const size_t lds = (size_t)pa.tab_units * 16;
+    const size_t lds = lds_table(pa, IDX);
     const uint4 *tab = plan_tab_ptr(plan_dev);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
                          (!idx || reinterpret_cast<uintptr_t>(idx) % 16 == 0);
@@ -733,7 +740,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         descs[i] = d;
         fam[(size_t)i] = (uint8_t)(f < 0 ? 255 : f);
         nblk[(size_t)i] = blocks;
-        if (f != 0 && f != 3) lds = std::max(lds, (size_t)d.pa.tab_units * 16);
+        if (f != 0 && f != 3) lds = std::max(lds, lds_table(d.pa, false));
     }
     // element-granular jobs (exact arithmetic, no table path) ride along with whichever d-domain launch exists
     for (int i = 0; i < n; i++)

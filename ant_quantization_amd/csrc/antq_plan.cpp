@@ -431,11 +431,12 @@ extern "C" int antq_plan_eval_host(const void *blob, const float *d, float *q, i
     return ANTQ_OK;
 }
 
-// Host model of the approximate-quotient element path (quant_vec_a in antq_device.h) for one quant group: out[i], idx[i]
-// for the inputs x[i] at scale s = alpha / gmax.  The device takes rs = v_rcp_f32(s), which is only specified to 1 ulp:
-// `rs_ulps` moves the model's reciprocal that many ulps off RN(1/s) (tests sweep -1, 0, +1 and require identical
-// results).  slow[i] (nullable) = 1 where the element was redone by the exact sequence.  No OVP (pairs are a lane-local
-// rule on top of q).  ANTQ_ERR_UNSUPPORTED when the plan has no `adom`.
+// Host model of the approximate-quotient element path (quant_vec_a in antq_k_approx.h) for one quant group: out[i],
+// idx[i] for the inputs x[i] at scale s = alpha / gmax: bucket from x * rs, decision from the sign of the exactly
+// rounded x - M' * s in double (M' = the rounding boundary below the bucket's threshold, nudged up for odd thresholds).
+// The device takes rs = v_rcp_f32(s), which is only specified to 1 ulp: `rs_ulps` moves the model's reciprocal that many
+// ulps off RN(1/s) (tests sweep it and require identical results).  slow[i] (nullable) = 1 where the element took the
+// literal sequence.  No OVP (pairs are a lane-local rule on top of q).  ANTQ_ERR_UNSUPPORTED when the plan has no `adom`.
 extern "C" int antq_plan_eval_host_a(const void *blob, const float *x, size_t n, float alpha, float gmax, int rs_ulps,
                                      float *out, int16_t *idx, uint8_t *slow)
 {
@@ -449,9 +450,16 @@ extern "C" int antq_plan_eval_host_a(const void *blob, const float *x, size_t n,
     const bool ok = (s >= kScaleLo) && (s <= kScaleHi);
     float rs = 1.0f / s;
     for (int k = 0; k < abs(rs_ulps) && ok; k++) rs = rs_ulps > 0 ? next_up(rs) : next_dn(rs);
+    auto boundary = [](float T) -> double {
+        if (!(T < INFINITY)) return (double)INFINITY;
+        const float P = next_dn(T);
+        const double M = 0.5 * ((double)P + (double)T);
+        if ((f2u(T) & 1u) == 0u) return M;
+        return nextafter(M, (double)INFINITY);
+    };
     for (size_t i = 0; i < n; i++) {
         const float dt = x[i] * rs;
-        bool fast = ok && (fabsf(dt) < h->xlim);
+        const bool fast = ok && (fabsf(dt) < h->xlim);
         float q = 0.0f;
         int j = ANTQ_IDX_NONE;
         if (fast) {
@@ -464,15 +472,13 @@ extern "C" int antq_plan_eval_host_a(const void *blob, const float *x, size_t n,
                 const uint32_t u = f2u(dt);
                 int32_t ks = (int32_t)(((uint32_t)((int32_t)u >> h->shift)) & h->keymask);
                 uint32_t k = (uint32_t)(std::min(std::max(ks, (int32_t)h->kmin), (int32_t)h->kmax) - (int32_t)h->kmin);
-                e = &ent[k + ((u >> 31) ? h->nbneg : 0u)];
+                // an unsigned grid (nbneg == 0) sends every negative dt to bucket 0, as the device's odd slots do
+                e = (h->nbneg == 0u && (u >> 31)) ? &ent[0] : &ent[k + ((u >> 31) ? h->nbneg : 0u)];
             }
-            const bool c = dt >= e->T;
-            if (fabsf(dt - e->T) < fabsf(e->T) * 0x1p-20f) fast = false;
-            q = c ? e->v_hi : e->v_lo;
+            const bool c = fma(-boundary(e->T), (double)s, (double)x[i]) >= 0.0;
+            q = (c ? e->v_hi : e->v_lo) + 0.0f;
             j = (int)((c ? (e->idx >> 16) : e->idx) & kIdxMask);
-        }
-        if (fast) {
-            out[i] = fmaf(q, s, 0.0f);
+            out[i] = q * s;
         } else {
             const float d = x[i] / s;
             q = scan_one(d, grid, (int)h->m, &j);
