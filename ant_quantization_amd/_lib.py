@@ -21,7 +21,7 @@ FLAG_DYNAMIC = 2
 IDX_NONE = -1
 IDX_VICTIM = -2
 MAX_GRID = 1024
-PLAN_MAX_BYTES = 96 + 4 * MAX_GRID + 16 * 3072
+PLAN_MAX_BYTES = 96 + 4 * MAX_GRID + 16 * 3072 + 20 * 1024
 
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.float64: F64}
 

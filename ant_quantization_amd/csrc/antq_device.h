@@ -118,6 +118,10 @@ template <> struct IO<f16_tag> {
     }
     __device__ __forceinline__ static uint32_t f2h(float f)
     {
+        // The fp32 result is rounded to half as a SECOND rounding (what `tensor.to(torch.float16)` does to an fp32
+        // tensor).  Without the barrier LLVM folds "fp32 multiply, then convert" into v_fma_mixlo_f16, which rounds
+        // the exact product to half once -- a different number about once in 2^13 elements.
+        asm volatile("" : "+v"(f));
         _Float16 h = (_Float16)f;
         return (uint32_t) * reinterpret_cast<uint16_t *>(&h);
     }
@@ -174,6 +178,7 @@ struct PlanArgs {
     float lin_bias;
     uint32_t adom;       // PlanHeader::adom: the approximate-quotient path (quant_vec_a) may be used
     float xlim;          // PlanHeader::xlim: |x * rcp(s)| below this -> table path of quant_vec_a
+    uint32_t atab_slots; // PlanHeader::atab_slots: entries of the a-table behind the plan's entries (adom plans)
 };
 
 // LDS view of the plan: [entries | grid]

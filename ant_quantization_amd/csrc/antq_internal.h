@@ -5,7 +5,7 @@
 namespace antq {
 
 constexpr uint32_t kPlanMagic = 0x51544E41u;  // "ANTQ"
-constexpr uint32_t kPlanVersion = 7;
+constexpr uint32_t kPlanVersion = 8;
 
 constexpr uint32_t kPlanScan = 0;  // kernels run the literal scan for every element
 constexpr uint32_t kPlanLut = 1;   // table plan: one LDS lookup + one compare per element
@@ -57,7 +57,7 @@ struct PlanHeader {      // 80 bytes
     // region for |d| < xlim, so out = fl((q+0)*s).  Elements whose approximate quotient lies within 2^-20 (relative)
     // of their bucket's threshold are redone with the true division.
     uint32_t adom;
-    uint32_t reserved[1];
+    uint32_t atab_slots;  // adom plans: number of a-table slots stored behind the entries (see blob layout below)
 };
 static_assert(sizeof(PlanHeader) == 96, "PlanHeader must be 96 bytes");
 
@@ -75,7 +75,20 @@ struct LutEntry {
 };
 static_assert(sizeof(LutEntry) == 16, "LutEntry must be 16 bytes");
 
+// The decision table of the approximate-quotient path (antq_k_approx.h), one slot per bucket: slot = bucket for a linear
+// key, 2 * (bucket - kmin) + sign for a float-bits key (an unsigned grid's odd slots all hold the lowest bucket).
+//   q = (x - Mp * s >= 0, one correctly rounded fma in double) ? v_hi : v_lo
+struct ATabEntry {
+    double Mp;     // the rounding boundary below the bucket's threshold T (mid-point of pred(T) and T), moved to the next
+                   // double above it when T's mantissa is odd (a tie then rounds DOWN to pred(T)); +inf: no threshold
+    float v_lo;    // -0.0 stored as +0.0, as the reference's (q - d) + d yields
+    float v_hi;
+};
+static_assert(sizeof(ATabEntry) == 16, "ATabEntry must be 16 bytes");
+constexpr uint32_t kATabMaxSlots = 1024;   // 16 KiB of LDS; bigger tables keep the exact-division path
+
 // blob layout:  PlanHeader | float grid[m_pad] | LutEntry entries[n_entries]
+//               | ATabEntry atab[atab_slots] | uint32 aidx[atab_slots rounded up to 4]      (adom plans only)
 inline const float *plan_grid(const void *blob)
 {
     return reinterpret_cast<const float *>(static_cast<const char *>(blob) + sizeof(PlanHeader));

@@ -48,68 +48,46 @@ __device__ __forceinline__ ScaleA make_scale_a(float alpha, float gmax)
     return sc;
 }
 
-// LDS image: [slots x {double M'; float v_lo; float v_hi}] [grid: m_pad floats] [IDX only: slots x packed index pair]
+// The a-table is part of the plan blob (built once per grid on the host, antq_plan.cpp): behind the plan's entries,
+//     atab[slots] x {double M'; float v_lo; float v_hi}     slot = bucket (linear key), or 2 * bucket + sign
+//     aidx[slots] x packed index pair (as LutEntry::idx)     read only when an index output is wanted
+// LDS image, staged per workgroup by a plain copy: [atab] [grid: m_pad floats] [IDX only: aidx]
 struct ATab {
     const char *tab;
     const float *grid;
     const uint32_t *idx;
 };
-__host__ __device__ inline uint32_t atab_slots(uint32_t n_entries, uint32_t nbneg, uint32_t linear)
+__host__ __device__ inline uint32_t atab_units(uint32_t slots, uint32_t m_pad, bool idx)
 {
-    return linear ? n_entries : 2u * (n_entries - nbneg);       // float-bits key: positive / negative buckets interleaved
-}
-__host__ __device__ inline size_t atab_bytes(uint32_t n_entries, uint32_t nbneg, uint32_t linear, uint32_t m_pad, bool idx)
-{
-    const size_t slots = atab_slots(n_entries, nbneg, linear);
-    return slots * 16u + (size_t)m_pad * 4u + (idx ? slots * 4u : 0u);
+    return slots + (m_pad >> 2) + (idx ? ((slots + 3u) >> 2) : 0u);      // 16-byte units to stage
 }
 
-__device__ __forceinline__ double atab_boundary(float T)
+// first = the caller's early fetch of atab_src(threadIdx.x) (issued ahead of its HBM loads, like stage_plan's)
+__device__ __forceinline__ uint4 atab_src(const PlanArgs &pa, const uint4 *__restrict__ plan_tab, uint32_t i)
 {
-    if (!(T < __builtin_inff())) return (double)__builtin_inff();       // bucket without a threshold: never >=
-    const uint32_t u = f2u(T);
-    const float P = u2f((int32_t)u >= 0 ? u - 1u : u + 1u);             // pred(T): next float towards -inf (T != 0)
-    const double M = 0.5 * ((double)P + (double)T);
-    if ((u & 1u) == 0u) return M;                                       // even T: a tie rounds up to T
-    const long long b = __double_as_longlong(M);
-    return __longlong_as_double(M > 0.0 ? b + 1 : b - 1);               // odd T: strictly above M (M != 0)
+    // plan_tab: [grid m_pad/4 units][entries n_entries units][atab slots units][aidx]
+    const uint32_t gu = pa.m_pad >> 2, s = pa.atab_slots;
+    const uint4 *at = plan_tab + gu + pa.n_entries;
+    return i < s ? at[i] : (i < s + gu ? plan_tab[i - s] : at[i - gu]);
 }
-
 template <bool IDX>
-__device__ __forceinline__ ATab stage_atab(const PlanArgs &pa, const uint4 *__restrict__ plan_tab, uint4 *smem)
+__device__ __forceinline__ ATab stage_atab(const PlanArgs &pa, const uint4 *__restrict__ plan_tab, uint4 *smem, uint4 first)
 {
-    const uint32_t slots = atab_slots(pa.n_entries, pa.nbneg, pa.linear);
-    const uint4 *entries = plan_tab + (pa.m_pad >> 2);
-    uint4 *tab = smem;
-    float *grid = reinterpret_cast<float *>(smem + slots);
-    uint32_t *idx = reinterpret_cast<uint32_t *>(grid + pa.m_pad);
-    const uint32_t nbp = pa.n_entries - pa.nbneg;
-    const bool lin = pa.linear != 0u;
-    const bool one_sided = !lin && pa.nbneg == 0u;      // unsigned grid: every negative x belongs to the lowest region
-    auto conv = [](const uint4 &e) {
-        const double Mp = atab_boundary(u2f(e.x));
-        const unsigned long long mb = (unsigned long long)__double_as_longlong(Mp);
-        return make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), f2u(u2f(e.y) + 0.0f), f2u(u2f(e.z) + 0.0f));
-    };
-    uint4 e0 = make_uint4(0, 0, 0, 0);
-    if (one_sided) e0 = entries[0];
-    for (uint32_t i = threadIdx.x; i < pa.n_entries; i += blockDim.x) {
-        const uint4 e = entries[i];
-        const uint32_t slot = lin ? i : (i < nbp ? 2u * i : 2u * (i - nbp) + 1u);
-        tab[slot] = conv(e);
-        if (IDX) idx[slot] = e.w;
-        if (one_sided) {
-            tab[2u * i + 1u] = conv(e0);
-            if (IDX) idx[2u * i + 1u] = e0.w;
-        }
-    }
-    const float *g = reinterpret_cast<const float *>(plan_tab);
-    for (uint32_t i = threadIdx.x; i < pa.m_pad; i += blockDim.x) grid[i] = g[i];
+    const uint32_t units = atab_units(pa.atab_slots, pa.m_pad, IDX);
+    if (threadIdx.x < units) smem[threadIdx.x] = first;
+    for (uint32_t i = threadIdx.x + blockDim.x; i < units; i += blockDim.x) smem[i] = atab_src(pa, plan_tab, i);
     ATab A;
-    A.tab = reinterpret_cast<const char *>(tab);
-    A.grid = grid;
-    A.idx = idx;
+    A.tab = reinterpret_cast<const char *>(smem);
+    A.grid = reinterpret_cast<const float *>(smem + pa.atab_slots);
+    A.idx = reinterpret_cast<const uint32_t *>(smem + pa.atab_slots + (pa.m_pad >> 2));
     return A;
+}
+template <bool IDX>
+__device__ __forceinline__ uint4 atab_prefetch(const PlanArgs &pa, const uint4 *__restrict__ plan_tab)
+{
+    uint4 first = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < atab_units(pa.atab_slots, pa.m_pad, IDX)) first = atab_src(pa, plan_tab, threadIdx.x);
+    return first;
 }
 
 template <int EPL, bool OVP, bool IDX>

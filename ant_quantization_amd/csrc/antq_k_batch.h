@@ -33,7 +33,7 @@ struct BatchDesc {   // 152 bytes, device-visible
     PlanArgs pa;
     float vout;            // PlanHeader::vout (x-domain kinds)
     float ratio;           // ANTQ_FLAG_DYNAMIC: alpha = max|row| * ratio
-    uint32_t pad[2];
+    uint32_t pad[1];
 };
 static_assert(sizeof(BatchDesc) == 152, "BatchDesc must be 152 bytes");
 
@@ -43,14 +43,16 @@ static_assert(sizeof(BatchDesc) == 152, "BatchDesc must be 152 bytes");
 //   family 1  k_fq_batch_d<AD>  d-domain table, approximate-quotient elements (plans with adom): kinds 0, 1 (+ 3)
 //   family 2  k_fq_batch_d      d-domain table, exact division (scan plans, arbitrary value lists): kinds 0, 1, 3
 //   family 3  k_fq_batch_dyn    ANTQ_FLAG_DYNAMIC rows of >= 128 vectors with an x-domain plan: kinds 4..7
+//   family 4  k_fq_batch_dyn16  the same for rows of 2049..8192 vectors, one row per 1024-thread workgroup: kinds 9, 10
 // (with ANTQ_FLAG_DYNAMIC families 1 / 2 run their DYN instantiation: groups of <= 64 vectors, rows of <= 256 vectors)
-constexpr int kBatchFamilies = 4;
+constexpr int kBatchFamilies = 5;
 
-struct BatchHeader {   // 48 bytes
+struct BatchHeader {   // 56 bytes
     uint32_t magic, n, dtype, flags, lds_bytes, map_offset, bytes, total_blocks;
     uint32_t fam_blocks[kBatchFamilies];
+    uint32_t pad;
 };
-static_assert(sizeof(BatchHeader) == 48, "BatchHeader must be 48 bytes");
+static_assert(sizeof(BatchHeader) == 56, "BatchHeader must be 56 bytes");
 
 __device__ __forceinline__ XArgs xargs_of(const BatchDesc &D)
 {
@@ -113,7 +115,8 @@ k_fq_batch_d(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ b
         return;
     }
     uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if ((!AD || D.kind == 3) && threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    if (AD && D.kind == 0) tab0 = atab_prefetch<false>(pa, plan_tab);
+    else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     if (D.kind == 0) {
         const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
@@ -123,7 +126,7 @@ k_fq_batch_d(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ b
         task_load<T, U>(D.x, D.alpha, D.per_row, active ? task : total - 1u, vpr, tpr, lane, DYN, v, a);
         PlanLds L;
         ATab A;
-        if (AD) A = stage_atab<false>(pa, plan_tab, smem);
+        if (AD) A = stage_atab<false>(pa, plan_tab, smem, tab0);
         else L = stage_plan(pa, plan_tab, smem, tab0);
         __syncthreads();
         if (active)
@@ -172,6 +175,32 @@ k_fq_batch_dyn(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__
         xrow_task<T, OVP, false, 8, true, 4>(D.x, D.out, nullptr, task, D.vpr, 4u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
                                              entries, grid, wtab_all[wv], lane, wv);
     }
+}
+
+// Family 4.  Rows of 2049..8192 vectors (C4's 28 672-wide rows): one row per 1024-thread workgroup, 4 or 8 vectors per lane.
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(1024)
+k_fq_batch_dyn16(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
+{
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[16][256];
+    const uint32_t j = block_map[blockIdx.x];
+    const BatchDesc &D = descs[j];
+    const PlanArgs pa = D.pa;
+    const uint32_t lb = blockIdx.x - D.first_block;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint4 *plan_tab = D.plan_tab;
+    const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 16u + wv);
+    const XArgs xa = xargs_of(D);
+    float *alpha_out = const_cast<float *>(D.alpha);
+    const uint4 *entries = plan_tab + (pa.m_pad >> 2);
+    const float *grid = reinterpret_cast<const float *>(plan_tab);
+    if (D.kind == 9)
+        xrow_task<T, OVP, false, 4, true, 16>(D.x, D.out, nullptr, task, D.vpr, 16u, nullptr, 1, D.gmax, D.ratio, alpha_out, xa,
+                                              entries, grid, wtab_all[wv], lane, wv);
+    else
+        xrow_task<T, OVP, false, 8, true, 16>(D.x, D.out, nullptr, task, D.vpr, 16u, nullptr, 1, D.gmax, D.ratio, alpha_out, xa,
+                                              entries, grid, wtab_all[wv], lane, wv);
 }
 
 static int epl_of(int dtype) { return dtype == ANTQ_F32 ? 4 : (dtype == ANTQ_BF16 || dtype == ANTQ_F16) ? 8 : 0; }

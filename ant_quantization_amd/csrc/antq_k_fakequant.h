@@ -109,7 +109,8 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
     // table fetch is issued FIRST (L2 hit) so that its wait (vmcnt is in-order) does not
     // also wait for the HBM loads of the task, which are issued right behind it
     uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if (!pa.adom && threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    if (pa.adom) tab0 = atab_prefetch<IDX>(pa, plan_tab);
+    else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
 
     uint4 v[U];
     float a;
@@ -118,7 +119,7 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
 
     PlanLds L;
     ATab A;
-    if (pa.adom) A = stage_atab<IDX>(pa, plan_tab, smem);      // (tab0 unused: the table is converted entry by entry)
+    if (pa.adom) A = stage_atab<IDX>(pa, plan_tab, smem, tab0);
     else L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
     // Big tables (8-bit grids: up to 48 KiB) are staged once per workgroup and amortised over a
@@ -349,12 +350,14 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
         for (int u = 0; u < U; u++)
             if (v0 + 64u * u < vpr) m = IO<T>::amax_acc(m, v[u]);
         m = wave_max_u32(IO<T>::amax_bits(m));
-        if (WPR == 4) {
-            // the row spans the 4 wavefronts of this workgroup (tpr == 4): combine their maxima
-            __shared__ uint32_t wmax[4];
+        if (WPR > 1) {
+            // the row spans the WPR (4 or 16) wavefronts of this workgroup (tpr == WPR): combine their maxima
+            __shared__ uint32_t wmax[WPR];
             if (lane == 0) wmax[wv] = m;
             __syncthreads();
-            m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+            m = wmax[0];
+#pragma unroll
+            for (int w = 1; w < WPR; w++) m = max(m, wmax[w]);
         }
         a = u2f(m) * ratio;
         if (alpha_out && lane == 0 && (WPR == 1 || wv == 0)) alpha_out[row] = a;
@@ -378,19 +381,22 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
     }
 }
 
+// WPR = 16 (DYN only): rows of up to 64 * U * 16 = 4096 / 8192 vectors (C4's 28 672-wide rows: 3584 bf16 / 7168 fp32
+// vectors) held in the registers of ONE 1024-thread workgroup -- abs-max and quantisation on a single HBM read.
 template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR = 1>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WPR > 4 ? 64 * WPR : 256)
 k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
           uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
           const float *__restrict__ alpha, int per_row, float gmax, float ratio,
           float *__restrict__ alpha_out, XArgs xa, const uint4 *__restrict__ entries,
           const float *__restrict__ grid)
 {
-    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
+    constexpr uint32_t WAVES = WPR > 4 ? WPR : 4;
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[WAVES][256];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
-    if (task >= total_tasks) return;   // no workgroup barrier in this kernel (WPR == 4: whole workgroups exit)
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wv);
+    if (task >= total_tasks) return;   // no workgroup barrier in this kernel (WPR > 1: whole workgroups exit)
     xrow_task<T, OVP, IDX, U, DYN, WPR>(x, out, idx, task, vpr, tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries,
                                         grid, wtab_all[wv], lane, wv);
 }
@@ -412,7 +418,8 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
 {
     constexpr int EPL = IO<T>::EPL;
     uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if (!AD && threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    if (AD) tab0 = atab_prefetch<IDX>(pa, plan_tab);
+    else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     uint4 v[U];
     float a[U];
 #pragma unroll
@@ -431,7 +438,7 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
     }
     PlanLds L;
     ATab A;
-    if (AD) A = stage_atab<IDX>(pa, plan_tab, smem);
+    if (AD) A = stage_atab<IDX>(pa, plan_tab, smem, tab0);
     else L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
 #pragma unroll

@@ -69,6 +69,7 @@ static bool plan_args_from_host(const void *plan_host, PlanArgs &pa)
     pa.lin_bias = h->lin_bias;
     pa.adom = (h->kind == kPlanLut && g_knob_a != 0) ? h->adom : 0u;
     pa.xlim = h->xlim;
+    pa.atab_slots = h->atab_slots;
     return true;
 }
 
@@ -81,7 +82,7 @@ static inline const uint4 *plan_tab_ptr(const void *plan_dev)
 static inline size_t lds_table(const PlanArgs &pa, bool idx)
 {
     const size_t plain = (size_t)pa.tab_units * 16;
-    return pa.adom ? std::max(plain, atab_bytes(pa.n_entries, pa.nbneg, pa.linear, pa.m_pad, idx)) : plain;
+    return pa.adom ? std::max(plain, (size_t)atab_units(pa.atab_slots, pa.m_pad, idx) * 16) : plain;
 }
 
 template <typename T, bool OVP, bool IDX, bool DYN>
@@ -93,14 +94,15 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const uint4 *tab = plan_tab_ptr(plan_dev);
     const uint4 *xv = static_cast<const uint4 *>(x);
     uint4 *ov = static_cast<uint4 *>(out);
-    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr && (!DYN || vpr <= 2048);
+    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr && (!DYN || vpr <= 8192);
     if (use_x) {
         // x-domain row kernel: 4 or 8 KiB of one row per wavefront (the per-row table is rebuilt per task)
         int U = 4;   // 4 KiB of the row per wavefront measured best at steady clocks (79 % of 8 TB/s on 1 GiB)
-        if (DYN) U = (vpr <= 256 || (vpr > 512 && vpr <= 1024)) ? 4 : 8;
+        if (DYN) U = (vpr <= 256 || (vpr > 512 && vpr <= 1024) || (vpr > 2048 && vpr <= 4096)) ? 4 : 8;
         if (g_knob_u) U = DYN ? U : g_knob_u;
-        const bool wpr4 = DYN && vpr > 512;            // one row per workgroup: 4 wavefronts x U x 64 vectors
-        const size_t tpr = wpr4 ? 4 : (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
+        const bool wpr4 = DYN && vpr > 512 && vpr <= 2048;   // one row per workgroup: 4 wavefronts x U x 64 vectors
+        const bool wpr16 = DYN && vpr > 2048;                // one row per 1024-thread workgroup: 16 wavefronts
+        const size_t tpr = wpr16 ? 16 : wpr4 ? 4 : (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
         const size_t total = rows * tpr;
         if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
         XArgs xa;
@@ -113,6 +115,18 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
 #define ANTQ_LAUNCH_X(UU)                                                                                           \
     hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, UU, DYN>), grid_dim, block, 0, st, xv, ov, idx, (uint32_t)total,     \
                        (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries, grid)
+        if (wpr16) {
+            const dim3 g16((unsigned)rows), b16(1024);
+            if (U == 8)
+                hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, 8, DYN, DYN ? 16 : 1>), g16, b16, 0, st, xv, ov, idx,
+                                   (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out,
+                                   xa, entries, grid);
+            else
+                hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, 4, DYN, DYN ? 16 : 1>), g16, b16, 0, st, xv, ov, idx,
+                                   (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out,
+                                   xa, entries, grid);
+            return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+        }
         if (wpr4) {
             if (U == 8)
                 hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, 8, DYN, DYN ? 4 : 1>), grid_dim, block, 0, st, xv, ov, idx,
@@ -151,7 +165,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
     size_t blocks = (total + 3) / 4;
-    const bool loop = !DYN && lds > 16384;
+    const bool loop = !DYN && lds > 3072;   // (int-8: 255 buckets = 5 KiB of table per 16 KiB of data)
     if (loop) {
         // staging a big table per 16 KiB of data would dominate: persistent workgroups instead
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (size_t)(144 * 1024) / lds));
@@ -486,9 +500,9 @@ static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_o
                                    vshift, (const float *)nullptr, 1, gmax, ratio, alpha_out, pa, tab);
             return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
         }
-        if (vpr <= 2048) {
-            // one quant group (row) per wavefront (<= 512 vectors) or per workgroup (<= 2048): the row
-            // lives in registers, single HBM read.  Plans without the x-domain table only have the
+        if (vpr <= 8192) {
+            // one quant group (row) per wavefront (<= 512 vectors) or per workgroup (<= 2048: 4 wavefronts, <= 8192:
+            // 16): the row lives in registers, single HBM read.  Plans without the x-domain table only have the
             // wavefront variant; longer rows fall through to the two-pass scheme.
             int rc = launch_uniform<T, OVP, IDX, true>(x, out, idx, rows, vpr, nullptr, 1, gmax, ratio, alpha_out, pa,
                                                        plan_host, plan_dev, lds, st);
@@ -688,7 +702,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     uint32_t *map = reinterpret_cast<uint32_t *>(p + h.map_offset);
     std::vector<uint8_t> fam((size_t)n);
     std::vector<size_t> nblk((size_t)n);
-    size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0}, lds = 0;
+    size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0, 0}, lds = 0;
     bool any_da = false;
     for (int i = 0; i < n; i++) {
         const antq_job &J = jobs[i];
@@ -719,11 +733,13 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                 if (d.vshift < 0 || d.vpr > 64u) return ANTQ_ERR_UNSUPPORTED;   // butterfly over a power-of-two group
                 f = d.pa.adom ? 1 : 2;
             } else if (xdom) {
-                if (d.vpr > 2048u) return ANTQ_ERR_UNSUPPORTED;
-                // one wavefront per row up to 512 vectors (4 or 8 per lane), one workgroup per row beyond
-                if (d.vpr <= 512u) { d.kind = d.vpr <= 256u ? 4 : 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4; }
-                else { d.kind = d.vpr <= 1024u ? 5 : 7; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
+                if (d.vpr > 8192u) return ANTQ_ERR_UNSUPPORTED;
+                // one wavefront per row up to 512 vectors (4 or 8 per lane), one workgroup per row beyond: 4 wavefronts up
+                // to 2048 vectors, 16 (a 1024-thread workgroup) up to 8192
                 f = 3;
+                if (d.vpr <= 512u) { d.kind = d.vpr <= 256u ? 4 : 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4; }
+                else if (d.vpr <= 2048u) { d.kind = d.vpr <= 1024u ? 5 : 7; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
+                else { d.kind = d.vpr <= 4096u ? 9 : 10; d.tpr = 16; d.total_tasks = (uint32_t)(J.rows * 16); blocks = J.rows; f = 4; }
             } else {
                 if (d.vpr > 64u * kBatchU) return ANTQ_ERR_UNSUPPORTED;         // the row in one wavefront's registers
                 d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4;
@@ -740,7 +756,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         descs[i] = d;
         fam[(size_t)i] = (uint8_t)(f < 0 ? 255 : f);
         nblk[(size_t)i] = blocks;
-        if (f != 0 && f != 3) lds = std::max(lds, lds_table(d.pa, false));
+        if (f == 1 || f == 2) lds = std::max(lds, lds_table(d.pa, false));
     }
     // element-granular jobs (exact arithmetic, no table path) ride along with whichever d-domain launch exists
     for (int i = 0; i < n; i++)
@@ -801,6 +817,10 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
         if (h->fam_blocks[3]) {                                                                                   \
             if (ovp) hipLaunchKernelGGL((k_fq_batch_dyn<TT, true>), dim3(h->fam_blocks[3]), block, 0, st, descs, fmap[3]);   \
             else hipLaunchKernelGGL((k_fq_batch_dyn<TT, false>), dim3(h->fam_blocks[3]), block, 0, st, descs, fmap[3]);      \
+        }                                                                                                         \
+        if (h->fam_blocks[4]) {                                                                                   \
+            if (ovp) hipLaunchKernelGGL((k_fq_batch_dyn16<TT, true>), dim3(h->fam_blocks[4]), dim3(1024), 0, st, descs, fmap[4]);   \
+            else hipLaunchKernelGGL((k_fq_batch_dyn16<TT, false>), dim3(h->fam_blocks[4]), dim3(1024), 0, st, descs, fmap[4]);      \
         }                                                                                                         \
     } while (0)
     switch (h->dtype) {

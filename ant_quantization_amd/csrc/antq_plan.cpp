@@ -390,11 +390,51 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         }
     }
 
+    // a-table (antq_k_approx.h): the same step function with the decision moved onto x, one slot per bucket
+    std::vector<ATabEntry> atab;
+    std::vector<uint32_t> aidx;
+    if (h.adom) {
+        const uint32_t nbp = h.n_entries - h.nbneg;
+        const uint32_t slots = h.linear ? h.n_entries : 2u * nbp;
+        if (slots > kATabMaxSlots) {
+            h.adom = 0;
+        } else {
+            auto conv = [&](const LutEntry &e) {
+                ATabEntry a;
+                if (!(e.T < INFINITY)) a.Mp = (double)INFINITY;
+                else {
+                    const double M = 0.5 * ((double)next_dn(e.T) + (double)e.T);
+                    a.Mp = (f2u(e.T) & 1u) ? nextafter(M, (double)INFINITY) : M;
+                }
+                a.v_lo = e.v_lo + 0.0f;
+                a.v_hi = e.v_hi + 0.0f;
+                return a;
+            };
+            atab.assign(slots, conv(ent[0]));
+            aidx.assign((slots + 3u) & ~3u, ent[0].idx);
+            for (uint32_t i = 0; i < h.n_entries; i++) {
+                const uint32_t slot = h.linear ? i : (i < nbp ? 2u * i : 2u * (i - nbp) + 1u);
+                atab[slot] = conv(ent[i]);
+                aidx[slot] = ent[i].idx;
+            }
+            // (an unsigned grid has no negative buckets: its odd slots keep bucket 0, the region of every negative x)
+            h.atab_slots = slots;
+            h.bytes += (uint32_t)(sizeof(ATabEntry) * atab.size() + 4 * aidx.size());
+            if (cap < h.bytes) return ANTQ_ERR_PLAN;
+        }
+    }
+
     char *p = static_cast<char *>(blob);
     memcpy(p, &h, sizeof(h));
     float *g = reinterpret_cast<float *>(p + sizeof(PlanHeader));
     for (size_t i = 0; i < m_pad; i++) g[i] = (i < (size_t)m) ? grid[i] : 0.0f;
-    memcpy(p + sizeof(PlanHeader) + 4 * m_pad, ent.data(), sizeof(LutEntry) * h.n_entries);
+    char *q = p + sizeof(PlanHeader) + 4 * m_pad;
+    memcpy(q, ent.data(), sizeof(LutEntry) * h.n_entries);
+    q += sizeof(LutEntry) * h.n_entries;
+    if (!atab.empty()) {
+        memcpy(q, atab.data(), sizeof(ATabEntry) * atab.size());
+        memcpy(q + sizeof(ATabEntry) * atab.size(), aidx.data(), 4 * aidx.size());
+    }
     return (int)h.bytes;
 }
 
@@ -450,34 +490,29 @@ extern "C" int antq_plan_eval_host_a(const void *blob, const float *x, size_t n,
     const bool ok = (s >= kScaleLo) && (s <= kScaleHi);
     float rs = 1.0f / s;
     for (int k = 0; k < abs(rs_ulps) && ok; k++) rs = rs_ulps > 0 ? next_up(rs) : next_dn(rs);
-    auto boundary = [](float T) -> double {
-        if (!(T < INFINITY)) return (double)INFINITY;
-        const float P = next_dn(T);
-        const double M = 0.5 * ((double)P + (double)T);
-        if ((f2u(T) & 1u) == 0u) return M;
-        return nextafter(M, (double)INFINITY);
-    };
+    const ATabEntry *atab = reinterpret_cast<const ATabEntry *>(ent + h->n_entries);
+    const uint32_t *aidx = reinterpret_cast<const uint32_t *>(atab + h->atab_slots);
     for (size_t i = 0; i < n; i++) {
         const float dt = x[i] * rs;
         const bool fast = ok && (fabsf(dt) < h->xlim);
         float q = 0.0f;
         int j = ANTQ_IDX_NONE;
         if (fast) {
-            const LutEntry *e;
+            uint32_t slot;
             if (h->linear) {
                 float kf = fmaf(dt, h->lin_scale, h->lin_bias);
                 kf = fminf(fmaxf(kf, 0.0f), (float)h->kmax);
-                e = &ent[(uint32_t)kf];
+                slot = (uint32_t)kf;
             } else {
                 const uint32_t u = f2u(dt);
                 int32_t ks = (int32_t)(((uint32_t)((int32_t)u >> h->shift)) & h->keymask);
-                uint32_t k = (uint32_t)(std::min(std::max(ks, (int32_t)h->kmin), (int32_t)h->kmax) - (int32_t)h->kmin);
-                // an unsigned grid (nbneg == 0) sends every negative dt to bucket 0, as the device's odd slots do
-                e = (h->nbneg == 0u && (u >> 31)) ? &ent[0] : &ent[k + ((u >> 31) ? h->nbneg : 0u)];
+                const uint32_t k = (uint32_t)(std::min(std::max(ks, (int32_t)h->kmin), (int32_t)h->kmax) - (int32_t)h->kmin);
+                slot = 2u * k + (u >> 31);
             }
-            const bool c = fma(-boundary(e->T), (double)s, (double)x[i]) >= 0.0;
-            q = (c ? e->v_hi : e->v_lo) + 0.0f;
-            j = (int)((c ? (e->idx >> 16) : e->idx) & kIdxMask);
+            const ATabEntry &e = atab[slot];
+            const bool c = fma(-e.Mp, (double)s, (double)x[i]) >= 0.0;
+            q = c ? e.v_hi : e.v_lo;
+            j = (int)((c ? (aidx[slot] >> 16) : aidx[slot]) & kIdxMask);
             out[i] = q * s;
         } else {
             const float d = x[i] / s;

@@ -60,7 +60,7 @@ extern "C" {
 #define ANTQ_IDX_VICTIM  (-2)      /* OliVe victim: value forced to zero             */
 
 #define ANTQ_MAX_GRID     1024     /* entries; the reference's LDS array holds 256   */
-#define ANTQ_PLAN_MAX_BYTES (96 + 4 * ANTQ_MAX_GRID + 16 * 3072)
+#define ANTQ_PLAN_MAX_BYTES (96 + 4 * ANTQ_MAX_GRID + 16 * 3072 + 20 * 1024)
 
 int         antq_abi_version(void);
 const char *antq_strerror(int code);

@@ -254,9 +254,31 @@ def test_dynamic_absmax_fakequant(antq_lib, oracle, dev, bf16):
     rng = np.random.default_rng(11)
     g = golden("ant_grids.npz")["flint_b4_s"]
     plan = antq_lib.plan_for(g)
+    O = golden("olive_grids.npz")
+    g_ol = np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])
+    plan_ol = antq_lib.plan_for(g_ol)
     for rows, K in [(64, 4096), (300, 16), (128, 64), (40, 576), (16, 8192), (64, 147), (5, 2048), (1000, 32), (3, 28672),
-                    (9, 16384), (7, 5120), (6, 11008), (2, 16392)]:
+                    (9, 16384), (7, 5120), (6, 11008), (2, 16392), (2, 65536), (1, 131080), (520, 8), (77, 256), (33, 512)]:
         x = make_x(rng, rows, K, specials=False)
+        # OliVe codebook with outlier-victim pairs, alpha = abs-max * ratio (no_outlier-style x_max, OQ:198): same kernels,
+        # OVP instantiation -- incl. the single-read paths for 28 672-wide rows (one row per 1024-thread workgroup)
+        xo = x.copy()
+        xo.reshape(-1)[::61] *= 30
+        if bf16:
+            xob = oracle.f32_to_bf16(xo)
+            a_ol = oracle.absmax(oracle.bf16_to_f32(xob), True, 0.25)
+            ref, ridx = oracle.forward(xob, a_ol, g_ol, 32.0, True)
+            out, a_dev, idx = antq_lib.fakequant_dynamic(to_dev(xob, dev, True), plan_ol, 32.0, rows, K, ratio=0.25, ovp=True,
+                                                         want_idx=True)
+            assert bf16_same(bf16_bits(out), ref, oracle), (rows, K, "ovp")
+        else:
+            a_ol = oracle.absmax(xo, True, 0.25)
+            ref, ridx = oracle.forward(xo, a_ol, g_ol, 32.0, True)
+            out, a_dev, idx = antq_lib.fakequant_dynamic(to_dev(xo, dev), plan_ol, 32.0, rows, K, ratio=0.25, ovp=True,
+                                                         want_idx=True)
+            assert f32_same(out.cpu().numpy(), ref), (rows, K, "ovp")
+        assert np.array_equal(a_dev.cpu().numpy(), a_ol), (rows, K, "ovp")
+        assert np.array_equal(idx.cpu().numpy().astype(np.int32), ridx), (rows, K, "ovp")
         for ratio in (1.0, 0.83):
             if bf16:
                 xb = oracle.f32_to_bf16(x)
@@ -1365,9 +1387,9 @@ def test_quantizer_follows_external_grid_edits(antq_lib, oracle, dev, capsys):
 
 @pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
 def test_dynamic_batched_launch_equals_per_tensor_dynamic(antq_lib, dev, dtype_name):
-    """ANTQ_FLAG_DYNAMIC: many tensors, alpha = row abs-max computed in the kernel, ONE launch -- same alphas and the
-    same bits as antq_fakequant_dynamic per tensor (itself oracle-checked), ANT and OliVe pairs; rows outside the
-    register-resident range are refused."""
+    """ANTQ_FLAG_DYNAMIC: many tensors, alpha = group / row abs-max computed in the kernel, ONE batch -- same alphas and
+    the same bits as antq_fakequant_dynamic per tensor (itself oracle-checked), ANT and OliVe pairs, from 1-vector groups
+    to 8192-vector rows; what cannot live in registers is refused."""
     import torch
     dtype = getattr(torch, dtype_name)
     epl = 4 if dtype == torch.float32 else 8
@@ -1377,7 +1399,11 @@ def test_dynamic_batched_launch_equals_per_tensor_dynamic(antq_lib, dev, dtype_n
     plan = antq_lib.plan_for(g)
     torch.manual_seed(14)
     shapes = [(64, 128 * epl), (33, 256 * epl), (17, 384 * epl), (9, 1024 * epl), (40, 200 * epl), (5, 777 * epl),
-              (6, 512 * epl), (3, 2048 * epl), (4, 1500 * epl)]
+              (6, 512 * epl), (3, 2048 * epl), (4, 1500 * epl),
+              # groups of 1 .. 64 vectors (group-16 bf16 = 2 lanes per group): butterfly over the group's lanes
+              (4096, epl), (2048, 2 * epl), (700, 4 * epl), (512, 16 * epl), (129, 32 * epl), (65, 64 * epl),
+              # rows of 2049 .. 8192 vectors (C4's 28 672-wide rows): one row per 1024-thread workgroup
+              (3, 2049 * epl), (2, 3584 * epl), (3, 4096 * epl), (2, 7168 * epl), (1, 8192 * epl)]
     for p, gmax, ovp in ((plan, 10.0, False), (pol, 32.0, True)):
         xs = [(torch.randn(*s, device=dev) * 0.03).to(dtype) for s in shapes]
         for x in xs:
@@ -1390,7 +1416,7 @@ def test_dynamic_batched_launch_equals_per_tensor_dynamic(antq_lib, dev, dtype_n
         bt.run()
         for (ro, ra, _), o, a, s in zip(refs, outs, alphas, shapes):
             assert torch.equal(a, ra) and torch.equal(o, ro), (s, ovp)
-    for bad in [(8, 64 * epl), (8, 2049 * epl)]:                      # too short for a row kernel / too long for registers
+    for bad in [(8, 72 * epl), (8, 8193 * epl)]:      # a small group that is no power of two / too long for the registers
         x = torch.randn(*bad, device=dev).to(dtype)
         with pytest.raises(antq_lib.AntqError):
             antq_lib.Batch([(x, torch.empty_like(x), torch.zeros(8, device=dev), plan, 10.0, bad[0], bad[1], True)], dynamic=True)
