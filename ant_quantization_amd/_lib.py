@@ -49,7 +49,8 @@ def lib():
                              "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
-                             "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted"):
+                             "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
+                             "antq_search_sse_multi", "antq_plan_eval_host_a"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
@@ -339,6 +340,33 @@ def search_sse(x, rows, row_len, xmax, per_row, ratios, plan, gmax, ovp=False):
                                      ctypes.c_float(gmax), plan.host_ptr(), _vp(pd),
                                      ctypes.c_uint(FLAG_OVP if ovp else 0), ctypes.c_int(dt), _vp(sse),
                                      _stream(x.device)), "antq_search_sse")
+    return sse
+
+
+def search_sse_multi(x, rows, row_len, xmax, per_row, ratios, plans, gmaxs, ovp=False):
+    """The sums of search_sse for up to 4 codebooks on ONE read of the tensor: [ntypes, ncand, rows] (or [.., 1]) float64;
+    None when the launch shape / a plan has no single-read path (the caller then issues one search_sse per type)."""
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    nt = len(plans)
+    if not 1 <= nt <= 4:
+        return None
+    ncand = ratios.numel()
+    na = rows if per_row else 1
+    sse = torch.zeros(nt, ncand, na, dtype=torch.float64, device=x.device)
+    ph = (ctypes.c_void_p * nt)(*[p.host_addr for p in plans])
+    pd = (ctypes.c_void_p * nt)(*[p.dev(x.device).data_ptr() for p in plans])
+    gm = (ctypes.c_float * nt)(*[float(g) for g in gmaxs])
+    with _on_device(x.device):
+        rc = lib().antq_search_sse_multi(_vp(x), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), _vp(xmax),
+                                         ctypes.c_int(1 if per_row else 0), _vp(ratios), ctypes.c_int(ncand),
+                                         ctypes.c_int(nt), gm, ph, pd, ctypes.c_uint(FLAG_OVP if ovp else 0),
+                                         ctypes.c_int(dt), _vp(sse), _stream(x.device))
+    if rc == -2:              # ANTQ_ERR_UNSUPPORTED
+        return None
+    _check(rc, "antq_search_sse_multi")
     return sse
 
 

@@ -100,6 +100,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._grid_key = None
         self._searched = False    # the last search_mse had at least one candidate
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
+        self._type_search = None  # during one calibration: grid bytes -> clip search result of the type selection's pass
 
     # ---------------------------------------------------------------- bookkeeping
     def disable_input_quantization(self):
@@ -189,7 +190,11 @@ class Quantizer(HostMirrorMixin, nn.Module):
         if self._bits() > 6:
             lb = int(95)
         plan = self._ensure_plan()
-        best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 1, plan, self._gmax)
+        hit = self._type_search.get(plan.grid.tobytes()) if self._type_search else None
+        if hit is not None:
+            best_score, alpha, ratios = hit       # this very search was part of the type selection's single pass
+        else:
+            best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 1, plan, self._gmax)
         self._searched = ratios is not None
         ratio = (alpha / x_max).mean()        # 0-dim tensor: the reference's float, without the sync
         if per_channel:
@@ -199,7 +204,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
     def search_adaptive_numeric_type(self, data):
         """AQ:328-415: per-tensor choice of the type with the smallest summed best-MSE.
         Quirk kept: the -float1..4 searches all use float_value(1) (AQ:370-397)."""
-        modes, mse_list = [], []
+        modes, mse_list, type_grids = [], [], []
         mode = self.mode
         bit, signed = self._bits(), self.is_signed
         for t in _TYPE_ORDER:
@@ -209,11 +214,28 @@ class Quantizer(HostMirrorMixin, nn.Module):
                 g = grids.ant_float(bit, signed, 1)
             else:
                 g = grids.ant_grid(t, bit, signed)
-            self.mode = t
-            self._install_grid(g)
-            best, _, _ = self.search_mse(data)
             modes.append(t)
-            mse_list.append(best.reshape(()))
+            type_grids.append(np.ascontiguousarray(g, dtype=np.float32))
+        # every candidate type's clip search on ONE read of the tensor (antq_search_sse_multi); the search on the grid
+        # that is installed afterwards is one of them and is not repeated (search_mse looks it up)
+        per_channel = self.is_perchannel and (not self.is_input)
+        lb = int(self.w_low) if per_channel else int(self.a_low)
+        ub = int(self.w_up) if per_channel else int(self.a_up)
+        uniq = list({g.tobytes(): g for g in type_grids}.values())          # (-float1..4 all search float_value(1))
+        plans = [_lib.plan_for(g) for g in uniq]
+        with np.errstate(all="ignore"):
+            gmaxs = [float(np.max(g)) for g in uniq]
+        x_max = core.row_absmax(data, per_channel)
+        res = core.clip_search_types(data, x_max, per_channel, lb, ub, 1, plans, gmaxs) if len(uniq) > 1 else None
+        if res is not None:
+            self._type_search = {g.tobytes(): r for g, r in zip(uniq, res)}
+            mse_list = [self._type_search[g.tobytes()][0].sum().reshape(()) for g in type_grids]
+        else:
+            for t, g in zip(modes, type_grids):
+                self.mode = t
+                self._install_grid(g)
+                best, _, _ = self.search_mse(data)
+                mse_list.append(best.reshape(()))
         mse_idx = np.argsort(torch.stack(mse_list).cpu().numpy())     # one read-back for all types
         self.mode = modes[mse_idx[0]]
 
@@ -309,6 +331,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
             self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
             self._hm_known('has_inited_quant_para', 1.0)
             self._steady = True
+            self._type_search = None
 
     # ---------------------------------------------------------------- steady state
     def _forward(self, data):

@@ -87,6 +87,27 @@ def clip_search(x, x_max, per_channel, lo, hi, step, plan, gmax, ovp=False):
     return best_score, best_alpha, ratios
 
 
+def clip_search_types(x, x_max, per_channel, lo, hi, step, plans, gmaxs, ovp=False):
+    """search_mse for SEVERAL codebooks (the type selection, AQ:328-415 / OQ:235-256) on one read of the tensor: a list
+    of (best_score, best_alpha, ratios) per plan, exactly what clip_search returns for each -- or None when there is no
+    single-read path for this shape / these plans (the caller then searches type by type)."""
+    if len(plans) < 2 or not list(range(int(lo), int(hi), int(step))):
+        return None
+    xc = x.detach().contiguous()
+    rows, row_len = view_rows(xc, per_channel)
+    ratios = _ratios(int(lo), int(hi), int(step), x.device)
+    xm = x_max.reshape(-1).to(torch.float32).contiguous()
+    out = []
+    for b in range(0, len(plans), 4):
+        sse = _lib.search_sse_multi(xc, rows, row_len, xm, per_channel, ratios, plans[b:b + 4], gmaxs[b:b + 4], ovp=ovp)
+        if sse is None:
+            return None
+        for t in range(sse.shape[0]):
+            best_score, best_alpha = _lib.search_pick(sse[t], xm, ratios, row_len)
+            out.append((best_score, best_alpha, ratios))
+    return out
+
+
 _ratio_cache = {}
 
 

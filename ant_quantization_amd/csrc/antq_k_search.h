@@ -105,6 +105,96 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The whole type selection on ONE read of the tensor (search_adaptive_numeric_type, AQ:328-415 / OQ:235-256: the
+// reference runs search_mse once per candidate type, 75-88 full passes each).  The task's vectors stay in registers
+// while the wavefront walks the flattened (type, clip ratio) list: for every entry it rebuilds its x-domain row table
+// for THAT codebook at THAT scale and accumulates the squared error -- the loop of k_search_sse<XD>, with the static
+// bucket entries of all (<= kMaxTypes) codebooks parked in LDS.  sse layout: [type][candidate][row].
+// ------------------------------------------------------------------------------------
+constexpr int kMaxTypes = 4;
+struct MultiArgs {
+    XArgs xa[kMaxTypes];
+    const uint4 *entries[kMaxTypes];
+    const float *grid[kMaxTypes];
+    float gmax[kMaxTypes];
+    int ntypes;
+};
+
+template <typename T, bool OVP, int U, bool PT>
+__global__ void __launch_bounds__(256)
+k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
+                   const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand,
+                   double *__restrict__ sse, MultiArgs ma, int flat_chunk)
+{
+    constexpr int EPL = IO<T>::EPL;
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
+    __shared__ __attribute__((aligned(16))) uint4 s_ent[kMaxTypes][128];
+    __shared__ double wacc[PT ? 4 : 1][PT ? kPtCand : 1];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const int nflat = ma.ntypes * ncand;
+    const int f_begin = (int)blockIdx.y * flat_chunk;            // PT: flat_chunk <= kPtCand
+    const int f_end = min(nflat, f_begin + flat_chunk);
+    const uint4 inf = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)ma.ntypes * 128u; i += 256u) {
+        const uint32_t t = i >> 7, b = i & 127u;
+        s_ent[t][b] = b < ma.xa[t].n_entries ? ma.entries[t][b] : inf;
+    }
+    if (PT)
+        for (int c = (int)lane; c < kPtCand; c += 64) wacc[wv][c] = 0.0;
+    __syncthreads();
+    uint4 *wtab = wtab_all[wv];
+    const size_t na = per_row ? rows : 1;
+    for (uint32_t task = blockIdx.x * 4u + wv; task < total_tasks; task += gridDim.x * 4u) {
+        uint4 v[U];
+        float xm;
+        task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
+        uint32_t row = task, g = 0;
+        if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+        const uint32_t v0 = g * (64u * U) + lane;
+        int t = f_begin / ncand, c = f_begin - t * ncand;
+        for (int f = f_begin; f < f_end; f++) {
+            const XArgs &xa = ma.xa[t];
+            const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
+            const Scale sc = make_scale(a, ma.gmax[t]);
+            const bool rowfast = build_row_table(xa, s_ent[t][lane], s_ent[t][lane + 64u], sc, wtab, lane);
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (v0 + 64u * u < vpr) {
+                    float xf[EPL], of[EPL];
+                    int j[EPL];
+                    IO<T>::unpack(v[u], xf);
+                    quant_vec_x<EPL, OVP, false>(xa, wtab, ma.grid[t], sc, rowfast, xf, of, j);
+                    float part = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) {
+                        const float df = fabsf(of[e] - xf[e]);  // AQ:282 (q - x).abs().pow(2)
+                        part += df * df;
+                    }
+                    acc += (double)part;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (PT) {
+                if (lane == 0) wacc[wv][f - f_begin] += acc;
+            } else if (lane == 0) {
+                double *dst = sse + ((size_t)t * ncand + c) * na + (per_row ? row : 0);
+                if (per_row && tpr == 1) *dst = acc; else atomicAdd(dst, acc);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // this candidate's table reads are done before the next one's writes
+            if (++c == ncand) { c = 0; t++; }
+        }
+    }
+    if (PT) {
+        __syncthreads();
+        for (int c = (int)threadIdx.x; c < f_end - f_begin; c += 256)
+            atomicAdd(sse + (size_t)(f_begin + c), (wacc[0][c] + wacc[1][c]) + (wacc[2][c] + wacc[3][c]));
+    }
+}
+
 // Element-granular clip search for ragged rows (row_len % EPL != 0, e.g. 3x3x3 conv rows) or
 // unaligned buffers: one wavefront per row (per strip of 16 Ki elements for a per-tensor
 // scale), exact slow-path arithmetic (true division + literal scan).  With OVP the partner

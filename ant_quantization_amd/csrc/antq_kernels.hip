@@ -580,7 +580,85 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+// all candidate types of a type selection on one read of the tensor; every plan must have the x-domain path
+template <typename T, bool OVP>
+static int launch_search_multi(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
+                               const float *ratios, int ncand, int ntypes, const float *gmax, const void *const *plan_host,
+                               const void *const *plan_dev, double *sse, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) return ANTQ_ERR_UNSUPPORTED;
+    if (!per_row) { row_len = rows * row_len; rows = 1; }
+    const size_t vpr = row_len / EPL;
+    if (vpr < kRowKernelMinVpr || vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
+    MultiArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    ma.ntypes = ntypes;
+    for (int t = 0; t < ntypes; t++) {
+        PlanArgs pa;
+        if (!plan_args_from_host(plan_host[t], pa)) return ANTQ_ERR_PLAN;
+        const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host[t]);
+        if (!(g_knob_x != 0 && pa.kind == kPlanLut && ph->xdom)) return ANTQ_ERR_UNSUPPORTED;
+        XArgs &xa = ma.xa[t];
+        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
+        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+        const uint4 *tab = plan_tab_ptr(plan_dev[t]);
+        ma.entries[t] = tab + (pa.m_pad >> 2);
+        ma.grid[t] = reinterpret_cast<const float *>(tab);
+        ma.gmax[t] = gmax[t];
+    }
+    constexpr int U = 4;
+    const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
+    const size_t total = rows * tpr;
+    if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+    const bool pt = rows == 1;
+    size_t blocks = (total + 3) / 4;
+    const size_t cap = pt ? 256 * 4 : 256 * 8;
+    if (blocks > cap) blocks = cap;
+    // enough wavefronts to fill 256 CUs x 8 waves/SIMD: split the flattened (type, ratio) list when there are few rows
+    const int nflat = ntypes * ncand;
+    int chunks = (int)std::min<size_t>((size_t)nflat, std::max<size_t>(1, (size_t)2048 / blocks));
+    if (pt) chunks = std::max(chunks, (nflat + kPtCand - 1) / kPtCand);
+    const int flat_chunk = (nflat + chunks - 1) / chunks;
+    chunks = (nflat + flat_chunk - 1) / flat_chunk;
+    const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
+    const uint4 *xv = static_cast<const uint4 *>(x);
+    if (pt)
+        hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U, true>), gdim, bdim, 0, st, xv, (uint32_t)total, (uint32_t)vpr,
+                           (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ma, flat_chunk);
+    else
+        hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U, false>), gdim, bdim, 0, st, xv, (uint32_t)total, (uint32_t)vpr,
+                           (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ma, flat_chunk);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
 }  // namespace antq
+
+extern "C" int antq_search_sse_multi(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
+                                     const float *ratios, int ncand, int ntypes, const float *gmax_host,
+                                     const void *const *plan_host, const void *const *plan_dev, unsigned flags, int dtype,
+                                     double *sse, void *stream)
+{
+    if (rows == 0 || row_len == 0 || ncand == 0 || ntypes == 0) return ANTQ_OK;
+    if (!x || !xmax || !ratios || !gmax_host || !plan_host || !plan_dev || !sse || ncand < 0 || ntypes < 0) return ANTQ_ERR_ARG;
+    if (ntypes > kMaxTypes) return ANTQ_ERR_UNSUPPORTED;
+    for (int t = 0; t < ntypes; t++)
+        if (!plan_host[t] || !plan_dev[t]) return ANTQ_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
+    const int pr = per_row ? 1 : 0;
+#define ANTQ_SM(TT)                                                                                                     \
+    (ovp ? launch_search_multi<TT, true>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, st)   \
+         : launch_search_multi<TT, false>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, st))
+    switch (dtype) {
+    case ANTQ_F32: return ANTQ_SM(float);
+    case ANTQ_BF16: return ANTQ_SM(bf16_tag);
+    case ANTQ_F16: return ANTQ_SM(f16_tag);
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+#undef ANTQ_SM
+}
 
 extern "C" int antq_fakequant_dynamic(const void *x, void *out, int16_t *idx, float *alpha_out, size_t rows,
                                       size_t row_len, float ratio, float gmax, const void *plan_host,
@@ -721,9 +799,13 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         int f;
         if (!dyn) {
             if (d.kind == 0 && xdom) d.kind = 2;
-            if (d.kind == 1 && xdom && J.alpha_per_row && !d.pa.adom &&
-                xs_eligible(d.vpr, d.pa.n_entries, d.pa.nbneg, d.pa.linear))
-                d.kind = 8;          // (plans with adom -- all that have xdom, unless the knob is off -- take the lane kernel)
+            // groups of 16 / 32 / 64 vectors: a per-group x-domain table (kind 8) against the per-lane exact decision
+            // (kind 1 with adom).  Measured on 16 x 4096^2 (profiles/r02_group_sweep.log): the table wins from 32 vectors
+            // (bf16 group-256 / 512: 75 vs 72 %, fp32 group-128 / 256: 79 vs 75 %) and for fp32 at 16 (77 vs 75.5 %), the
+            // lane kernel for bf16 groups of 128 elements (72 vs 69 %).
+            if (d.kind == 1 && xdom && J.alpha_per_row && xs_eligible(d.vpr, d.pa.n_entries, d.pa.nbneg, d.pa.linear) &&
+                (!d.pa.adom || d.vpr >= 32u || dtype == ANTQ_F32))
+                d.kind = 8;
             f = (d.kind == 2 || d.kind == 8) ? 0 : (d.kind == 3 ? -1 : (d.pa.adom ? 1 : 2));
         } else {
             // alpha computed in the kernel: the group / row has to live in the registers of a few lanes, one wavefront

@@ -80,6 +80,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._grid_key = None
         self._searched = False
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
+        self._type_search = None  # during one calibration: grid bytes -> clip search result of the type selection's pass
 
     # ---------------------------------------------------------------- bookkeeping
     def disable_input_quantization(self):
@@ -185,8 +186,12 @@ class Quantizer(HostMirrorMixin, nn.Module):
         lb = int(self.w_low) if per_channel else int(self.a_low)
         ub = int(self.w_up) if per_channel else int(self.a_up)
         plan = self._ensure_plan()
-        best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 2, plan, self._gmax,
-                                                     ovp=not self._no_outlier)
+        hit = self._type_search.get(plan.grid.tobytes()) if self._type_search else None
+        if hit is not None:
+            best_score, alpha, ratios = hit       # this very search was part of the type selection's single pass
+        else:
+            best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 2, plan, self._gmax,
+                                                         ovp=not self._no_outlier)
         self._searched = ratios is not None
         ratio = (alpha / x_max).mean()        # 0-dim tensor: the reference's float, without the sync
         if per_channel:
@@ -196,17 +201,29 @@ class Quantizer(HostMirrorMixin, nn.Module):
     @torch.no_grad()
     def search_adaptive_numeric_type(self, data):
         """OQ:235-256: int vs flint, smallest summed best-MSE wins."""
-        modes, mse_list = [], []
         mode = self.mode
-        outl = grids.olive_outliers(self._bits(), self.is_signed)
-        for t in ("int", "flint"):
-            if ("-" + t) not in mode:
-                continue
-            self.mode = t
-            self._install(grids.olive_grid(t, self._bits(), self.is_signed), outl)
-            best, _, _ = self.search_mse(data)
-            modes.append(t)
-            mse_list.append(best.reshape(()))
+        outl = np.ascontiguousarray(grids.olive_outliers(self._bits(), self.is_signed), dtype=np.float32)
+        modes = [t for t in ("int", "flint") if ("-" + t) in mode]
+        normals = [np.ascontiguousarray(grids.olive_grid(t, self._bits(), self.is_signed), dtype=np.float32) for t in modes]
+        fulls = [n if self._no_outlier else np.concatenate([n, outl]) for n in normals]
+        # both codebooks' clip searches on ONE read of the tensor (antq_search_sse_multi); the search on the grid that is
+        # installed afterwards is one of them and is not repeated (search_mse looks it up)
+        per_channel = self.is_perchannel and (not self.is_input)
+        lb = int(self.w_low) if per_channel else int(self.a_low)
+        ub = int(self.w_up) if per_channel else int(self.a_up)
+        res = core.clip_search_types(data, self._three_sigma(data, per_channel), per_channel, lb, ub, 2,
+                                     [_lib.plan_for(f) for f in fulls], [float(np.max(n)) for n in normals],
+                                     ovp=not self._no_outlier)
+        mse_list = []
+        if res is not None:
+            self._type_search = {f.tobytes(): r for f, r in zip(fulls, res)}
+            mse_list = [r[0].sum().reshape(()) for r in res]
+        else:
+            for t, n in zip(modes, normals):
+                self.mode = t
+                self._install(n, outl)
+                best, _, _ = self.search_mse(data)
+                mse_list.append(best.reshape(()))
         self.mode = modes[np.argsort(torch.stack(mse_list).cpu().numpy())[0]]   # one read-back for both types
 
     @torch.no_grad()
@@ -250,6 +267,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
         self._hm_known('has_inited_quant_para', 1.0)
         self._steady = True
+        self._type_search = None
 
     # ---------------------------------------------------------------- steady state
     @torch.no_grad()

@@ -184,6 +184,18 @@ int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
                     const void *plan_host, const void *plan_dev,
                     unsigned flags, int dtype, double *sse_dev, void *stream);
 
+/* The type selection (search_adaptive_numeric_type, AQ:328-415 / OQ:235-256) on ONE read of the tensor: the sums of
+ * antq_search_sse for `ntypes` (<= 4) codebooks at once,
+ *     sse[t, c, r]  = sum_col ( fl32|fakequant_t(x; xmax[r] * ratios[c])[r,col] - x[r,col]| )^2
+ * sse_dev: [ntypes, ncand, rows] doubles (per_row) or [ntypes, ncand], zeroed by the caller.  gmax_host, plan_host,
+ * plan_dev: host arrays of ntypes entries.  Every plan must have the x-domain path (all ANT / OliVe codebooks up to 128
+ * buckets) and rows must be whole 16-byte vectors, at least 128 of them (2 KiB): otherwise ANTQ_ERR_UNSUPPORTED and the
+ * caller issues one antq_search_sse per type. */
+int antq_search_sse_multi(const void *x_dev, size_t rows, size_t row_len, const float *xmax_dev, int per_row,
+                          const float *ratios_dev, int ncand, int ntypes, const float *gmax_host,
+                          const void *const *plan_host, const void *const *plan_dev,
+                          unsigned flags, int dtype, double *sse_dev, void *stream);
+
 /* The selection step of search_mse on the device (AQ:299-306 / :317-324): for every row r
  *     score_c = fl32(sse[c, r] / row_len), c ascending; best starts at 1e10 and is replaced on a strict `<`
  *     best_alpha[r] = fl32(xmax[r] * ratios[c*]) of the first best candidate, xmax[r] if none qualifies.

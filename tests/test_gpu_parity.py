@@ -1694,7 +1694,7 @@ def test_bert_base_real_shapes_weights_and_activations(antq_lib, oracle, dev, ca
         q = qm.TensorQuantizer(mode="ant-int-pot-flint", bit=4, is_signed=True, is_enable=True, args=args).to(dev)
         q.name = "L%d" % li
         q.alpha.data = torch.ones(r, 1, device=dev)
-        out = q(w)
+        out = q(w).detach()
         grid = q.quant_grid.cpu().numpy()
         alpha = q.alpha.detach().reshape(-1)
         if li % 6 == 0 or r == 2:             # 14 layers get the oracle's calibration on sampled rows
@@ -1725,7 +1725,7 @@ def test_bert_base_real_shapes_weights_and_activations(antq_lib, oracle, dev, ca
         x = torch.nn.functional.gelu(torch.randn(*shape, device=dev, generator=gen))
         q = qm.TensorQuantizer(mode="ant-int-pot-flint", bit=4, is_signed=False, is_enable=True, is_input=True, args=args).to(dev)
         q.name = "act"
-        out = q(x)
+        out = q(x).detach()
         assert q.is_signed                                                  # gelu output has negatives: AQ:71-73
         grid = q.quant_grid.cpu().numpy()
         a = q.alpha.detach().reshape(1).cpu().numpy()
@@ -1746,4 +1746,82 @@ def test_bert_base_real_shapes_weights_and_activations(antq_lib, oracle, dev, ca
             oq, _ = oracle.forward(xn, np.float32([ac]), grid, 10.0, False)
             ref_mse = oracle.mse(oq, xn, per_row=False)
             np.testing.assert_allclose(mse[c], np.asarray(ref_mse).reshape(-1)[0], rtol=2e-5, err_msg=str((shape, c)))
+    capsys.readouterr()
+
+
+def test_type_selection_on_one_read_equals_per_type_searches(antq_lib, oracle, dev, capsys):
+    """antq_search_sse_multi (every candidate type of a type selection on ONE read of the tensor) against one
+    antq_search_sse per type: the same sums (rows held by one wavefront: identical bits; split rows / per-tensor sums:
+    fp64 atomics in another order), hence the same picks; and the quantiser's calibration issues exactly one search
+    launch for an `ant-` list where it used to issue one per type plus one for the installed grid."""
+    import torch
+    from ant_quantization_amd import core, grids
+    G = golden("ant_grids.npz")
+    O = golden("olive_grids.npz")
+    ant = [G["int_b4_s"], G["flint_b4_s"], G["pot_b4_s"], G["float_b4_s"]]
+    ol = [np.concatenate([O["int_b4_s"], O["outlier_b4_s"]]), np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])]
+    torch.manual_seed(23)
+    cases = [(torch.randn(64, 768, device=dev) * 0.02, True, ant, [10.0] * 4, False, 1),
+             (torch.randn(48, 3072, device=dev) * 0.02, True, ant[:3], [10.0] * 3, False, 1),
+             (torch.nn.functional.gelu(torch.randn(16, 64, 768, device=dev)), False, ant[:3], [10.0] * 3, False, 1),
+             ((torch.randn(128, 4096, device=dev) * 0.02).bfloat16(), True, ol, [28.0, 32.0], True, 2),
+             (torch.randn(9, 130000, device=dev).half(), False, ol, [28.0, 32.0], True, 2)]
+    for x, per_row, gl, gmaxs, ovp, step in cases:
+        x = x.contiguous()
+        if ovp:
+            x.view(-1)[::211] *= 20
+        plans = [antq_lib.plan_for(g) for g in gl]
+        rows, row_len = core.view_rows(x, per_row)
+        xmax = core.row_absmax(x, per_row)
+        ratios = core._ratios(75, 150, step, dev)
+        multi = antq_lib.search_sse_multi(x, rows, row_len, xmax, per_row, ratios, plans, gmaxs, ovp=ovp)
+        assert multi is not None and multi.shape[0] == len(gl)
+        res = core.clip_search_types(x, xmax, per_row, 75, 150, step, plans, gmaxs, ovp=ovp)
+        for t, (p, gm) in enumerate(zip(plans, gmaxs)):
+            one = antq_lib.search_sse(x, rows, row_len, xmax, per_row, ratios, p, gm, ovp=ovp)
+            exact = per_row and row_len * x.element_size() <= 4096
+            if exact:
+                assert torch.equal(multi[t], one), t
+            else:
+                torch.testing.assert_close(multi[t], one, rtol=1e-12, atol=0)
+            b1, a1, _ = core.clip_search(x, xmax, per_row, 75, 150, step, p, gm, ovp=ovp)
+            flips = (res[t][1] != a1)
+            assert flips.float().mean() <= (0.0 if exact else 0.02), t
+    # a shape without the single-read path falls back (None), the quantiser then searches type by type
+    small = torch.randn(64, 64, device=dev)
+    assert antq_lib.search_sse_multi(small, 64, 64, core.row_absmax(small, True), True, core._ratios(75, 150, 1, dev),
+                                     [antq_lib.plan_for(g) for g in ant[:2]], [10.0, 10.0]) is None
+    # launch count of a complete calibration
+    from ant_quantization_amd.ant import quant_modules as qm
+    calls = {"multi": 0, "single": 0}
+    real_m, real_s = antq_lib.search_sse_multi, antq_lib.search_sse
+
+    def cm(*a, **k):
+        calls["multi"] += 1
+        return real_m(*a, **k)
+
+    def cs(*a, **k):
+        calls["single"] += 1
+        return real_s(*a, **k)
+
+    antq_lib.search_sse_multi, antq_lib.search_sse = cm, cs
+    try:
+        w = torch.randn(96, 1024, device=dev) * 0.02
+        q = qm.TensorQuantizer(mode="ant-int-pot-flint", bit=4, is_signed=True, is_enable=True, args=_args()).to(dev)
+        q.name = "n1"
+        q.alpha.data = torch.ones(96, 1, device=dev)
+        out = q(w)
+    finally:
+        antq_lib.search_sse_multi, antq_lib.search_sse = real_m, real_s
+    assert calls == {"multi": 1, "single": 0}, calls
+    # ... and it is the calibration the per-type path produces
+    antq_lib.lib().antq_debug_set(2, 0)           # no x-domain path: the multi entry declines, four searches as before
+    try:
+        q2 = qm.TensorQuantizer(mode="ant-int-pot-flint", bit=4, is_signed=True, is_enable=True, args=_args()).to(dev)
+        q2.name = "n1"
+        q2.alpha.data = torch.ones(96, 1, device=dev)
+        out2 = q2(w)
+    finally:
+        antq_lib.lib().antq_debug_set(2, 1)
+    assert q.mode == q2.mode and torch.equal(q.alpha.detach(), q2.alpha.detach()) and torch.equal(out.detach(), out2.detach())
     capsys.readouterr()
