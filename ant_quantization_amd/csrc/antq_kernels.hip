@@ -838,7 +838,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         descs[i] = d;
         fam[(size_t)i] = (uint8_t)(f < 0 ? 255 : f);
         nblk[(size_t)i] = blocks;
-        if (f == 1 || f == 2) lds = std::max(lds, lds_table(d.pa, false));
+        if (f == 1 || f == 2 || f < 0) lds = std::max(lds, lds_table(d.pa, false));
     }
     // element-granular jobs (exact arithmetic, no table path) ride along with whichever d-domain launch exists
     for (int i = 0; i < n; i++)

@@ -1549,7 +1549,7 @@ def test_dropin_operator_never_trusts_a_buffer_identity(antq_lib, oracle, dev):
     q.name = "t"
     w = torch.randn(64, 256, device=dev)
     o1 = q(w)
-    q.quant_grid.data = (q.quant_grid * 0.5).clone()                   # rebinding behind the quantiser's back
+    q.quant_grid.data = torch.from_numpy(G["flint_b4_s"]).to(dev)        # rebinding behind the quantiser's back (int -> flint)
     q._grid_key = q._grid_now()                                        # worst case: the host watch is fooled too
     o2 = q(w)
     scale = q.percent_value_int4 / torch.max(q.quant_grid)
