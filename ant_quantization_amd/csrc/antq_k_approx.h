@@ -24,7 +24,7 @@ namespace antq {
 // redo inside the margin spent most of its time in the redo.
 //     dt = x * rcp(s)                 only picks the bucket (within 2^-22 of fl(x / s); the plan builder duplicates a
 //                                     threshold within 2^-20 of a bucket edge into the neighbouring bucket)
-//     {M', v_lo, v_hi} = atab[bucket] one ds_read_b128 (the table is rebuilt from the plan's entries by every workgroup)
+//     {M', v_lo, v_hi} = atab[bucket] one ds_read_b128 (the table is part of the plan blob; every workgroup copies it to LDS)
 //     q   = fma64(-M', s, x) >= 0 ? v_hi : v_lo
 //     out = fl(q * s)                 == ((q - d) + d) * s: the straight-through step is exact in every region of an
 //                                     `adom` plan (Sterbenz); -0.0 codebook entries are stored as +0.0, as (q - d) + d gives
@@ -53,7 +53,7 @@ __device__ __forceinline__ ScaleA make_scale_a(float alpha, float gmax)
 //     aidx[slots] x packed index pair (as LutEntry::idx)     read only when an index output is wanted
 // LDS image, staged per workgroup by a plain copy: [atab] [grid: m_pad floats] [IDX only: aidx]
 struct ATab {
-    const char *tab;
+    const uint4 *tab;
     const float *grid;
     const uint32_t *idx;
 };
@@ -77,7 +77,7 @@ __device__ __forceinline__ ATab stage_atab(const PlanArgs &pa, const uint4 *__re
     if (threadIdx.x < units) smem[threadIdx.x] = first;
     for (uint32_t i = threadIdx.x + blockDim.x; i < units; i += blockDim.x) smem[i] = atab_src(pa, plan_tab, i);
     ATab A;
-    A.tab = reinterpret_cast<const char *>(smem);
+    A.tab = smem;
     A.grid = reinterpret_cast<const float *>(smem + pa.atab_slots);
     A.idx = reinterpret_cast<const uint32_t *>(smem + pa.atab_slots + (pa.m_pad >> 2));
     return A;
@@ -119,17 +119,19 @@ __device__ __forceinline__ void quant_vec_a(const PlanArgs &pa, const ATab &A, c
                 const int32_t t = (u >> sh) & km;
                 int32_t ck;
                 asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
-                slot[e] = __builtin_amdgcn_alignbit((uint32_t)(ck - lo), (uint32_t)u, 31);
+                slot[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);    // 2 * kmin too high: folded into tab0
             }
         }
+        const uint4 *tab0 = pa.linear ? A.tab : A.tab - 2u * pa.kmin;
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
-            const uint4 ent = *reinterpret_cast<const uint4 *>(A.tab + (slot[e] << 4));
+            uint4 ent = tab0[slot[e]];
+            asm volatile("" : "+v"(ent.x), "+v"(ent.y), "+v"(ent.z), "+v"(ent.w));   // one ds_read_b128, not two b64 halves
             const double Mp = __longlong_as_double((long long)(((unsigned long long)ent.y << 32) | ent.x));
             const bool c = __builtin_fma(-Mp, sc.sd, (double)x[e]) >= 0.0;
             q[e] = c ? u2f(ent.w) : u2f(ent.z);
             if (IDX) {
-                const uint32_t w = A.idx[slot[e]];
+                const uint32_t w = (pa.linear ? A.idx : A.idx - 2u * pa.kmin)[slot[e]];
                 j[e] = (int)((c ? (w >> 16) : w) & kIdxMask);
             }
         }

@@ -139,6 +139,69 @@ k_fq_batch_d(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ b
     }
 }
 
+// A MIXED static batch (jobs of more than one of the families 0 / 1 / 2, e.g. ResNet-50 per channel: rows of >= 128
+// vectors, shorter rows and conv1's ragged K = 147) goes out as ONE launch of this all-in-one kernel: a family per launch
+// would pay two or three ramps, tails and kernel boundaries on a pass of ~35 us (measured: 66 % against 75 % in one
+// launch).  The price is the union of all paths' registers, which is why single-family batches -- the headline -- do
+// not use it.
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(256)
+k_fq_batch_all(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
+{
+    constexpr int U = kBatchU;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
+    const uint32_t j = block_map[blockIdx.x];
+    const BatchDesc &D = descs[j];
+    const PlanArgs pa = D.pa;
+    const uint32_t lb = blockIdx.x - D.first_block;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint4 *plan_tab = D.plan_tab;
+    if (D.kind == 2) {
+        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
+        if (task >= D.total_tasks) return;
+        xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
+                                              nullptr, xargs_of(D), plan_tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
+                                              wtab_all[wv], lane, wv);
+    } else if (D.kind == 8) {
+        lane_xs_task<T, OVP, false, U>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
+                                       ((size_t)lb * U) * 256u + threadIdx.x, xargs_of(D), plan_tab + (pa.m_pad >> 2),
+                                       reinterpret_cast<const float *>(plan_tab), wtab_all[wv], lane);
+    } else if (D.kind == 1) {
+        const size_t first = ((size_t)lb * U) * 256u + threadIdx.x;
+        if (pa.adom)
+            lane_task<T, OVP, false, U, false, true>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row,
+                                                     D.gmax, 1.0f, nullptr, pa, plan_tab, smem, first);
+        else
+            lane_task<T, OVP, false, U, false, false>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row,
+                                                      D.gmax, 1.0f, nullptr, pa, plan_tab, smem, first);
+    } else if (D.kind == 0) {
+        const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
+        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
+        const bool active = task < total;
+        uint4 tab0 = make_uint4(0, 0, 0, 0);
+        if (pa.adom) tab0 = atab_prefetch<false>(pa, plan_tab);
+        else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+        uint4 v[U];
+        float a;
+        task_load<T, U>(D.x, D.alpha, D.per_row, active ? task : total - 1u, vpr, tpr, lane, false, v, a);
+        PlanLds L;
+        ATab A;
+        if (pa.adom) A = stage_atab<false>(pa, plan_tab, smem, tab0);
+        else L = stage_plan(pa, plan_tab, smem, tab0);
+        __syncthreads();
+        if (active) task_run<T, OVP, false, U, false, -1>(D.out, nullptr, nullptr, 1.0f, task, vpr, tpr, lane, D.gmax, pa, L, A, v, a);
+    } else {
+        uint4 tab0 = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+        const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+        __syncthreads();
+        scalar_pair<T, OVP, false>(D.x, D.out, nullptr, (size_t)lb * 256u + threadIdx.x, 0, (size_t)D.n_vec, (size_t)D.n_vec,
+                                   (size_t)D.vpr, D.alpha, D.per_row, D.gmax, pa, L);
+    }
+}
+
 // Family 3.  ANTQ_FLAG_DYNAMIC rows: alpha = row abs-max (x ratio) computed from the registers that hold the row -- one
 // HBM read -- for every tensor of the batch in one launch.  A kernel of its own so that the 8-vectors-per-lane variants
 // do not raise the register count (and lower the occupancy) of the static kernel above.

@@ -843,6 +843,17 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     // element-granular jobs (exact arithmetic, no table path) ride along with whichever d-domain launch exists
     for (int i = 0; i < n; i++)
         if (fam[(size_t)i] == 255) fam[(size_t)i] = any_da ? 1 : 2;
+    if (!dyn) {
+        // jobs of more than one static family: ONE launch of the all-in-one kernel instead of a launch per family
+        bool seen[kBatchFamilies] = {false, false, false, false, false};
+        int nf = 0;
+        for (int i = 0; i < n; i++)
+            if (!seen[fam[(size_t)i]]) { seen[fam[(size_t)i]] = true; nf++; }
+        if (nf > 1) {
+            h.pad = 1u;
+            for (int i = 0; i < n; i++) fam[(size_t)i] = 0;
+        }
+    }
     size_t total_blocks = 0;
     for (int i = 0; i < n; i++) {
         descs[i].first_block = (uint32_t)fam_blocks[fam[(size_t)i]];
@@ -890,6 +901,11 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
     } while (0)
 #define ANTQ_LAUNCH_B(TT)                                                                                         \
     do {                                                                                                          \
+        if (h->pad) {      /* mixed static batch: the all-in-one kernel */                                       \
+            if (ovp) hipLaunchKernelGGL((k_fq_batch_all<TT, true>), dim3(h->fam_blocks[0]), block, h->lds_bytes, st, descs, fmap[0]);  \
+            else hipLaunchKernelGGL((k_fq_batch_all<TT, false>), dim3(h->fam_blocks[0]), block, h->lds_bytes, st, descs, fmap[0]);     \
+            break;                                                                                                \
+        }                                                                                                         \
         if (h->fam_blocks[0]) {                                                                                   \
             if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true>), dim3(h->fam_blocks[0]), block, 0, st, descs, fmap[0]);   \
             else hipLaunchKernelGGL((k_fq_batch<TT, false>), dim3(h->fam_blocks[0]), block, 0, st, descs, fmap[0]);      \

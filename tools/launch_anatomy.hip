@@ -19,6 +19,9 @@
 
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
+// s_memtime counters are per XCD and not synchronised with each other: every wavefront also records which XCD it ran on
+__device__ __forceinline__ uint64_t xcc_id() { return (uint64_t)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf); }   // HW_REG_XCC_ID
+
 __device__ __forceinline__ u4 work(u4 v, int n, float c1, float c2)
 {
     float a = __uint_as_float(v.x), b = __uint_as_float(v.y), c = __uint_as_float(v.z), d = __uint_as_float(v.w);
@@ -48,7 +51,7 @@ __global__ void __launch_bounds__(THREADS) probe(const u4 *__restrict__ s, u4 *_
         if (first + 64 * u < n) __builtin_nontemporal_store(w, d + first + 64 * u);
     }
     const uint64_t t2 = __builtin_readcyclecounter();
-    if ((threadIdx.x & 63) == 0) { ts[3 * wave] = t0; ts[3 * wave + 1] = t1; ts[3 * wave + 2] = t2; }
+    if ((threadIdx.x & 63) == 0) { ts[4 * wave] = t0; ts[4 * wave + 1] = t1; ts[4 * wave + 2] = t2; ts[4 * wave + 3] = xcc_id(); }
 }
 
 // staged: the wave's U vectors in two halves; the second half is LOADED only after the first half has been stored
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(256) probe_staged(const u4 *__restrict__ s, u4
         }
     }
     const uint64_t t2 = __builtin_readcyclecounter();
-    if ((threadIdx.x & 63) == 0) { ts[3 * wave] = t0; ts[3 * wave + 1] = t1; ts[3 * wave + 2] = t2; }
+    if ((threadIdx.x & 63) == 0) { ts[4 * wave] = t0; ts[4 * wave + 1] = t1; ts[4 * wave + 2] = t2; ts[4 * wave + 3] = xcc_id(); }
 }
 
 // persistent: G workgroups, each wave walks tasks of U x 1 KiB with stride; the next task's loads are issued before the
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(256) probe_persist(const u4 *__restrict__ s, u
         task = nt;
     }
     const uint64_t t2 = __builtin_readcyclecounter();
-    if (lane == 0) { ts[3 * w0] = t0; ts[3 * w0 + 1] = t1; ts[3 * w0 + 2] = t2; }
+    if (lane == 0) { ts[4 * w0] = t0; ts[4 * w0 + 1] = t1; ts[4 * w0 + 2] = t2; ts[4 * w0 + 3] = xcc_id(); }
 }
 
 struct Ctx {
@@ -136,26 +139,35 @@ static void run(Ctx &C, const char *name, size_t waves, L launch)
     float ms;
     CK(hipEventElapsedTime(&ms, C.e0, C.e1));
     const double us = ms * 1e3 / reps;
-    // anatomy of the LAST launch
-    std::vector<uint64_t> h(3 * waves);
-    CK(hipMemcpy(h.data(), C.ts, 3 * waves * 8, hipMemcpyDeviceToHost));
-    uint64_t t_min = ~0ull, t_end = 0;
-    for (size_t w = 0; w < waves; w++) { t_min = std::min(t_min, h[3 * w]); t_end = std::max(t_end, h[3 * w + 2]); }
-    const double span = (double)(t_end - t_min);
+    // anatomy of the LAST launch, per XCD (each XCD has its own s_memtime); ticks -> us by equating the median XCD's
+    // first-start-to-last-end span with the launch time measured by the events
+    std::vector<uint64_t> h(4 * waves);
+    CK(hipMemcpy(h.data(), C.ts, 4 * waves * 8, hipMemcpyDeviceToHost));
+    uint64_t t_min[16], t_end[16];
+    for (int x = 0; x < 16; x++) { t_min[x] = ~0ull; t_end[x] = 0; }
+    for (size_t w = 0; w < waves; w++) {
+        const int x = (int)(h[4 * w + 3] & 15);
+        t_min[x] = std::min(t_min[x], h[4 * w]);
+        t_end[x] = std::max(t_end[x], h[4 * w + 2]);
+    }
+    std::vector<double> spans;
+    for (int x = 0; x < 16; x++) if (t_end[x]) spans.push_back((double)(t_end[x] - t_min[x]));
+    std::sort(spans.begin(), spans.end());
+    const double k = us / spans[spans.size() / 2];
     std::vector<double> st(waves), fd(waves), life(waves), en(waves);
     for (size_t w = 0; w < waves; w++) {
-        st[w] = (double)(h[3 * w] - t_min);
-        fd[w] = (double)(h[3 * w + 1] - h[3 * w]);
-        life[w] = (double)(h[3 * w + 2] - h[3 * w]);
-        en[w] = (double)(h[3 * w + 2] - t_min);
+        const int x = (int)(h[4 * w + 3] & 15);
+        st[w] = (double)(h[4 * w] - t_min[x]);
+        fd[w] = (double)(h[4 * w + 1] - h[4 * w]);
+        life[w] = (double)(h[4 * w + 2] - h[4 * w]);
+        en[w] = (double)(h[4 * w + 2] - t_min[x]);
     }
     auto pct = [&](std::vector<double> &v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
-    // ticks -> us: s_memtime runs at a constant 100 MHz on gfx9 parts (10 ns per tick)
-    const double k = 0.01;
-    printf("%-34s %6.2f us/launch %5.1f%% of 8 TB/s | start p50 %5.2f p99 %5.2f max %5.2f | first data p50 %5.2f p99 %5.2f | "
-           "life p50 %5.2f p99 %5.2f | end p50 %5.2f last %5.2f us\n",
-           name, us, 2.0 * C.bytes / (us * 1e-6) / 8e12 * 100.0, pct(st, .5) * k, pct(st, .99) * k, pct(st, 1.0) * k,
-           pct(fd, .5) * k, pct(fd, .99) * k, pct(life, .5) * k, pct(life, .99) * k, pct(en, .5) * k, span * k);
+    printf("%-36s %6.2f us/launch %5.1f%% of 8 TB/s | wave start p50 %5.2f p99 %5.2f | load -> first use p50 %5.2f p99 %5.2f | "
+           "wave life p50 %5.2f p99 %5.2f | wave end p50 %5.2f p99 %5.2f us  (%zu XCDs, %.0f ticks/us)\n",
+           name, us, 2.0 * C.bytes / (us * 1e-6) / 8e12 * 100.0, pct(st, .5) * k, pct(st, .99) * k,
+           pct(fd, .5) * k, pct(fd, .99) * k, pct(life, .5) * k, pct(life, .99) * k, pct(en, .5) * k, pct(en, .99) * k,
+           spans.size(), 1.0 / k);
 }
 
 int main(int argc, char **argv)
@@ -174,14 +186,14 @@ int main(int argc, char **argv)
         C.src.push_back(a);
         C.dst.push_back(b);
     }
-    CK(hipMalloc(&C.ts, 3 * 8 * (C.n / 64 + 4096)));
+    CK(hipMalloc(&C.ts, 4 * 8 * (C.n / 64 + 4096)));
     CK(hipStreamCreate(&C.st));
     CK(hipEventCreate(&C.e0));
     CK(hipEventCreate(&C.e1));
     const size_t n = C.n;
-    printf("tensor %zu bytes, %d rotating buffer pairs; s_memtime ticks taken as 10 ns\n", C.bytes, nb);
+    printf("tensor %zu bytes, %d rotating buffer pairs\n", C.bytes, nb);
     char nm[96];
-    for (int nwork : {0, 48, 96, 160}) {
+    for (int nwork : {4, 48, 96, 160}) {   // (4: one fma per float, so that the first-use stamp waits for the data)
 #define ONE(U, THREADS)                                                                                               \
     snprintf(nm, 96, "one-shot U=%d wg=%d work=%d/vec", U, THREADS, nwork);                                           \
     run(C, nm, (n + 64 * U - 1) / (64 * U), [&](void *s, void *d) {                                                    \
