@@ -11,6 +11,21 @@ namespace antq {
 // one vector per lane in flight, the lane kernel 60 / 79 %; from 128 vectors up the row-table kernel wins (73-80 %).
 constexpr unsigned kRowKernelMinVpr = 128;
 
+// vectors per lane and task for rows of `vpr` vectors handled by whole wavefronts: the U in {4, 3, 2} with the best lane
+// utilisation (ties: the larger one, fewer tasks)
+__host__ __device__ inline uint32_t row_task_u(uint32_t vpr)
+{
+    uint32_t best_u = 4;
+    double best = -1.0;
+    for (uint32_t u = 4; u >= 2; u--) {
+        const uint32_t span = 64u * u, tasks = (vpr + span - 1u) / span;
+        const double util = (double)vpr / (double)(tasks * span);
+        if (util > best + 1e-9) { best = util; best_u = u; }
+    }
+    return best_u;
+}
+
+
 // ------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------

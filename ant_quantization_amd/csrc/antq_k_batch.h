@@ -33,7 +33,8 @@ struct BatchDesc {   // 152 bytes, device-visible
     PlanArgs pa;
     float vout;            // PlanHeader::vout (x-domain kinds)
     float ratio;           // ANTQ_FLAG_DYNAMIC: alpha = max|row| * ratio
-    uint32_t pad[1];
+    uint32_t u;            // x-domain row kinds (2, 4): vectors per lane and task, 2 / 3 / 4 -- the value that leaves the fewest
+                           // idle lanes for this row length (rows of 128 vectors: 2; ResNet's 3x3 rows of 144 / 288 / 576: 3)
 };
 static_assert(sizeof(BatchDesc) == 152, "BatchDesc must be 152 bytes");
 
@@ -84,9 +85,12 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
         // x-domain rows: wave-private table, no workgroup barrier
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
         if (task >= D.total_tasks) return;
-        xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
-                                              nullptr, xa, plan_tab + (D.pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
-                                              wtab_all[wv], lane, wv);
+#define ANTQ_XROW(UU)                                                                                                   \
+    xrow_task<T, OVP, false, UU, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f, nullptr, \
+                                           xa, plan_tab + (D.pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),        \
+                                           wtab_all[wv], lane, wv)
+        if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else ANTQ_XROW(2);
+#undef ANTQ_XROW
     } else {
         // groups of 16 / 32 / 64 vectors with an x-domain plan: a table per group in a slice of the wavefront's area
         lane_xs_task<T, OVP, false, U>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
@@ -161,9 +165,13 @@ k_fq_batch_all(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__
     if (D.kind == 2) {
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
         if (task >= D.total_tasks) return;
-        xrow_task<T, OVP, false, U, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f,
-                                              nullptr, xargs_of(D), plan_tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),
-                                              wtab_all[wv], lane, wv);
+        const XArgs xa = xargs_of(D);
+#define ANTQ_XROW(UU)                                                                                                   \
+    xrow_task<T, OVP, false, UU, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f, nullptr, \
+                                           xa, plan_tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),          \
+                                           wtab_all[wv], lane, wv)
+        if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else ANTQ_XROW(2);
+#undef ANTQ_XROW
     } else if (D.kind == 8) {
         lane_xs_task<T, OVP, false, U>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
                                        ((size_t)lb * U) * 256u + threadIdx.x, xargs_of(D), plan_tab + (pa.m_pad >> 2),
@@ -224,9 +232,13 @@ k_fq_batch_dyn(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__
     const float *grid = reinterpret_cast<const float *>(plan_tab);
     const float ratio = D.ratio;
     if (D.kind == 4) {
-        if (task < D.total_tasks)
-            xrow_task<T, OVP, false, 4, true, 1>(D.x, D.out, nullptr, task, D.vpr, 1u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
-                                                 entries, grid, wtab_all[wv], lane, wv);
+        if (task < D.total_tasks) {
+#define ANTQ_XROW(UU)                                                                                                   \
+    xrow_task<T, OVP, false, UU, true, 1>(D.x, D.out, nullptr, task, D.vpr, 1u, nullptr, 1, D.gmax, ratio, alpha_out, xa,  \
+                                          entries, grid, wtab_all[wv], lane, wv)
+            if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else ANTQ_XROW(2);
+#undef ANTQ_XROW
+        }
     } else if (D.kind == 6) {
         if (task < D.total_tasks)
             xrow_task<T, OVP, false, 8, true, 1>(D.x, D.out, nullptr, task, D.vpr, 1u, nullptr, 1, D.gmax, ratio, alpha_out, xa,

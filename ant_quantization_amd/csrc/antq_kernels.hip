@@ -97,8 +97,10 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr && (!DYN || vpr <= 8192);
     if (use_x) {
         // x-domain row kernel: 4 or 8 KiB of one row per wavefront (the per-row table is rebuilt per task)
-        int U = 4;   // 4 KiB of the row per wavefront measured best at steady clocks (79 % of 8 TB/s on 1 GiB)
-        if (DYN) U = (vpr <= 256 || (vpr > 512 && vpr <= 1024) || (vpr > 2048 && vpr <= 4096)) ? 4 : 8;
+        // 4 KiB of the row per wavefront measured best at steady clocks (79 % of 8 TB/s on 1 GiB); 2 or 3 KiB when that
+        // leaves fewer idle lanes (rows of 128 vectors: 2; 144 / 288 / 576: 3)
+        int U = (int)row_task_u((uint32_t)std::min<size_t>(vpr, 0x7fffffffu));
+        if (DYN) U = vpr <= 128 ? 2 : vpr <= 192 ? 3 : (vpr <= 256 || (vpr > 512 && vpr <= 1024) || (vpr > 2048 && vpr <= 4096)) ? 4 : 8;
         if (g_knob_u) U = DYN ? U : g_knob_u;
         const bool wpr4 = DYN && vpr > 512 && vpr <= 2048;   // one row per workgroup: 4 wavefronts x U x 64 vectors
         const bool wpr16 = DYN && vpr > 2048;                // one row per 1024-thread workgroup: 16 wavefronts
@@ -141,6 +143,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
         switch (U) {
         case 8: ANTQ_LAUNCH_X(8); break;
         case 4: ANTQ_LAUNCH_X(4); break;
+        case 3: ANTQ_LAUNCH_X(3); break;
         case 2: ANTQ_LAUNCH_X(2); break;
         default: ANTQ_LAUNCH_X(1); break;
         }
@@ -760,7 +763,8 @@ extern "C" size_t antq_batch_capacity(const antq_job *jobs, int n, int dtype)
     if (!jobs || n < 1 || !epl) return 0;
     size_t blocks = 0;
     // (the dynamic variant gives rows of 257..1024 vectors a workgroup each: never more than max(static, rows))
-    for (int i = 0; i < n; i++) blocks += std::max(job_blocks(jobs[i], epl, nullptr), jobs[i].rows);
+    // (x-domain rows may be cut into tasks of 2 or 3 vectors per lane instead of 4: at most twice the blocks)
+    for (int i = 0; i < n; i++) blocks += std::max(2 * job_blocks(jobs[i], epl, nullptr) + 1, jobs[i].rows);
     return sizeof(BatchHeader) + sizeof(BatchDesc) * (size_t)n + 4 * blocks;
 }
 
@@ -797,8 +801,18 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         d.vout = ph->vout;
         d.ratio = 1.0f;
         int f;
+        d.u = (uint32_t)kBatchU;
         if (!dyn) {
-            if (d.kind == 0 && xdom) d.kind = 2;
+            if (d.kind == 0 && xdom) {
+                // x-domain rows: the task size that leaves the fewest idle lanes for this row length
+                d.kind = 2;
+                d.u = row_task_u(d.vpr);
+                d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
+                const size_t total = J.rows * (size_t)d.tpr;
+                if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+                d.total_tasks = (uint32_t)total;
+                blocks = (total + 3) / 4;
+            }
             // groups of 16 / 32 / 64 vectors: a per-group x-domain table (kind 8) against the per-lane exact decision
             // (kind 1 with adom).  Measured on 16 x 4096^2 (profiles/r02_group_sweep.log): the table wins from 32 vectors
             // (bf16 group-256 / 512: 75 vs 72 %, fp32 group-128 / 256: 79 vs 75 %) and for fp32 at 16 (77 vs 75.5 %), the
@@ -819,7 +833,10 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                 // one wavefront per row up to 512 vectors (4 or 8 per lane), one workgroup per row beyond: 4 wavefronts up
                 // to 2048 vectors, 16 (a 1024-thread workgroup) up to 8192
                 f = 3;
-                if (d.vpr <= 512u) { d.kind = d.vpr <= 256u ? 4 : 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4; }
+                if (d.vpr <= 512u) {
+                    d.kind = d.vpr <= 256u ? 4 : 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4;
+                    d.u = d.vpr <= 128u ? 2u : d.vpr <= 192u ? 3u : 4u;
+                }
                 else if (d.vpr <= 2048u) { d.kind = d.vpr <= 1024u ? 5 : 7; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
                 else { d.kind = d.vpr <= 4096u ? 9 : 10; d.tpr = 16; d.total_tasks = (uint32_t)(J.rows * 16); blocks = J.rows; f = 4; }
             } else {
