@@ -808,7 +808,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                 d.kind = 2;
                 d.u = row_task_u(d.vpr);
                 d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
-                const size_t total = J.rows * (size_t)d.tpr;
+                const size_t total = (J.alpha_per_row ? J.rows : (size_t)1) * (size_t)d.tpr;   // per tensor: ONE row
                 if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
                 d.total_tasks = (uint32_t)total;
                 blocks = (total + 3) / 4;
@@ -828,7 +828,13 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             if (d.kind == 1) {
                 if (d.vshift < 0 || d.vpr > 64u) return ANTQ_ERR_UNSUPPORTED;   // butterfly over a power-of-two group
                 f = d.pa.adom ? 1 : 2;
-            } else if (xdom) {
+                // per-group tables where they beat the per-lane decision (same rule as the static batch)
+                if (xdom && xs_eligible(d.vpr, d.pa.n_entries, d.pa.nbneg, d.pa.linear) &&
+                    (!d.pa.adom || d.vpr >= 32u || dtype == ANTQ_F32)) {
+                    d.kind = 12;
+                    f = 3;
+                }
+            } else if (xdom && !(d.pa.adom && d.vpr <= 64u * kBatchU && g_knob_u != 1)) {
                 if (d.vpr > 8192u) return ANTQ_ERR_UNSUPPORTED;
                 // one wavefront per row up to 512 vectors (4 or 8 per lane), one workgroup per row beyond: 4 wavefronts up
                 // to 2048 vectors, 16 (a 1024-thread workgroup) up to 8192

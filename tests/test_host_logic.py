@@ -397,3 +397,80 @@ def test_approximate_quotient_path_host_model_equals_oracle(antq_lib, oracle):
                 n_slow += int(slow[-4000 - 0:].sum()) if False else 0
             n_total += x.size
     assert n_plans > 120, n_plans
+
+
+def test_batch_descriptor_builder_host_logic(antq_lib):
+    """antq_batch_build is pure host code: every job of a batch gets its blocks exactly once, inside its family's map
+    region, row jobs have tasks that cover their rows (per-tensor jobs are ONE row), mixed static batches collapse to the
+    all-in-one launch, dynamic batches refuse what cannot live in registers -- checked here with made-up device addresses."""
+    from ant_quantization_amd import grids
+    L = antq_lib.lib()
+    flint = antq_lib.Plan(grids.ant_flint(4, True))
+    int8 = antq_lib.Plan(grids.ant_int(8, True))
+    scan = antq_lib.Plan(np.float32([3, 1, 2, 1, 3, -7]))
+    pol = antq_lib.Plan(np.concatenate([grids.olive_flint(4, True), grids.olive_outliers(4, True)]))
+
+    def build(jobs, dtype=0, flags=0):
+        arr = (antq_lib._Job * len(jobs))()
+        for k, (r, c, per_row, plan) in enumerate(jobs):
+            arr[k] = antq_lib._Job(0x10000000 + k * 0x4000000, 0x50000000 + k * 0x4000000, 0x30000000 + 4096 * k, r, c,
+                                   1 if per_row else 0, 10.0, plan.host_addr, 0x40000000)
+        cap = L.antq_batch_capacity(arr, len(jobs), dtype)
+        host = np.zeros(cap, dtype=np.uint8)
+        n = L.antq_batch_build(arr, len(jobs), dtype, flags, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
+        if n <= 0:
+            return n, None
+        assert n <= cap
+        h = host[:56].view(np.uint32)
+        total, fam, mixed = int(h[7]), [int(v) for v in h[8:13]], int(h[13])
+        assert sum(fam) == total and int(h[6]) == n == int(h[5]) + 4 * total
+        bmap = host[int(h[5]):n].view(np.uint32)
+        descs = []
+        for k in range(len(jobs)):
+            d = host[56 + 152 * k:56 + 152 * (k + 1)]
+            w = d[40:72].view(np.uint32)          # total_tasks vpr tpr vshift first_block kind per_row gmax
+            descs.append(dict(n_vec=int(d[32:40].view(np.uint64)[0]), total_tasks=int(w[0]), vpr=int(w[1]), tpr=int(w[2]),
+                              first_block=int(w[4]), kind=int(w[5]), u=int(d[148:152].view(np.uint32)[0])))
+        assert sorted(set(bmap.tolist())) == list(range(len(jobs)))              # every job owns blocks
+        offs = np.cumsum([0] + fam)
+        for k, d in enumerate(descs):
+            pos = np.flatnonzero(bmap == k)
+            assert np.array_equal(pos, np.arange(pos[0], pos[0] + pos.size))      # contiguous
+            f = int(np.searchsorted(offs, pos[0], side="right") - 1)
+            assert pos[0] - offs[f] == d["first_block"], (k, d)                   # first_block is relative to the family
+            d["blocks"], d["family"] = int(pos.size), f
+        return n, dict(descs=descs, fam=fam, mixed=mixed, lds=int(h[4]))
+
+    # static, single family (the headline shape) stays on the lean kernel; rows of 128 / 144 vectors pick U = 2 / 3
+    n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint), (64, 1152, True, flint)], dtype=1)
+    assert b["mixed"] == 0 and b["fam"][0] > 0 and sum(b["fam"][1:]) == 0
+    assert [d["u"] for d in b["descs"]] == [4, 4, 4, 2, 3] and all(d["kind"] == 2 for d in b["descs"])
+    for d, rows in zip(b["descs"], (4096, 4096, 4096, 512, 64)):
+        assert d["total_tasks"] == rows * d["tpr"] and d["tpr"] * 64 * d["u"] >= d["vpr"] and d["blocks"] == -(-d["total_tasks"] // 4)
+    # per-tensor scale: ONE row however the caller shaped the tensor
+    n, b = build([(256, 512, False, pol), (64, 147, False, pol), (7, 33, False, pol)], flags=1)
+    assert b["descs"][0]["kind"] == 2 and b["descs"][0]["total_tasks"] == b["descs"][0]["tpr"] and b["descs"][0]["vpr"] == 32768
+    assert b["descs"][1]["kind"] == 2 and b["descs"][1]["total_tasks"] == b["descs"][1]["tpr"]      # 9408 elements: whole vectors
+    assert b["descs"][2]["kind"] == 3 and b["mixed"] == 1
+    # ResNet-50 per channel: long rows, short rows and conv1's ragged K = 147 -> one all-in-one launch
+    n, b = build([(64, 147, True, flint), (64, 64, True, flint), (256, 576, True, flint), (2048, 512, True, flint)])
+    assert b["mixed"] == 1 and b["fam"][0] == sum(d["blocks"] for d in b["descs"]) and b["lds"] > 0
+    assert [d["kind"] for d in b["descs"]] == [3, 8, 2, 2]
+    # group-16 (all lane jobs, adom): family 1 alone; a scan plan: family 2; both together: mixed
+    n, b = build([(1 << 16, 16, True, flint)] * 2, dtype=1)
+    assert b["mixed"] == 0 and b["fam"][1] > 0 and b["fam"][0] == 0 and all(d["kind"] == 1 for d in b["descs"])
+    n, b = build([(1 << 12, 64, True, scan)])
+    assert b["fam"][2] > 0 and b["mixed"] == 0
+    n, b = build([(1 << 12, 64, True, scan), (1 << 12, 64, True, flint)])
+    assert b["mixed"] == 1
+    # big tables (int-8: no per-row copy) through the exact-decision path, rows per wavefront
+    n, b = build([(512, 4096, True, int8)])
+    assert b["descs"][0]["kind"] == 0 and b["fam"][1] > 0 and b["lds"] >= 255 * 16
+    # dynamic: groups (power of two, <= 64 vectors), rows in a wavefront / a workgroup / a 1024-thread workgroup
+    n, b = build([(1 << 14, 16, True, flint), (4096, 512, True, flint), (512, 4096, True, flint), (64, 28672, True, flint),
+                  (16, 65536, True, flint), (300, 2048, True, flint)], dtype=1, flags=2)
+    assert [d["kind"] for d in b["descs"]] == [1, 12, 6, 9, 10, 0] and [d["family"] for d in b["descs"]] == [1, 3, 3, 4, 4, 1]
+    assert b["descs"][3]["blocks"] == 64 and b["descs"][2]["blocks"] == 128
+    for bad in ([(8, 576, True, flint)], [(8, 65544, True, flint)], [(8, 147, True, flint)], [(64, 64, False, flint)]):
+        n, _ = build(bad, dtype=1, flags=2)
+        assert n == -2, bad                              # ANTQ_ERR_UNSUPPORTED
