@@ -27,7 +27,7 @@ struct BatchDesc {   // 152 bytes, device-visible
                            // 8 = groups of 16 / 32 / 64 vectors, a per-group x-domain table in a slice of the wavefront's area
                            // 4..7 = kind 2 with the alpha computed in the kernel (ANTQ_FLAG_DYNAMIC, k_fq_batch_dyn): the row in
                            //         one wavefront, 4 / 8 vectors per lane (<= 256 / <= 512 vectors: kinds 4 / 6), or spread
-                           //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7); 12 = kind 8 with the group abs-max
+                           //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7; <= 512 with 2 vectors per lane: kind 12)
     int32_t per_row;
     float gmax;
     PlanArgs pa;
@@ -244,10 +244,9 @@ k_fq_batch_dyn(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__
             xrow_task<T, OVP, false, 8, true, 1>(D.x, D.out, nullptr, task, D.vpr, 1u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
                                                  entries, grid, wtab_all[wv], lane, wv);
     } else if (D.kind == 12) {
-        // groups of 16 / 32 / 64 vectors: abs-max over the group's lanes, then the per-group table (kind 8 with DYN)
-        lane_xs_task<T, OVP, false, kBatchU, true>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, nullptr, 1, D.gmax,
-                                                   ((size_t)lb * kBatchU) * 256u + threadIdx.x, xa, entries, grid, wtab_all[wv],
-                                                   lane, ratio, alpha_out);
+        // rows of 257..512 vectors spread over the 4 wavefronts of the workgroup, 2 vectors per lane
+        xrow_task<T, OVP, false, 2, true, 4>(D.x, D.out, nullptr, task, D.vpr, 4u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
+                                             entries, grid, wtab_all[wv], lane, wv);
     } else if (D.kind == 5) {
         xrow_task<T, OVP, false, 4, true, 4>(D.x, D.out, nullptr, task, D.vpr, 4u, nullptr, 1, D.gmax, ratio, alpha_out, xa,
                                              entries, grid, wtab_all[wv], lane, wv);

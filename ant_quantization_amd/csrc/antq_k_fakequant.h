@@ -489,13 +489,12 @@ k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
 // no division, no straight-through arithmetic in the element loop.  Host-side condition (xs_eligible): the table of one
 // group fits the 2 * vpr slots of its slice.
 // ------------------------------------------------------------------------------------
-// DYN: alpha = max|group| * ratio from a butterfly over the group's lanes, written to alpha_out by the group's first lane.
-template <typename T, bool OVP, bool IDX, int U, bool DYN = false>
+template <typename T, bool OVP, bool IDX, int U>
 __device__ __forceinline__ void lane_xs_task(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
                                              size_t n_vec, uint32_t vpr, int vshift, const float *__restrict__ alpha,
                                              int per_row, float gmax, size_t first, const XArgs &xa,
                                              const uint4 *__restrict__ entries, const float *__restrict__ grid,
-                                             uint4 *wtab, uint32_t lane, float ratio = 1.0f, float *__restrict__ alpha_out = nullptr)
+                                             uint4 *wtab, uint32_t lane)
 {
     constexpr int EPL = IO<T>::EPL;
     const uint32_t p = lane & (vpr - 1u);               // position inside the group (vpr is a power of two <= 64)
@@ -513,7 +512,7 @@ __device__ __forceinline__ void lane_xs_task(const uint4 *__restrict__ x, uint4 
         a[u] = 1.0f;
         if (vi < n_vec) {
             v[u] = ld_stream(x + vi);
-            if (!DYN) a[u] = alpha[per_row ? (vi >> vshift) : 0];
+            a[u] = alpha[per_row ? (vi >> vshift) : 0];
         }
     }
     const uint32_t nbp = xa.n_entries - xa.nbneg;
@@ -521,13 +520,6 @@ __device__ __forceinline__ void lane_xs_task(const uint4 *__restrict__ x, uint4 
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const size_t vi = first + (size_t)u * 256u;
-        if (DYN) {
-            // lanes past n_vec hold zeros and belong to no real group (n_vec % vpr == 0)
-            uint32_t m = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
-            for (uint32_t off = 1; off < vpr; off <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, (int)off, 64));
-            a[u] = u2f(m) * ratio;
-            if (alpha_out && vi < n_vec && p == 0u) alpha_out[vi >> vshift] = a[u];
-        }
         const Scale sc = make_scale(a[u], gmax);
         const bool gfast = sc.ok && (sc.s > 0.0f);       // the same for every lane of a group
         auto put = [&](uint32_t i, const uint4 &e) {

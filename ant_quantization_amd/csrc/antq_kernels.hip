@@ -827,22 +827,18 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             if (!J.alpha_per_row || d.kind == 3 || J.rows > 0x3ffffff0ull) return ANTQ_ERR_UNSUPPORTED;
             if (d.kind == 1) {
                 if (d.vshift < 0 || d.vpr > 64u) return ANTQ_ERR_UNSUPPORTED;   // butterfly over a power-of-two group
-                f = d.pa.adom ? 1 : 2;
-                // per-group tables where they beat the per-lane decision (same rule as the static batch)
-                if (xdom && xs_eligible(d.vpr, d.pa.n_entries, d.pa.nbneg, d.pa.linear) &&
-                    (!d.pa.adom || d.vpr >= 32u || dtype == ANTQ_F32)) {
-                    d.kind = 12;
-                    f = 3;
-                }
+                f = d.pa.adom ? 1 : 2;       // (per-group tables with the abs-max in front measured slower: 66 vs 71 %)
             } else if (xdom && !(d.pa.adom && d.vpr <= 64u * kBatchU && g_knob_u != 1)) {
                 if (d.vpr > 8192u) return ANTQ_ERR_UNSUPPORTED;
                 // one wavefront per row up to 512 vectors (4 or 8 per lane), one workgroup per row beyond: 4 wavefronts up
                 // to 2048 vectors, 16 (a 1024-thread workgroup) up to 8192
                 f = 3;
-                if (d.vpr <= 512u) {
-                    d.kind = d.vpr <= 256u ? 4 : 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4;
+                if (d.vpr <= 256u) {
+                    d.kind = 4; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4;
                     d.u = d.vpr <= 128u ? 2u : d.vpr <= 192u ? 3u : 4u;
                 }
+                else if (d.vpr <= 512u && g_knob_u != 8) { d.kind = 12; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
+                else if (d.vpr <= 512u) { d.kind = 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4; }
                 else if (d.vpr <= 2048u) { d.kind = d.vpr <= 1024u ? 5 : 7; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
                 else { d.kind = d.vpr <= 4096u ? 9 : 10; d.tpr = 16; d.total_tasks = (uint32_t)(J.rows * 16); blocks = J.rows; f = 4; }
             } else {

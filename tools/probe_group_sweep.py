@@ -34,6 +34,16 @@ def main():
                 tdb = "%5.1f%%" % (16 * n * bpe / timed(bd.run, 20) / 8e10)
             except _lib.AntqError:
                 tdb = "   n/a"
+            alt = []
+            for knob in (1, 8):          # A/B of the dynamic row variants: knob 0 = 1 -> rows of <= 256 vectors through the per-row
+                _lib.lib().antq_debug_set(0, knob)   # table kernel; = 8 -> rows of 257..512 vectors in ONE wavefront (8 per lane)
+                try:
+                    bd2 = _lib.Batch([(x, o, torch.empty_like(a), plan, 10.0, n // G, G, True) for x, a, o in zip(xs, al, outs)],
+                                     dynamic=True)
+                    alt.append("%5.1f%%" % (16 * n * bpe / timed(bd2.run, 20) / 8e10))
+                except _lib.AntqError:
+                    alt.append("   n/a")
+                _lib.lib().antq_debug_set(0, 0)
             # A/B on the same box: knob 4 = 0 turns the approximate-quotient element path off (exact division per element;
             # groups of 16 / 32 / 64 vectors then use per-group x-domain tables in the batched launch)
             _lib.lib().antq_debug_set(4, 0)
@@ -42,9 +52,9 @@ def main():
             tp0 = timed(lambda: [_lib.fakequant(x, a, plan, 10.0, n // G, G, True, out=o) for x, a, o in zip(xs, al, outs)], 5)
             _lib.lib().antq_debug_set(4, 1)
             print("%-9s group-%-5d static: batched %5.1f%%  per tensor %5.1f%%   dynamic: batched %s  per tensor %5.1f%%  of 8 TB/s"
-                  "   [exact-division path: batched %5.1f%%  per tensor %5.1f%%]" % (
+                  "   [exact-division path: batched %5.1f%%  per tensor %5.1f%%]   [dynamic batched, other row variants: %s]" % (
                 str(dt)[6:], G, 16 * n * bpe / tb / 8e10, 16 * n * bpe / tp / 8e10, tdb, 16 * n * bpe / td / 8e10,
-                16 * n * bpe / tb0 / 8e10, 16 * n * bpe / tp0 / 8e10), flush=True)
+                16 * n * bpe / tb0 / 8e10, 16 * n * bpe / tp0 / 8e10, " ".join(alt)), flush=True)
         del xs, outs
 
 
