@@ -94,7 +94,11 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     const uint4 *tab = plan_tab_ptr(plan_dev);
     const uint4 *xv = static_cast<const uint4 *>(x);
     uint4 *ov = static_cast<uint4 *>(out);
-    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr && (!DYN || vpr <= 8192);
+    // (dynamic rows of <= 256 vectors -- fp32: <= 128 -- run faster through the exact per-element decision of the d-domain
+    //  kernel than through a per-row table that can only be built once the row's abs-max is known: see antq_batch_build)
+    const bool small_dyn = DYN && pa.adom && vpr <= (IO<T>::EPL == 4 ? 128u : 256u) && g_knob_u != 1;
+    const bool use_x = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr && (!DYN || vpr <= 8192) &&
+                       !small_dyn;
     if (use_x) {
         // x-domain row kernel: 4 or 8 KiB of one row per wavefront (the per-row table is rebuilt per task)
         // 4 KiB of the row per wavefront measured best at steady clocks (79 % of 8 TB/s on 1 GiB); 2 or 3 KiB when that
@@ -828,7 +832,9 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             if (d.kind == 1) {
                 if (d.vshift < 0 || d.vpr > 64u) return ANTQ_ERR_UNSUPPORTED;   // butterfly over a power-of-two group
                 f = d.pa.adom ? 1 : 2;       // (per-group tables with the abs-max in front measured slower: 66 vs 71 %)
-            } else if (xdom && !(d.pa.adom && d.vpr <= 64u * kBatchU && g_knob_u != 1)) {
+            } else if (xdom && !(d.pa.adom && d.vpr <= (dtype == ANTQ_F32 ? 128u : 256u) && g_knob_u != 1)) {
+                // (rows of <= 256 vectors: bf16 / f16 measured faster through the exact per-element decision below -- 70 vs
+                //  61 % at 128 vectors, 79 vs 72 % at 256 -- fp32 only at 128; profiles/r02_group_sweep.log)
                 if (d.vpr > 8192u) return ANTQ_ERR_UNSUPPORTED;
                 // one wavefront per row up to 512 vectors (4 or 8 per lane), one workgroup per row beyond: 4 wavefronts up
                 // to 2048 vectors, 16 (a 1024-thread workgroup) up to 8192
@@ -837,7 +843,11 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                     d.kind = 4; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4;
                     d.u = d.vpr <= 128u ? 2u : d.vpr <= 192u ? 3u : 4u;
                 }
-                else if (d.vpr <= 512u && g_knob_u != 8) { d.kind = 12; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
+                else if (d.vpr <= 512u && dtype == ANTQ_F32 && g_knob_u != 8) {
+                    // fp32 rows of 257..512 vectors over the 4 wavefronts of a workgroup (80 vs 78 %); 16-bit rows of that many
+                    // vectors are twice the elements and stay in one wavefront (74 vs 63 %)
+                    d.kind = 12; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows;
+                }
                 else if (d.vpr <= 512u) { d.kind = 6; d.tpr = 1; d.total_tasks = (uint32_t)J.rows; blocks = (J.rows + 3) / 4; }
                 else if (d.vpr <= 2048u) { d.kind = d.vpr <= 1024u ? 5 : 7; d.tpr = 4; d.total_tasks = (uint32_t)(J.rows * 4); blocks = J.rows; }
                 else { d.kind = d.vpr <= 4096u ? 9 : 10; d.tpr = 16; d.total_tasks = (uint32_t)(J.rows * 16); blocks = J.rows; f = 4; }

@@ -469,8 +469,8 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
     # dynamic: groups (power of two, <= 64 vectors), rows in a wavefront / a workgroup / a 1024-thread workgroup
     n, b = build([(1 << 14, 16, True, flint), (4096, 512, True, flint), (512, 4096, True, flint), (64, 28672, True, flint),
                   (16, 65536, True, flint), (300, 2048, True, flint)], dtype=1, flags=2)
-    assert [d["kind"] for d in b["descs"]] == [1, 1, 12, 9, 10, 0] and [d["family"] for d in b["descs"]] == [1, 1, 3, 4, 4, 1]
-    assert b["descs"][3]["blocks"] == 64 and b["descs"][2]["blocks"] == 512
+    assert [d["kind"] for d in b["descs"]] == [1, 1, 6, 9, 10, 0] and [d["family"] for d in b["descs"]] == [1, 1, 3, 4, 4, 1]
+    assert b["descs"][3]["blocks"] == 64 and b["descs"][2]["blocks"] == 128
     for bad in ([(8, 576, True, flint)], [(8, 65544, True, flint)], [(8, 147, True, flint)], [(64, 64, False, flint)]):
         n, _ = build(bad, dtype=1, flags=2)
         assert n == -2, bad                              # ANTQ_ERR_UNSUPPORTED
