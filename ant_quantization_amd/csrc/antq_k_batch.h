@@ -65,10 +65,18 @@ __device__ __forceinline__ XArgs xargs_of(const BatchDesc &D)
     return xa;
 }
 
-// Family 0.  Occupancy (measured): the plain kernel is best at the 6 wavefronts per SIMD its 80 VGPRs give it
-// (8 loses 1.3 points); with the outlier-victim rule the extra VALU work per element wants 8 (64 VGPRs): +1 to +1.5 points.
+// Family 0: the x-domain paths only.
+// (A/B builds: tools/probe_ab_lib.py.  Round 2, same box, three interleaved rounds: plain 5 / 6 / 7 waves and pairs
+//  6 / 7 / 8 waves all within 79.4-80.3 % -- since the d-domain paths left this kernel its occupancy no longer matters;
+//  7 for the pair rule is the highest value that does not spill (8 needed 44 bytes of scratch).)
+#ifndef ANTQ_OVP_WAVES
+#define ANTQ_OVP_WAVES 7
+#endif
+#ifndef ANTQ_PLAIN_WAVES
+#define ANTQ_PLAIN_WAVES 6
+#endif
 template <typename T, bool OVP>
-__global__ void __launch_bounds__(256, OVP ? 8 : 6)
+__global__ void __launch_bounds__(256, OVP ? ANTQ_OVP_WAVES : ANTQ_PLAIN_WAVES)
 k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
 {
     constexpr int U = kBatchU;
