@@ -122,8 +122,13 @@ k_fq_batch_d(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ b
     const uint4 *plan_tab = D.plan_tab;
     float *alpha_out = DYN ? const_cast<float *>(D.alpha) : nullptr;
     if (D.kind == 1) {
-        lane_task<T, OVP, false, U, DYN, AD>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
-                                             D.ratio, alpha_out, pa, plan_tab, smem, ((size_t)lb * U) * 256u + threadIdx.x);
+        // 4 vectors per lane and workgroup, or 2 when the whole batch is only a few rounds of workgroups (antq_batch_build)
+        if (D.u == 2u)
+            lane_task<T, OVP, false, 2, DYN, AD>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
+                                                 D.ratio, alpha_out, pa, plan_tab, smem, ((size_t)lb * 2) * 256u + threadIdx.x);
+        else
+            lane_task<T, OVP, false, U, DYN, AD>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
+                                                 D.ratio, alpha_out, pa, plan_tab, smem, ((size_t)lb * U) * 256u + threadIdx.x);
         return;
     }
     uint4 tab0 = make_uint4(0, 0, 0, 0);
@@ -185,13 +190,18 @@ k_fq_batch_all(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__
                                        ((size_t)lb * U) * 256u + threadIdx.x, xargs_of(D), plan_tab + (pa.m_pad >> 2),
                                        reinterpret_cast<const float *>(plan_tab), wtab_all[wv], lane);
     } else if (D.kind == 1) {
-        const size_t first = ((size_t)lb * U) * 256u + threadIdx.x;
-        if (pa.adom)
-            lane_task<T, OVP, false, U, false, true>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row,
-                                                     D.gmax, 1.0f, nullptr, pa, plan_tab, smem, first);
-        else
+        const size_t first = ((size_t)lb * D.u) * 256u + threadIdx.x;
+        if (pa.adom) {
+            if (D.u == 2u)
+                lane_task<T, OVP, false, 2, false, true>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row,
+                                                         D.gmax, 1.0f, nullptr, pa, plan_tab, smem, first);
+            else
+                lane_task<T, OVP, false, U, false, true>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row,
+                                                         D.gmax, 1.0f, nullptr, pa, plan_tab, smem, first);
+        } else {
             lane_task<T, OVP, false, U, false, false>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row,
                                                       D.gmax, 1.0f, nullptr, pa, plan_tab, smem, first);
+        }
     } else if (D.kind == 0) {
         const uint32_t total = D.total_tasks, vpr = D.vpr, tpr = D.tpr;
         const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);

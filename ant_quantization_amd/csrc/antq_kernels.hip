@@ -872,6 +872,21 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     // element-granular jobs (exact arithmetic, no table path) ride along with whichever d-domain launch exists
     for (int i = 0; i < n; i++)
         if (fam[(size_t)i] == 255) fam[(size_t)i] = any_da ? 1 : 2;
+    {
+        // Lane jobs (kind 1, adom) take 2 instead of 4 vectors per lane when the batch is only a few rounds of workgroups
+        // (256 CUs x 8 workgroups = 2048 per round): smaller workgroups shorten the ramp and the tail of a short pass
+        // (ResNet-50 group-16, 3 rounds: 72 -> ~75 %).  Knob 0: 2 forces it, 4 forbids it (A/B).
+        size_t all_blocks = 0;
+        for (int i = 0; i < n; i++) all_blocks += nblk[(size_t)i];
+        const bool small = g_knob_u == 2 || (g_knob_u != 4 && all_blocks < 4u * 2048u);
+        for (int i = 0; i < n && small; i++) {
+            BatchDesc &d = descs[i];
+            if (d.kind == 1 && d.pa.adom) {
+                d.u = 2u;
+                nblk[(size_t)i] = (size_t)((d.n_vec + 511u) / 512u);
+            }
+        }
+    }
     if (!dyn) {
         // jobs of more than one static family: ONE launch of the all-in-one kernel instead of a launch per family
         bool seen[kBatchFamilies] = {false, false, false, false, false};

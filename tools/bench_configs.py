@@ -120,6 +120,10 @@ def main():
         bt = _lib.Batch(jobs)
         report("C1 ResNet-50 54 W, flint4 %s, fp32, BATCHED launch" % nm, elems, 8, timed(bt.run, 50),
                1 + len(bt.singles))
+        _lib.lib().antq_debug_set(0, 4)      # A/B: lane jobs with 4 vectors per lane as in big batches (default here: 2)
+        bt4 = _lib.Batch(jobs)
+        _lib.lib().antq_debug_set(0, 0)
+        report("   (the same with 4-vector lane tasks)", elems, 8, timed(bt4.run, 50), 1 + len(bt4.singles))
     # one big concatenated buffer: what a multi-tensor launch could reach for group-16
     flat = torch.cat([w.reshape(-1) for w in ws]).contiguous()
     fo = torch.empty_like(flat)
