@@ -24,7 +24,6 @@ struct BatchDesc {   // 152 bytes, device-visible
     uint32_t kind;         // 0 = row-run per wavefront, d-domain table; 1 = per-lane scale (vpr < kRowKernelMinVpr);
                            // 2 = row-run per wavefront, x-domain table
                            // 3 = element-granular (ragged rows / unaligned buffers): n_vec = elements, vpr = row_len
-                           // 8 = groups of 16 / 32 / 64 vectors, a per-group x-domain table in a slice of the wavefront's area
                            // 4..7 = kind 2 with the alpha computed in the kernel (ANTQ_FLAG_DYNAMIC, k_fq_batch_dyn): the row in
                            //         one wavefront, 4 / 8 vectors per lane (<= 256 / <= 512 vectors: kinds 4 / 6), or spread
                            //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7; <= 512 with 2 vectors per lane: kind 12)
@@ -40,7 +39,7 @@ static_assert(sizeof(BatchDesc) == 152, "BatchDesc must be 152 bytes");
 
 // A batch is up to four launches, one per kernel FAMILY, so that no kernel carries the registers of code paths its
 // jobs never take (the headline x-domain row kernel keeps its 80 VGPRs whatever else a batch may contain):
-//   family 0  k_fq_batch        x-domain tables: kinds 2, 8
+//   family 0  k_fq_batch        x-domain row tables: kind 2
 //   family 1  k_fq_batch_d<AD>  d-domain table, approximate-quotient elements (plans with adom): kinds 0, 1 (+ 3)
 //   family 2  k_fq_batch_d      d-domain table, exact division (scan plans, arbitrary value lists): kinds 0, 1, 3
 //   family 3  k_fq_batch_dyn    ANTQ_FLAG_DYNAMIC rows of >= 128 vectors with an x-domain plan: kinds 4..7
@@ -79,7 +78,6 @@ template <typename T, bool OVP>
 __global__ void __launch_bounds__(256, OVP ? ANTQ_OVP_WAVES : ANTQ_PLAIN_WAVES)
 k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
 {
-    constexpr int U = kBatchU;
     const uint32_t j = block_map[blockIdx.x];
     const BatchDesc &D = descs[j];
     const uint32_t lb = blockIdx.x - D.first_block;
@@ -88,23 +86,16 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
     const uint4 *plan_tab = D.plan_tab;
     const XArgs xa = xargs_of(D);
 
-    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];     // wave-private row / group tables
-    if (D.kind == 2) {
-        // x-domain rows: wave-private table, no workgroup barrier
-        const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
-        if (task >= D.total_tasks) return;
+    __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];     // wave-private row tables
+    // x-domain rows: wave-private table, no workgroup barrier
+    const uint32_t task = __builtin_amdgcn_readfirstlane(lb * 4u + wv);
+    if (task >= D.total_tasks) return;
 #define ANTQ_XROW(UU)                                                                                                   \
     xrow_task<T, OVP, false, UU, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f, nullptr, \
                                            xa, plan_tab + (D.pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),        \
                                            wtab_all[wv], lane, wv)
-        if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else ANTQ_XROW(2);
+    if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else ANTQ_XROW(2);
 #undef ANTQ_XROW
-    } else {
-        // groups of 16 / 32 / 64 vectors with an x-domain plan: a table per group in a slice of the wavefront's area
-        lane_xs_task<T, OVP, false, U>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
-                                       ((size_t)lb * U) * 256u + threadIdx.x, xa, plan_tab + (D.pa.m_pad >> 2),
-                                       reinterpret_cast<const float *>(plan_tab), wtab_all[wv], lane);
-    }
 }
 
 // Families 1 / 2: the plan's own (d-domain) table staged per workgroup.
@@ -185,10 +176,6 @@ k_fq_batch_all(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__
                                            wtab_all[wv], lane, wv)
         if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else ANTQ_XROW(2);
 #undef ANTQ_XROW
-    } else if (D.kind == 8) {
-        lane_xs_task<T, OVP, false, U>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
-                                       ((size_t)lb * U) * 256u + threadIdx.x, xargs_of(D), plan_tab + (pa.m_pad >> 2),
-                                       reinterpret_cast<const float *>(plan_tab), wtab_all[wv], lane);
     } else if (D.kind == 1) {
         const size_t first = ((size_t)lb * D.u) * 256u + threadIdx.x;
         if (pa.adom) {

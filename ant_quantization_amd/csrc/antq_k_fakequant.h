@@ -483,79 +483,6 @@ k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
 }
 
 // ------------------------------------------------------------------------------------
-// K1b'  groups of 16 / 32 / 64 vectors (bf16 group-128 ... 512, fp32 group-64 ... 256) with an x-domain plan: the lanes of
-// a group build THEIR group's table (lane p of the group: buckets p and p + vpr) in a private slice of the wavefront's
-// LDS area, then every lane looks its elements up there -- the per-row scheme of K1x at sub-wavefront granularity:
-// no division, no straight-through arithmetic in the element loop.  Host-side condition (xs_eligible): the table of one
-// group fits the 2 * vpr slots of its slice.
-// ------------------------------------------------------------------------------------
-template <typename T, bool OVP, bool IDX, int U>
-__device__ __forceinline__ void lane_xs_task(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
-                                             size_t n_vec, uint32_t vpr, int vshift, const float *__restrict__ alpha,
-                                             int per_row, float gmax, size_t first, const XArgs &xa,
-                                             const uint4 *__restrict__ entries, const float *__restrict__ grid,
-                                             uint4 *wtab, uint32_t lane)
-{
-    constexpr int EPL = IO<T>::EPL;
-    const uint32_t p = lane & (vpr - 1u);               // position inside the group (vpr is a power of two <= 64)
-    const uint32_t S = 2u * vpr;                         // slots per group slice; (64 / vpr) * S = 128 slots per wavefront
-    uint4 *gtab = wtab + (lane >> vshift) * S;
-    const uint4 inf = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u);
-    const uint4 ent = p < xa.n_entries ? entries[p] : inf;
-    const uint4 ent2 = p + vpr < xa.n_entries ? entries[p + vpr] : inf;
-    uint4 v[U];
-    float a[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const size_t vi = first + (size_t)u * 256u;
-        v[u] = make_uint4(0, 0, 0, 0);
-        a[u] = 1.0f;
-        if (vi < n_vec) {
-            v[u] = ld_stream(x + vi);
-            a[u] = alpha[per_row ? (vi >> vshift) : 0];
-        }
-    }
-    const uint32_t nbp = xa.n_entries - xa.nbneg;
-    const bool lin = xa.linear != 0u;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const size_t vi = first + (size_t)u * 256u;
-        const Scale sc = make_scale(a[u], gmax);
-        const bool gfast = sc.ok && (sc.s > 0.0f);       // the same for every lane of a group
-        auto put = [&](uint32_t i, const uint4 &e) {
-            bool ok = true;
-            float Ux = u2f(e.x);
-            if (gfast && i < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
-            const uint4 w = make_uint4(f2u(Ux), f2u((u2f(e.y) + 0.0f) * sc.s), f2u((u2f(e.z) + 0.0f) * sc.s), e.w);
-            if (i < xa.n_entries) gtab[lin ? i : (i < nbp ? 2u * i : 2u * (i - nbp) + 1u)] = w;
-            return w;
-        };
-        const uint4 w0 = put(p, ent);
-        if (!lin && xa.nbneg == 0u && p == 0u) gtab[1] = w0;     // unsigned grid: every negative x lands in slot 1
-        put(p + vpr, ent2);
-        __builtin_amdgcn_s_waitcnt(0xc07f);              // the wavefront's LDS writes have landed
-        if (vi < n_vec) {
-            float xf[EPL], of[EPL];
-            int j[EPL];
-            IO<T>::unpack(v[u], xf);
-            quant_vec_x<EPL, OVP, IDX>(xa, gtab, grid, sc, gfast, xf, of, j);
-            st_stream(out + vi, IO<T>::pack(of));
-            if (IDX) store_idx<EPL>(idx, vi, j);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);              // reads done before the next vector's tables overwrite the slices
-    }
-}
-
-// is the sub-wavefront table scheme applicable to groups of `vpr` vectors?  (host and device agree through this)
-__host__ __device__ inline bool xs_eligible(uint32_t vpr, uint32_t n_entries, uint32_t nbneg, uint32_t linear)
-{
-    if (!(vpr == 16u || vpr == 32u || vpr == 64u)) return false;
-    if (linear) return n_entries <= 2u * vpr;
-    const uint32_t nb = nbneg ? nbneg : n_entries;       // buckets per sign
-    return nb <= vpr;
-}
-
-// ------------------------------------------------------------------------------------
 // K1c  element-granular fallback: any row_len (e.g. conv1's K = 147), any alignment,
 // and the < EPL tail of a per-tensor launch.  One thread per PAIR (2p, 2p+1) of the flat
 // tensor so the OliVe victim rule stays inside a thread; with an odd element count the

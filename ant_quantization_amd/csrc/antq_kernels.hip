@@ -223,8 +223,6 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
             constexpr int U = 2;
             const size_t blocks = (n_vec + 256 * U - 1) / (256 * U);
             if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
-            // (the per-group table variant, lane_xs_task, is used by the batched launch only: as a single-round launch per
-            //  tensor it measured slower than this kernel, 47 vs 52 % for bf16 group-128)
             if (pa.adom)
                 hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, false, true>), dim3((unsigned)blocks), dim3(256), lds, st,
                                    static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
@@ -817,14 +815,10 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                 d.total_tasks = (uint32_t)total;
                 blocks = (total + 3) / 4;
             }
-            // groups of 16 / 32 / 64 vectors: a per-group x-domain table (kind 8) against the per-lane exact decision
-            // (kind 1 with adom).  Measured on 16 x 4096^2 (profiles/r02_group_sweep.log): the table wins from 32 vectors
-            // (bf16 group-256 / 512: 75 vs 72 %, fp32 group-128 / 256: 79 vs 75 %) and for fp32 at 16 (77 vs 75.5 %), the
-            // lane kernel for bf16 groups of 128 elements (72 vs 69 %).
-            if (d.kind == 1 && xdom && J.alpha_per_row && xs_eligible(d.vpr, d.pa.n_entries, d.pa.nbneg, d.pa.linear) &&
-                (!d.pa.adom || d.vpr >= 32u || dtype == ANTQ_F32))
-                d.kind = 8;
-            f = (d.kind == 2 || d.kind == 8) ? 0 : (d.kind == 3 ? -1 : (d.pa.adom ? 1 : 2));
+            // (groups of 16 / 32 / 64 vectors: a per-group x-domain table was round 1's answer for bf16 group-128 ... 512; the
+            //  lane kernel with the exact per-element decision matches it for 16-bit data -- 75.2-76.7 vs 76.5-77.5 % -- and
+            //  beats it for fp32 with 2-vector tasks -- 79.7-80.4 vs 77-79 %: profiles/r02_lane_task_ab.log -- so it is gone)
+            f = d.kind == 2 ? 0 : (d.kind == 3 ? -1 : (d.pa.adom ? 1 : 2));
         } else {
             // alpha computed in the kernel: the group / row has to live in the registers of a few lanes, one wavefront
             // or one workgroup
@@ -878,7 +872,8 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         // (ResNet-50 group-16, 3 rounds: 72 -> ~75 %).  Knob 0: 2 forces it, 4 forbids it (A/B).
         size_t all_blocks = 0;
         for (int i = 0; i < n; i++) all_blocks += nblk[(size_t)i];
-        const bool small = g_knob_u == 2 || (g_knob_u != 4 && all_blocks < 4u * 2048u);
+        // fp32 lane jobs always: 79.7-80.4 % with 2 against 75.7-76.3 % with 4 vectors per lane on 16 x 4096^2
+        const bool small = g_knob_u == 2 || (g_knob_u != 4 && (all_blocks < 4u * 2048u || dtype == ANTQ_F32));
         for (int i = 0; i < n && small; i++) {
             BatchDesc &d = descs[i];
             if (d.kind == 1 && d.pa.adom) {

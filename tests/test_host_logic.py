@@ -455,7 +455,7 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
     # ResNet-50 per channel: long rows, short rows and conv1's ragged K = 147 -> one all-in-one launch
     n, b = build([(64, 147, True, flint), (64, 64, True, flint), (256, 576, True, flint), (2048, 512, True, flint)])
     assert b["mixed"] == 1 and b["fam"][0] == sum(d["blocks"] for d in b["descs"]) and b["lds"] > 0
-    assert [d["kind"] for d in b["descs"]] == [3, 8, 2, 2]
+    assert [d["kind"] for d in b["descs"]] == [3, 1, 2, 2]
     # group-16 (all lane jobs, adom): family 1 alone; a scan plan: family 2; both together: mixed
     n, b = build([(1 << 16, 16, True, flint)] * 2, dtype=1)
     assert b["mixed"] == 0 and b["fam"][1] > 0 and b["fam"][0] == 0 and all(d["kind"] == 1 for d in b["descs"])

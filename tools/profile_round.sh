@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box.  Run from the repo root through gpurun:
-#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01'
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'
 # Everything is written under gpurun_out/<tag>/ (small text files only); copy what should be judged into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -11,22 +11,26 @@ export TMPDIR=/tmp
 PY="python"
 
 $PY bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"
-tail -1 "$OUT/${TAG}_bench.json"
+tail -1 "$OUT/${TAG}_bench.json" | cut -c1-400
 
 # kernel trace of the same command (no PMC in this pass)
 ( cd /tmp && rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- \
     $PY "$REPO/bench.py" --no-cpu-baseline > "$OUT/bench_profiled.json" 2> /tmp/prof_kt.err )
 KS=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/${TAG}_bench_kernel_stats.csv"
-tail -1 "$OUT/bench_profiled.json"
+tail -1 "$OUT/bench_profiled.json" | cut -c1-200
 
-# HBM traffic: one counter per pass, kernel trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section)
+# HBM traffic of the bench command: one counter per pass, kernel trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section)
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rm -rf /tmp/prof_$C && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -- \
       $PY "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/prof_$C.err )
 done
 $PY tools/pmc_summary.py $(find /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE -name '*counter_collection.csv') \
     > "$OUT/${TAG}_pmc_summary.txt" 2>&1
+
+# SQ / LDS / memory counters of every hot kernel
+bash tools/profile_counters.sh "$TAG" > "$OUT/counters.log" 2>&1
+[ -f "$REPO/gpurun_out/${TAG}_pmc_kernels.txt" ] && mv "$REPO/gpurun_out/${TAG}_pmc_kernels.txt" "$OUT/"
 
 $PY tools/bench_configs.py       > "$OUT/${TAG}_configs.log" 2>&1
 $PY tools/probe_grid_types.py    > "$OUT/${TAG}_grid_types.log" 2>&1
@@ -35,5 +39,8 @@ $PY tools/probe_weight_bank.py 2>&1 | grep -v "golden,\|bit \s" > "$OUT/${TAG}_w
 $PY tools/probe_graph_forward.py 2>&1 | grep -v "bit \s\|amdgpu" > "$OUT/${TAG}_graph_forward.log"
 $PY tools/probe_size_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_size_sweep.log"
 $PY tools/probe_group_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_group_sweep.log"
+$PY tools/probe_lane_u.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_lane_task_u.log"
 ( $PY tools/bench_sharded.py --model opt6.7b; $PY tools/bench_sharded.py --model llama70b --inplace ) 2>&1 | grep "^{" > "$OUT/${TAG}_sharded.log"
+[ -x tools/launch_anatomy ] && ./tools/launch_anatomy 2>&1 | cut -c1-70 > "$OUT/${TAG}_launch_anatomy.log"
+[ -x tools/valu_rates ] && ./tools/valu_rates > "$OUT/${TAG}_valu_rates.log" 2>&1
 ls -la "$OUT"
