@@ -6,6 +6,13 @@ validated by (data_ptr, _version, device) of the buffer: an in-place edit (`fill
 rebinding (`.bit.data = torch.tensor(8)`, AQ/quant_model.py:83) or nothing at all are told apart without touching
 the device; only a changed buffer is read back, once.  Device / dtype moves (`.to()`, `.cuda()`, `.half()`) keep
 the value and re-key the mirror.
+
+What the key cannot see: a write through `.data` that lands on the SAME address with the same `_version` (an in-place
+`buf.data.copy_(...)`, or two rebindings between forwards whose second allocation recycles the first address).  The
+in-package writers (`_to_8bit`, `set_8_bit_layer_*`, `load_state_dict`, calibration) re-key or re-arm themselves; external
+code that edits `bit` / `has_inited_quant_para` / `quant_grid` that way must call the quantiser's `rearm()` afterwards
+(INTEGRATION.md, section 2).  The operator-level drop-in (`quant_cuda.quant`) does not rely on keys at all: its kernel
+verifies the grid on the device.
 """
 
 

@@ -124,9 +124,12 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._plan = None
 
     def rearm(self):
-        """Force the next forward to re-read `bit` / `has_inited_quant_para` (set_8_bit_layer_*)."""
+        """Force the next forward to re-read `bit` / `has_inited_quant_para` / `quant_grid` from the device, whatever the
+        buffers' (data_ptr, _version) keys say (set_8_bit_layer_*, and any outside edit through `.data`)."""
         self._steady = False
         self._plan = None
+        for ent in self._hm.values():
+            ent[0] = None
 
     # ---------------------------------------------------------------- grids (AQ:75-278)
     def _bits(self):
@@ -303,6 +306,13 @@ class Quantizer(HostMirrorMixin, nn.Module):
             else:
                 if "ant-" in self.mode:
                     self.search_adaptive_numeric_type(data)
+                    if _dist_on():
+                        # The reference picks `mode` per rank and then broadcasts rank 0's quant_grid (AQ:531): ranks
+                        # whose near-tied types resolve differently end up with a mode string that contradicts their
+                        # grid.  Agree on rank 0's pick instead (identical whenever the ranks agreed anyway).
+                        pick = torch.tensor([_TYPE_ORDER.index(self.mode)], device=data.device)
+                        dist.broadcast(pick, 0)
+                        self.mode = _TYPE_ORDER[int(pick.item())]
 
             if self.mode not in _TYPE_ORDER:
                 raise RuntimeError("Unsupported mode: " + self.mode)

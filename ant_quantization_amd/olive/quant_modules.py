@@ -104,8 +104,12 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._plan = None
 
     def rearm(self):
+        """Force the next forward to re-read `bit` / `has_inited_quant_para` / `quant_grid` from the device, whatever the
+        buffers' (data_ptr, _version) keys say (set_8_bit_layer_*, and any outside edit through `.data`)."""
         self._steady = False
         self._plan = None
+        for ent in self._hm.values():
+            ent[0] = None
 
     @property
     def _no_outlier(self):

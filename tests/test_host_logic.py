@@ -320,6 +320,14 @@ def test_host_mirror_of_bit_and_inited_buffers(tree, monkeypatch):
     assert q._bits() == 5 and q._hm_get("has_inited_quant_para") == 1 and len(reads) == 4
     q._hm_known("bit", 3)                                         # what the host writes itself needs no read
     assert q._bits() == 3 and len(reads) == 4
+    # the one edit the keys cannot see: through `.data`, same address, same version -- rearm() is the documented remedy
+    q.bit.fill_(4)
+    assert q._bits() == 4
+    n0, v0, p0 = len(reads), q.bit._version, q.bit.data_ptr()
+    q.bit.data.fill_(7)
+    assert (q.bit._version, q.bit.data_ptr()) == (v0, p0) and q._bits() == 4 and len(reads) == n0      # unseen ...
+    q.rearm()
+    assert q._bits() == 7 and len(reads) == n0 + 1                                                      # ... until re-armed
 
 
 def test_dropin_directories_import_the_reference_way(tmp_path):
