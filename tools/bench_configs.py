@@ -152,11 +152,22 @@ def main():
     evals = elems * 3 * 70
     print("%-58s %9.1f G candidate-evals/s  %8.1f ms/pass (3 types x 70 clip ratios, %d tensors)" % (
         "C2 BERT-base calibration (type select + clip search)", evals / secs / 1e9, secs * 1e3, len(ws)), flush=True)
+
+    def c2_cal_multi():          # the same work as the quantiser issues it since round 2: all three types on ONE read
+        for w, a in zip(ws, al):
+            core.clip_search_types(w, a, True, 80, 150, 1, [plans[t] for t in ("int", "pot", "flint")], [10.0] * 3)
+
+    secs = timed(c2_cal_multi, 2)
+    print("%-58s %9.1f G candidate-evals/s  %8.1f ms/pass (the same, ONE launch and one read per tensor for all 3 types)" % (
+        "   (antq_search_sse_multi)", evals / secs / 1e9, secs * 1e3), flush=True)
     big = torch.randn(4096, 4096, device=dev) * 0.02
     ab = _lib.absmax(big, 4096, 4096)
     secs = timed(lambda: core.clip_search(big, ab, True, 80, 150, 1, plans["flint"], 10.0), 3)
     print("%-58s %9.1f G candidate-evals/s  %8.2f ms (one 4096x4096 fp32 tensor, 70 clip ratios)" % (
         "clip search on a large tensor", big.numel() * 70 / secs / 1e9, secs * 1e3), flush=True)
+    secs = timed(lambda: core.clip_search_types(big, ab, True, 80, 150, 1, [plans[t] for t in ("int", "pot", "flint")], [10.0] * 3), 3)
+    print("%-58s %9.1f G candidate-evals/s  %8.2f ms (the same tensor, 3 types x 70 ratios on one read)" % (
+        "   (antq_search_sse_multi)", big.numel() * 210 / secs / 1e9, secs * 1e3), flush=True)
     del big
     x = torch.nn.functional.gelu(torch.randn(64, 128, 3072, device=dev))
     pu = _lib.plan_for(grids.ant_flint(4, True))
