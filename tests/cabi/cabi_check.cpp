@@ -4,7 +4,7 @@
 // This is what a C/C++ host of the reference's path would do: build a plan on the host,
 // upload it, call the fused entry points on its own stream and buffers.  Covers antq_nearest (the quant_cuda.quant
 // replacement, KQ/quant_kernel.cu:11-62), antq_fakequant (AQ:535-551), the OliVe victim rule (OQ:311-320),
-// antq_fakequant_dynamic + antq_absmax, antq_fakequant_batch and the packed 4-bit codec.
+// antq_fakequant_dynamic + antq_absmax, antq_fakequant_batch, the packed 4-bit codec, antq_nearest_hinted and group-16.
 // Exit code 0 = every comparison bit-exact; prints one line per check.
 #include <hip/hip_runtime.h>
 
@@ -188,6 +188,43 @@ int main()
     ANTQ_OK_(antq_decode4(dcodes.p, dout.p, rows, K, dalpha3.p, 1, 32.0f, plan2.data(), dplan2.p, n_normal, ANTQ_FLAG_OVP, ANTQ_F32, st));
     antq_oracle_forward_f32(xf.data(), ref.data(), ridx.data(), rows, K, alpha3.data(), 1, olive.data(), (int)olive.size(), 32.0f, 1);
     same_bits("antq_decode4(antq_encode4(x)) OliVe, 0.5 B/elem", dout.down(st), ref);
+
+    // 7b. the operator with a plan as a hint: right plan -> table path; a plan of ANOTHER grid -> the kernel notices, scans the
+    //     device grid literally and raises the stale flag (antq_nearest_hinted)
+    {
+        DevBuf<int> dstale(1);
+        std::vector<int> zero(1, 0);
+        dstale.up(zero, st);
+        ANTQ_OK_(antq_nearest_hinted(dxf.p, dout.p, didx.p, n, dgrid.p, (int)flint.size(), plan.data(), dplan.p, dstale.p, ANTQ_F32, st));
+        antq_oracle_nearest_f32(xf.data(), ref.data(), ridx.data(), n, flint.data(), (int)flint.size());
+        same_bits("antq_nearest_hinted, right hint", dout.down(st), ref);
+        same_idx("antq_nearest_hinted indices", didx.down(st), ridx);
+        if (dstale.down(st)[0] != 0) { printf("stale flag raised on a right hint\n"); failures++; }
+        std::vector<float> other(flint);                       // same size, other values at the same address
+        for (auto &v : other) v *= 0.7f;
+        other[3] = 1.0f;
+        HIP_OK(hipMemcpyAsync(dgrid.p, other.data(), other.size() * 4, hipMemcpyHostToDevice, st));
+        ANTQ_OK_(antq_nearest_hinted(dxf.p, dout.p, didx.p, n, dgrid.p, (int)other.size(), plan.data(), dplan.p, dstale.p, ANTQ_F32, st));
+        antq_oracle_nearest_f32(xf.data(), ref.data(), ridx.data(), n, other.data(), (int)other.size());
+        same_bits("antq_nearest_hinted, stale hint (scans the device grid)", dout.down(st), ref);
+        same_idx("antq_nearest_hinted indices, stale hint", didx.down(st), ridx);
+        if (dstale.down(st)[0] != 1) { printf("stale flag not raised\n"); failures++; }
+    }
+
+    // 7c. group-16 (rows := n / 16, row_len := 16): calibrated alpha, and the abs-max computed in the kernel
+    {
+        const size_t g_rows = n / 16;
+        std::vector<float> ag(g_rows);
+        antq_oracle_absmax_f32(xf.data(), ag.data(), g_rows, 16, 1, 1.0f);
+        DevBuf<float> dag(g_rows), dag2(g_rows);
+        dag.up(ag, st);
+        ANTQ_OK_(antq_fakequant(dxf.p, dout.p, nullptr, g_rows, 16, dag.p, 1, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
+        antq_oracle_forward_f32(xf.data(), ref.data(), ridx.data(), g_rows, 16, ag.data(), 1, flint.data(), (int)flint.size(), 10.0f, 0);
+        same_bits("antq_fakequant group-16 (exact decision on x)", dout.down(st), ref);
+        ANTQ_OK_(antq_fakequant_dynamic(dxf.p, dout.p, nullptr, dag2.p, g_rows, 16, 1.0f, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
+        same_bits("antq_fakequant_dynamic group-16 alpha", dag2.down(st), ag);
+        same_bits("antq_fakequant_dynamic group-16 values", dout.down(st), ref);
+    }
 
     // 8. error behaviour: codes, not exceptions
     if (antq_fakequant(nullptr, dout.p, nullptr, rows, K, dalpha.p, 1, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st) != ANTQ_ERR_ARG) { printf("null x not rejected\n"); failures++; }
