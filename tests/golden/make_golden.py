@@ -597,9 +597,70 @@ def gen_olive_wide(outdir):
     _save(outdir, "olive_select_wide_traces.npz", tr)
 
 
+# ----------------------------------------------------------------------------
+# Rows long enough (1024 fp32 elements = 256 sixteen-byte vectors) for the single-read type selection of the HIP path
+# (antq_search_sse_multi): complete calibrations of `ant-...` lists with 2, 3 and 4 candidate types, with their traces.
+# ----------------------------------------------------------------------------
+def gen_long(outdir, tree):
+    import torch
+
+    _install_shim()
+    if tree == "ant":
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        sys.path.insert(0, os.path.join(REF, "ant_quantization", "antquant"))
+    else:
+        sys.path.insert(0, os.path.join(REF, "olive_quantization", "antquant"))
+    import quant_modules as qm
+
+    scores, tr, sel, keys = _record_mse_loss(qm), {}, {}, []
+    torch.manual_seed(41 if tree == "ant" else 43)
+    w = torch.distributions.Laplace(0.0, 0.03).sample((8, 1024))
+    w[::3] *= 0.4
+    xa = torch.nn.functional.gelu(torch.randn(4, 1024) * 1.5)
+    if tree == "olive":
+        m = torch.rand(8, 1024) < 0.01
+        w[m] *= torch.empty(int(m.sum())).uniform_(6, 40)
+        xa.view(-1)[::53] *= 9
+    sel.update({"w__x": w.numpy(), "xa__x": xa.numpy()})
+    if tree == "ant":
+        combos = [("ant-int-pot-flint", 4, {}), ("ant-int-pot-flint-float", 4, {}), ("ant-int-flint", 4, {}),
+                  ("ant-float1-float2-flint", 4, {}), ("ant-int-pot-flint", 3, {}), ("ant-int-flint-float3-apot", 5, {})]
+        lo, up, step = 75, 150, 1
+    else:
+        combos = [("ant-int-flint", 4, dict(no_outlier=False)), ("ant-int-flint", 4, dict(no_outlier=True)),
+                  ("ant-int-flint", 5, dict(no_outlier=False)), ("ant-int-flint", 3, dict(no_outlier=False))]
+        lo, up, step = 75, 250, 2
+    for name, x, is_input in (("w", w, False), ("xa", xa, True)):
+        for mode, bit, kw in combos:
+            q = qm.TensorQuantizer(mode=mode, bit=bit, is_signed=not is_input, is_enable=True, is_input=is_input,
+                                   args=_args(w_low=lo, a_low=lo, w_up=up, a_up=up, **kw))
+            q.name = "golden"
+            if not is_input:
+                q.alpha.data = torch.ones(x.shape[0], 1)
+            del scores[:]
+            out = q(x)
+            k = "%s__%s__b%d__%d_%d" % (name, mode, bit, lo, up)
+            if tree == "olive":
+                k += "__noout" if kw["no_outlier"] else "__ovp"
+                sel[k + "__outliers"] = q.outliers.data.numpy()
+            keys.append(k)
+            sel[k + "__mode"] = np.array(q.mode)
+            sel[k + "__signed"] = np.array(bool(q.is_signed))
+            sel[k + "__alpha"] = q.alpha.data.numpy().reshape(-1)
+            sel[k + "__grid"] = q.quant_grid.data.numpy()
+            sel[k + "__out"] = out.detach().numpy()
+            sel[k + "__mse"] = np.float32(q.mse.item())
+            tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, len(range(lo, up, step)))
+    sel["keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(outdir, "%s_select_long.npz" % tree), **sel)
+    np.savez_compressed(os.path.join(outdir, "%s_select_long_traces.npz" % tree), **tr)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "olive_wide", "all"], default="all")
+    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long", "all"], default="all")
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--traces-only", action="store_true",
                     help="write only the *_traces.npz files (per-candidate MSE of the complete calibrations)")
@@ -609,13 +670,15 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
     if a.tree == "all":
-        for t in ("ant", "ant_wide", "olive", "olive_wide"):
+        for t in ("ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", t, "--out", a.out] +
                                   (["--traces-only"] if a.traces_only else []))
         return
     import torch
     torch.set_num_threads(1)   # deterministic reductions for the recorded MSE traces
-    if a.tree == "ant":
+    if a.tree in ("ant_long", "olive_long"):
+        gen_long(a.out, a.tree[:-5])
+    elif a.tree == "ant":
         gen_ant(a.out)
     elif a.tree == "ant_wide":
         gen_ant_wide(a.out)

@@ -1140,6 +1140,62 @@ def test_olive_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
     capsys.readouterr()
 
 
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_quantizer_end_to_end_long_rows_single_read_type_selection(antq_lib, dev, tree, capsys):
+    """*_select_long.npz: complete `ant-...` calibrations recorded from the reference on rows of 1024 elements -- the
+    shapes on which the quantiser selects the type on ONE read of the tensor (antq_search_sse_multi: 2, 3 and 4 candidate
+    codebooks, the installed grid's search reused).  Picks against the reference's own scores, outputs for every row on
+    the reference's alpha; and exactly one search launch per calibration."""
+    import importlib
+    import torch
+    qm = importlib.import_module("ant_quantization_amd.%s.quant_modules" % tree)
+    sel, tr = golden("%s_select_long.npz" % tree), golden("%s_select_long_traces.npz" % tree)
+    calls = {"multi": 0, "single": 0}
+    real_m, real_s = antq_lib.search_sse_multi, antq_lib.search_sse
+
+    def cm(*a, **k):
+        calls["multi"] += 1
+        return real_m(*a, **k)
+
+    def cs(*a, **k):
+        calls["single"] += 1
+        return real_s(*a, **k)
+
+    antq_lib.search_sse_multi, antq_lib.search_sse = cm, cs
+    n_cases = 0
+    try:
+        for k in [str(v) for v in sel["keys"]]:
+            parts = k.split("__")
+            name, mode, b, win = parts[:4]
+            om = parts[4] if tree == "olive" else "noout"
+            bit, (lo, up) = int(b[1:]), map(int, win.split("_"))
+            x_np = sel[name + "__x"]
+            is_input = name != "w"
+            kw = dict(w_low=lo, a_low=lo, w_up=up, a_up=up)
+            if tree == "olive":
+                kw["no_outlier"] = om == "noout"
+            q = qm.TensorQuantizer(mode=mode, bit=bit, is_signed=not is_input, is_enable=True, is_input=is_input,
+                                   args=_args(**kw)).to(dev)
+            q.name = "golden"
+            x = to_dev(np.ascontiguousarray(x_np), dev)
+            if not is_input:
+                q.alpha.data = torch.ones(x.shape[0], 1, device=dev)
+            calls["multi"] = calls["single"] = 0
+            out = q(x)
+            # float1-4 all search float_value(1) (AQ:370-397): their installed grid is another one and is searched again
+            expect_single = 1 if any(t in mode for t in ("float1", "float2", "float3", "float4")) and "float" in q.mode and q.mode != "float" else 0
+            assert calls["multi"] >= 1 and calls["single"] == expect_single, (k, calls, q.mode)
+            same = _check_calibration(antq_lib, dev, q, x, out, k, sel, tr, lo, up, 1 if tree == "ant" else 2,
+                                      tree == "olive" and om == "ovp", 2e-6 if (tree == "olive" and om == "ovp") else 0.0)
+            if same is not None:
+                n_cases += 1
+            np.testing.assert_allclose(q.mse.item(), sel[k + "__mse"], rtol=5e-3, err_msg=k)
+    finally:
+        antq_lib.search_sse_multi, antq_lib.search_sse = real_m, real_s
+    assert n_cases >= len(sel["keys"]) - 1
+    capsys.readouterr()
+
+
 def test_calibration_collectives_single_rank_group(antq_lib, dev, capsys):
     """The reference's DDP syncs inside _init_quant_para (broadcast(mse), all_reduce(alpha)/world, broadcast(grid),
     AQ:520-531) run when a process group exists: with a one-rank RCCL group they must leave the result unchanged."""

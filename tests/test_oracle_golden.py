@@ -229,11 +229,13 @@ def test_search_mse_traces(oracle, tree):
 _TYPE_ORDER = ("int", "flint", "pot", "float", "float1", "float2", "float3", "float4", "apot")
 
 
-def test_full_calibration_wide_fixture_set(oracle):
+@pytest.mark.parametrize("which", ["wide", "long"])
+def test_full_calibration_wide_fixture_set(oracle, which):
     """a11 + a12 on the CPU: type selection (AQ:328-415, incl. the -floatN searches on float_value(1)), the final clip
     search and the forward, against 90 calibrations recorded from the reference (ant_select_wide.npz).  A pick may
     differ from the reference's only where the reference's OWN scores tie (ant_select_wide_traces.npz)."""
-    sel, tr = golden("ant_select_wide.npz"), golden("ant_select_wide_traces.npz")
+    # ("long": rows of 1024 elements, the shapes on which the HIP path selects the type on ONE read of the tensor)
+    sel, tr = golden("ant_select_%s.npz" % which), golden("ant_select_%s_traces.npz" % which)
     n_alpha = n_same = 0
     for k in [str(v) for v in sel["keys"]]:
         name, mode, b, win = k.split("__")
@@ -278,11 +280,12 @@ def test_full_calibration_wide_fixture_set(oracle):
     assert n_same >= 0.97 * n_alpha, (n_same, n_alpha)       # (informative: how often the noise flips a pick at all)
 
 
-def test_olive_full_calibration_wide_fixture_set(oracle):
+@pytest.mark.parametrize("which", ["wide", "long"])
+def test_olive_full_calibration_wide_fixture_set(oracle, which):
     """OliVe a10-a12 on the CPU (OQ:189-292): 3-sigma x_max, step-2 clip search with the victim rule inside the loss,
     int / flint selection, final forward -- against olive_select_wide.npz (bits 3..8, outliers on / off, odd numel),
     picks checked against the reference's own scores (olive_select_wide_traces.npz)."""
-    sel, tr = golden("olive_select_wide.npz"), golden("olive_select_wide_traces.npz")
+    sel, tr = golden("olive_select_%s.npz" % which), golden("olive_select_%s_traces.npz" % which)
     n_alpha = n_same = 0
     for k in [str(v) for v in sel["keys"]]:
         name, mode, b, win, om = k.split("__")
