@@ -1184,7 +1184,12 @@ def test_quantizer_end_to_end_long_rows_single_read_type_selection(antq_lib, dev
             out = q(x)
             # float1-4 all search float_value(1) (AQ:370-397): their installed grid is another one and is searched again
             expect_single = 1 if any(t in mode for t in ("float1", "float2", "float3", "float4")) and "float" in q.mode and q.mode != "float" else 0
-            assert calls["multi"] >= 1 and calls["single"] == expect_single, (k, calls, q.mode)
+            if tree == "olive" and bit >= 5 and om == "ovp":
+                # 5-bit codebook + outliers: more than 128 buckets, no per-row table -> the single-read entry declines and the
+                # quantiser searches type by type (2 types + the installed grid)
+                assert calls == {"multi": 1, "single": 3}, (k, calls)
+            else:
+                assert calls["multi"] >= 1 and calls["single"] == expect_single, (k, calls, q.mode)
             same = _check_calibration(antq_lib, dev, q, x, out, k, sel, tr, lo, up, 1 if tree == "ant" else 2,
                                       tree == "olive" and om == "ovp", 2e-6 if (tree == "olive" and om == "ovp") else 0.0)
             if same is not None:
