@@ -4,6 +4,7 @@
 #define ANTQ_K_CODEC_H
 
 #include "antq_device.h"
+#include "antq_k_approx.h"
 
 namespace antq {
 
@@ -48,7 +49,8 @@ k_encode4(const void *__restrict__ x, uint32_t *__restrict__ codes, size_t n_oct
     constexpr int U = VEC ? UE : 1;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 tab0 = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    if (pa.adom) tab0 = atab_prefetch<true>(pa, plan_tab);         // exact decision on x (antq_k_approx.h), with indices
+    else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;   // octet index: elements [8o, 8o+8)
     float xf[U][8], a[U];
 #pragma unroll
@@ -67,16 +69,24 @@ k_encode4(const void *__restrict__ x, uint32_t *__restrict__ codes, size_t n_oct
             }
         }
     }
-    const PlanLds L = stage_plan(pa, plan_tab, smem, tab0);
+    PlanLds L;
+    ATab A;
+    if (pa.adom) A = stage_atab<true>(pa, plan_tab, smem, tab0);
+    else L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const size_t o = first + (size_t)u * 256u;
         if (o >= n_oct) continue;
-        const Scale sc = make_scale(a[u], gmax);
         float of[8];
         int j[8];
-        quant_vec<8, OVP, true>(pa, L, sc, xf[u], of, j);
+        if (pa.adom) {
+            const ScaleA sc = make_scale_a(a[u], gmax);
+            quant_vec_a<8, OVP, true>(pa, A, sc, xf[u], of, j);
+        } else {
+            const Scale sc = make_scale(a[u], gmax);
+            quant_vec<8, OVP, true>(pa, L, sc, xf[u], of, j);
+        }
         uint32_t word = 0;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -170,7 +180,7 @@ static int launch_codec(bool enc, const void *x, void *codes_or_out, const uint8
     for (int i = 0; i < (ovp ? n_normal : m); i++) if (grid_host[i] == 0.0f) zero_code = i;
     const dim3 gd((unsigned)blocks), bd(256);
     if (enc) {
-        const size_t lds = (size_t)pa.tab_units * 16;
+        const size_t lds = lds_table(pa, true);
         uint32_t *codes = static_cast<uint32_t *>(codes_or_out);
 #define ANTQ_ENC(O, V) hipLaunchKernelGGL((k_encode4<T, O, V, kEncU>), gd, bd, lds, st, x, codes, n_oct, row_len, alpha, per_row, gmax, \
                                           n_normal, zero_code, pa, plan_tab_ptr(plan_dev))
