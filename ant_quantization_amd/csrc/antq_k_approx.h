@@ -28,9 +28,10 @@ namespace antq {
 //     q   = fma64(-M', s, x) >= 0 ? v_hi : v_lo
 //     out = fl(q * s)                 == ((q - d) + d) * s: the straight-through step is exact in every region of an
 //                                     `adom` plan (Sterbenz); -0.0 codebook entries are stored as +0.0, as (q - d) + d gives
-// ~13 VALU ops per element (3 of them f64, full rate on CDNA4) and no data-dependent branch.  Elements with
-// |dt| >= xlim (clipped beyond twice the outermost value), NaN / Inf and groups whose scale is not in [2^-40, 2^40]
-// take the literal reference sequence (true division, scan, straight-through arithmetic), per lane, rarely.
+// ~13 VALU ops per element (3 of them f64, full rate on CDNA4) and no data-dependent branch.  Elements clipped beyond
+// twice the outermost value (|dt| >= xlim) keep the table's q and redo only the arithmetic with the true quotient;
+// NaN / Inf / |d| beyond the table's domain and groups whose scale is not in [2^-40, 2^40] take the literal reference
+// sequence (true division, scan, straight-through arithmetic) -- per lane, rarely.
 // ------------------------------------------------------------------------------------
 struct ScaleA {
     float s;
@@ -38,11 +39,17 @@ struct ScaleA {
     double sd;    // (double)s
     bool ok;      // s in [2^-40, 2^40] (positive, finite): the table path may be used
 };
-__device__ __forceinline__ ScaleA make_scale_a(float alpha, float gmax)
+// inv_gmax = 1.0 / (double)gmax.  s = fl32(alpha / gmax) (AQ:536) without the division: the double product is within
+// 2^-52 of the quotient, and a quotient of two floats is never that close to a float rounding boundary without being on
+// the same side of it (boundary x gmax has <= 49 significant bits, alpha 24: their distance is >= 2^-49 relative), so
+// rounding the product to float gives the correctly rounded quotient.  Outside the table path's scale range (denormal,
+// zero, negative, Inf, NaN) the division is done literally.
+__device__ __forceinline__ ScaleA make_scale_a(float alpha, float gmax, double inv_gmax)
 {
     ScaleA sc;
-    sc.s = alpha / gmax;                                // exactly as the reference divides it (AQ:536)
+    sc.s = (float)((double)alpha * inv_gmax);
     sc.ok = (sc.s >= kScaleLo) && (sc.s <= kScaleHi);
+    if (!sc.ok) sc.s = alpha / gmax;
     sc.rs = __builtin_amdgcn_rcpf(sc.s);
     sc.sd = (double)sc.s;
     return sc;
@@ -56,6 +63,17 @@ struct ATab {
     const uint4 *tab;
     const float *grid;
     const uint32_t *idx;
+};
+// One a-table entry as the element loop reads it: ONE ds_read_b128 into four consecutive registers (the barrier keeps
+// the compiler from splitting it into two b64 halves), M' = the register pair .xy, no copies.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+struct AEnt {
+    u32x4_t v;
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ double Mp() const { return __builtin_bit_cast(double, (u32x2_t)v.xy); }
+    __device__ __forceinline__ uint32_t lo() const { return v.z; }     // bits of v_lo / v_hi (the encoder: their codes)
+    __device__ __forceinline__ uint32_t hi() const { return v.w; }
 };
 __host__ __device__ inline uint32_t atab_units(uint32_t slots, uint32_t m_pad, bool idx)
 {
@@ -90,46 +108,75 @@ __device__ __forceinline__ uint4 atab_prefetch(const PlanArgs &pa, const uint4 *
     return first;
 }
 
+// max |v[e]| over a lane's EPL values (v_max3 with |.| modifiers; max drops NaNs) and whether any of them is a NaN
+// (v_cmp_u on pairs): 10 instructions for 8 values instead of a compare per value and limit.
+template <int EPL>
+__device__ __forceinline__ float absmax_nan(const float (&v)[EPL], bool &nan)
+{
+    float m = __builtin_fmaxf(fabsf(v[0]), fabsf(v[1]));
+    nan = __builtin_isunordered(v[0], v[1]);
+#pragma unroll
+    for (int e = 2; e < EPL; e += 2) {
+        m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v[e])), fabsf(v[e + 1]));
+        nan = nan || __builtin_isunordered(v[e], v[e + 1]);
+    }
+    return m;
+}
+
+// Slot of the a-table for EPL approximate quotients (all |dt| inside the table's domain).
+template <int EPL>
+__device__ __forceinline__ void a_slots(const PlanArgs &pa, const float (&dt)[EPL], uint32_t (&slot)[EPL])
+{
+    if (pa.linear) {
+        const float khi = (float)pa.kmax;
+#pragma unroll
+        for (int e = 0; e < EPL; e++)
+            slot[e] = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(dt[e], pa.lin_scale, pa.lin_bias), 0.0f, khi);
+    } else {
+        // slot = 2 * (clamp(key) - kmin) + sign: one v_med3 and one v_alignbit (an unsigned grid keeps a negative key:
+        // it clamps to kmin, slot 1)
+        // key: the magnitude bits [shift, 31) (v_bfe_u32), or for an unsigned grid the arithmetic shift (keymask all ones)
+        const uint32_t sh = pa.shift, wd = 31u - pa.shift;
+        const bool mag = pa.keymask != 0xffffffffu;
+        const int32_t lo = (int32_t)pa.kmin, hi = (int32_t)pa.kmax;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int32_t u = (int32_t)f2u(dt[e]);
+            const int32_t t = mag ? (int32_t)__builtin_amdgcn_ubfe((uint32_t)u, sh, wd) : (u >> sh);
+            int32_t ck;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+            slot[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);    // 2 * kmin too high: folded into tab0
+        }
+    }
+}
+
 template <int EPL, bool OVP, bool IDX>
 __device__ __forceinline__ void quant_vec_a(const PlanArgs &pa, const ATab &A, const ScaleA &sc, const float (&x)[EPL],
                                             float (&o)[EPL], int (&j)[EPL])
 {
     float dt[EPL], q[EPL];
-    bool fast = sc.ok;
+    // fast: the table decides (|d| inside the table's domain); ste: the straight-through step is exact as well (|d| < xlim).
+    // Elements clipped beyond xlim but inside the table's domain keep the table's q and only redo the arithmetic.
+    const float flim = pa.fastlim * 0.99999f;             // (the approximate quotient is within 2^-22 of d)
 #pragma unroll
-    for (int e = 0; e < EPL; e++) {
-        dt[e] = x[e] * sc.rs;
-        fast = fast && (fabsf(dt[e]) < pa.xlim);  // false for NaN / Inf / far beyond the grid
-    }
+    for (int e = 0; e < EPL; e++) dt[e] = x[e] * sc.rs;
+    bool nan;
+    const float dmax = absmax_nan<EPL>(dt, nan);
+    const bool fast = sc.ok && !nan && dmax < flim;       // false for NaN / Inf / huge
+    const bool ste = dmax < pa.xlim;
     if (fast) {
         uint32_t slot[EPL];
-        if (pa.linear) {
-            const float khi = (float)pa.kmax;
+        a_slots<EPL>(pa, dt, slot);
+        const AEnt *tab0 = reinterpret_cast<const AEnt *>(pa.linear ? A.tab : A.tab - 2u * pa.kmin);
+        AEnt ents[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; e++)
-                slot[e] = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(dt[e], pa.lin_scale, pa.lin_bias), 0.0f, khi);
-        } else {
-            // slot = 2 * (clamp(key) - kmin) + sign: one v_med3 and one v_alignbit (an unsigned grid keeps a negative key:
-            // it clamps to kmin, slot 1)
-            const int32_t sh = (int32_t)pa.shift, km = (int32_t)pa.keymask;
-            const int32_t lo = (int32_t)pa.kmin, hi = (int32_t)pa.kmax;
-#pragma unroll
-            for (int e = 0; e < EPL; e++) {
-                const int32_t u = (int32_t)f2u(dt[e]);
-                const int32_t t = (u >> sh) & km;
-                int32_t ck;
-                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
-                slot[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);    // 2 * kmin too high: folded into tab0
-            }
-        }
-        const uint4 *tab0 = pa.linear ? A.tab : A.tab - 2u * pa.kmin;
+        for (int e = 0; e < EPL; e++) ents[e] = tab0[slot[e]];     // all reads in flight before the first use
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
-            uint4 ent = tab0[slot[e]];
-            asm volatile("" : "+v"(ent.x), "+v"(ent.y), "+v"(ent.z), "+v"(ent.w));   // one ds_read_b128, not two b64 halves
-            const double Mp = __longlong_as_double((long long)(((unsigned long long)ent.y << 32) | ent.x));
-            const bool c = __builtin_fma(-Mp, sc.sd, (double)x[e]) >= 0.0;
-            q[e] = c ? u2f(ent.w) : u2f(ent.z);
+            AEnt ent = ents[e];
+            ent.pin();
+            const bool c = __builtin_fma(-ent.Mp(), sc.sd, (double)x[e]) >= 0.0;
+            q[e] = c ? u2f(ent.hi()) : u2f(ent.lo());
             if (IDX) {
                 const uint32_t w = (pa.linear ? A.idx : A.idx - 2u * pa.kmin)[slot[e]];
                 j[e] = (int)((c ? (w >> 16) : w) & kIdxMask);
@@ -148,8 +195,18 @@ __device__ __forceinline__ void quant_vec_a(const PlanArgs &pa, const ATab &A, c
                 }
             }
         }
+        if (ste) {
 #pragma unroll
-        for (int e = 0; e < EPL; e++) o[e] = q[e] * sc.s;
+            for (int e = 0; e < EPL; e++) o[e] = q[e] * sc.s;
+        } else {
+            // clipped far beyond the grid (|d| >= twice the outermost value): q is right, (q - d) + d is not q -- literally
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const float d = x[e] / sc.s;
+                const float t = (q[e] - d) + d;
+                o[e] = t * sc.s;
+            }
+        }
     } else {
         // exact reference sequence for this lane's EPL elements
         float d[EPL];

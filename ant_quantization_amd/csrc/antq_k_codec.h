@@ -8,12 +8,108 @@
 
 namespace antq {
 
-// One lane: 8 consecutive elements (4 pairs) of one row -> 4 bytes of codes: the fused quantiser (quant_vec with the
-// index output), then every index is folded into a nibble.  VEC (16-byte aligned tensors): the octet is one (bf16 / f16)
-// or two (fp32) 16-byte loads and each thread has 4 octets in flight; otherwise element loads.
-template <typename T> struct Oct;                      // 8 elements <-> 16-byte vectors
+// floor(o / opr) without an integer division: one f64 multiply by the reciprocal and a +-1 fix-up (o < 2^32, exact).
+__device__ __forceinline__ uint32_t oct_row(uint32_t o, uint32_t opr, double inv)
+{
+    uint32_t q = (uint32_t)((double)o * inv);
+    const uint32_t qo = q * opr;
+    if (qo > o) q--;
+    else if (o - qo >= opr) q++;
+    return q;
+}
+
+// The encoder only needs codes: its LDS table is the plan's a-table with the two values of every entry replaced, once per
+// workgroup, by their nibbles (bit 8 = the pair rule's outlier test |v| > 32): {M' (double), code_lo, code_hi}.  One
+// ds_read_b128, the exact decision (antq_k_approx.h) and one select per element; no second table read, no dequantised value.
+constexpr uint32_t kOutlierBit = 0x100u;
+template <bool OVP>
+__device__ __forceinline__ uint32_t code_of(uint32_t j, float v, int n_normal)
+{
+    uint32_t c = (OVP && (int)j >= n_normal) ? j - (uint32_t)n_normal : j;
+    c &= 15u;
+    if (OVP && fabsf(v) > 32.0f) c |= kOutlierBit;                // OQ:314
+    return c;
+}
+template <bool OVP>
+__device__ __forceinline__ void atab_to_codes(const PlanArgs &pa, uint4 *smem, const ATab &A, int n_normal)
+{
+    for (uint32_t i = threadIdx.x; i < pa.atab_slots; i += blockDim.x) {
+        uint4 e = smem[i];
+        const uint32_t w = A.idx[i];
+        e.z = code_of<OVP>(w & kIdxMask, u2f(e.z), n_normal);
+        e.w = code_of<OVP>((w >> 16) & kIdxMask, u2f(e.w), n_normal);
+        smem[i] = e;
+    }
+}
+// 8 codes (4 pairs) -> one word of nibbles; OVP: the pair rule on the outlier bits first (OQ:313-320)
+template <bool OVP>
+__device__ __forceinline__ uint32_t pack_codes(uint32_t (&c)[8])
+{
+    uint32_t pr[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        uint32_t c0 = c[2 * p], c1 = c[2 * p + 1];
+        if (OVP) {
+            const bool me = c0 >= kOutlierBit, mo = c1 >= kOutlierBit;
+            const bool ve = mo && !me;
+            c0 = ve ? 15u : c0;                                  // the identifier 1111 marks the victim
+            c1 = me ? 15u : c1;
+        }
+        pr[p] = (c1 << 4) | c0;                                  // byte 0 = the pair; the outlier bits land in byte 1
+    }
+    if (OVP) {
+        const uint32_t w01 = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0400u);
+        const uint32_t w23 = __builtin_amdgcn_perm(pr[3], pr[2], 0x0c0c0400u);
+        return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+    }
+    return pr[0] | (pr[1] << 8) | (pr[2] << 16) | (pr[3] << 24);
+}
+// 8 consecutive elements of one row (the first at an index that is a multiple of 8) -> 8 nibbles
+template <bool OVP>
+__device__ __forceinline__ uint32_t encode_oct_a(const PlanArgs &pa, const uint4 *etab, const float *grid, const ScaleA &sc,
+                                                 const float (&x)[8], int n_normal, int zero_code)
+{
+    float dt[8];
+    uint32_t c[8];
+    const float flim = pa.fastlim * 0.99999f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) dt[e] = x[e] * sc.rs;
+    bool nan;
+    const float dmax = absmax_nan<8>(dt, nan);
+    if (sc.ok && !nan && dmax < flim) {                 // false for NaN / Inf / beyond the table's domain
+        uint32_t slot[8];
+        a_slots<8>(pa, dt, slot);
+        const AEnt *tab0 = reinterpret_cast<const AEnt *>(pa.linear ? etab : etab - 2u * pa.kmin);
+        AEnt ents[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) ents[e] = tab0[slot[e]];      // all reads in flight before the first use
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            AEnt ent = ents[e];
+            ent.pin();
+            c[e] = (__builtin_fma(-ent.Mp(), sc.sd, (double)x[e]) >= 0.0) ? ent.hi() : ent.lo();
+        }
+    } else {
+        // the literal sequence (true division, scan) for this lane's octet
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            int jj;
+            const float q = scan_lds(x[e] / sc.s, grid, (int)pa.m, jj);
+            c[e] = jj == ANTQ_IDX_NONE ? (uint32_t)zero_code : code_of<OVP>((uint32_t)jj, q, n_normal);
+        }
+    }
+    return pack_codes<OVP>(c);
+}
+
+// One lane: 8 consecutive elements (4 pairs) of one row -> 4 bytes of codes; VEC: the octet is one (bf16 / f16) or two
+// (fp32) 16-byte loads, U octets in flight per thread.
+template <typename T> struct Oct {                     // 8 elements <- 16-byte vectors
+    __device__ __forceinline__ static void load(const void *p, size_t o, float (&f)[8])
+    {
+        IO<T>::unpack(ld_stream(static_cast<const uint4 *>(p) + o), f);
+    }
+};
 template <> struct Oct<float> {
-    static constexpr int NV = 2;
     __device__ __forceinline__ static void load(const void *p, size_t o, float (&f)[8])
     {
         const uint4 *v = static_cast<const uint4 *>(p) + 2 * o;
@@ -21,28 +117,12 @@ template <> struct Oct<float> {
         f[0] = u2f(a.x); f[1] = u2f(a.y); f[2] = u2f(a.z); f[3] = u2f(a.w);
         f[4] = u2f(b.x); f[5] = u2f(b.y); f[6] = u2f(b.z); f[7] = u2f(b.w);
     }
-    __device__ __forceinline__ static void store(void *p, size_t o, const float (&f)[8])
-    {
-        uint4 *v = static_cast<uint4 *>(p) + 2 * o;
-        st_stream(v, make_uint4(f2u(f[0]), f2u(f[1]), f2u(f[2]), f2u(f[3])));
-        st_stream(v + 1, make_uint4(f2u(f[4]), f2u(f[5]), f2u(f[6]), f2u(f[7])));
-    }
-};
-template <typename T> struct Oct {
-    static constexpr int NV = 1;
-    __device__ __forceinline__ static void load(const void *p, size_t o, float (&f)[8])
-    {
-        IO<T>::unpack(ld_stream(static_cast<const uint4 *>(p) + o), f);
-    }
-    __device__ __forceinline__ static void store(void *p, size_t o, const float (&f)[8])
-    {
-        st_stream(static_cast<uint4 *>(p) + o, IO<T>::pack(f));
-    }
 };
 
+// Persistent workgroups (the plan's table is staged once), each looping over tasks of 256 * U octets.
 template <typename T, bool OVP, bool VEC, int UE>
 __global__ void __launch_bounds__(256)
-k_encode4(const void *__restrict__ x, uint32_t *__restrict__ codes, size_t n_oct, size_t row_len,
+k_encode4(const void *__restrict__ x, uint32_t *__restrict__ codes, size_t n_oct, size_t row_len, size_t n_tasks,
           const float *__restrict__ alpha, int per_row, float gmax, int n_normal, int zero_code,
           PlanArgs pa, const uint4 *__restrict__ plan_tab)
 {
@@ -51,54 +131,64 @@ k_encode4(const void *__restrict__ x, uint32_t *__restrict__ codes, size_t n_oct
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (pa.adom) tab0 = atab_prefetch<true>(pa, plan_tab);         // exact decision on x (antq_k_approx.h), with indices
     else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
-    const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;   // octet index: elements [8o, 8o+8)
-    float xf[U][8], a[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const size_t o = first + (size_t)u * 256u;
-        a[u] = 1.0f;
-#pragma unroll
-        for (int e = 0; e < 8; e++) xf[u][e] = 0.0f;
-        if (o < n_oct) {
-            // row_len % 8 == 0: an octet (4 pairs) lies inside one row -> one scale
-            a[u] = alpha[per_row ? (o * 8 / row_len) : 0];
-            if (VEC) Oct<T>::load(x, o, xf[u]);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; e++) xf[u][e] = IO<T>::load1(x, o * 8 + e);
-            }
-        }
-    }
     PlanLds L;
     ATab A;
-    if (pa.adom) A = stage_atab<true>(pa, plan_tab, smem, tab0);
-    else L = stage_plan(pa, plan_tab, smem, tab0);
+    if (pa.adom) {
+        A = stage_atab<true>(pa, plan_tab, smem, tab0);
+        __syncthreads();
+        atab_to_codes<OVP>(pa, smem, A, n_normal);
+    } else L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
+    const size_t opr = row_len / 8;                    // row_len % 8 == 0: an octet (4 pairs) lies inside one row -> one scale
+    const bool small = n_oct <= 0xffffffffull && opr <= 0xffffffffull;
+    const bool pow2 = (opr & (opr - 1)) == 0;          // the usual case: the row index is a shift
+    const int rsh = pow2 ? __builtin_ctzll(opr | (1ull << 63)) : 0;
+    const double inv = 1.0 / (double)opr;
+    const float a0 = per_row ? 1.0f : alpha[0];
+    const double inv_gmax = 1.0 / (double)gmax;
+    for (size_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const size_t first = (task * U) * 256u + threadIdx.x;   // octet index: elements [8o, 8o+8)
+        float xf[U][8], a[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const size_t o = first + (size_t)u * 256u;
-        if (o >= n_oct) continue;
-        float of[8];
-        int j[8];
-        if (pa.adom) {
-            const ScaleA sc = make_scale_a(a[u], gmax);
-            quant_vec_a<8, OVP, true>(pa, A, sc, xf[u], of, j);
-        } else {
+        for (int u = 0; u < U; u++) {
+            const size_t o = first + (size_t)u * 256u;
+            a[u] = a0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) xf[u][e] = 0.0f;
+            if (o < n_oct) {
+                if (per_row) a[u] = alpha[pow2 ? (o >> rsh) : small ? (size_t)oct_row((uint32_t)o, (uint32_t)opr, inv) : o / opr];
+                if constexpr (VEC) Oct<T>::load(x, o, xf[u]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) xf[u][e] = IO<T>::load1(x, o * 8 + e);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t o = first + (size_t)u * 256u;
+            if (o >= n_oct) continue;
+            if (pa.adom) {
+                codes[o] = encode_oct_a<OVP>(pa, A.tab, A.grid, make_scale_a(a[u], gmax, inv_gmax), xf[u], n_normal, zero_code);
+                continue;
+            }
+            float of[8];
+            int j[8];
             const Scale sc = make_scale(a[u], gmax);
             quant_vec<8, OVP, true>(pa, L, sc, xf[u], of, j);
-        }
-        uint32_t word = 0;
+            uint32_t word = 0;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int jj = j[e];
-            uint32_t c;
-            if (jj == ANTQ_IDX_VICTIM) c = 15u;
-            else if (jj == ANTQ_IDX_NONE) c = (uint32_t)zero_code;
-            else if (OVP && jj >= n_normal) c = (uint32_t)(jj - n_normal);
-            else c = (uint32_t)jj;
-            word |= (c & 15u) << (4 * e);
+            for (int e = 0; e < 8; e++) {
+                const int jj = j[e];
+                uint32_t c;
+                if (jj == ANTQ_IDX_VICTIM) c = 15u;
+                else if (jj == ANTQ_IDX_NONE) c = (uint32_t)zero_code;
+                else if (OVP && jj >= n_normal) c = (uint32_t)(jj - n_normal);
+                else c = (uint32_t)jj;
+                word |= (c & 15u) << (4 * e);
+            }
+            codes[o] = word;
         }
-        codes[o] = word;
     }
 }
 
@@ -171,9 +261,11 @@ static int launch_codec(bool enc, const void *x, void *codes_or_out, const uint8
     else if (m > 16) return ANTQ_ERR_UNSUPPORTED;
     const size_t n_oct = n / 8;
     const bool vec = reinterpret_cast<uintptr_t>(enc ? x : codes_or_out) % 16 == 0;     // 16-byte vector I/O
-    constexpr int kEncU = 1;                           // octets per thread when encoding: VALU-bound, more in flight did not pay
-    const size_t per_block = vec ? (enc ? 256 * kEncU : 1024 * IO<T>::EPL / 8) : 256;     // octets per workgroup
-    const size_t blocks = (n_oct + per_block - 1) / per_block;
+    constexpr int kEncU = 2;                           // octets per thread and task when encoding
+    const size_t per_block = vec ? (enc ? 256 * kEncU : 1024 * IO<T>::EPL / 8) : 256;     // octets per workgroup (task)
+    const size_t n_tasks = (n_oct + per_block - 1) / per_block;
+    size_t blocks = n_tasks;
+    if (enc && blocks > (size_t)g_knob_encwg) blocks = (size_t)g_knob_encwg;   // persistent workgroups
     if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
     const float *grid_host = plan_grid(plan_host);
     int zero_code = 0;
@@ -182,7 +274,7 @@ static int launch_codec(bool enc, const void *x, void *codes_or_out, const uint8
     if (enc) {
         const size_t lds = lds_table(pa, true);
         uint32_t *codes = static_cast<uint32_t *>(codes_or_out);
-#define ANTQ_ENC(O, V) hipLaunchKernelGGL((k_encode4<T, O, V, kEncU>), gd, bd, lds, st, x, codes, n_oct, row_len, alpha, per_row, gmax, \
+#define ANTQ_ENC(O, V) hipLaunchKernelGGL((k_encode4<T, O, V, kEncU>), gd, bd, lds, st, x, codes, n_oct, row_len, n_tasks, alpha, per_row, gmax, \
                                           n_normal, zero_code, pa, plan_tab_ptr(plan_dev))
         if (ovp) { if (vec) ANTQ_ENC(true, true); else ANTQ_ENC(true, false); }
         else     { if (vec) ANTQ_ENC(false, true); else ANTQ_ENC(false, false); }

@@ -78,7 +78,7 @@ __device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__res
     const bool ad = ADM < 0 ? (pa.adom != 0u) : (ADM != 0);
     ScaleA sa;
     Scale sc;
-    if (ad) sa = make_scale_a(a, gmax); else sc = make_scale(a, gmax);
+    if (ad) sa = make_scale_a(a, gmax, 1.0 / (double)gmax); else sc = make_scale(a, gmax);
 #pragma unroll
     for (int u = 0; u < U; u++) {
         if (v0 + 64u * u < vpr) {
@@ -441,6 +441,7 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
     if (AD) A = stage_atab<IDX>(pa, plan_tab, smem, tab0);
     else L = stage_plan(pa, plan_tab, smem, tab0);
     __syncthreads();
+    const double inv_gmax = 1.0 / (double)gmax;
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const size_t vi = first + (size_t)u * 256u;
@@ -458,7 +459,7 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
             float of[EPL];
             int j[EPL];
             if (AD) {
-                const ScaleA sc = make_scale_a(a[u], gmax);
+                const ScaleA sc = make_scale_a(a[u], gmax, inv_gmax);
                 quant_vec_a<EPL, OVP, IDX>(pa, A, sc, xf, of, j);
             } else {
                 const Scale sc = make_scale(a[u], gmax);

@@ -40,7 +40,7 @@ namespace antq {
 // later calls only, so a probe that forgets to reset them cannot change which kernel another thread's calls run, and the
 // library keeps no process-global mutable state.
 static thread_local int g_knob_u = 0;        // force U of the uniform kernel (0 = heuristic)
-static thread_local int g_knob_blocks = 0;   // (unused since the kernels are one-shot)
+static thread_local int g_knob_encwg = 2048;  // persistent workgroups of the 4-bit encoder (256 CUs x 8)
 static thread_local int g_knob_x = 1;        // 0 disables the x-domain row kernel (A/B measurements)
 static thread_local int g_knob_nearest_fast = 1;   // 0: antq_nearest always runs the literal scan
 static thread_local int g_knob_a = 1;        // 0 disables the approximate-quotient element path (quant_vec_a): exact division
@@ -451,7 +451,7 @@ extern "C" int antq_copy(const void *src, void *dst, size_t bytes, void *stream)
 extern "C" int antq_debug_set(int key, int value)
 {
     if (key == 0) g_knob_u = value;
-    else if (key == 1) g_knob_blocks = value;
+    else if (key == 1) g_knob_encwg = value > 0 ? value : 2048;
     else if (key == 2) g_knob_x = value;
     else if (key == 3) g_knob_nearest_fast = value;
     else if (key == 4) g_knob_a = value;

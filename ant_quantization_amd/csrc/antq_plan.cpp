@@ -494,7 +494,8 @@ extern "C" int antq_plan_eval_host_a(const void *blob, const float *x, size_t n,
     const uint32_t *aidx = reinterpret_cast<const uint32_t *>(atab + h->atab_slots);
     for (size_t i = 0; i < n; i++) {
         const float dt = x[i] * rs;
-        const bool fast = ok && (fabsf(dt) < h->xlim);
+        const bool fast = ok && (fabsf(dt) < h->fastlim * 0.99999f);
+        const bool ste = fabsf(dt) < h->xlim;
         float q = 0.0f;
         int j = ANTQ_IDX_NONE;
         if (fast) {
@@ -513,7 +514,8 @@ extern "C" int antq_plan_eval_host_a(const void *blob, const float *x, size_t n,
             const bool c = fma(-e.Mp, (double)s, (double)x[i]) >= 0.0;
             q = c ? e.v_hi : e.v_lo;
             j = (int)((c ? (aidx[slot] >> 16) : aidx[slot]) & kIdxMask);
-            out[i] = q * s;
+            if (ste) out[i] = q * s;
+            else { const float d = x[i] / s; out[i] = ((q - d) + d) * s; }
         } else {
             const float d = x[i] / s;
             q = scan_one(d, grid, (int)h->m, &j);

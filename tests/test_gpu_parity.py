@@ -103,6 +103,8 @@ def test_ant_fakequant_vs_oracle(antq_lib, oracle, dev, gname, bf16):
         alpha = (safe_absmax(x).max(1) * 0.9 + 1e-6).astype(np.float32)
         run_case(antq_lib, oracle, dev, x, alpha, g, float(g.max()), True, False, bf16)
         run_case(antq_lib, oracle, dev, x, np.float32(alpha.max()), g, float(g.max()), False, False, bf16)
+        # heavy clipping: many |x / s| beyond twice the outermost value, where (q - d) + d is no longer q
+        run_case(antq_lib, oracle, dev, x, (alpha * 0.07).astype(np.float32), g, float(g.max()), True, False, bf16)
 
 
 @pytest.mark.parametrize("bf16", [False, True])

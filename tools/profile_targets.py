@@ -58,6 +58,17 @@ def main():
     act = torch.nn.functional.gelu(torch.randn(64, 128, 3072, device=dev))
     am = core.row_absmax(act, False)
     runs.append(lambda: _lib.search_sse(act, 1, act.numel(), am, False, ratios, flint, 10.0))            # per-tensor (PT)
+    # packed 4-bit codec (fp32 and bf16, OliVe pairs)
+    gn = grids.olive_flint(4, True).size
+    codec = []
+    for x in (xf[0], xs[0]):
+        a = _lib.absmax(x, 4096, 4096) * 0.25
+        codes = _lib.encode4(x, a, ol, 32.0, 4096, 4096, True, n_normal=gn, ovp=True)
+        codec.append(lambda x=x, a=a: _lib.encode4(x, a, ol, 32.0, 4096, 4096, True, n_normal=gn, ovp=True))      # k_encode4
+        codec.append(lambda x=x, a=a, c=codes: _lib.decode4(c, a, ol, 32.0, 4096, 4096, True, x.dtype, n_normal=gn, ovp=True))
+    runs += codec
+    if os.environ.get("ANTQ_TARGETS") == "codec":
+        runs = codec
     for r in runs:
         for _ in range(REPS):
             r()
