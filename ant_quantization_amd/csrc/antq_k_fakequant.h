@@ -38,14 +38,21 @@ __device__ __forceinline__ void task_load(const uint4 *__restrict__ x, const flo
     if (!dyn) a = alpha[per_row ? row : 0];
 }
 
-// wave-wide max of a non-negative float (bit patterns order like integers); NaN propagates
-// as in torch.max because a NaN's magnitude bits exceed every finite value's.
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m)
+// max over aligned groups of g = 1, 2, 4, ... 64 adjacent lanes (g wave-uniform): DPP lane exchanges up to 16 lanes
+// (one VALU instruction per step: quad_perm, row_half_mirror, row_mirror), ds_bpermute beyond.
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t m, uint32_t g)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if (g >= 2) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    if (g >= 4) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    if (g >= 8) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    if (g >= 16) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, false));  // row_mirror
+    if (g >= 32) m = max(m, (uint32_t)__shfl_xor((int)m, 16, 64));
+    if (g >= 64) m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));
     return m;
 }
+// wave-wide max of a non-negative float (bit patterns order like integers); NaN propagates
+// as in torch.max because a NaN's magnitude bits exceed every finite value's.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m) { return group_max_u32(m, 64u); }
 
 // ADM: 1 / 0 = the approximate-quotient element path is / is not compiled in; -1 = both, chosen per launch by pa.adom
 template <typename T, bool OVP, bool IDX, int U, bool DYN, int ADM = -1>
@@ -451,7 +458,7 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
             // group = vpr (power of two <= 64) adjacent lanes; butterfly max inside the group.
             // Lanes past n_vec hold zeros and belong to no real group (n_vec % vpr == 0).
             uint32_t m = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
-            for (uint32_t off = 1; off < vpr; off <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, (int)off, 64));
+            m = group_max_u32(m, vpr);
             a[u] = u2f(m) * ratio;
             if (alpha_out && vi < n_vec && (vi & (vpr - 1)) == 0) alpha_out[vi >> vshift] = a[u];
         }
