@@ -53,6 +53,7 @@ def lib():
                              "antq_search_sse_multi", "antq_plan_eval_host_a"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
+                L.antq_search_workspace_bytes.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
                 vp, sz, ci, cf, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_uint
                 L.antq_fakequant.argtypes = [vp, vp, vp, sz, sz, vp, ci, cf, vp, vp, cu, ci, vp]
@@ -324,6 +325,14 @@ def alpha_grad(x, out, gout, rows, row_len, per_row=True):
     return gsum
 
 
+def _search_workspace(device, rows, per_row):
+    """Scratch for the workgroup partials of a whole-tensor sum (antq_search_workspace_bytes; a fresh block from torch's
+    stream-ordered allocator per call, so calls on different streams never share one)."""
+    if per_row and rows > 1:
+        return None
+    return torch.empty(int(lib().antq_search_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
 def search_sse(x, rows, row_len, xmax, per_row, ratios, plan, gmax, ovp=False):
     """sum of squared errors of every clip candidate: [ncand, rows] (or [ncand, 1]) float64."""
     _require_gpu(x, "x")
@@ -332,14 +341,15 @@ def search_sse(x, rows, row_len, xmax, per_row, ratios, plan, gmax, ovp=False):
         raise AntqError("unsupported dtype %s" % x.dtype)
     ncand = ratios.numel()
     na = rows if per_row else 1
-    sse = torch.zeros(ncand, na, dtype=torch.float64, device=x.device)
+    sse = torch.empty(ncand, na, dtype=torch.float64, device=x.device)
+    ws = _search_workspace(x.device, rows, per_row)
     pd = plan.dev(x.device)
     with torch.cuda.device(x.device):
         _check(lib().antq_search_sse(_vp(x), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), _vp(xmax),
                                      ctypes.c_int(1 if per_row else 0), _vp(ratios), ctypes.c_int(ncand),
                                      ctypes.c_float(gmax), plan.host_ptr(), _vp(pd),
                                      ctypes.c_uint(FLAG_OVP if ovp else 0), ctypes.c_int(dt), _vp(sse),
-                                     _stream(x.device)), "antq_search_sse")
+                                     _vp(ws), _stream(x.device)), "antq_search_sse")
     return sse
 
 
@@ -355,7 +365,8 @@ def search_sse_multi(x, rows, row_len, xmax, per_row, ratios, plans, gmaxs, ovp=
         return None
     ncand = ratios.numel()
     na = rows if per_row else 1
-    sse = torch.zeros(nt, ncand, na, dtype=torch.float64, device=x.device)
+    sse = torch.empty(nt, ncand, na, dtype=torch.float64, device=x.device)
+    ws = _search_workspace(x.device, rows, per_row)
     ph = (ctypes.c_void_p * nt)(*[p.host_addr for p in plans])
     pd = (ctypes.c_void_p * nt)(*[p.dev(x.device).data_ptr() for p in plans])
     gm = (ctypes.c_float * nt)(*[float(g) for g in gmaxs])
@@ -363,7 +374,8 @@ def search_sse_multi(x, rows, row_len, xmax, per_row, ratios, plans, gmaxs, ovp=
         rc = lib().antq_search_sse_multi(_vp(x), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), _vp(xmax),
                                          ctypes.c_int(1 if per_row else 0), _vp(ratios), ctypes.c_int(ncand),
                                          ctypes.c_int(nt), gm, ph, pd, ctypes.c_uint(FLAG_OVP if ovp else 0),
-                                         ctypes.c_int(dt), _vp(sse), _stream(x.device))
+                                         ctypes.c_int(dt), _vp(sse), _vp(ws),
+                                         _stream(x.device))
     if rc == -2:              # ANTQ_ERR_UNSUPPORTED
         return None
     _check(rc, "antq_search_sse_multi")

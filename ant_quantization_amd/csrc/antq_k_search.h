@@ -13,10 +13,43 @@ namespace antq {
 // fake-quantised row against the row itself, WITHOUT writing the quantised tensor: x is
 // read once into registers and all `ncand` candidates are evaluated on it.
 //   sse[c, r] += sum_col fl32( fl32|out - x| ^ 2 )      (fp32 terms, fp64 accumulation)
-// Same task decomposition as K1a (U*64 vectors of one row per task); tasks of one row add
-// their partial sums with a double atomicAdd.
+// Tasks of U*64 vectors.  Every sum is formed in ONE fixed order (no floating-point atomics, so a score never depends
+// on which workgroup finished first and near-tied candidates resolve the same way on every run and rank):
+//   per row    : one wavefront owns a row and walks its tasks in order; its per-candidate sums live in LDS
+//   per tensor : every workgroup writes its per-candidate partial to the caller's workspace and k_sum_partials adds
+//                the partials of a candidate in a fixed tree
+// Nothing has to be zeroed by the caller.
 // ------------------------------------------------------------------------------------
-constexpr int kPtCand = 128;   // candidates per workgroup in the one-scale-per-tensor mode (LDS accumulators)
+constexpr int kPtCand = 128;     // candidates per workgroup (LDS accumulators); blockIdx.y splits longer lists
+constexpr int kWsSlots = 8192;   // workgroup partials the per-tensor workspace holds (kWsSlots * kPtCand doubles = 8 MiB)
+
+// per-wavefront accumulators: lane 0 of the owning wavefront adds, its lanes read back (LDS is in order inside a wavefront)
+struct WaveAcc {
+    double (*w)[kPtCand];
+    __device__ __forceinline__ void zero(uint32_t wv, uint32_t lane) const
+    {
+        for (int c = (int)lane; c < kPtCand; c += 64) w[wv][c] = 0.0;
+    }
+};
+
+// out[f] = sum over the n_wg workgroup partials of candidate f, in a fixed order (strided per thread, then a tree)
+__global__ void __launch_bounds__(256)
+k_sum_partials(const double *__restrict__ ws, uint32_t n_wg, int chunk, double *__restrict__ out)
+{
+    const int f = (int)blockIdx.x;
+    const int y = f / chunk, c = f - y * chunk;
+    const double *p = ws + ((size_t)y * n_wg) * kPtCand + c;
+    double s = 0.0;
+    for (uint32_t w = threadIdx.x; w < n_wg; w += 256u) s += p[(size_t)w * kPtCand];
+    __shared__ double sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 128u; off >= 1u; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[f] = sh[0];
+}
 
 // XD: grids with an x-domain plan (PlanHeader::xdom: every ANT / OliVe 4-bit codebook).  For every candidate the
 // wavefront rebuilds its row table for THAT scale (closed-form thresholds, ~14 ops per lane) and the element loop is
@@ -26,7 +59,8 @@ template <typename T, bool OVP, int U, bool PT, bool XD>
 __global__ void __launch_bounds__(256)
 k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
              const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand, float gmax,
-             double *__restrict__ sse, PlanArgs pa, const uint4 *__restrict__ plan_tab, int cand_chunk, XArgs xa)
+             double *__restrict__ sse, double *__restrict__ ws, PlanArgs pa, const uint4 *__restrict__ plan_tab,
+             int cand_chunk, XArgs xa)
 {
     constexpr int EPL = IO<T>::EPL;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -50,58 +84,66 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
         if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
         L = stage_plan(pa, plan_tab, smem, tab0);
     }
-    // PT (one scale for the whole tensor): every task adds to the same ncand sums.  Global atomics on 75 addresses
-    // from every task serialise in L2 (measured: 4x the arithmetic), so each wavefront keeps its sums in LDS and the
-    // workgroup issues one atomic per candidate at the end.
-    __shared__ double wacc[PT ? 4 : 1][PT ? kPtCand : 1];
-    if (PT)
-        for (int c = (int)lane; c < kPtCand; c += 64) wacc[threadIdx.x >> 6][c] = 0.0;
+    // Per-candidate sums of this wavefront (PT: over all its tasks; rows: over the tasks of the row it owns).
+    __shared__ double wacc[4][kPtCand];
+    const uint32_t wv = threadIdx.x >> 6;
+    const WaveAcc W{wacc};
+    if (PT) W.zero(wv, lane);
     __syncthreads();
     const size_t na = per_row ? rows : 1;
-    for (uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6); task < total_tasks; task += gridDim.x * 4u) {
-        uint4 v[U];
-        float xm;
-        task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
-        uint32_t row = task, g = 0;
-        if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
-        const uint32_t v0 = g * (64u * U) + lane;
-        for (int c = c_begin; c < c_end; c++) {
-            const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
-            const Scale sc = make_scale(a, gmax);
-            bool rowfast = false;
-            if (XD) rowfast = build_row_table(xa, ent, ent2, sc, wtab, lane);
-            double acc = 0.0;
+    // PT: tasks grid-strided over all wavefronts.  rows: `units` = rows, a wavefront walks the tpr tasks of its row.
+    const uint32_t units = PT ? total_tasks : (uint32_t)rows;
+    for (uint32_t unit = blockIdx.x * 4u + wv; unit < units; unit += gridDim.x * 4u) {
+        const uint32_t row = PT ? 0u : unit;
+        const uint32_t g_end = PT ? 1u : tpr;
+        if (!PT && tpr != 1) W.zero(wv, lane);
+        for (uint32_t gi = 0; gi < g_end; gi++) {
+            const uint32_t task = PT ? unit : row * tpr + gi;
+            const uint32_t g = PT ? unit : gi;
+            uint4 v[U];
+            float xm;
+            task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
+            const uint32_t v0 = g * (64u * U) + lane;
+            for (int c = c_begin; c < c_end; c++) {
+                const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
+                const Scale sc = make_scale(a, gmax);
+                bool rowfast = false;
+                if (XD) rowfast = build_row_table(xa, ent, ent2, sc, wtab, lane);
+                double acc = 0.0;
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (v0 + 64u * u < vpr) {
-                    float xf[EPL], of[EPL];
-                    int j[EPL];
-                    IO<T>::unpack(v[u], xf);
-                    if (XD) quant_vec_x<EPL, OVP, false>(xa, wtab, grid_g, sc, rowfast, xf, of, j);
-                    else quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
-                    float part = 0.0f;
+                for (int u = 0; u < U; u++) {
+                    if (v0 + 64u * u < vpr) {
+                        float xf[EPL], of[EPL];
+                        int j[EPL];
+                        IO<T>::unpack(v[u], xf);
+                        if (XD) quant_vec_x<EPL, OVP, false>(xa, wtab, grid_g, sc, rowfast, xf, of, j);
+                        else quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
+                        float part = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < EPL; e++) {
-                        const float df = fabsf(of[e] - xf[e]);  // AQ:282 (q - x).abs().pow(2)
-                        part += df * df;
+                        for (int e = 0; e < EPL; e++) {
+                            const float df = fabsf(of[e] - xf[e]);  // AQ:282 (q - x).abs().pow(2)
+                            part += df * df;
+                        }
+                        acc += (double)part;
                     }
-                    acc += (double)part;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if (lane == 0) {
+                    if (!PT && tpr == 1) sse[(size_t)c * na + row] = acc;
+                    else wacc[wv][c - c_begin] += acc;
                 }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-            if (PT) {
-                if (lane == 0) wacc[threadIdx.x >> 6][c - c_begin] += acc;
-            } else if (lane == 0) {
-                double *dst = sse + (size_t)c * na + (per_row ? row : 0);
-                if (per_row && tpr == 1) *dst = acc; else atomicAdd(dst, acc);
-            }
         }
+        if (!PT && tpr != 1)
+            for (int c = (int)lane; c < c_end - c_begin; c += 64) sse[(size_t)(c_begin + c) * na + row] = wacc[wv][c];
     }
     if (PT) {
+        // this workgroup's partial, in a fixed order; k_sum_partials adds the workgroups
         __syncthreads();
+        double *part = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kPtCand;
         for (int c = (int)threadIdx.x; c < c_end - c_begin; c += 256)
-            atomicAdd(sse + (size_t)(c_begin + c), (wacc[0][c] + wacc[1][c]) + (wacc[2][c] + wacc[3][c]));
+            part[c] = (wacc[0][c] + wacc[1][c]) + (wacc[2][c] + wacc[3][c]);
     }
 }
 
@@ -125,73 +167,85 @@ template <typename T, bool OVP, int U, bool PT>
 __global__ void __launch_bounds__(256)
 k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
                    const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand,
-                   double *__restrict__ sse, MultiArgs ma, int flat_chunk)
+                   double *__restrict__ sse, double *__restrict__ ws, MultiArgs ma, int flat_chunk)
 {
     constexpr int EPL = IO<T>::EPL;
     __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
     __shared__ __attribute__((aligned(16))) uint4 s_ent[kMaxTypes][128];
-    __shared__ double wacc[PT ? 4 : 1][PT ? kPtCand : 1];
+    __shared__ double wacc[4][kPtCand];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
+    const WaveAcc W{wacc};
     const int nflat = ma.ntypes * ncand;
-    const int f_begin = (int)blockIdx.y * flat_chunk;            // PT: flat_chunk <= kPtCand
+    const int f_begin = (int)blockIdx.y * flat_chunk;            // flat_chunk <= kPtCand
     const int f_end = min(nflat, f_begin + flat_chunk);
     const uint4 inf = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u);
     for (uint32_t i = threadIdx.x; i < (uint32_t)ma.ntypes * 128u; i += 256u) {
         const uint32_t t = i >> 7, b = i & 127u;
         s_ent[t][b] = b < ma.xa[t].n_entries ? ma.entries[t][b] : inf;
     }
-    if (PT)
-        for (int c = (int)lane; c < kPtCand; c += 64) wacc[wv][c] = 0.0;
+    if (PT) W.zero(wv, lane);
     __syncthreads();
     uint4 *wtab = wtab_all[wv];
     const size_t na = per_row ? rows : 1;
-    for (uint32_t task = blockIdx.x * 4u + wv; task < total_tasks; task += gridDim.x * 4u) {
-        uint4 v[U];
-        float xm;
-        task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
-        uint32_t row = task, g = 0;
-        if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
-        const uint32_t v0 = g * (64u * U) + lane;
-        int t = f_begin / ncand, c = f_begin - t * ncand;
-        for (int f = f_begin; f < f_end; f++) {
-            const XArgs &xa = ma.xa[t];
-            const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
-            const Scale sc = make_scale(a, ma.gmax[t]);
-            const bool rowfast = build_row_table(xa, s_ent[t][lane], s_ent[t][lane + 64u], sc, wtab, lane);
-            double acc = 0.0;
+    const uint32_t units = PT ? total_tasks : (uint32_t)rows;    // rows: a wavefront owns a row and walks its tasks in order
+    for (uint32_t unit = blockIdx.x * 4u + wv; unit < units; unit += gridDim.x * 4u) {
+        const uint32_t row = PT ? 0u : unit;
+        const uint32_t g_end = PT ? 1u : tpr;
+        if (!PT && tpr != 1) W.zero(wv, lane);
+        for (uint32_t gi = 0; gi < g_end; gi++) {
+            const uint32_t task = PT ? unit : row * tpr + gi;
+            const uint32_t g = PT ? unit : gi;
+            uint4 v[U];
+            float xm;
+            task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
+            const uint32_t v0 = g * (64u * U) + lane;
+            // the flattened list [f_begin, f_end) type by type: a type's bucket entries and plan fields are fetched once
+            int f = f_begin;
+            for (int t = f_begin / ncand; f < f_end; t++) {
+            const XArgs xa = ma.xa[t];
+            const uint4 ent = s_ent[t][lane], ent2 = s_ent[t][lane + 64u];
+            const float gmax_t = ma.gmax[t];
+            const float *grid_t = ma.grid[t];
+            const int c_first = f - t * ncand, c_last = min(ncand, f_end - t * ncand);
+            for (int c = c_first; c < c_last; c++, f++) {
+                const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
+                const Scale sc = make_scale(a, gmax_t);
+                const bool rowfast = build_row_table(xa, ent, ent2, sc, wtab, lane);
+                double acc = 0.0;
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (v0 + 64u * u < vpr) {
-                    float xf[EPL], of[EPL];
-                    int j[EPL];
-                    IO<T>::unpack(v[u], xf);
-                    quant_vec_x<EPL, OVP, false>(xa, wtab, ma.grid[t], sc, rowfast, xf, of, j);
-                    float part = 0.0f;
+                for (int u = 0; u < U; u++) {
+                    if (v0 + 64u * u < vpr) {
+                        float xf[EPL], of[EPL];
+                        int j[EPL];
+                        IO<T>::unpack(v[u], xf);
+                        quant_vec_x<EPL, OVP, false>(xa, wtab, grid_t, sc, rowfast, xf, of, j);
+                        float part = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < EPL; e++) {
-                        const float df = fabsf(of[e] - xf[e]);  // AQ:282 (q - x).abs().pow(2)
-                        part += df * df;
+                        for (int e = 0; e < EPL; e++) {
+                            const float df = fabsf(of[e] - xf[e]);  // AQ:282 (q - x).abs().pow(2)
+                            part += df * df;
+                        }
+                        acc += (double)part;
                     }
-                    acc += (double)part;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if (lane == 0) {
+                    if (!PT && tpr == 1) sse[((size_t)t * ncand + c) * na + row] = acc;
+                    else wacc[wv][f - f_begin] += acc;
                 }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-            if (PT) {
-                if (lane == 0) wacc[wv][f - f_begin] += acc;
-            } else if (lane == 0) {
-                double *dst = sse + ((size_t)t * ncand + c) * na + (per_row ? row : 0);
-                if (per_row && tpr == 1) *dst = acc; else atomicAdd(dst, acc);
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // this candidate's table reads are done before the next one's writes
-            if (++c == ncand) { c = 0; t++; }
         }
+        if (!PT && tpr != 1)
+            for (int f = (int)lane; f < f_end - f_begin; f += 64) sse[(size_t)(f_begin + f) * na + row] = wacc[wv][f];
     }
     if (PT) {
         __syncthreads();
+        double *part = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kPtCand;
         for (int c = (int)threadIdx.x; c < f_end - f_begin; c += 256)
-            atomicAdd(sse + (size_t)(f_begin + c), (wacc[0][c] + wacc[1][c]) + (wacc[2][c] + wacc[3][c]));
+            part[c] = (wacc[0][c] + wacc[1][c]) + (wacc[2][c] + wacc[3][c]);
     }
 }
 
@@ -204,8 +258,12 @@ template <typename T, bool OVP>
 __global__ void __launch_bounds__(256)
 k_search_sse_scalar(const void *__restrict__ x, size_t rows, size_t row_len, const float *__restrict__ xmax,
                     int per_row, const float *__restrict__ ratios, int ncand, float gmax, double *__restrict__ sse,
-                    PlanArgs pa, const uint4 *__restrict__ plan_tab)
+                    double *__restrict__ ws, PlanArgs pa, const uint4 *__restrict__ plan_tab)
 {
+    __shared__ double wacc[4][kPtCand];                // per tensor: this wavefront's sums over its strips
+    const int c_begin = (int)blockIdx.y * kPtCand, c_end = min(ncand, c_begin + kPtCand);
+    if (!per_row)
+        for (int c = (int)(threadIdx.x & 63u); c < kPtCand; c += 64) wacc[threadIdx.x >> 6][c] = 0.0;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
@@ -219,7 +277,7 @@ k_search_sse_scalar(const void *__restrict__ x, size_t rows, size_t row_len, con
     for (size_t st = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6); st < nstrips; st += (size_t)gridDim.x * 4u) {
         const size_t b = st * strip;
         const size_t e = per_row ? b + row_len : (b + strip < n ? b + strip : n);
-        for (int c = 0; c < ncand; c++) {
+        for (int c = c_begin; c < c_end; c++) {
             const float r = ratios[c];
             double acc = 0.0;
             for (size_t i = b + lane; i < e; i += 64) {
@@ -251,10 +309,16 @@ k_search_sse_scalar(const void *__restrict__ x, size_t rows, size_t row_len, con
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
             if (lane == 0) {
-                double *dst = sse + (size_t)c * na + (per_row ? st : 0);
-                if (per_row) *dst = acc; else atomicAdd(dst, acc);
+                if (per_row) sse[(size_t)c * na + st] = acc;
+                else wacc[threadIdx.x >> 6][c - c_begin] += acc;
             }
         }
+    }
+    if (!per_row) {
+        __syncthreads();
+        double *part = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kPtCand;
+        for (int c = (int)threadIdx.x; c < c_end - c_begin; c += 256)
+            part[c] = (wacc[0][c] + wacc[1][c]) + (wacc[2][c] + wacc[3][c]);
     }
 }
 

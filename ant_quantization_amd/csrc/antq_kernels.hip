@@ -539,16 +539,23 @@ static int launch_dynamic_flags(const void *x, void *out, int16_t *idx, float *a
 template <typename T, bool OVP>
 static int launch_search(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                          const float *ratios, int ncand, float gmax, const PlanArgs &pa, const void *plan_host,
-                         const void *plan_dev, double *sse, hipStream_t st)
+                         const void *plan_dev, double *sse, double *ws, hipStream_t st)
 {
     constexpr int EPL = IO<T>::EPL;
     const size_t lds = (size_t)pa.tab_units * 16;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) {
         size_t strips = per_row ? rows : (rows * row_len + 16383) / 16384;
         size_t blocks = (strips + 3) / 4;
+        const size_t ychunks = ((size_t)ncand + kPtCand - 1) / kPtCand;
         if (blocks > 256 * 8) blocks = 256 * 8;
-        hipLaunchKernelGGL((k_search_sse_scalar<T, OVP>), dim3((unsigned)blocks), dim3(256), lds, st, x, rows, row_len,
-                           xmax, per_row, ratios, ncand, gmax, sse, pa, plan_tab_ptr(plan_dev));
+        if (!per_row) {
+            if (ychunks > (size_t)kWsSlots) return ANTQ_ERR_UNSUPPORTED;
+            blocks = std::min(blocks, (size_t)kWsSlots / ychunks);
+        }
+        hipLaunchKernelGGL((k_search_sse_scalar<T, OVP>), dim3((unsigned)blocks, (unsigned)ychunks), dim3(256), lds, st, x, rows,
+                           row_len, xmax, per_row, ratios, ncand, gmax, sse, ws, pa, plan_tab_ptr(plan_dev));
+        if (!per_row)
+            hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)blocks, kPtCand, sse);
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }
     if (!per_row) { row_len = rows * row_len; rows = 1; }
@@ -559,14 +566,19 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
     const bool pt = rows == 1;
-    size_t blocks = (total + 3) / 4;
+    // per tensor: tasks over all wavefronts; per row: one wavefront per row (it walks the row's tasks in order)
+    size_t blocks = ((pt ? total : rows) + 3) / 4;
     const size_t cap = pt ? 256 * 4 : 256 * 8;
     if (blocks > cap) blocks = cap;
     // enough wavefronts to fill 256 CUs x 8 waves/SIMD: split the candidates when there are few rows
     int chunks = (int)std::min<size_t>((size_t)ncand, std::max<size_t>(1, (size_t)2048 / blocks));
-    if (pt) chunks = std::max(chunks, (ncand + kPtCand - 1) / kPtCand);
+    chunks = std::max(chunks, (ncand + kPtCand - 1) / kPtCand);
     const int cand_chunk = (ncand + chunks - 1) / chunks;
     chunks = (ncand + cand_chunk - 1) / cand_chunk;
+    if (pt) {
+        if (chunks > kWsSlots) return ANTQ_ERR_UNSUPPORTED;
+        blocks = std::min(blocks, (size_t)(kWsSlots / chunks));
+    }
     const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
     const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr;
     XArgs xa;
@@ -577,11 +589,12 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     const uint4 *xv = static_cast<const uint4 *>(x);
 #define ANTQ_LAUNCH_S(PT_, XD_)                                                                                    \
     hipLaunchKernelGGL((k_search_sse<T, OVP, U, PT_, XD_>), gdim, bdim, (XD_) ? 0 : lds, st, xv, (uint32_t)total,    \
-                       (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, gmax, sse, pa,              \
+                       (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, gmax, sse, ws, pa,          \
                        plan_tab_ptr(plan_dev), cand_chunk, xa)
     if (pt) { if (xd) ANTQ_LAUNCH_S(true, true); else ANTQ_LAUNCH_S(true, false); }
     else    { if (xd) ANTQ_LAUNCH_S(false, true); else ANTQ_LAUNCH_S(false, false); }
 #undef ANTQ_LAUNCH_S
+    if (pt) hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)blocks, cand_chunk, sse);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
@@ -589,7 +602,7 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
 template <typename T, bool OVP>
 static int launch_search_multi(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                                const float *ratios, int ncand, int ntypes, const float *gmax, const void *const *plan_host,
-                               const void *const *plan_dev, double *sse, hipStream_t st)
+                               const void *const *plan_dev, double *sse, double *ws, hipStream_t st)
 {
     constexpr int EPL = IO<T>::EPL;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) return ANTQ_ERR_UNSUPPORTED;
@@ -618,23 +631,28 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
     const bool pt = rows == 1;
-    size_t blocks = (total + 3) / 4;
+    size_t blocks = ((pt ? total : rows) + 3) / 4;
     const size_t cap = pt ? 256 * 4 : 256 * 8;
     if (blocks > cap) blocks = cap;
     // enough wavefronts to fill 256 CUs x 8 waves/SIMD: split the flattened (type, ratio) list when there are few rows
     const int nflat = ntypes * ncand;
     int chunks = (int)std::min<size_t>((size_t)nflat, std::max<size_t>(1, (size_t)2048 / blocks));
-    if (pt) chunks = std::max(chunks, (nflat + kPtCand - 1) / kPtCand);
+    chunks = std::max(chunks, (nflat + kPtCand - 1) / kPtCand);
     const int flat_chunk = (nflat + chunks - 1) / chunks;
     chunks = (nflat + flat_chunk - 1) / flat_chunk;
+    if (pt) {
+        if (chunks > kWsSlots) return ANTQ_ERR_UNSUPPORTED;
+        blocks = std::min(blocks, (size_t)(kWsSlots / chunks));
+    }
     const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
     const uint4 *xv = static_cast<const uint4 *>(x);
-    if (pt)
+    if (pt) {
         hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U, true>), gdim, bdim, 0, st, xv, (uint32_t)total, (uint32_t)vpr,
-                           (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ma, flat_chunk);
-    else
+                           (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, flat_chunk);
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nflat), dim3(256), 0, st, ws, (uint32_t)blocks, flat_chunk, sse);
+    } else
         hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U, false>), gdim, bdim, 0, st, xv, (uint32_t)total, (uint32_t)vpr,
-                           (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ma, flat_chunk);
+                           (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, flat_chunk);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
@@ -643,10 +661,12 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
 extern "C" int antq_search_sse_multi(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                                      const float *ratios, int ncand, int ntypes, const float *gmax_host,
                                      const void *const *plan_host, const void *const *plan_dev, unsigned flags, int dtype,
-                                     double *sse, void *stream)
+                                     double *sse, void *workspace, void *stream)
 {
     if (rows == 0 || row_len == 0 || ncand == 0 || ntypes == 0) return ANTQ_OK;
     if (!x || !xmax || !ratios || !gmax_host || !plan_host || !plan_dev || !sse || ncand < 0 || ntypes < 0) return ANTQ_ERR_ARG;
+    if ((!per_row || rows == 1) && !workspace) return ANTQ_ERR_ARG;
+    double *ws = static_cast<double *>(workspace);
     if (ntypes > kMaxTypes) return ANTQ_ERR_UNSUPPORTED;
     for (int t = 0; t < ntypes; t++)
         if (!plan_host[t] || !plan_dev[t]) return ANTQ_ERR_ARG;
@@ -654,8 +674,8 @@ extern "C" int antq_search_sse_multi(const void *x, size_t rows, size_t row_len,
     const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
     const int pr = per_row ? 1 : 0;
 #define ANTQ_SM(TT)                                                                                                     \
-    (ovp ? launch_search_multi<TT, true>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, st)   \
-         : launch_search_multi<TT, false>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, st))
+    (ovp ? launch_search_multi<TT, true>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, ws, st)   \
+         : launch_search_multi<TT, false>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, ws, st))
     switch (dtype) {
     case ANTQ_F32: return ANTQ_SM(float);
     case ANTQ_BF16: return ANTQ_SM(bf16_tag);
@@ -730,10 +750,12 @@ extern "C" int antq_absmax(const void *x, float *amax, size_t rows, size_t row_l
 
 extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                                const float *ratios, int ncand, float gmax, const void *plan_host, const void *plan_dev,
-                               unsigned flags, int dtype, double *sse, void *stream)
+                               unsigned flags, int dtype, double *sse, void *workspace, void *stream)
 {
     if (rows == 0 || row_len == 0 || ncand == 0) return ANTQ_OK;
     if (!x || !xmax || !ratios || !plan_host || !plan_dev || !sse || ncand < 0) return ANTQ_ERR_ARG;
+    if ((!per_row || rows == 1) && !workspace) return ANTQ_ERR_ARG;
+    double *ws = static_cast<double *>(workspace);
     PlanArgs pa;
     if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -741,18 +763,20 @@ extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const
     const int pr = per_row ? 1 : 0;
     switch (dtype) {
     case ANTQ_F32:
-        return ovp ? launch_search<float, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st)
-                   : launch_search<float, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st);
+        return ovp ? launch_search<float, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st)
+                   : launch_search<float, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st);
     case ANTQ_BF16:
-        return ovp ? launch_search<bf16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st)
-                   : launch_search<bf16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st);
+        return ovp ? launch_search<bf16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st)
+                   : launch_search<bf16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st);
     case ANTQ_F16:
-        return ovp ? launch_search<f16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st)
-                   : launch_search<f16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, st);
+        return ovp ? launch_search<f16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st)
+                   : launch_search<f16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st);
     default:
         return ANTQ_ERR_UNSUPPORTED;
     }
 }
+
+extern "C" size_t antq_search_workspace_bytes(void) { return (size_t)kWsSlots * kPtCand * sizeof(double); }
 
 // ======================================================================================
 // Batched launch (antq_batch_build / antq_fakequant_batch)

@@ -175,26 +175,34 @@ int antq_alpha_grad(const void *x_dev, const void *out_dev, const void *gout_dev
  *     sse[c, r]  = sum_col ( fl32|fakequant(x; alpha_c)[r,col] - x[r,col]| )^2
  * accumulated in fp32 per lane and fp64 across lanes.  The caller divides by
  * row_len and picks the arg-min (strict '<', first best), as search_mse does.
- * sse_dev: [ncand, rows] doubles (per_row) or [ncand] (per tensor), zeroed by
- * the caller.  ratios_dev: ncand floats.  xmax_dev: rows floats or 1.
+ * sse_dev: [ncand, rows] doubles (per_row) or [ncand] (per tensor); it need not
+ * be initialised.  ratios_dev: ncand floats.  xmax_dev: rows floats or 1.
+ * Every sum is formed in one fixed order (no floating-point atomics): the result
+ * is bit-identical from run to run, so near-tied candidates resolve the same way
+ * every time and on every rank.  A sum over the whole tensor (per_row == 0, or a
+ * single row) is formed from workgroup partials kept in workspace_dev:
+ * antq_search_workspace_bytes() bytes of device memory owned by the caller, not
+ * shared with a call running concurrently on another stream; contents are
+ * scratch (no initialisation).  May be NULL for per_row with rows > 1.
  * ------------------------------------------------------------------------- */
+size_t antq_search_workspace_bytes(void);
 int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
                     const float *xmax_dev, int per_row,
                     const float *ratios_dev, int ncand, float gmax,
                     const void *plan_host, const void *plan_dev,
-                    unsigned flags, int dtype, double *sse_dev, void *stream);
+                    unsigned flags, int dtype, double *sse_dev, void *workspace_dev, void *stream);
 
 /* The type selection (search_adaptive_numeric_type, AQ:328-415 / OQ:235-256) on ONE read of the tensor: the sums of
  * antq_search_sse for `ntypes` (<= 4) codebooks at once,
  *     sse[t, c, r]  = sum_col ( fl32|fakequant_t(x; xmax[r] * ratios[c])[r,col] - x[r,col]| )^2
- * sse_dev: [ntypes, ncand, rows] doubles (per_row) or [ntypes, ncand], zeroed by the caller.  gmax_host, plan_host,
- * plan_dev: host arrays of ntypes entries.  Every plan must have the x-domain path (all ANT / OliVe codebooks up to 128
+ * sse_dev: [ntypes, ncand, rows] doubles (per_row) or [ntypes, ncand], not initialised; workspace_dev as for
+ * antq_search_sse (same order-fixed sums).  gmax_host, plan_host, plan_dev: host arrays of ntypes entries.  Every plan must have the x-domain path (all ANT / OliVe codebooks up to 128
  * buckets) and rows must be whole 16-byte vectors, at least 128 of them (2 KiB): otherwise ANTQ_ERR_UNSUPPORTED and the
  * caller issues one antq_search_sse per type. */
 int antq_search_sse_multi(const void *x_dev, size_t rows, size_t row_len, const float *xmax_dev, int per_row,
                           const float *ratios_dev, int ncand, int ntypes, const float *gmax_host,
                           const void *const *plan_host, const void *const *plan_dev,
-                          unsigned flags, int dtype, double *sse_dev, void *stream);
+                          unsigned flags, int dtype, double *sse_dev, void *workspace_dev, void *stream);
 
 /* The selection step of search_mse on the device (AQ:299-306 / :317-324): for every row r
  *     score_c = fl32(sse[c, r] / row_len), c ascending; best starts at 1e10 and is replaced on a strict `<`
