@@ -1938,3 +1938,61 @@ def test_calibration_sums_are_bit_reproducible(antq_lib, dev):
                     assert torch.equal(ref[t], antq_lib.search_sse(x, rows, row_len, xmax, per_row, ratios, p, 10.0)), (t, per_row)
     finally:
         torch.empty = real_empty
+
+
+@pytest.mark.gpu
+def test_more_than_2_pow_32_elements(antq_lib, oracle, dev):
+    """Maximum sizes: one tensor of 2^32 + 2^22 bf16 elements (8.6 GB in, 8.6 GB out; every index past 32 bits).  The
+    oracle cannot run at this size, so the launch over the whole tensor is compared, bit for bit, with launches over row
+    blocks of it (each far below 2^32) -- per row, in 16-element groups (static and abs-max in the kernel) and as a
+    batched launch -- and the tail rows against the oracle."""
+    import torch
+    from ant_quantization_amd import grids
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40e9:
+        pytest.skip("needs 40 GB of free HBM")
+    K = 4096
+    rows = (1 << 20) + 1024                       # 2^32 + 2^22 elements
+    x = torch.empty(rows, K, dtype=torch.bfloat16, device=dev)
+    blk = 1 << 17
+    g = torch.Generator(device=dev).manual_seed(11)
+    for r0 in range(0, rows, blk):                # filled block-wise (a 17 GB fp32 temporary otherwise)
+        r1 = min(rows, r0 + blk)
+        x[r0:r1] = (torch.randn(r1 - r0, K, device=dev, generator=g) * 0.02).bfloat16()
+    assert x.numel() > (1 << 32)
+    plan = antq_lib.plan_for(grids.ant_flint(4, True))
+    out = torch.empty_like(x)
+
+    def blocks_equal(full_fn, block_fn):
+        full_fn()
+        torch.cuda.synchronize()
+        tmp = torch.empty(blk, K, dtype=torch.bfloat16, device=dev)
+        for r0 in list(range(0, rows, 8 * blk)) + [rows - blk]:       # a sample of blocks incl. the last (indices > 2^32)
+            r1 = min(rows, r0 + blk)
+            block_fn(r0, r1, tmp[: r1 - r0])
+            assert torch.equal(out[r0:r1], tmp[: r1 - r0]), r0
+
+    # per row
+    alpha = antq_lib.absmax(x, rows, K)
+    assert torch.equal(alpha[-blk:], antq_lib.absmax(x[-blk:], blk, K))
+    blocks_equal(lambda: antq_lib.fakequant(x, alpha, plan, 10.0, rows, K, True, out=out),
+                 lambda r0, r1, t: antq_lib.fakequant(x[r0:r1], alpha[r0:r1], plan, 10.0, r1 - r0, K, True, out=t))
+    # the last rows against the oracle
+    xt = x[-4:].view(torch.int16).cpu().numpy().view(np.uint16)
+    ref, _ = oracle.forward(xt, alpha[-4:].cpu().numpy(), grids.ant_flint(4, True), 10.0, False)
+    assert np.array_equal(out[-4:].view(torch.int16).cpu().numpy().view(np.uint16), ref)
+    # 16-element groups, static alpha and abs-max in the kernel
+    G = 16
+    ag = antq_lib.absmax(x, x.numel() // G, G)
+    blocks_equal(lambda: antq_lib.fakequant(x, ag, plan, 10.0, x.numel() // G, G, True, out=out),
+                 lambda r0, r1, t: antq_lib.fakequant(x[r0:r1], ag[r0 * K // G: r1 * K // G], plan, 10.0,
+                                                      (r1 - r0) * K // G, G, True, out=t))
+    blocks_equal(lambda: antq_lib.fakequant_dynamic(x, plan, 10.0, x.numel() // G, G, out=out, want_alpha=False),
+                 lambda r0, r1, t: antq_lib.fakequant_dynamic(x[r0:r1], plan, 10.0, (r1 - r0) * K // G, G, out=t,
+                                                              want_alpha=False))
+    # one batched launch over the whole tensor as a single job
+    b = antq_lib.Batch([(x, out, alpha, plan, 10.0, rows, K, True)])
+    blocks_equal(b.run,
+                 lambda r0, r1, t: antq_lib.fakequant(x[r0:r1], alpha[r0:r1], plan, 10.0, r1 - r0, K, True, out=t))
+    del x, out
+    torch.cuda.empty_cache()
