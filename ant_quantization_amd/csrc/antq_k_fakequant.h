@@ -222,7 +222,8 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
     if (fast) {
         // slot = 2 * clamp(key) + sign: positive and negative buckets interleaved, so that the sign costs one
         // v_alignbit and the clamp one v_med3 (an unsigned grid keeps a negative key: it clamps to kmin, slot 1)
-        const int32_t sh = (int32_t)xa.shift, km = (int32_t)xa.keymask;
+        const uint32_t sh = xa.shift, wd = 31u - xa.shift;
+        const bool mag = xa.keymask != 0xffffffffu;     // key = magnitude bits [shift, 31) (v_bfe_u32); unsigned grid: arithmetic shift
         const int32_t lo = (int32_t)xa.kmin, hi = (int32_t)xa.kmax;
         const bool lin = xa.linear != 0u;               // wave-uniform
         const char *t0 = reinterpret_cast<const char *>(wtab) - (lin ? 0 : (lo << 5));
@@ -238,21 +239,30 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
                 const int32_t u = (int32_t)f2u(dt[e]);
-                const int32_t t = (u >> sh) & km;
+                const int32_t t = mag ? (int32_t)__builtin_amdgcn_ubfe((uint32_t)u, sh, wd) : (u >> sh);
                 int32_t ck;
                 asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
                 slots[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);
             }
         }
+        // {U, O_lo, O_hi, idx pair}: one ds_read_b128 each, NB of them in flight before the first use (all 8 would cost
+        // the one-launch-per-tensor kernel its 8th wave per SIMD: 72 registers)
+        constexpr int NB = EPL < 4 ? EPL : 4;
 #pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            const uint32_t slot = slots[e];
-            uint4 ent = *reinterpret_cast<const uint4 *>(t0 + (slot << 4));
-            if (!IDX) asm volatile("" : "+v"(ent.w));
-            const bool c = x[e] >= u2f(ent.x);
-            o[e] = c ? u2f(ent.z) : u2f(ent.y);
-            if (OVP) isout[e] = fabsf(o[e]) >= othr;      // |v| > 32 (PlanHeader::vout)
-            if (IDX) j[e] = (int)((c ? (ent.w >> 16) : ent.w) & kIdxMask);
+        for (int b = 0; b < EPL; b += NB) {
+            AEnt ents[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) ents[k].v = *reinterpret_cast<const u32x4_t *>(t0 + (slots[b + k] << 4));
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int e = b + k;
+                AEnt ent = ents[k];
+                ent.pin();
+                const bool c = x[e] >= u2f(ent.v.x);
+                o[e] = c ? u2f(ent.v.z) : u2f(ent.v.y);
+                if (OVP) isout[e] = fabsf(o[e]) >= othr;      // |v| > 32 (PlanHeader::vout)
+                if (IDX) j[e] = (int)((c ? (ent.v.w >> 16) : ent.v.w) & kIdxMask);
+            }
         }
         if (OVP) {
 #pragma unroll

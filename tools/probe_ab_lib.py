@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Same-box A/B of library builds (ANTQ_LIB): the headline batch (32 x 4096^2 bf16, flint-4) and the same with OliVe's
-outlier-victim pairs, each build in its own process, builds interleaved over several rounds (clock / thermal drift shows up
+"""Same-box A/B of library builds (ANTQ_LIB): the headline batch (32 x 4096^2 bf16, flint-4), the same with OliVe's
+outlier-victim pairs, and the same tensors as one launch each, each build in its own process, builds interleaved over several rounds (clock / thermal drift shows up
 as a trend over rounds, not as a difference between builds).
     python tools/probe_ab_lib.py libantq.so libantq_OVP7.so ...        (paths relative to ant_quantization_amd/)"""
 import os
@@ -23,7 +23,8 @@ ol = _lib.plan_for(np.concatenate([grids.olive_flint(4, True), grids.olive_outli
 b1 = _lib.Batch([(x, o, a, flint, 10.0, 4096, 4096, True) for x, o, a in zip(xs, outs, al)])
 b2 = _lib.Batch([(x, o, a * 0.25, ol, 32.0, 4096, 4096, True) for x, o, a in zip(xs, outs, al)], ovp=True)
 n = 32 * 4096 * 4096 * 4
-print("%%.2f %%.2f" %% (n / timed(b1.run, 30) / 8e10, n / timed(b2.run, 30) / 8e10))
+pt = lambda: [_lib.fakequant(x, a, flint, 10.0, 4096, 4096, True, out=o) for x, o, a in zip(xs, outs, al)]
+print("%%.2f %%.2f %%.2f" %% (n / timed(b1.run, 30) / 8e10, n / timed(b2.run, 30) / 8e10, n / timed(pt, 10) / 8e10))
 """ % (ROOT, ROOT)
 
 
@@ -37,7 +38,7 @@ def main():
             line = [x for x in out.stdout.strip().splitlines() if x and x[0].isdigit()]
             res[l].append(line[-1] if line else "failed: " + out.stderr[-200:])
     for l in libs:
-        print("%-22s plain / OVP %% of 8 TB/s per round: %s" % (l, "   ".join(res[l])))
+        print("%-22s batched plain / batched OVP / one launch per tensor, %% of 8 TB/s, per round: %s" % (l, "   ".join(res[l])))
 
 
 if __name__ == "__main__":
