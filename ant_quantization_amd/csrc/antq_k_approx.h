@@ -139,13 +139,24 @@ __device__ __forceinline__ void a_slots(const PlanArgs &pa, const float (&dt)[EP
         const uint32_t sh = pa.shift, wd = 31u - pa.shift;
         const bool mag = pa.keymask != 0xffffffffu;
         const int32_t lo = (int32_t)pa.kmin, hi = (int32_t)pa.kmax;
+        if (mag) {                                        // (a branch per loop, not a select per element)
 #pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            const int32_t u = (int32_t)f2u(dt[e]);
-            const int32_t t = mag ? (int32_t)__builtin_amdgcn_ubfe((uint32_t)u, sh, wd) : (u >> sh);
-            int32_t ck;
-            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
-            slot[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);    // 2 * kmin too high: folded into tab0
+            for (int e = 0; e < EPL; e++) {
+                const uint32_t u = f2u(dt[e]);
+                const int32_t t = (int32_t)__builtin_amdgcn_ubfe(u, sh, wd);
+                int32_t ck;
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+                slot[e] = __builtin_amdgcn_alignbit((uint32_t)ck, u, 31);    // 2 * kmin too high: folded into tab0
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int32_t u = (int32_t)f2u(dt[e]);
+                const int32_t t = u >> sh;
+                int32_t ck;
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+                slot[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);
+            }
         }
     }
 }

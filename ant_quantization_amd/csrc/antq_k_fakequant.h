@@ -235,11 +235,20 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
 #pragma unroll
             for (int e = 0; e < EPL; e++)
                 slots[e] = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(dt[e], xa.lin_scale, xa.lin_bias), 0.0f, khi);
+        } else if (mag) {                                 // (a branch per loop, not a select per element)
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const uint32_t u = f2u(dt[e]);
+                const int32_t t = (int32_t)__builtin_amdgcn_ubfe(u, sh, wd);
+                int32_t ck;
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+                slots[e] = __builtin_amdgcn_alignbit((uint32_t)ck, u, 31);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
                 const int32_t u = (int32_t)f2u(dt[e]);
-                const int32_t t = mag ? (int32_t)__builtin_amdgcn_ubfe((uint32_t)u, sh, wd) : (u >> sh);
+                const int32_t t = u >> sh;
                 int32_t ck;
                 asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
                 slots[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);

@@ -40,6 +40,7 @@ $PY tools/probe_graph_forward.py 2>&1 | grep -v "bit \s\|amdgpu" > "$OUT/${TAG}_
 $PY tools/probe_size_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_size_sweep.log"
 $PY tools/probe_group_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_group_sweep.log"
 $PY tools/probe_lane_u.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_lane_task_u.log"
+$PY tools/probe_codec.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_codec.log"
 ( $PY tools/bench_sharded.py --model opt6.7b; $PY tools/bench_sharded.py --model llama70b --inplace ) 2>&1 | grep "^{" > "$OUT/${TAG}_sharded.log"
 [ -x tools/launch_anatomy ] && ./tools/launch_anatomy 2>&1 | cut -c1-70 > "$OUT/${TAG}_launch_anatomy.log"
 [ -x tools/valu_rates ] && ./tools/valu_rates > "$OUT/${TAG}_valu_rates.log" 2>&1
