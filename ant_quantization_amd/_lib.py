@@ -53,7 +53,8 @@ def lib():
                              "antq_search_sse_multi", "antq_plan_eval_host_a"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
-                L.antq_search_workspace_bytes.restype = ctypes.c_size_t
+                if hasattr(L, "antq_search_workspace_bytes"):      # (absent from older builds loaded through ANTQ_LIB for A/B runs)
+                    L.antq_search_workspace_bytes.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
                 vp, sz, ci, cf, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_uint
                 L.antq_fakequant.argtypes = [vp, vp, vp, sz, sz, vp, ci, cf, vp, vp, cu, ci, vp]
