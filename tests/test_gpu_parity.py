@@ -630,6 +630,44 @@ def test_packed_4bit_codec_roundtrip_equals_fakequant(antq_lib, oracle, dev, dty
             assert torch.equal(nib[is_out], (ridx[is_out] - gn.size)) and torch.equal(nib[~vic & ~is_out], ridx[~vic & ~is_out])
             dec = antq_lib.decode4(codes, alpha, plan, float(gn.max()), rows, K, True, dtype, n_normal=gn.size, ovp=True)
             assert torch.equal(dec, ref), (t, rows, K)
+    # heavy clipping (most |x / s| beyond twice the outermost value), signed zeros, a denormal, magnitudes past the
+    # scan's 102400 horizon (-> the zero code), rows whose scale is outside the table path's range (2^-60: literal path)
+    for rows, K in [(16, 4096), (9, 40)]:
+        x_np = (rng.standard_normal((rows, K)) * 0.02).astype(np.float32)
+        f = x_np.reshape(-1)
+        f[3], f[4], f[6], f[11], f[12] = 0.0, -0.0, 1e-41, 3e30, -3e30
+        x = torch.from_numpy(x_np).to(dev).to(dtype)
+        for gname, ovp in (("flint_b4_s", False), ("int_b4_s", False), ("olive", True)):
+            if ovp:
+                gn, go = O["flint_b4_s"], O["outlier_b4_s"]
+                g, gmax, nn = np.concatenate([gn, go]), float(gn.max()), gn.size
+            else:
+                g, gmax, nn = G[gname], 10.0, 0
+            plan = antq_lib.plan_for(g)
+            alpha = (torch.nan_to_num(x.float()).abs().clamp(max=1.0).amax(1) * 0.07).contiguous()
+            alpha[1] = 2.0 ** -60
+            ref, ridx = antq_lib.fakequant(x, alpha, plan, gmax, rows, K, True, ovp=ovp, want_idx=True)
+            assert torch.isfinite(ref.float()).all()
+            codes = antq_lib.encode4(x, alpha, plan, gmax, rows, K, True, n_normal=nn, ovp=ovp)
+            nib = torch.stack([(codes & 15), (codes >> 4)], 1).reshape(rows, K).to(torch.int16)
+            zero_code = int(np.flatnonzero((g[:nn] if ovp else g) == 0)[-1])
+            want = ridx.clone()
+            want[ridx == antq_lib.IDX_VICTIM] = 15
+            want[ridx == antq_lib.IDX_NONE] = zero_code
+            if ovp:
+                want[ridx >= nn] -= nn
+            assert torch.equal(nib, want), (gname, rows, K)
+            # the decoder multiplies the code's value by the scale; the reference's (q - d) + d is that value only while
+            # |d| <= 2 |q|: compare where the element is not clipped beyond twice the outermost value
+            dec = antq_lib.decode4(codes, alpha, plan, gmax, rows, K, True, dtype, n_normal=nn, ovp=ovp)
+            near = x.float().abs() <= 1.9 * alpha[:, None] * float(np.abs(g).max()) / gmax
+            near[1] = False
+            assert torch.equal(dec[near], ref[near]), (gname, rows, K)
+            antq_lib.lib().antq_debug_set(4, 0)           # the same through the exact-division encoder
+            try:
+                assert torch.equal(antq_lib.encode4(x, alpha, plan, gmax, rows, K, True, n_normal=nn, ovp=ovp), codes)
+            finally:
+                antq_lib.lib().antq_debug_set(4, 1)
     # group-16 view and per-tensor scale
     g = G["flint_b4_s"]
     plan = antq_lib.plan_for(g)
