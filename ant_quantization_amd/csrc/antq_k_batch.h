@@ -114,7 +114,11 @@ k_fq_batch_d(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ b
     float *alpha_out = DYN ? const_cast<float *>(D.alpha) : nullptr;
     if (D.kind == 1) {
         // 4 vectors per lane and workgroup, or 2 when the whole batch is only a few rounds of workgroups (antq_batch_build)
-        if (D.u == 2u)
+        if (DYN && AD && D.vpr > 64u)                    // 16-bit rows of 128 vectors: groups of 2 wavefronts
+            lane_task<T, OVP, false, U, DYN, AD, true>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row,
+                                                       D.gmax, D.ratio, alpha_out, pa, plan_tab, smem,
+                                                       ((size_t)lb * U) * 256u + threadIdx.x);
+        else if (D.u == 2u)
             lane_task<T, OVP, false, 2, DYN, AD>(D.x, D.out, nullptr, (size_t)D.n_vec, D.vpr, D.vshift, D.alpha, D.per_row, D.gmax,
                                                  D.ratio, alpha_out, pa, plan_tab, smem, ((size_t)lb * 2) * 256u + threadIdx.x);
         else

@@ -452,9 +452,10 @@ k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
 // ------------------------------------------------------------------------------------
 // AD: the plan allows the approximate-quotient element path (quant_vec_a): no exact division and no straight-through
 // arithmetic in the element loop -- what keeps 16-element groups of bf16 (2 lanes per group) from being VALU-bound.
-// DYN: alpha = max|group| * ratio from a butterfly over the group's lanes (vpr a power of two <= 64).
+// DYN: alpha = max|group| * ratio from a butterfly over the group's lanes (vpr a power of two <= 256; beyond 64 lanes the
+// wavefronts of the workgroup exchange their maxima through LDS).
 // Body shared by k_fq_lane and the batched d-domain kernel (k_fq_batch_d).
-template <typename T, bool OVP, bool IDX, int U, bool DYN, bool AD>
+template <typename T, bool OVP, bool IDX, int U, bool DYN, bool AD, bool XW = false>
 __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
                                           size_t n_vec, uint32_t vpr, int vshift, const float *__restrict__ alpha, int per_row,
                                           float gmax, float ratio, float *__restrict__ alpha_out, const PlanArgs &pa,
@@ -480,6 +481,21 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
             }
         }
     }
+    // DYN: group = vpr (a power of two) adjacent lanes.  Butterfly max inside the wavefront, the U vectors of a lane (U
+    // different groups) step by step together.  XW (vpr = 128): a group spans 2 wavefronts of the workgroup (its 256
+    // threads hold 256 consecutive vectors per u), which exchange their maxima through LDS across the barrier the table
+    // staging needs anyway.  Lanes past n_vec hold zeros and belong to no real group (n_vec % vpr == 0).
+    __shared__ uint32_t s_gmax[(DYN && XW) ? U : 1][4];
+    uint32_t m[U];
+    if constexpr (DYN && XW) {
+#pragma unroll
+        for (int u = 0; u < U; u++) m[u] = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
+        group_max_multi<U>(m, 64u);
+        if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+            for (int u = 0; u < U; u++) s_gmax[u][threadIdx.x >> 6] = m[u];
+        }
+    }
     PlanLds L;
     ATab A;
     if (AD) A = stage_atab<IDX>(pa, plan_tab, smem, tab0);
@@ -487,16 +503,18 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
     __syncthreads();
     const double inv_gmax = 1.0 / (double)gmax;
     if (DYN) {
-        // group = vpr (power of two <= 64) adjacent lanes; butterfly max inside the group, the U vectors of a lane
-        // (U different groups) step by step together.  Lanes past n_vec hold zeros and belong to no real group
-        // (n_vec % vpr == 0).
-        uint32_t m[U];
+        if constexpr (XW) {
+            const uint32_t w = threadIdx.x >> 6;
 #pragma unroll
-        for (int u = 0; u < U; u++) m[u] = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
-        if (EPL == 8) group_max_multi<U>(m, vpr);     // (fp32, 2 vectors per lane: one after the other measured 0.5 points better)
-        else {
+            for (int u = 0; u < U; u++) m[u] = max(s_gmax[u][w & 2u], s_gmax[u][w | 1u]);
+        } else {
 #pragma unroll
-            for (int u = 0; u < U; u++) m[u] = group_max_u32(m[u], vpr);
+            for (int u = 0; u < U; u++) m[u] = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
+            if (EPL == 8) group_max_multi<U>(m, vpr);     // (fp32, 2 vectors per lane: one after the other measured 0.5 points better)
+            else {
+#pragma unroll
+                for (int u = 0; u < U; u++) m[u] = group_max_u32(m[u], vpr);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -534,8 +552,12 @@ k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
           float *__restrict__ alpha_out, PlanArgs pa, const uint4 *__restrict__ plan_tab)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-    lane_task<T, OVP, IDX, U, DYN, AD>(x, out, idx, n_vec, vpr, vshift, alpha, per_row, gmax, ratio, alpha_out, pa, plan_tab,
-                                       smem, ((size_t)blockIdx.x * U) * 256u + threadIdx.x);
+    if (DYN && AD && vpr > 64u)                          // 16-bit rows of 128 vectors: groups of 2 wavefronts
+        lane_task<T, OVP, IDX, U, DYN, AD, true>(x, out, idx, n_vec, vpr, vshift, alpha, per_row, gmax, ratio, alpha_out, pa,
+                                                 plan_tab, smem, ((size_t)blockIdx.x * U) * 256u + threadIdx.x);
+    else
+        lane_task<T, OVP, IDX, U, DYN, AD>(x, out, idx, n_vec, vpr, vshift, alpha, per_row, gmax, ratio, alpha_out, pa, plan_tab,
+                                           smem, ((size_t)blockIdx.x * U) * 256u + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------

@@ -66,13 +66,14 @@ k_nearest_fast(const T *__restrict__ x, T *__restrict__ z, int16_t *__restrict__
                const T *__restrict__ grid, int m)
 {
     __shared__ float y[256];      // scan order
-    __shared__ float sv[256];     // sorted values
+    __shared__ float sv[512];     // sorted values, +inf beyond m (m = 256: the search probes up to index 2 m - 2)
     __shared__ int16_t win[256];  // sorted position -> last scan index with that value
     __shared__ int s_bad;
     __shared__ float s_mingap, s_maxgap, s_fastlim;
     const int t = threadIdx.x;
     if (t == 0) { s_bad = 0; s_mingap = 3.0e38f; s_maxgap = 0.0f; }
     sv[t] = __builtin_inff();                          // padding for the fixed-step search
+    sv[t + 256] = __builtin_inff();
     if (t < m) y[t] = (float)grid[t];
     __syncthreads();
     if (t < m) {

@@ -487,8 +487,9 @@ static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_o
     if (aligned && row_len % EPL == 0) {
         const size_t vpr = row_len / EPL;
         const bool pow2 = (vpr & (vpr - 1)) == 0;
-        if (vpr <= 64 && pow2) {
-            // several groups per wavefront (or one: 64 vectors): butterfly max over vpr adjacent lanes
+        if ((vpr <= 64 && pow2) || (pa.adom && EPL == 8 && vpr == 128 && g_knob_u != 1)) {
+            // several groups per wavefront (or one: 64 vectors): butterfly max over vpr adjacent lanes; 16-bit rows of
+            // 128 vectors: the 2 wavefronts of a group exchange their maxima through LDS
             int vshift = 0;
             while (((size_t)1 << vshift) < vpr) vshift++;
             const size_t n_vec = rows * vpr;
@@ -847,8 +848,15 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             // alpha computed in the kernel: the group / row has to live in the registers of a few lanes, one wavefront
             // or one workgroup
             if (!J.alpha_per_row || d.kind == 3 || J.rows > 0x3ffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+            if (d.kind == 0 && d.pa.adom && dtype != ANTQ_F32 && d.vpr == 128u && g_knob_u != 1) {
+                // 16-bit rows of 128 vectors as lane jobs whose groups span 2 wavefronts of a workgroup (LDS exchange of
+                // the wavefront maxima): 4 vectors in flight per lane instead of a wavefront per row: 71 -> 75 %; at 256
+                // vectors the wavefront-per-row kernel stays ahead (79 vs 75 %)
+                d.kind = 1; d.total_tasks = 0; d.tpr = 1; d.vshift = 7;
+                blocks = (size_t)((d.n_vec + 256u * kBatchU - 1u) / (256u * kBatchU));
+            }
             if (d.kind == 1) {
-                if (d.vshift < 0 || d.vpr > 64u) return ANTQ_ERR_UNSUPPORTED;   // butterfly over a power-of-two group
+                if (d.vshift < 0 || d.vpr > 256u) return ANTQ_ERR_UNSUPPORTED;  // butterfly over a power-of-two group
                 f = d.pa.adom ? 1 : 2;       // (per-group tables with the abs-max in front measured slower: 66 vs 71 %)
             } else if (xdom && !(d.pa.adom && d.vpr <= (dtype == ANTQ_F32 ? 128u : 256u) && g_knob_u != 1)) {
                 // (rows of <= 256 vectors: bf16 / f16 measured faster through the exact per-element decision below -- 70 vs
@@ -900,7 +908,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         const bool small = g_knob_u == 2 || (g_knob_u != 4 && (all_blocks < 4u * 2048u || dtype == ANTQ_F32));
         for (int i = 0; i < n && small; i++) {
             BatchDesc &d = descs[i];
-            if (d.kind == 1 && d.pa.adom) {
+            if (d.kind == 1 && d.pa.adom && !(dyn && d.vpr > 64u)) {    // (groups of 2 wavefronts keep 4 vectors per lane)
                 d.u = 2u;
                 nblk[(size_t)i] = (size_t)((d.n_vec + 511u) / 512u);
             }

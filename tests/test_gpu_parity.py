@@ -2034,3 +2034,28 @@ def test_more_than_2_pow_32_elements(antq_lib, oracle, dev):
                  lambda r0, r1, t: antq_lib.fakequant(x[r0:r1], alpha[r0:r1], plan, 10.0, r1 - r0, K, True, out=t))
     del x, out
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_nearest_256_entry_grid_above_its_top_value(antq_lib, oracle, dev):
+    """The binary search of antq_nearest probes sorted[p + step - 1]; with m = 256 (a power of two) and x above the top
+    entry that index runs to 2 m - 2.  The LDS behind the table used to be whatever the previous kernel left there: run
+    kernels with large LDS images in between and compare every call with the oracle."""
+    import torch
+    from ant_quantization_amd import grids
+    rng = np.random.default_rng(97)
+    int8 = antq_lib.plan_for(grids.ant_int(8, True))
+    junk = torch.randn(512, 4096, device=dev)
+    ja = antq_lib.absmax(junk, 512, 4096)
+    for trial in range(12):
+        g = np.sort(rng.standard_normal(256).astype(np.float32) * np.float32(3.0))
+        top = float(g.max())
+        x = np.concatenate([np.float32(top) + np.abs(rng.standard_normal(4000)).astype(np.float32) * np.float32(5.0),
+                            rng.standard_normal(4000).astype(np.float32) * np.float32(4.0),
+                            np.float32([top, np.nextafter(np.float32(top), np.float32(np.inf)), 60000.0, -60000.0])])
+        zr, jr = oracle.nearest(x, g)
+        for dt in (np.float32, np.float64):
+            antq_lib.fakequant(junk, ja, int8, 10.0, 512, 4096, True)          # leaves a 4 KiB+ table image in LDS
+            z, j = antq_lib.nearest(to_dev(x.astype(dt), dev), to_dev(g.astype(dt), dev), want_idx=True)
+            assert f32_same(z.cpu().numpy().astype(np.float32), zr), (trial, dt)
+            assert np.array_equal(j.cpu().numpy().astype(np.int32), jr), (trial, dt)
