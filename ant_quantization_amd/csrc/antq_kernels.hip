@@ -212,7 +212,12 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
 
     if (aligned && row_len % EPL == 0) {
         const size_t vpr = row_len / EPL;
-        if (vpr >= kRowKernelMinVpr) {
+        // Rows of a power of two of vectors (4096, 8192, ... elements) with an exact-decision plan: the lane kernel (alpha
+        // index = a shift) instead of a table per row -- since the instruction diet of the element path it is ahead at
+        // every tensor size: 33.5 MB bf16 59.3 -> 62.9 %, fp32 69.4 -> 74.1 %; 134 MB 74.0 -> 77.1 / 79.7 -> 81.9 %
+        // (tools/probe_lane_rows.py; knob 0 = 7 restores the row kernel)
+        const bool lane_rows = pa.adom && (vpr & (vpr - 1)) == 0 && g_knob_u != 7;
+        if (vpr >= kRowKernelMinVpr && !lane_rows) {
             if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
             return launch_uniform<T, OVP, IDX, false>(x, out, idx, rows, vpr, alpha, per_row, gmax, 1.0f, nullptr, pa,
                                                       plan_host, plan_dev, lds, st);
@@ -830,6 +835,13 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         int f;
         d.u = (uint32_t)kBatchU;
         if (!dyn) {
+            if (d.kind == 0 && d.pa.adom && (d.vpr & (d.vpr - 1u)) == 0u && g_knob_u != 7) {
+                // long rows of a power of two of vectors as lane jobs (alpha index = a shift): 32 x 4096^2 bf16 80.3 -> 80.8 %,
+                // fp32 78.9 -> 81.0 % against the per-row table kernel (tools/probe_batch_lane.py; knob 0 = 7 restores it)
+                d.kind = 1; d.total_tasks = 0; d.tpr = 1; d.vshift = 0;
+                while ((1u << d.vshift) < d.vpr) d.vshift++;
+                blocks = (size_t)((d.n_vec + 256u * kBatchU - 1u) / (256u * kBatchU));
+            }
             if (d.kind == 0 && xdom) {
                 // x-domain rows: the task size that leaves the fewest idle lanes for this row length
                 d.kind = 2;

@@ -284,7 +284,7 @@ def main():
             last = ev0.elapsed_time(ev1) * 1e-3 / per_call
         return last
 
-    # ---- setup pass: the same work as one launch per tensor (k_fq_xrow, the reference's granularity).
+    # ---- setup pass: the same work as one launch per tensor (k_fq_lane, the reference's granularity).
     # Reported beside the headline; it also keeps the GPU busy for >= 0.3 s before anything is timed,
     # which is what it takes for an idle MI355X to reach steady clocks (the first ~50 ms of load run
     # up to 20 % slower: tools/probe_clock_ramp.py).
@@ -292,7 +292,7 @@ def main():
 
     # ---- the timed region: HIP events on the launch stream (= torch's current stream) inside the barriers
     elapsed = h.timed(step, args.steps, args.warmup, on_start=ev0.record, on_stop=ev1.record)
-    # roofline of the dominant kernel (antq::k_fq_batch): the timed region is nothing but back-to-back
+    # roofline of the dominant kernel (antq::k_fq_batch_d: lane jobs of the batch): the timed region is nothing but back-to-back
     # launches of it on one stream, so its average launch duration = event time / launches.
     launch_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
     algo_bytes = args.nbuf * ROWS * COLS * BYTES_PER_ELEM
@@ -314,7 +314,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # rocprofv3 --pmc result, see profiles/README.md
     if os.path.exists(tpath):
         try:
-            per_tensor = json.load(open(tpath)).get("k_fq_batch_bf16_bytes_per_tensor")
+            tj = json.load(open(tpath))
+            per_tensor = tj.get("headline_bytes_per_tensor", tj.get("k_fq_batch_bf16_bytes_per_tensor"))
             traffic = int(per_tensor * args.nbuf) if per_tensor else None
             traffic_note = ("from profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                             "command (FETCH_SIZE x2 per the guide's gfx950 correction), NOT measured in this run")
@@ -328,14 +329,14 @@ def main():
                    "io_dtype": "bf16", "elements_per_step_per_gpu": args.nbuf * ROWS * COLS,
                    "sharding": "independent tensors per rank, no data-path collective",
                    "idempotence_check": ok,
-                   "per_tensor_launches": {"kernel": "antq::k_fq_xrow<bf16,...,U=4> (antq_fakequant, one launch per tensor)",
+                   "per_tensor_launches": {"kernel": "antq::k_fq_lane<bf16,...,U=2,AD> (antq_fakequant, one launch per tensor)",
                                            "launch_us": round(pt_launch_s * 1e6, 2),
                                            "gelem_per_s": round(ROWS * COLS / pt_launch_s / 1e9, 1),
                                            "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9, 1),
                                            "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": "antq::k_fq_batch<bf16,false>", "launch_us": round(launch_s * 1e6, 2),
+                     "kernel": "antq::k_fq_batch_d<bf16,false,true,false>", "launch_us": round(launch_s * 1e6, 2),
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "copy_ceiling": {"antq_copy_GBps": round(algo_bytes / copy_s / 1e9, 1),
                                       "hipMemcpyDtoD_GBps": round(algo_bytes / d2d_s / 1e9, 1),
