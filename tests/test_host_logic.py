@@ -449,21 +449,27 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
             d["blocks"], d["family"] = int(pos.size), f
         return n, dict(descs=descs, fam=fam, mixed=mixed, lds=int(h[4]))
 
-    # static, single family (the headline shape) stays on the lean kernel; rows of 128 / 144 vectors pick U = 2 / 3
-    n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint), (64, 1152, True, flint)], dtype=1)
+    # static rows that are NOT a power of two of vectors (3x3 conv rows): the per-row table family alone, on its lean kernel;
+    # rows of 576 / 144 / 192 vectors are cut into tasks of 3 vectors per lane
+    n, b = build([(4096, 4608, True, flint)] * 3 + [(512, 1152, True, flint), (64, 1536, True, flint)], dtype=1)
     assert b["mixed"] == 0 and b["fam"][0] > 0 and sum(b["fam"][1:]) == 0
-    assert [d["u"] for d in b["descs"]] == [4, 4, 4, 2, 3] and all(d["kind"] == 2 for d in b["descs"])
+    assert [d["u"] for d in b["descs"]] == [3, 3, 3, 3, 3] and all(d["kind"] == 2 for d in b["descs"])
     for d, rows in zip(b["descs"], (4096, 4096, 4096, 512, 64)):
         assert d["total_tasks"] == rows * d["tpr"] and d["tpr"] * 64 * d["u"] >= d["vpr"] and d["blocks"] == -(-d["total_tasks"] // 4)
+    # rows of a power of two of vectors (the headline shape: 4096 bf16 elements = 512 vectors): lane jobs, family 1 alone
+    n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint)], dtype=1)
+    assert b["mixed"] == 0 and b["fam"][1] > 0 and b["fam"][0] == 0 and all(d["kind"] == 1 for d in b["descs"])
+    assert [d["n_vec"] for d in b["descs"]] == [4096 * 512] * 3 + [512 * 128]
+    assert all(d["blocks"] == -(-d["n_vec"] // (256 * d["u"])) for d in b["descs"])
     # per-tensor scale: ONE row however the caller shaped the tensor
     n, b = build([(256, 512, False, pol), (64, 147, False, pol), (7, 33, False, pol)], flags=1)
-    assert b["descs"][0]["kind"] == 2 and b["descs"][0]["total_tasks"] == b["descs"][0]["tpr"] and b["descs"][0]["vpr"] == 32768
+    assert b["descs"][0]["kind"] == 1 and b["descs"][0]["vpr"] == 32768 and b["descs"][0]["n_vec"] == 32768   # 2^15 vectors: a lane job
     assert b["descs"][1]["kind"] == 2 and b["descs"][1]["total_tasks"] == b["descs"][1]["tpr"]      # 9408 elements: whole vectors
     assert b["descs"][2]["kind"] == 3 and b["mixed"] == 1
     # ResNet-50 per channel: long rows, short rows and conv1's ragged K = 147 -> one all-in-one launch
     n, b = build([(64, 147, True, flint), (64, 64, True, flint), (256, 576, True, flint), (2048, 512, True, flint)])
     assert b["mixed"] == 1 and b["fam"][0] == sum(d["blocks"] for d in b["descs"]) and b["lds"] > 0
-    assert [d["kind"] for d in b["descs"]] == [3, 1, 2, 2]
+    assert [d["kind"] for d in b["descs"]] == [3, 1, 2, 1]
     # group-16 (all lane jobs, adom): family 1 alone; a scan plan: family 2; both together: mixed
     n, b = build([(1 << 16, 16, True, flint)] * 2, dtype=1)
     assert b["mixed"] == 0 and b["fam"][1] > 0 and b["fam"][0] == 0 and all(d["kind"] == 1 for d in b["descs"])
@@ -471,9 +477,10 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
     assert b["fam"][2] > 0 and b["mixed"] == 0
     n, b = build([(1 << 12, 64, True, scan), (1 << 12, 64, True, flint)])
     assert b["mixed"] == 1
-    # big tables (int-8: no per-row copy) through the exact-decision path, rows per wavefront
-    n, b = build([(512, 4096, True, int8)])
-    assert b["descs"][0]["kind"] == 0 and b["fam"][1] > 0 and b["lds"] >= 255 * 16
+    # big tables (int-8: no per-row copy) through the exact-decision path: rows per wavefront, or lane jobs when the row
+    # is a power of two of vectors
+    n, b = build([(512, 4608, True, int8), (512, 4096, True, int8)])
+    assert [d["kind"] for d in b["descs"]] == [0, 1] and b["fam"][1] > 0 and b["lds"] >= 255 * 16
     # dynamic: groups (power of two, <= 64 vectors), rows in a wavefront / a workgroup / a 1024-thread workgroup
     n, b = build([(1 << 14, 16, True, flint), (4096, 512, True, flint), (512, 4096, True, flint), (64, 28672, True, flint),
                   (16, 65536, True, flint), (300, 2048, True, flint)], dtype=1, flags=2)
