@@ -43,6 +43,7 @@ static thread_local int g_knob_u = 0;        // force U of the uniform kernel (0
 static thread_local int g_knob_encwg = 2048;  // persistent workgroups of the 4-bit encoder (256 CUs x 8)
 static thread_local int g_knob_x = 1;        // 0 disables the x-domain row kernel (A/B measurements)
 static thread_local int g_knob_nearest_fast = 1;   // 0: antq_nearest always runs the literal scan
+static thread_local int g_knob_lane_rows = 1;   // 0: rows of a power of two of vectors through the per-row table kernels (A/B)
 static thread_local int g_knob_a = 1;        // 0 disables the approximate-quotient element path (quant_vec_a): exact division
 
 // ------------------------------------------------------------------------------------
@@ -215,8 +216,8 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
         // Rows of a power of two of vectors (4096, 8192, ... elements) with an exact-decision plan: the lane kernel (alpha
         // index = a shift) instead of a table per row -- since the instruction diet of the element path it is ahead at
         // every tensor size: 33.5 MB bf16 59.3 -> 62.9 %, fp32 69.4 -> 74.1 %; 134 MB 74.0 -> 77.1 / 79.7 -> 81.9 %
-        // (tools/probe_lane_rows.py; knob 0 = 7 restores the row kernel)
-        const bool lane_rows = pa.adom && (vpr & (vpr - 1)) == 0 && g_knob_u != 7;
+        // (tools/probe_lane_rows.py; knob 5 = 0 restores the row kernel)
+        const bool lane_rows = pa.adom && (vpr & (vpr - 1)) == 0 && g_knob_lane_rows != 0;
         if (vpr >= kRowKernelMinVpr && !lane_rows) {
             if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
             return launch_uniform<T, OVP, IDX, false>(x, out, idx, rows, vpr, alpha, per_row, gmax, 1.0f, nullptr, pa,
@@ -460,6 +461,7 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 2) g_knob_x = value;
     else if (key == 3) g_knob_nearest_fast = value;
     else if (key == 4) g_knob_a = value;
+    else if (key == 5) g_knob_lane_rows = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }
@@ -835,9 +837,11 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         int f;
         d.u = (uint32_t)kBatchU;
         if (!dyn) {
-            if (d.kind == 0 && d.pa.adom && (d.vpr & (d.vpr - 1u)) == 0u && g_knob_u != 7) {
-                // long rows of a power of two of vectors as lane jobs (alpha index = a shift): 32 x 4096^2 bf16 80.3 -> 80.8 %,
-                // fp32 78.9 -> 81.0 % against the per-row table kernel (tools/probe_batch_lane.py; knob 0 = 7 restores it)
+            if (d.kind == 0 && d.pa.adom && (d.vpr & (d.vpr - 1u)) == 0u && dtype == ANTQ_F32 && g_knob_lane_rows != 0) {
+                // fp32 rows of a power of two of vectors as lane jobs (alpha index = a shift): 16 x 4096^2 78.9 -> 81.0 %, with
+                // OliVe's pairs 79.4 -> 81.0 % against the per-row table kernel.  16-bit rows stay on the table kernel: equal
+                // without the pair rule (80.3 vs 80.8, 81.1 vs 81.2 %), 0.6-1.3 points ahead with it
+                // (tools/probe_batch_lane.py; knob 5 = 0 restores the table kernel for fp32 too)
                 d.kind = 1; d.total_tasks = 0; d.tpr = 1; d.vshift = 0;
                 while ((1u << d.vshift) < d.vpr) d.vshift++;
                 blocks = (size_t)((d.n_vec + 256u * kBatchU - 1u) / (256u * kBatchU));

@@ -292,7 +292,7 @@ def main():
 
     # ---- the timed region: HIP events on the launch stream (= torch's current stream) inside the barriers
     elapsed = h.timed(step, args.steps, args.warmup, on_start=ev0.record, on_stop=ev1.record)
-    # roofline of the dominant kernel (antq::k_fq_batch_d: lane jobs of the batch): the timed region is nothing but back-to-back
+    # roofline of the dominant kernel (antq::k_fq_batch): the timed region is nothing but back-to-back
     # launches of it on one stream, so its average launch duration = event time / launches.
     launch_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
     algo_bytes = args.nbuf * ROWS * COLS * BYTES_PER_ELEM
@@ -336,7 +336,7 @@ def main():
                                            "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": "antq::k_fq_batch_d<bf16,false,true,false>", "launch_us": round(launch_s * 1e6, 2),
+                     "kernel": "antq::k_fq_batch<bf16,false>", "launch_us": round(launch_s * 1e6, 2),
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "copy_ceiling": {"antq_copy_GBps": round(algo_bytes / copy_s / 1e9, 1),
                                       "hipMemcpyDtoD_GBps": round(algo_bytes / d2d_s / 1e9, 1),

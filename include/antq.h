@@ -285,11 +285,11 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
 
 /* Development / benchmark tuning knobs (thread-local: only the calling thread's later calls are affected; not part of
  * the stable surface):
- *   key 0: force the per-task unroll U of the row kernels (0 = heuristic); 7 = rows of a power of two of vectors
- *          through the per-row table kernel instead of the lane kernel (A/B)
+ *   key 0: force the per-task unroll U of the row kernels (0 = heuristic)
  *   key 1: number of persistent workgroups of antq_encode4 (0 = default, 2048)
  *   key 2: 0 disables the per-row (x-domain) table kernels, the d-domain kernels run instead (A/B measurements)
- *   key 3: 0 disables the binary-search path of antq_nearest (literal scan only) */
+ *   key 3: 0 disables the binary-search path of antq_nearest (literal scan only)
+ *   key 5: 0 sends rows of a power of two of vectors through the per-row table kernels instead of the lane kernel (A/B) */
 int antq_debug_set(int key, int value);
 
 #ifdef __cplusplus

@@ -53,6 +53,19 @@ def bf16_same(got_bits, ref_bits, oracle):
 
 
 def run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16):
+    """One tensor through antq_fakequant against the oracle.  Rows of a power of two of vectors take the lane kernel by
+    default; knob 5 = 0 sends them through the per-row table kernel: both are checked."""
+    _run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16)
+    vec = (x.shape[1] if per_row else x.size) // (8 if bf16 else 4)
+    if vec >= 128 and vec & (vec - 1) == 0 and (x.shape[1] if per_row else x.size) % (8 if bf16 else 4) == 0:
+        antq_lib.lib().antq_debug_set(5, 0)
+        try:
+            _run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16)
+        finally:
+            antq_lib.lib().antq_debug_set(5, 1)
+
+
+def _run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16):
     rows, K = x.shape
     plan = antq_lib.plan_for(grid)
     import torch
@@ -63,7 +76,9 @@ def run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16):
         out, idx = antq_lib.fakequant(to_dev(xb, dev, True), a_t, plan, gmax, rows, K, per_row, ovp=ovp, want_idx=True)
         out2 = antq_lib.fakequant(to_dev(xb, dev, True), a_t, plan, gmax, rows, K, per_row, ovp=ovp)
         assert bf16_same(bf16_bits(out), ref, oracle)
-        assert np.array_equal(bf16_bits(out), bf16_bits(out2))
+        bad = np.flatnonzero(bf16_bits(out).reshape(-1) != bf16_bits(out2).reshape(-1))
+        assert bad.size == 0, ("index output on / off differ", bad[:16], bad.size, bf16_bits(out).reshape(-1)[bad[:8]],
+                               bf16_bits(out2).reshape(-1)[bad[:8]], xb.reshape(-1)[bad[:8]])
     else:
         ref, ridx = oracle.forward(x, alpha, grid, gmax, ovp)
         out, idx = antq_lib.fakequant(to_dev(x, dev), a_t, plan, gmax, rows, K, per_row, ovp=ovp, want_idx=True)
@@ -1737,8 +1752,9 @@ def test_row_sharded_odd_numel_ovp_wrap(antq_lib, oracle, dev, bf16):
 def test_bench_workload_batched_kernel_vs_oracle(antq_lib, oracle, dev):
     """The launch bench.py times, checked DIRECTLY: the same batch (32 x [4096, 4096] bf16, randn * 0.02 from the device
     generator seeded 6, signed flint-4, alpha = row abs-max, one antq_fakequant_batch launch = k_fq_batch<bf16,false>),
-    72 rows of every tensor against the oracle (values), the same rows' indices through the per-tensor kernel, and every
-    element of the batched output against the per-tensor launch."""
+    72 rows of every tensor against the oracle (values), the same rows' indices through the per-tensor kernel (the lane
+    kernel with the exact per-element decision), and every element of the batched output against the per-tensor launch;
+    then the per-tensor launches through the per-row table kernel too (knob 5 = 0): identical bits."""
     import torch
     from ant_quantization_amd import grids
     g = grids.ant_flint(4, True)
@@ -1772,6 +1788,13 @@ def test_bench_workload_batched_kernel_vs_oracle(antq_lib, oracle, dev):
         assert torch.equal(o1.view(torch.int16), outs[i].view(torch.int16)), i               # batch == per tensor, everywhere
         n_rows += rows.size
     assert n_rows >= 64 * nbuf
+    antq_lib.lib().antq_debug_set(5, 0)
+    try:
+        for i in range(0, nbuf, 8):
+            o2 = antq_lib.fakequant(xs[i], alphas[i], plan, 10.0, R, K, True)
+            assert torch.equal(o2.view(torch.int16), outs[i].view(torch.int16)), i
+    finally:
+        antq_lib.lib().antq_debug_set(5, 1)
 
 
 def test_bert_base_real_shapes_weights_and_activations(antq_lib, oracle, dev, capsys):

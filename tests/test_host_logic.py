@@ -456,10 +456,14 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
     assert [d["u"] for d in b["descs"]] == [3, 3, 3, 3, 3] and all(d["kind"] == 2 for d in b["descs"])
     for d, rows in zip(b["descs"], (4096, 4096, 4096, 512, 64)):
         assert d["total_tasks"] == rows * d["tpr"] and d["tpr"] * 64 * d["u"] >= d["vpr"] and d["blocks"] == -(-d["total_tasks"] // 4)
-    # rows of a power of two of vectors (the headline shape: 4096 bf16 elements = 512 vectors): lane jobs, family 1 alone
+    # rows of a power of two of vectors: 16-bit data (the headline shape: 4096 bf16 elements = 512 vectors) stays on the
+    # per-row table kernel, fp32 becomes lane jobs (family 1 alone)
     n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint)], dtype=1)
+    assert b["mixed"] == 0 and b["fam"][0] > 0 and sum(b["fam"][1:]) == 0 and all(d["kind"] == 2 for d in b["descs"])
+    assert [d["u"] for d in b["descs"]] == [4, 4, 4, 2]
+    n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint)], dtype=0)
     assert b["mixed"] == 0 and b["fam"][1] > 0 and b["fam"][0] == 0 and all(d["kind"] == 1 for d in b["descs"])
-    assert [d["n_vec"] for d in b["descs"]] == [4096 * 512] * 3 + [512 * 128]
+    assert [d["n_vec"] for d in b["descs"]] == [4096 * 1024] * 3 + [512 * 256]
     assert all(d["blocks"] == -(-d["n_vec"] // (256 * d["u"])) for d in b["descs"])
     # per-tensor scale: ONE row however the caller shaped the tensor
     n, b = build([(256, 512, False, pol), (64, 147, False, pol), (7, 33, False, pol)], flags=1)

@@ -1,5 +1,5 @@
 """The headline batch (32 x 4096^2 bf16 / 16 x fp32, per-row alpha, plain and with OliVe's pairs) through the per-row table
-kernel (knob 0 = 7) and as lane jobs with the exact per-element decision (the default for rows of a power of two of vectors)."""
+kernel (knob 5 = 0) and as lane jobs with the exact per-element decision (the default for rows of a power of two of vectors)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
@@ -16,11 +16,11 @@ for dt, bpe in ((torch.bfloat16, 4), (torch.float32, 8)):
     n = nt * 4096 * 4096 * bpe
     for rnd in range(3):
         res = []
-        for knob in (7, 0):
-            _lib.lib().antq_debug_set(0, knob)
+        for knob in (0, 1):
+            _lib.lib().antq_debug_set(5, knob)
             b1 = _lib.Batch([(x, o, a, flint, 10.0, 4096, 4096, True) for x, o, a in zip(xs, outs, al)])
             b2 = _lib.Batch([(x, o, a * 0.25, ol, 32.0, 4096, 4096, True) for x, o, a in zip(xs, outs, al)], ovp=True)
-            _lib.lib().antq_debug_set(0, 0)
+            _lib.lib().antq_debug_set(5, 1)
             res += [n / timed(b1.run, 30) / 8e10, n / timed(b2.run, 30) / 8e10]
         print(str(dt)[6:], "row-table kernel plain/OVP %.2f %.2f   lane kernel plain/OVP %.2f %.2f" % tuple(res), flush=True)
     del xs, outs

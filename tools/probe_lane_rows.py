@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One launch per tensor, static alpha, rows of 1024 ... 65536 elements (a power of two of vectors): the x-domain row kernel
-(knob 0 = 7) against the lane kernel with the exact per-element decision (the default for such rows), same process."""
+(knob 5 = 0) against the lane kernel with the exact per-element decision (the default for such rows), same process."""
 import os
 import sys
 
@@ -26,11 +26,11 @@ for dt, bpe in ((torch.bfloat16, 4), (torch.float32, 8)):
             per_row = G != n
             al = [_lib.absmax(x, n // G, G) * (0.25 if ovp else 1.0) if per_row else x.float().abs().max().reshape(1) for x in xs]
             res = []
-            for knob in (7, 0):
-                _lib.lib().antq_debug_set(0, knob)
+            for knob in (0, 1):
+                _lib.lib().antq_debug_set(5, knob)
                 t = timed(lambda: [_lib.fakequant(x, a, plan, gmax, n // G if per_row else 1, G, per_row, ovp=ovp, out=o)
                                    for x, a, o in zip(xs, al, outs)], 5)
                 res.append(NT * n * bpe / t / 8e10)
-            _lib.lib().antq_debug_set(0, 0)
+            _lib.lib().antq_debug_set(5, 1)
             print("%-9s %5d^2 %-22s rows of %9d: row kernel %5.1f%%   lane kernel %5.1f%%  of 8 TB/s" % (str(dt)[6:], R, name, G, res[0], res[1]), flush=True)
     del xs, outs

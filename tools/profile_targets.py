@@ -33,7 +33,7 @@ def main():
 
     runs = []
     b, al = batch(xs, outs, 4096, flint, 10.0)
-    runs.append(b.run)                                                                   # k_fq_batch_d<bf16,false,true,false>: headline (lane jobs)
+    runs.append(b.run)                                                                   # k_fq_batch<bf16,false>: headline
     runs.append(lambda: [_lib.fakequant(x, a, flint, 10.0, 4096, 4096, True, out=o) for x, a, o in zip(xs, al, outs)])   # k_fq_lane
     # rows that are not a power of two of vectors (ResNet's 3x3 rows: 4608 = 576 bf16 vectors): the per-row table kernels
     x46 = [x.view(-1)[:3640 * 4608].view(3640, 4608) for x in xs]
@@ -46,7 +46,7 @@ def main():
     runs.append(lambda: [_lib.fakequant(x, a, flint, 10.0, n // 16, 16, True, out=o) for x, a, o in zip(xs, al16, outs)])  # k_fq_lane
     runs.append(batch(xs, outs, 16, flint, 10.0, dynamic=True)[0].run)                   # ... dynamic
     runs.append(batch(xs, outs, 256, flint, 10.0)[0].run)                                # group-256: lane jobs
-    runs.append(batch(xs, outs, 4096, ol, 32.0, ovp=True)[0].run)                        # OliVe pairs (lane jobs)
+    runs.append(batch(xs, outs, 4096, ol, 32.0, ovp=True)[0].run)                        # k_fq_batch<bf16,true>: OliVe pairs
     runs.append(batch(xs, outs, 4096, flint, 10.0, dynamic=True)[0].run)                 # k_fq_batch_dyn
     xl = [x.view(-1)[:512 * 28672].view(512, 28672) for x in xs[:4]]
     ol_ = [o.view(-1)[:512 * 28672].view(512, 28672) for o in outs[:4]]
