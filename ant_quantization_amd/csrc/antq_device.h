@@ -175,6 +175,17 @@ template <> struct IO<f16_tag> {
     __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return f2u(h2f(max(m & 0xffffu, m >> 16))); }
 };
 
+// floor(o / opr) without an integer division: one f64 multiply by the reciprocal (inv = 1.0 / opr) and a +-1 fix-up
+// (o < 2^32, exact).
+__device__ __forceinline__ uint32_t oct_row(uint32_t o, uint32_t opr, double inv)
+{
+    uint32_t q = (uint32_t)((double)o * inv);
+    const uint32_t qo = q * opr;
+    if (qo > o) q--;
+    else if (o - qo >= opr) q++;
+    return q;
+}
+
 // Plan fields the kernels need, passed by value (lands in SGPRs).
 struct PlanArgs {
     uint32_t kind;

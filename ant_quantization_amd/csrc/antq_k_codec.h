@@ -8,16 +8,6 @@
 
 namespace antq {
 
-// floor(o / opr) without an integer division: one f64 multiply by the reciprocal and a +-1 fix-up (o < 2^32, exact).
-__device__ __forceinline__ uint32_t oct_row(uint32_t o, uint32_t opr, double inv)
-{
-    uint32_t q = (uint32_t)((double)o * inv);
-    const uint32_t qo = q * opr;
-    if (qo > o) q--;
-    else if (o - qo >= opr) q++;
-    return q;
-}
-
 // The encoder only needs codes: its LDS table is the plan's a-table with the two values of every entry replaced, once per
 // workgroup, by their nibbles (bit 8 = the pair rule's outlier test |v| > 32): {M' (double), code_lo, code_hi}.  One
 // ds_read_b128, the exact decision (antq_k_approx.h) and one select per element; no second table read, no dequantised value.

@@ -467,6 +467,7 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
     else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
     uint4 v[U];
     float a[U];
+    const double inv_vpr = 1.0 / (double)vpr;
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const size_t vi = first + (size_t)u * 256u;
@@ -476,7 +477,9 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
             v[u] = ld_stream(x + vi);
             if (!DYN) {
                 size_t row = 0;
-                if (per_row) row = (vshift >= 0) ? (vi >> vshift) : (vi / vpr);
+                if (per_row)   // a shift; else the f64-reciprocal quotient (exact below 2^32 vectors); else a 64-bit division
+                    row = (vshift >= 0) ? (vi >> vshift)
+                                        : (n_vec <= 0xffffffffull ? (size_t)oct_row((uint32_t)vi, vpr, inv_vpr) : vi / vpr);
                 a[u] = alpha[row];
             }
         }

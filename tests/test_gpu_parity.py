@@ -53,16 +53,17 @@ def bf16_same(got_bits, ref_bits, oracle):
 
 
 def run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16):
-    """One tensor through antq_fakequant against the oracle.  Rows of a power of two of vectors take the lane kernel by
-    default; knob 5 = 0 sends them through the per-row table kernel: both are checked."""
+    """One tensor through antq_fakequant against the oracle.  Long rows take the lane kernel or the per-row table kernel
+    depending on their length and dtype (knob 5: 0 = always the table kernel, 2 = always the lane kernel): both are checked."""
     _run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16)
     vec = (x.shape[1] if per_row else x.size) // (8 if bf16 else 4)
-    if vec >= 128 and vec & (vec - 1) == 0 and (x.shape[1] if per_row else x.size) % (8 if bf16 else 4) == 0:
-        antq_lib.lib().antq_debug_set(5, 0)
-        try:
-            _run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16)
-        finally:
-            antq_lib.lib().antq_debug_set(5, 1)
+    if vec >= 128 and (x.shape[1] if per_row else x.size) % (8 if bf16 else 4) == 0:
+        for knob in (0, 2):
+            antq_lib.lib().antq_debug_set(5, knob)
+            try:
+                _run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16)
+            finally:
+                antq_lib.lib().antq_debug_set(5, 1)
 
 
 def _run_case(antq_lib, oracle, dev, x, alpha, grid, gmax, per_row, ovp, bf16):
