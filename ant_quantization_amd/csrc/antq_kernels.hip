@@ -839,13 +839,14 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         int f;
         d.u = (uint32_t)kBatchU;
         if (!dyn) {
-            if (d.kind == 0 && d.pa.adom && (d.vpr & (d.vpr - 1u)) == 0u && dtype == ANTQ_F32 && g_knob_lane_rows != 0) {
-                // fp32 rows of a power of two of vectors as lane jobs (alpha index = a shift): 16 x 4096^2 78.9 -> 81.0 %, with
-                // OliVe's pairs 79.4 -> 81.0 % against the per-row table kernel.  16-bit rows stay on the table kernel: equal
-                // without the pair rule (80.3 vs 80.8, 81.1 vs 81.2 %), 0.6-1.3 points ahead with it
-                // (tools/probe_batch_lane.py; knob 5 = 0 restores the table kernel for fp32 too)
-                d.kind = 1; d.total_tasks = 0; d.tpr = 1; d.vshift = 0;
-                while ((1u << d.vshift) < d.vpr) d.vshift++;
+            if (d.kind == 0 && d.pa.adom && (dtype == ANTQ_F32 || g_knob_lane_rows == 2) && g_knob_lane_rows != 0) {
+                // fp32 long rows as lane jobs (alpha index = a shift, or the f64-reciprocal quotient): 16 x 4096^2 78.9 -> 81.0 %,
+                // with OliVe's pairs 79.4 -> 81.0 %, BERT-base's 768 / 3072-wide rows 79.0 -> 80.8 %, ResNet-50 75.2 -> 76.0 %
+                // against the per-row table kernel.  16-bit rows stay on the table kernel: equal without the pair rule (80.3 vs
+                // 80.8, 81.1 vs 81.2 %), 0.6-1.3 points ahead with it, 0.7 ahead on BERT's shapes (tools/probe_batch_lane.py;
+                // knob 5 = 0 restores the table kernel for fp32 too, 2 makes every long row a lane job)
+                d.kind = 1; d.total_tasks = 0; d.tpr = 1; d.vshift = -1;
+                if ((d.vpr & (d.vpr - 1u)) == 0u) { d.vshift = 0; while ((1u << d.vshift) < d.vpr) d.vshift++; }
                 blocks = (size_t)((d.n_vec + 256u * kBatchU - 1u) / (256u * kBatchU));
             }
             if (d.kind == 0 && xdom) {

@@ -468,10 +468,14 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
     # per-tensor scale: ONE row however the caller shaped the tensor
     n, b = build([(256, 512, False, pol), (64, 147, False, pol), (7, 33, False, pol)], flags=1)
     assert b["descs"][0]["kind"] == 1 and b["descs"][0]["vpr"] == 32768 and b["descs"][0]["n_vec"] == 32768   # 2^15 vectors: a lane job
-    assert b["descs"][1]["kind"] == 2 and b["descs"][1]["total_tasks"] == b["descs"][1]["tpr"]      # 9408 elements: whole vectors
-    assert b["descs"][2]["kind"] == 3 and b["mixed"] == 1
-    # ResNet-50 per channel: long rows, short rows and conv1's ragged K = 147 -> one all-in-one launch
+    assert b["descs"][1]["kind"] == 1 and b["descs"][1]["n_vec"] == 2352          # 9408 fp32 elements: whole vectors, a lane job
+    assert b["descs"][2]["kind"] == 3 and b["mixed"] == 0 and b["fam"][1] == sum(d["blocks"] for d in b["descs"])
+    # ResNet-50 per channel, fp32: every aligned row is a lane job, conv1's ragged K = 147 rides along: one family
     n, b = build([(64, 147, True, flint), (64, 64, True, flint), (256, 576, True, flint), (2048, 512, True, flint)])
+    assert b["mixed"] == 0 and b["fam"][1] == sum(d["blocks"] for d in b["descs"]) and b["lds"] > 0
+    assert [d["kind"] for d in b["descs"]] == [3, 1, 1, 1]
+    # the same in bf16: rows of 144 vectors keep their per-row table -> long rows, short rows, ragged rows: one all-in-one launch
+    n, b = build([(64, 147, True, flint), (64, 64, True, flint), (256, 1152, True, flint), (2048, 512, True, flint)], dtype=1)
     assert b["mixed"] == 1 and b["fam"][0] == sum(d["blocks"] for d in b["descs"]) and b["lds"] > 0
     assert [d["kind"] for d in b["descs"]] == [3, 1, 2, 1]
     # group-16 (all lane jobs, adom): family 1 alone; a scan plan: family 2; both together: mixed
@@ -483,8 +487,10 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
     assert b["mixed"] == 1
     # big tables (int-8: no per-row copy) through the exact-decision path: rows per wavefront, or lane jobs when the row
     # is a power of two of vectors
+    n, b = build([(512, 4608, True, int8), (512, 4096, True, int8)], dtype=1)
+    assert [d["kind"] for d in b["descs"]] == [0, 0] and b["fam"][1] > 0 and b["lds"] >= 255 * 16
     n, b = build([(512, 4608, True, int8), (512, 4096, True, int8)])
-    assert [d["kind"] for d in b["descs"]] == [0, 1] and b["fam"][1] > 0 and b["lds"] >= 255 * 16
+    assert [d["kind"] for d in b["descs"]] == [1, 1] and b["fam"][1] > 0 and b["lds"] >= 255 * 16
     # dynamic: groups (power of two, <= 64 vectors), rows in a wavefront / a workgroup / a 1024-thread workgroup
     n, b = build([(1 << 14, 16, True, flint), (4096, 512, True, flint), (512, 4096, True, flint), (64, 28672, True, flint),
                   (16, 65536, True, flint), (300, 2048, True, flint)], dtype=1, flags=2)
