@@ -1998,6 +1998,20 @@ def test_calibration_sums_are_bit_reproducible(antq_lib, dev):
                 # the multi kernel forms the very same sums as one search per type
                 for t, p in enumerate(plans):
                     assert torch.equal(ref[t], antq_lib.search_sse(x, rows, row_len, xmax, per_row, ratios, p, 10.0)), (t, per_row)
+        # candidate lists longer than one workgroup's accumulators (128): split over blockIdx.y in every kernel
+        r150 = core._ratios(1, 151, 1, dev)
+        assert r150.numel() == 150
+        for x, per_row in cases:
+            rows, row_len = x.shape
+            xmax = core.row_absmax(x, per_row)
+            full = antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150, flint, 10.0)
+            assert torch.isfinite(full).all() and torch.equal(full, antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150, flint, 10.0))
+            halves = torch.cat([antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[:75].contiguous(), flint, 10.0),
+                                antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[75:].contiguous(), flint, 10.0)])
+            if per_row and rows > 1:
+                assert torch.equal(full, halves)
+            else:
+                torch.testing.assert_close(full, halves, rtol=1e-12, atol=0)
     finally:
         torch.empty = real_empty
 
