@@ -4,7 +4,8 @@
 // This is what a C/C++ host of the reference's path would do: build a plan on the host,
 // upload it, call the fused entry points on its own stream and buffers.  Covers antq_nearest (the quant_cuda.quant
 // replacement, KQ/quant_kernel.cu:11-62), antq_fakequant (AQ:535-551), the OliVe victim rule (OQ:311-320),
-// antq_fakequant_dynamic + antq_absmax, antq_fakequant_batch, the packed 4-bit codec, antq_nearest_hinted and group-16.
+// antq_fakequant_dynamic + antq_absmax, antq_fakequant_batch, the packed 4-bit codec, antq_nearest_hinted, group-16 and the
+// calibration entry points (antq_search_sse with its workspace, antq_search_pick).
 // Exit code 0 = every comparison bit-exact; prints one line per check.
 #include <hip/hip_runtime.h>
 
@@ -22,6 +23,9 @@ void antq_oracle_nearest_f32(const float *x, float *z, int32_t *idx, size_t n, c
 void antq_oracle_forward_f32(const float *x, float *out, int32_t *idx, size_t rows, size_t row_len, const float *alpha,
                              int alpha_per_row, const float *grid, int m, float gmax, int ovp);
 void antq_oracle_absmax_f32(const float *x, float *alpha, size_t rows, size_t row_len, int per_row, float ratio);
+int antq_oracle_search_mse_f32(const float *x, size_t rows, size_t row_len, int per_row, const float *x_max, int lb, int ub,
+                               int step, const float *grid, int m, float gmax, int ovp, float *best_score, float *best_alpha,
+                               float *trace);
 }
 
 #define HIP_OK(e)                                                                                          \
@@ -224,6 +228,53 @@ int main()
         ANTQ_OK_(antq_fakequant_dynamic(dxf.p, dout.p, nullptr, dag2.p, g_rows, 16, 1.0f, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
         same_bits("antq_fakequant_dynamic group-16 alpha", dag2.down(st), ag);
         same_bits("antq_fakequant_dynamic group-16 values", dout.down(st), ref);
+    }
+
+    // 7d. calibration (search_mse, AQ:287-326): abs-max, every clip candidate's squared error on one read, selection on
+    //     the device -- per row and per tensor (whole-tensor sums need the caller's workspace).  The scores are sums in another
+    //     order than the oracle's, so a pick may differ only where the ORACLE's own scores tie within 2e-5.
+    for (int per_row = 1; per_row >= 0; per_row--) {
+        const size_t na = per_row ? rows : 1;
+        const int lb = 75, ub = 150, ncand = ub - lb;
+        std::vector<float> ratios((size_t)ncand), xmax(na), o_score(na), o_alpha(na), trace((size_t)ncand * na);
+        for (int i = 0; i < ncand; i++) ratios[(size_t)i] = (float)((double)(lb + i) * 0.01);
+        antq_oracle_absmax_f32(xf.data(), xmax.data(), rows, K, per_row, 1.0f);
+        antq_oracle_search_mse_f32(xf.data(), rows, K, per_row, xmax.data(), lb, ub, 1, flint.data(), (int)flint.size(), 10.0f, 0,
+                                   o_score.data(), o_alpha.data(), trace.data());
+        DevBuf<float> dratios((size_t)ncand), dxmax(na), dscore(na), dalpha_best(na);
+        DevBuf<double> dsse((size_t)ncand * na);
+        DevBuf<uint8_t> dws(antq_search_workspace_bytes());
+        dratios.up(ratios, st);
+        ANTQ_OK_(antq_absmax(dxf.p, dxmax.p, rows, K, per_row, ANTQ_F32, st));
+        same_bits(per_row ? "antq_absmax per row" : "antq_absmax per tensor", dxmax.down(st), xmax);
+        if (!per_row && antq_search_sse(dxf.p, rows, K, dxmax.p, 0, dratios.p, ncand, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32,
+                                        dsse.p, nullptr, st) != ANTQ_ERR_ARG) { printf("missing workspace not rejected\n"); failures++; }
+        ANTQ_OK_(antq_search_sse(dxf.p, rows, K, dxmax.p, per_row, dratios.p, ncand, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32,
+                                 dsse.p, dws.p, st));
+        ANTQ_OK_(antq_search_pick(dsse.p, dxmax.p, dratios.p, ncand, na, per_row ? K : n, dscore.p, dalpha_best.p, st));
+        const std::vector<double> sse = dsse.down(st);
+        const std::vector<float> g_alpha = dalpha_best.down(st), g_score = dscore.down(st);
+        int bad = 0, flips = 0;
+        for (size_t r = 0; r < na; r++) {
+            const double len = per_row ? (double)K : (double)n;
+            int c_gpu = -1, c_ora = -1;
+            for (int c = 0; c < ncand; c++) {
+                const double want = (double)trace[(size_t)c * na + r];
+                if (std::fabs(sse[(size_t)c * na + r] / len - want) > 2e-6 * want) bad++;          // fp32 terms, other order
+                if (xmax[r] * ratios[(size_t)c] == g_alpha[r] && c_gpu < 0) c_gpu = c;
+                if (xmax[r] * ratios[(size_t)c] == o_alpha[r] && c_ora < 0) c_ora = c;
+            }
+            if (c_gpu < 0 || c_ora < 0) { bad++; continue; }
+            if (c_gpu != c_ora) {
+                flips++;
+                const double a = trace[(size_t)c_gpu * na + r], b = trace[(size_t)c_ora * na + r];
+                if (std::fabs(a - b) > 2e-5 * b) bad++;                                           // not a tie by the oracle's scores
+            }
+        }
+        printf("%-62s %s (%d of %zu picks differ, all ties)\n", per_row ? "antq_search_sse + antq_search_pick, per row"
+                                                                       : "antq_search_sse + antq_search_pick, per tensor",
+               bad ? "MISMATCH" : "ok", flips, na);
+        if (bad) failures++;
     }
 
     // 8. error behaviour: codes, not exceptions
