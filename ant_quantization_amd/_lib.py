@@ -318,11 +318,12 @@ def alpha_grad(x, out, gout, rows, row_len, per_row=True):
     dt = _DTYPES.get(x.dtype)
     if dt is None or dt == F64 or out.dtype != x.dtype or gout.dtype != x.dtype:
         raise AntqError("alpha_grad: x / out / gout must share one of float32 / bfloat16 / float16")
-    gsum = torch.zeros(rows if per_row else 1, dtype=torch.float64, device=x.device)
+    gsum = torch.empty(rows if per_row else 1, dtype=torch.float64, device=x.device)
+    ws = None if per_row else torch.empty(int(lib().antq_search_workspace_bytes()), dtype=torch.uint8, device=x.device)
     with _on_device(x.device):
         _check(lib().antq_alpha_grad(_vp(x), _vp(out), _vp(gout), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
-                                     ctypes.c_int(1 if per_row else 0), _vp(gsum), ctypes.c_int(dt), _stream(x.device)),
-               "antq_alpha_grad")
+                                     ctypes.c_int(1 if per_row else 0), _vp(gsum), _vp(ws), ctypes.c_int(dt),
+                                     _stream(x.device)), "antq_alpha_grad")
     return gsum
 
 

@@ -180,13 +180,15 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
 // Backward of the fused fake-quant w.r.t. alpha (QAT, AQ:39 alpha is a Parameter; AQ:544-549 straight-through
 // graph): d out / d alpha = (q - d) / gmax = (out - x) / alpha, so
 //     gsum[r] = sum_c fl32( gout[r,c] * fl32(out[r,c] - x[r,c]) )          (the caller divides by alpha[r])
-// fp32 terms, fp64 accumulation.  One wavefront per row; one scale per tensor: block-strided with one atomic per
-// workgroup.  d out / d x is the identity (no clip mask in the reference), so there is no kernel for it.
+// fp32 terms, fp64 accumulation.  One wavefront per row; one scale per tensor: block-strided, every workgroup writes its
+// partial to the caller's workspace and k_sum_partials adds them in a fixed order (no floating-point atomics).  d out / d x is the identity (no clip mask in the reference), so there is no kernel for it.
 // ------------------------------------------------------------------------------------
+constexpr int kPartialStride = 128;   // doubles between two workgroup partials in the workspace (= kPtCand, antq_k_search.h)
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_alpha_grad(const void *__restrict__ x, const void *__restrict__ out, const void *__restrict__ gout,
-             double *__restrict__ gsum, size_t rows, size_t row_len, int per_row, int vec_ok)
+             double *__restrict__ gsum, double *__restrict__ ws, size_t rows, size_t row_len, int per_row, int vec_ok)
 {
     constexpr int EPL = IO<T>::EPL;
     const uint32_t lane = threadIdx.x & 63u;
@@ -246,7 +248,8 @@ k_alpha_grad(const void *__restrict__ x, const void *__restrict__ out, const voi
         __shared__ double wsum[4];
         if (lane == 0) wsum[threadIdx.x >> 6] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(gsum, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+        // this workgroup's partial; k_sum_partials (antq_k_search.h) adds the workgroups in a fixed tree
+        if (threadIdx.x == 0) ws[(size_t)blockIdx.x * kPartialStride] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     }
 }
 

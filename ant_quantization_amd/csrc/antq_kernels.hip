@@ -714,9 +714,10 @@ extern "C" int antq_fakequant_dynamic(const void *x, void *out, int16_t *idx, fl
 
 namespace antq {
 template <typename T>
-static int launch_alpha_grad(const void *x, const void *out, const void *gout, double *gsum, size_t rows, size_t row_len,
-                             int per_row, hipStream_t st)
+static int launch_alpha_grad(const void *x, const void *out, const void *gout, double *gsum, double *ws, size_t rows,
+                             size_t row_len, int per_row, hipStream_t st)
 {
+    static_assert(kPartialStride == kPtCand, "k_sum_partials reads partials kPtCand doubles apart");
     constexpr int EPL = IO<T>::EPL;
     const bool al = (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gout)) % 16 == 0;
     const int vec_ok = per_row ? (al && row_len % EPL == 0) : al;
@@ -725,22 +726,24 @@ static int launch_alpha_grad(const void *x, const void *out, const void *gout, d
     const size_t cap = per_row ? 4096 : 1024;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_alpha_grad<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, out, gout, gsum, rows, row_len, per_row,
-                       vec_ok);
+    hipLaunchKernelGGL((k_alpha_grad<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, out, gout, gsum, ws, rows, row_len,
+                       per_row, vec_ok);
+    if (!per_row) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, ws, (uint32_t)blocks, 1, gsum);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 }  // namespace antq
 
 extern "C" int antq_alpha_grad(const void *x, const void *out, const void *gout, size_t rows, size_t row_len, int per_row,
-                               double *gsum, int dtype, void *stream)
+                               double *gsum, void *workspace, int dtype, void *stream)
 {
     if (rows == 0 || row_len == 0) return ANTQ_OK;
-    if (!x || !out || !gout || !gsum) return ANTQ_ERR_ARG;
+    if (!x || !out || !gout || !gsum || (!per_row && !workspace)) return ANTQ_ERR_ARG;
+    double *ws = static_cast<double *>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (dtype) {
-    case ANTQ_F32: return launch_alpha_grad<float>(x, out, gout, gsum, rows, row_len, per_row ? 1 : 0, st);
-    case ANTQ_BF16: return launch_alpha_grad<bf16_tag>(x, out, gout, gsum, rows, row_len, per_row ? 1 : 0, st);
-    case ANTQ_F16: return launch_alpha_grad<f16_tag>(x, out, gout, gsum, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_F32: return launch_alpha_grad<float>(x, out, gout, gsum, ws, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_BF16: return launch_alpha_grad<bf16_tag>(x, out, gout, gsum, ws, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_F16: return launch_alpha_grad<f16_tag>(x, out, gout, gsum, ws, rows, row_len, per_row ? 1 : 0, st);
     default: return ANTQ_ERR_UNSUPPORTED;
     }
 }

@@ -163,10 +163,12 @@ int antq_absmax(const void *x_dev, float *amax_dev, size_t rows, size_t row_len,
  * AQ:535-551 gives d out / d alpha = (q - d) / max(grid) = (out - x) / alpha and d out / d x = 1):
  *     gsum[r] = sum_c fl32( gout[r,c] * fl32(out[r,c] - x[r,c]) )     fp32 terms, fp64 accumulation
  * The caller divides by alpha[r].  x / out / gout: [rows, row_len] of `dtype` (F32 / BF16 / F16); gsum_dev: `rows`
- * doubles (alpha_per_row) or 1, zeroed by the caller in the per-tensor case (workgroup partials are added atomically).
+ * doubles (alpha_per_row) or 1, not initialised.  The per-tensor sum is formed from workgroup partials in
+ * workspace_dev (antq_search_workspace_bytes() bytes of scratch, as for antq_search_sse; may be NULL per row) in a
+ * fixed order: no floating-point atomics, the same bits on every run.
  * ------------------------------------------------------------------------- */
 int antq_alpha_grad(const void *x_dev, const void *out_dev, const void *gout_dev, size_t rows, size_t row_len,
-                    int alpha_per_row, double *gsum_dev, int dtype, void *stream);
+                    int alpha_per_row, double *gsum_dev, void *workspace_dev, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------
  * mse_loss of a fake-quantised tensor against its source without materialising

@@ -1998,6 +1998,15 @@ def test_calibration_sums_are_bit_reproducible(antq_lib, dev):
                 # the multi kernel forms the very same sums as one search per type
                 for t, p in enumerate(plans):
                     assert torch.equal(ref[t], antq_lib.search_sse(x, rows, row_len, xmax, per_row, ratios, p, 10.0)), (t, per_row)
+        # the alpha gradient's whole-tensor sum goes through the same fixed-order reduction
+        x = torch.randn(777, 4096, device=dev)
+        o = x + torch.randn_like(x) * 0.01
+        go = torch.randn_like(x)
+        ref = antq_lib.alpha_grad(x, o, go, 777, 4096, per_row=False)
+        want = (go.double() * (o - x).double()).sum()
+        assert torch.isfinite(ref).all() and abs(float(ref) - float(want)) <= 1e-6 * abs(float(want)) + 1e-9
+        for _ in range(9):
+            assert torch.equal(antq_lib.alpha_grad(x, o, go, 777, 4096, per_row=False), ref)
         # candidate lists longer than one workgroup's accumulators (128): split over blockIdx.y in every kernel
         r150 = core._ratios(1, 151, 1, dev)
         assert r150.numel() == 150
