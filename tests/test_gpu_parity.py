@@ -2106,3 +2106,31 @@ def test_nearest_256_entry_grid_above_its_top_value(antq_lib, oracle, dev):
             z, j = antq_lib.nearest(to_dev(x.astype(dt), dev), to_dev(g.astype(dt), dev), want_idx=True)
             assert f32_same(z.cpu().numpy().astype(np.float32), zr), (trial, dt)
             assert np.array_equal(j.cpu().numpy().astype(np.int32), jr), (trial, dt)
+
+
+@pytest.mark.gpu
+def test_empty_inputs(antq_lib, dev):
+    """Zero-sized tensors are a no-op everywhere (the reference's launcher returns its freshly allocated, empty z / idx,
+    KQ/quant_kernel.cu:42-62): operator, fused entry points, dynamic variant, codec, abs-max, and a batch never sees one."""
+    import torch
+    from ant_quantization_amd import grids, quant_cuda
+    g = grids.ant_flint(4, True)
+    plan = antq_lib.plan_for(g)
+    gt = torch.from_numpy(g).to(dev)
+    for dt in (torch.float32, torch.float64, torch.bfloat16):
+        x = torch.empty(0, dtype=dt, device=dev)
+        z, idx = quant_cuda.quant(x, gt.to(dt) if dt != torch.bfloat16 else gt)
+        assert z.shape == (0,) and z.dtype == dt and idx.numel() == 0
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.empty(0, 64, dtype=dt, device=dev)
+        a = torch.empty(0, dtype=torch.float32, device=dev)
+        out, idx = antq_lib.fakequant(x, a, plan, 10.0, 0, 64, True, want_idx=True)
+        assert out.shape == (0, 64) and idx.shape == (0, 64)
+        out, alpha, _ = antq_lib.fakequant_dynamic(x, plan, 10.0, 0, 64)
+        assert out.shape == (0, 64) and alpha.numel() == 0
+        assert antq_lib.absmax(x, 0, 64).numel() == 0
+        codes = antq_lib.encode4(x, a, plan, 10.0, 0, 64, True)
+        assert codes.numel() == 0
+        assert antq_lib.decode4(codes, a, plan, 10.0, 0, 64, True, dt).numel() == 0
+    with pytest.raises(antq_lib.AntqError):
+        antq_lib.Batch([(torch.empty(0, 64, device=dev), torch.empty(0, 64, device=dev), torch.empty(0, device=dev), plan, 10.0, 0, 64, True)])
