@@ -175,9 +175,21 @@ def cpu_baseline(seconds_budget=12.0):
     used = orc.forward_omp(x, out, alpha, g, 10.0, reps=reps, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": round(rows * COLS * reps / dt / 1e9, 5), "unit": "Gelem/s", "cores": used, "kind": "port",
-            "single_thread_gelem_per_s": round(one_thread / 1e9, 6),
+            "single_thread_gelem_per_s": round(one_thread / 1e9, 6), "cpu_model": _cpu_model(),
+            "nproc": os.cpu_count(), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
             "sample": "%d rows x %d cols bf16 (64 rows per thread), flint 4-bit per-row alpha, %d sweeps, %d OpenMP "
                       "threads (static row split), %.1f s wall" % (rows, COLS, reps, used, dt)}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def cpu_baseline_torch(seconds_budget=6.0):
