@@ -11,7 +11,8 @@ namespace antq {
 // Why.  The d-domain core (quant_vec) spends most of its VALU time on per-element work whose only purpose is to be
 // exact: the 5-FMA division d = fl(x / s), the straight-through add / subtract and the multiply back.  For rows of
 // >= 128 vectors the x-domain kernels hoist all of that into a per-row table; for 16-element groups (2 bf16 lanes per
-// scale) there is nothing to hoist it into, and the kernel is VALU-bound (~21 ops per bf16 element, 61 % of HBM).
+// scale) there is nothing to hoist it into, and the kernel is VALU-bound (~21 ops per bf16 element, 61-65 % of HBM; with the
+// path below: 78-80 %).
 //
 // What.  Plans with `adom` (every ANT / OliVe codebook) let the decision be made on x itself, per element, exactly:
 //     fl(x / s) >= T   <=>   x / s > M,  or  x / s == M and T has an even mantissa  (M = the rounding boundary below T:
@@ -28,7 +29,7 @@ namespace antq {
 //     q   = fma64(-M', s, x) >= 0 ? v_hi : v_lo
 //     out = fl(q * s)                 == ((q - d) + d) * s: the straight-through step is exact in every region of an
 //                                     `adom` plan (Sterbenz); -0.0 codebook entries are stored as +0.0, as (q - d) + d gives
-// ~13 VALU ops per element (3 of them f64, full rate on CDNA4) and no data-dependent branch.  Elements clipped beyond
+// ~11 VALU ops per element (3 of them f64, full rate on CDNA4) and no data-dependent branch.  Elements clipped beyond
 // twice the outermost value (|dt| >= xlim) keep the table's q and redo only the arithmetic with the true quotient;
 // NaN / Inf / |d| beyond the table's domain and groups whose scale is not in [2^-40, 2^40] take the literal reference
 // sequence (true division, scan, straight-through arithmetic) -- per lane, rarely.
