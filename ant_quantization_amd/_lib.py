@@ -286,13 +286,19 @@ def fakequant_dynamic(x, plan, gmax, rows, row_len, ratio=1.0, ovp=False, want_i
     if out is None:
         out = torch.empty_like(x)
     idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
-    # the two-pass fallback for very long rows needs the alpha buffer as scratch: always provide it
-    alpha = torch.empty(rows, dtype=torch.float32, device=x.device)
     pd = plan.dev(x.device)
+    alpha, rc = None, -1
     with _on_device(x.device):
-        rc = lib().antq_fakequant_dynamic(x.data_ptr(), out.data_ptr(), _ptr(idx), alpha.data_ptr(), rows, row_len,
-                                          ratio, gmax, plan.host_addr, pd.data_ptr(), FLAG_OVP if ovp else 0, dt,
-                                          _stream_int(x.device))
+        if not want_alpha:
+            # nobody wants the scales: the single-read kernels then skip the store; only the two-pass fallback for very long
+            # or ragged rows needs the buffer as scratch and says so (ANTQ_ERR_ARG)
+            rc = lib().antq_fakequant_dynamic(x.data_ptr(), out.data_ptr(), _ptr(idx), None, rows, row_len, ratio, gmax,
+                                              plan.host_addr, pd.data_ptr(), FLAG_OVP if ovp else 0, dt, _stream_int(x.device))
+        if rc == -1:
+            alpha = torch.empty(rows, dtype=torch.float32, device=x.device)
+            rc = lib().antq_fakequant_dynamic(x.data_ptr(), out.data_ptr(), _ptr(idx), alpha.data_ptr(), rows, row_len,
+                                              ratio, gmax, plan.host_addr, pd.data_ptr(), FLAG_OVP if ovp else 0, dt,
+                                              _stream_int(x.device))
     if rc:
         _check(rc, "antq_fakequant_dynamic")
     return out, (alpha if want_alpha else None), idx
@@ -470,8 +476,9 @@ class Batch:
     forwards."""
 
     def __init__(self, jobs, ovp=False, dynamic=False):
-        """dynamic=True: every job's alpha tensor is an OUTPUT (row abs-max computed in the kernel); rows must be
-        2 KiB..32 KiB long, per_row, and the grid's plan x-domain eligible -- otherwise AntqError."""
+        """dynamic=True: every job's alpha tensor is an OUTPUT (group / row abs-max computed in the kernel), or None when the
+        caller has no use for the scales (the kernel then skips the store); per_row, groups of a power of two of 16-byte
+        vectors or rows of 128 .. 8192 vectors -- otherwise AntqError."""
         jobs = [tuple(j) for j in jobs]
         if not jobs:
             raise AntqError("empty batch")
@@ -491,7 +498,8 @@ class Batch:
         if batched:
             arr = (_Job * len(batched))()
             for k, (x, out, alpha, plan, gmax, rows, row_len, per_row) in enumerate(batched):
-                arr[k] = _Job(x.data_ptr(), out.data_ptr(), alpha.data_ptr(), rows, row_len, 1 if per_row else 0, gmax,
+                arr[k] = _Job(x.data_ptr(), out.data_ptr(), alpha.data_ptr() if alpha is not None else 0, rows, row_len,
+                              1 if per_row else 0, gmax,
                               plan.host_addr, plan.dev(self.device).data_ptr())
             cap = lib().antq_batch_capacity(arr, len(batched), self.dtype)
             host = np.zeros(cap, dtype=np.uint8)

@@ -827,7 +827,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     bool any_da = false;
     for (int i = 0; i < n; i++) {
         const antq_job &J = jobs[i];
-        if (!J.x_dev || !J.out_dev || !J.alpha_dev || !J.plan_host || !J.plan_dev) return ANTQ_ERR_ARG;
+        if (!J.x_dev || !J.out_dev || (!J.alpha_dev && !dyn) || !J.plan_host || !J.plan_dev) return ANTQ_ERR_ARG;
         const uintptr_t esz = (dtype == ANTQ_F32) ? 4 : 2;
         if (reinterpret_cast<uintptr_t>(J.x_dev) % esz || reinterpret_cast<uintptr_t>(J.out_dev) % esz) return ANTQ_ERR_ALIGN;
         BatchDesc d;

@@ -234,10 +234,11 @@ int antq_affine(const float *x_dev, float *out_dev, int32_t *q_dev,
  *   antq_batch_build : pure host code; writes the descriptor blob (returns its size in bytes).  All jobs share dtype
  *                      and flags.  Jobs whose rows are not a multiple of 16 bytes (conv1: K = 147) or whose
  *                      buffers are not 16-byte aligned run element-granular inside the same launch.
- *                      With ANTQ_FLAG_DYNAMIC every job's alpha_dev is an OUTPUT: alpha[r] = max_c |x[r,c]| is computed
- *                      in the kernel from the registers holding the row (antq_fakequant_dynamic with ratio 1, many
- *                      tensors, one launch); rows must be per-row, 2 KiB..32 KiB long and the plan x-domain
- *                      eligible (every ANT / OliVe 4-bit codebook), otherwise ANTQ_ERR_UNSUPPORTED.
+ *                      With ANTQ_FLAG_DYNAMIC every job's alpha_dev is an OUTPUT (NULL: the scales are not stored):
+ *                      alpha[r] = max_c |x[r,c]| is computed in the kernel from the registers holding the group / row
+ *                      (antq_fakequant_dynamic with ratio 1, many tensors, one launch); per row only, groups of a
+ *                      power of two of 16-byte vectors up to 64, or rows of 128 .. 8192 vectors (beyond 512 the plan
+ *                      must be x-domain eligible: every ANT / OliVe 4-bit codebook), otherwise ANTQ_ERR_UNSUPPORTED.
  *   antq_fakequant_batch : one launch for all jobs; batch_dev is the caller's device copy.
  * ------------------------------------------------------------------------- */
 typedef struct antq_job {

@@ -1533,6 +1533,13 @@ def test_dynamic_batched_launch_equals_per_tensor_dynamic(antq_lib, dev, dtype_n
         bt.run()
         for (ro, ra, _), o, a, s in zip(refs, outs, alphas, shapes):
             assert torch.equal(a, ra) and torch.equal(o, ro), (s, ovp)
+        # nobody wants the scales: no alpha buffers (the kernels skip the store), same values; per tensor and batched
+        outs2 = [torch.zeros_like(x) for x in xs]
+        antq_lib.Batch([(x, o, None, p, gmax, x.shape[0], x.shape[1], True) for x, o in zip(xs, outs2)], ovp=ovp, dynamic=True).run()
+        for (ro, _, _), o, x, s in zip(refs, outs2, xs, shapes):
+            assert torch.equal(o, ro), (s, ovp)
+            o3, a3, _ = antq_lib.fakequant_dynamic(x, p, gmax, x.shape[0], x.shape[1], ovp=ovp, want_alpha=False)
+            assert a3 is None and torch.equal(o3, ro), (s, ovp)
     for bad in [(8, 72 * epl), (8, 8193 * epl)]:      # a small group that is no power of two / too long for the registers
         x = torch.randn(*bad, device=dev).to(dtype)
         with pytest.raises(antq_lib.AntqError):

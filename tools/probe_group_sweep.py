@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Group-size sweep: 16 x [4096,4096] tensors viewed as groups of G elements (one alpha per group), ANT flint-4.
-Static alpha through the batched launch and one launch per tensor, and the dynamic (abs-max in the kernel) variant.
+Static alpha through the batched launch and one launch per tensor, and the dynamic (abs-max in the kernel) variant -- batched
+with the scales stored and without (alpha_dev = NULL), per tensor without (want_alpha=False).
 Fractions count x / out bytes only; the alpha stream adds 4 / (G * element size) on top (6 % for bf16 group-16)."""
 import os
 import sys
@@ -32,6 +33,8 @@ def main():
                 bd = _lib.Batch([(x, o, torch.empty_like(a), plan, 10.0, n // G, G, True) for x, a, o in zip(xs, al, outs)],
                                 dynamic=True)
                 tdb = "%5.1f%%" % (16 * n * bpe / timed(bd.run, 20) / 8e10)
+                bdn = _lib.Batch([(x, o, None, plan, 10.0, n // G, G, True) for x, o in zip(xs, outs)], dynamic=True)
+                tdb += " (scales not stored: %5.1f%%)" % (16 * n * bpe / timed(bdn.run, 20) / 8e10)
             except _lib.AntqError:
                 tdb = "   n/a"
             alt = []
