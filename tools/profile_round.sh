@@ -45,4 +45,5 @@ $PY tools/probe_codec.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_codec.log"
 ( $PY tools/bench_sharded.py --model opt6.7b; $PY tools/bench_sharded.py --model llama70b --inplace ) 2>&1 | grep "^{" > "$OUT/${TAG}_sharded.log"
 [ -x tools/launch_anatomy ] && ./tools/launch_anatomy 2>&1 | cut -c1-70 > "$OUT/${TAG}_launch_anatomy.log"
 [ -x tools/valu_rates ] && ./tools/valu_rates > "$OUT/${TAG}_valu_rates.log" 2>&1
+[ -x tools/ubench ] && ( cd tools && ./ubench 2>&1 | head -38; $PY probe_lane_rows.py 2>&1 | grep -v "amdgpu\|OliVe" | head -5 ) > "$OUT/${TAG}_ubench_copy_variants.log"
 ls -la "$OUT"
