@@ -217,9 +217,10 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
         // index = a shift) instead of a table per row -- since the instruction diet of the element path it is ahead at
         // every tensor size: 33.5 MB bf16 59.3 -> 62.9 %, fp32 69.4 -> 74.1 %; 134 MB 74.0 -> 77.1 / 79.7 -> 81.9 %
         // (tools/probe_lane_rows.py; knob 5 = 0 restores the row kernel).  Other row lengths pay ~8 instructions per vector for
-        // the row index (f64 reciprocal + fix-up): fp32 still gains 1-3.5 points (4608 / 11008 / 28672 wide: 70.7 -> 71.8,
-        // 68.6 -> 72.1, 69.0 -> 71.9 %), bf16 does not (tools/probe_lane_rows_np2.py; knob 5 = 2 forces the lane kernel)
-        const bool lane_rows = pa.adom && ((vpr & (vpr - 1)) == 0 || EPL == 4 || g_knob_lane_rows == 2) && g_knob_lane_rows != 0;
+        // the row index (f64 reciprocal + fix-up) and still gain: fp32 1-3.5 points (4608 / 11008 / 28672 wide: 70.7 -> 71.8,
+        // 68.6 -> 72.1, 69.0 -> 71.9 %), bf16 0-3.5 on three boxes (57.3 -> 60.0, 58.2 -> 59.9, 58.9 -> 60.4 % on the last;
+        // 768-wide rows: equal) -- tools/probe_lane_rows_np2.py
+        const bool lane_rows = pa.adom && g_knob_lane_rows != 0;
         if (vpr >= kRowKernelMinVpr && !lane_rows) {
             if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
             return launch_uniform<T, OVP, IDX, false>(x, out, idx, rows, vpr, alpha, per_row, gmax, 1.0f, nullptr, pa,

@@ -292,8 +292,8 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
  *   key 1: number of persistent workgroups of antq_encode4 (0 = default, 2048)
  *   key 2: 0 disables the per-row (x-domain) table kernels, the d-domain kernels run instead (A/B measurements)
  *   key 3: 0 disables the binary-search path of antq_nearest (literal scan only)
- *   key 5: 0 sends long rows through the per-row table kernels, 2 through the lane kernel whatever their length (1 = the
- *          measured default: lane kernel for rows of a power of two of vectors and for fp32) */
+ *   key 5: 0 sends long rows through the per-row table kernels, 2 through the lane kernel in batches too (1 = the measured
+ *          default: lane kernel for one-launch-per-tensor calls and fp32 batches) */
 int antq_debug_set(int key, int value);
 
 #ifdef __cplusplus
