@@ -499,3 +499,14 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
     for bad in ([(8, 576, True, flint)], [(8, 65544, True, flint)], [(8, 147, True, flint)], [(64, 64, False, flint)]):
         n, _ = build(bad, dtype=1, flags=2)
         assert n == -2, bad                              # ANTQ_ERR_UNSUPPORTED
+    # 16-bit dynamic rows of 128 vectors: lane jobs whose groups span 2 wavefronts (4 vectors per lane, never 2)
+    n, b = build([(4096, 1024, True, flint)], dtype=1, flags=2)
+    assert b["descs"][0]["kind"] == 1 and b["descs"][0]["vpr"] == 128 and b["descs"][0]["u"] == 4 and b["descs"][0]["family"] == 1
+    # alpha_dev: required for a static job, optional (the scales are simply not stored) for a dynamic one
+    arr = (antq_lib._Job * 1)()
+    for flags, want in ((0, -1), (2, None)):
+        arr[0] = antq_lib._Job(0x10000000, 0x50000000, 0, 4096, 128, 1, 10.0, flint.host_addr, 0x40000000)
+        cap = L.antq_batch_capacity(arr, 1, 1)
+        host = np.zeros(cap, dtype=np.uint8)
+        rc = L.antq_batch_build(arr, 1, 1, flags, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
+        assert (rc == want) if want is not None else rc > 0, (flags, rc)
