@@ -215,7 +215,14 @@ k_alpha_grad(const void *__restrict__ x, const void *__restrict__ out, const voi
                 const uint4 *px = static_cast<const uint4 *>(x) + r * vpr;
                 const uint4 *po = static_cast<const uint4 *>(out) + r * vpr;
                 const uint4 *pg = static_cast<const uint4 *>(gout) + r * vpr;
-                for (size_t i = lane; i < vpr; i += 64) acc += (double)vec_term(px[i], po[i], pg[i]);
+                size_t i = lane;
+                for (; i + 64 < vpr; i += 128) {           // six 16-byte streaming loads in flight per lane
+                    const uint4 x0 = ld_stream(px + i), o0 = ld_stream(po + i), g0 = ld_stream(pg + i);
+                    const uint4 x1 = ld_stream(px + i + 64), o1 = ld_stream(po + i + 64), g1 = ld_stream(pg + i + 64);
+                    acc += (double)vec_term(x0, o0, g0);
+                    acc += (double)vec_term(x1, o1, g1);
+                }
+                for (; i < vpr; i += 64) acc += (double)vec_term(ld_stream(px + i), ld_stream(po + i), ld_stream(pg + i));
             } else {
                 for (size_t i = lane; i < row_len; i += 64) acc += (double)one_term(r * row_len + i);
             }
@@ -233,12 +240,12 @@ k_alpha_grad(const void *__restrict__ x, const void *__restrict__ out, const voi
             const uint4 *pg = static_cast<const uint4 *>(gout);
             size_t i = tid;
             for (; i + stride < nv; i += 2 * stride) {
-                const uint4 x0 = px[i], o0 = po[i], g0 = pg[i];
-                const uint4 x1 = px[i + stride], o1 = po[i + stride], g1 = pg[i + stride];
+                const uint4 x0 = ld_stream(px + i), o0 = ld_stream(po + i), g0 = ld_stream(pg + i);
+                const uint4 x1 = ld_stream(px + i + stride), o1 = ld_stream(po + i + stride), g1 = ld_stream(pg + i + stride);
                 acc += (double)vec_term(x0, o0, g0);
                 acc += (double)vec_term(x1, o1, g1);
             }
-            for (; i < nv; i += stride) acc += (double)vec_term(px[i], po[i], pg[i]);
+            for (; i < nv; i += stride) acc += (double)vec_term(ld_stream(px + i), ld_stream(po + i), ld_stream(pg + i));
             for (size_t k = nv * EPL + tid; k < n; k += stride) acc += (double)one_term(k);
         } else {
             for (size_t k = tid; k < n; k += stride) acc += (double)one_term(k);

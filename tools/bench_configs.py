@@ -175,6 +175,18 @@ def main():
     ox = torch.empty_like(x)
     report("C2 activation [64,128,3072] fp32, per-tensor flint4", x.numel(), 8,
            timed(lambda: _lib.fakequant(x, ax, pu, 10.0, 1, x.numel(), False, out=ox), 20), 1)
+    # QAT backward w.r.t. alpha (N3): sum gout * (out - x) per row / per tensor -- three reads per element, no write
+    for dt, esz in ((torch.float32, 4), (torch.bfloat16, 2)):
+        xg = [(torch.randn(4096, 4096, device=dev) * 0.02).to(dt) for _ in range(8)]
+        og = [t + (torch.randn_like(t.float()) * 0.001).to(dt) for t in xg]
+        gg = [torch.randn(4096, 4096, device=dev).to(dt) for _ in range(8)]
+        for per_row in (True, False):
+            secs = timed(lambda: [_lib.alpha_grad(a, b, c, 4096, 4096, per_row=per_row) for a, b, c in zip(xg, og, gg)], 5)
+            byt = 8 * 4096 * 4096 * 3 * esz
+            print("%-58s %9.1f Gelem/s  %6.3f TB/s (%4.1f%% of 8)  %8.1f us/pass   %2d launches" % (
+                "alpha gradient %s, %s, 8 x 4096^2" % (str(dt)[6:], "per row" if per_row else "per tensor"),
+                8 * 4096 * 4096 / secs / 1e9, byt / secs / 1e12, byt / secs / 8e10, secs * 1e6, 8 if per_row else 16), flush=True)
+        del xg, og, gg
     del ws, outs, x, ox
 
     # ---------------- C3: OPT-6.7B weights (4 of 32 layers resident), OliVe flint4 + outliers, OVP
