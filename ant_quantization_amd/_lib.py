@@ -309,11 +309,11 @@ def absmax(x, rows, row_len, per_row=True):
     dt = _DTYPES.get(x.dtype)
     if dt is None or dt == F64:
         raise AntqError("unsupported dtype %s" % x.dtype)
-    amax = torch.zeros(rows if per_row else 1, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        _check(lib().antq_absmax(_vp(x), _vp(amax), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
-                                 ctypes.c_int(1 if per_row else 0), ctypes.c_int(dt), _stream(x.device)),
-               "antq_absmax")
+    amax = torch.empty(rows if per_row else 1, dtype=torch.float32, device=x.device)     # (the entry point initialises it)
+    with _on_device(x.device):
+        rc = lib().antq_absmax(x.data_ptr(), amax.data_ptr(), rows, row_len, 1 if per_row else 0, dt, _stream_int(x.device))
+    if rc:
+        _check(rc, "antq_absmax")
     return amax
 
 

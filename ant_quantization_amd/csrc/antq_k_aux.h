@@ -122,6 +122,8 @@ __global__ void __launch_bounds__(256) k_scale_inplace(float *__restrict__ a, si
 // float's bit pattern (non-negative floats order like unsigned ints; NaN sorts above Inf,
 // so a NaN anywhere yields NaN like torch.max).
 // ------------------------------------------------------------------------------------
+__global__ void k_zero_f32(float *p) { if (threadIdx.x == 0) *p = 0.0f; }      // (cheaper than hipMemsetAsync of 4 bytes)
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size_t row_len, int per_row, int vec_ok)
@@ -135,8 +137,14 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
             uint32_t m = 0;
             if (vec_ok) {
                 const uint4 *p = static_cast<const uint4 *>(x) + r * (row_len / EPL);
+                const size_t vpr = row_len / EPL;
                 uint32_t mp = 0;
-                for (size_t i = lane; i < row_len / EPL; i += 64) mp = IO<T>::amax_acc(mp, p[i]);
+                size_t i = lane;
+                for (; i + 192 < vpr; i += 256) {          // four 16-byte loads in flight per lane
+                    const uint4 a0 = p[i], a1 = p[i + 64], a2 = p[i + 128], a3 = p[i + 192];
+                    mp = IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(mp, a0), a1), a2), a3);
+                }
+                for (; i < vpr; i += 64) mp = IO<T>::amax_acc(mp, p[i]);
                 m = IO<T>::amax_bits(mp);
             } else {
                 for (size_t i = lane; i < row_len; i += 64) m = max(m, f2u(IO<T>::load1(x, r * row_len + i)) & 0x7fffffffu);
@@ -145,7 +153,7 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
             if (lane == 0) amax[r] = u2f(m);
         }
     } else {
-        // one scale for the whole tensor: block-strided, four independent 16-byte loads in flight per lane, one
+        // one scale for the whole tensor: block-strided, eight independent 16-byte loads in flight per lane, one
         // atomicMax per workgroup (plain loads: the clip search reads the same bytes next, out of the Infinity Cache)
         const size_t n = rows * row_len;
         const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, stride = (size_t)gridDim.x * 256u;
@@ -155,6 +163,12 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
             const size_t nv = n / EPL;
             uint32_t mp = 0;
             size_t i = tid;
+            for (; i + 7 * stride < nv; i += 8 * stride) {         // eight 16-byte loads in flight per lane
+                const uint4 a0 = p[i], a1 = p[i + stride], a2 = p[i + 2 * stride], a3 = p[i + 3 * stride];
+                const uint4 a4 = p[i + 4 * stride], a5 = p[i + 5 * stride], a6 = p[i + 6 * stride], a7 = p[i + 7 * stride];
+                mp = IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(mp, a0), a1), a2), a3);
+                mp = IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(mp, a4), a5), a6), a7);
+            }
             for (; i + 3 * stride < nv; i += 4 * stride) {
                 const uint4 a0 = p[i], a1 = p[i + stride], a2 = p[i + 2 * stride], a3 = p[i + 3 * stride];
                 mp = IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(mp, a0), a1), a2), a3);
@@ -173,6 +187,32 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
             m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
             if (m) atomicMax(reinterpret_cast<unsigned int *>(amax), m);
         }
+    }
+}
+
+// Small groups (a power of two <= 64 of 16-byte vectors per group, e.g. group-16): several groups per wavefront, four
+// vectors per lane, butterfly max over the group's lanes (DPP) -- a wavefront per 2-vector group would idle 62 lanes.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_absmax_groups(const uint4 *__restrict__ x, float *__restrict__ amax, size_t n_vec, uint32_t vpr, int vshift)
+{
+    constexpr int U = 4;
+    const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t vi = first + (size_t)u * 256u;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (vi < n_vec) v[u] = x[vi];
+    }
+    uint32_t m[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) m[u] = IO<T>::amax_bits(IO<T>::amax_acc(0u, v[u]));
+    group_max_multi<U>(m, vpr);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t vi = first + (size_t)u * 256u;
+        if (vi < n_vec && (vi & (vpr - 1)) == 0) amax[vi >> vshift] = u2f(m[u]);
     }
 }
 

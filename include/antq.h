@@ -152,8 +152,9 @@ int antq_fakequant_dynamic(const void *x_dev, void *out_dev, int16_t *idx_dev,
 
 /* ---------------------------------------------------------------------------
  * Row abs-max (AQ:289,474 / per-tensor AQ:308,477):  amax[r] = max_c |x[r,c]|.
- * per_row == 0: one value for the whole tensor; amax_dev must then be zeroed by
- * the caller beforehand (the kernel combines workgroup partials with atomicMax).
+ * per_row == 0: one value for the whole tensor (workgroup maxima combined with an
+ * integer atomicMax on the float's bits: order-independent, so bit-reproducible).
+ * amax_dev need not be initialised in either mode.
  * ------------------------------------------------------------------------- */
 int antq_absmax(const void *x_dev, float *amax_dev, size_t rows, size_t row_len,
                 int per_row, int dtype, void *stream);

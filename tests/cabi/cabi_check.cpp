@@ -161,7 +161,7 @@ int main()
     antq_oracle_forward_f32(xf.data(), ref.data(), ridx.data(), rows, K, adyn.data(), 1, flint.data(), (int)flint.size(), 10.0f, 0);
     same_bits("antq_fakequant_dynamic alpha", damax.down(st), adyn);
     same_bits("antq_fakequant_dynamic values", dout.down(st), ref);
-    HIP_OK(hipMemsetAsync(damax.p, 0, 4, st));
+    HIP_OK(hipMemsetAsync(damax.p, 0xff, 4, st));                            // poisoned: the entry point initialises it
     ANTQ_OK_(antq_absmax(dxf.p, damax.p, rows, K, 0, ANTQ_F32, st));
     std::vector<float> amax_t(1);
     antq_oracle_absmax_f32(xf.data(), amax_t.data(), rows, K, 0, 1.0f);
