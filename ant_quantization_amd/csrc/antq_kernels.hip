@@ -356,20 +356,23 @@ static int launch_nearest_plan(const void *x, void *z, int16_t *idx, size_t n, c
         (idx && reinterpret_cast<uintptr_t>(idx) % 16))
         return ANTQ_ERR_UNSUPPORTED;                     // ragged / unaligned: use antq_nearest (the literal scan)
     const size_t n_vec = n / epl;
-    const size_t blocks = (n_vec + 1023) / 1024;
-    if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = (size_t)pa.tab_units * 16;
+    const bool u2 = !gcheck && lds <= 2048;
+    const size_t per_wg = u2 ? 512 : 1024;
+    const size_t blocks = (n_vec + per_wg - 1) / per_wg;
+    if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
     const uint4 *xv = static_cast<const uint4 *>(x);
     uint4 *zv = static_cast<uint4 *>(z);
     const uint4 *tab = plan_tab_ptr(plan_dev);
-#define ANTQ_LAUNCH_N2(TT, II, HH)                                                                                 \
-    hipLaunchKernelGGL((k_nearest_plan<TT, II, HH>), dim3((unsigned)blocks), dim3(256), lds, st, xv, zv, idx, n_vec, pa, \
+#define ANTQ_LAUNCH_N2(TT, II, HH, UU)                                                                             \
+    hipLaunchKernelGGL((k_nearest_plan<TT, II, HH, UU>), dim3((unsigned)blocks), dim3(256), lds, st, xv, zv, idx, n_vec, pa, \
                        tab, gcheck, stale)
 #define ANTQ_LAUNCH_N(TT)                                                                                          \
     do {                                                                                                           \
-        if (gcheck) { if (idx) ANTQ_LAUNCH_N2(TT, true, true); else ANTQ_LAUNCH_N2(TT, false, true); }             \
-        else { if (idx) ANTQ_LAUNCH_N2(TT, true, false); else ANTQ_LAUNCH_N2(TT, false, false); }                  \
+        if (gcheck) { if (idx) ANTQ_LAUNCH_N2(TT, true, true, 4); else ANTQ_LAUNCH_N2(TT, false, true, 4); }       \
+        else if (u2) { if (idx) ANTQ_LAUNCH_N2(TT, true, false, 2); else ANTQ_LAUNCH_N2(TT, false, false, 2); }    \
+        else { if (idx) ANTQ_LAUNCH_N2(TT, true, false, 4); else ANTQ_LAUNCH_N2(TT, false, false, 4); }            \
     } while (0)
     switch (dtype) {
     case ANTQ_F32: ANTQ_LAUNCH_N(float); break;
