@@ -37,11 +37,15 @@ k_affine(const float *__restrict__ x, float *__restrict__ out, int32_t *__restri
 // Vector variant (16-byte aligned, row_len % 4 == 0): 4 floats per lane per access, 4 accesses in flight, the row's
 // scale / zero point computed once per vector, and the final (q + zp) / scale as the exact 5-FMA division when the
 // operands are inside its domain (true division otherwise).  Same arithmetic, same order, same bits as k_affine.
+#ifndef ANTQ_AFFINE_U
+#define ANTQ_AFFINE_U 2
+#endif
+constexpr int kAffineU = ANTQ_AFFINE_U;   // vectors per lane (2 measured best for one-launch-per-tensor kernels)
 __global__ void __launch_bounds__(256)
 k_affine_vec(const uint4 *__restrict__ x, uint4 *__restrict__ out, int4 *__restrict__ qout, size_t n_vec, size_t vpr, int k,
              const float *__restrict__ xmin, const float *__restrict__ xmax, int per_row)
 {
-    constexpr int U = 4;
+    constexpr int U = kAffineU;
     const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
     const float nlev = (float)((1 << k) - 1);
     const float half = (float)(1 << (k - 1));

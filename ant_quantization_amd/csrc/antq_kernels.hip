@@ -433,7 +433,7 @@ extern "C" int antq_affine(const float *x, float *out, int32_t *q, size_t rows, 
                      reinterpret_cast<uintptr_t>(out) % 16 == 0 && (!q || reinterpret_cast<uintptr_t>(q) % 16 == 0);
     if (vec) {
         const size_t n_vec = n / 4, vpr = (per_row ? row_len : n) / 4;
-        const size_t blocks = (n_vec + 1023) / 1024;
+        const size_t blocks = (n_vec + 256 * kAffineU - 1) / (256 * kAffineU);
         if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k_affine_vec, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint4 *>(x),
                            reinterpret_cast<uint4 *>(out), reinterpret_cast<int4 *>(q), n_vec, vpr, k, xmin, xmax,
