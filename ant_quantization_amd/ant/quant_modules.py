@@ -184,16 +184,23 @@ class Quantizer(HostMirrorMixin, nn.Module):
         else:
             return (quant_tensor - source_tensor).abs().pow(p).mean()
 
-    def search_mse(self, tensor):
-        """AQ:287-326: clip search over i in [lb, ub), alpha_i = x_max * (i*0.01)."""
-        per_channel = self.is_perchannel and (not self.is_input)
-        x_max = core.row_absmax(tensor, per_channel)
+    def _search_window(self, per_channel):
+        """[lb, ub) of the clip search in percent of x_max (AQ:293-296 / :311-314): the configured window, its lower end
+        raised to 95 for layers of more than 6 bits.  One helper for search_mse and the fused type selection."""
         lb = int(self.w_low) if per_channel else int(self.a_low)
         ub = int(self.w_up) if per_channel else int(self.a_up)
         if self._bits() > 6:
             lb = int(95)
+        return lb, ub
+
+    def search_mse(self, tensor):
+        """AQ:287-326: clip search over i in [lb, ub), alpha_i = x_max * (i*0.01)."""
+        per_channel = self.is_perchannel and (not self.is_input)
+        x_max = core.row_absmax(tensor, per_channel)
+        lb, ub = self._search_window(per_channel)
         plan = self._ensure_plan()
-        hit = self._type_search.get(plan.grid.tobytes()) if self._type_search else None
+        # (keyed on the window as well: a pass over another [lb, ub) can never stand in for this search)
+        hit = self._type_search.get((plan.grid.tobytes(), lb, ub)) if self._type_search else None
         if hit is not None:
             best_score, alpha, ratios = hit       # this very search was part of the type selection's single pass
         else:
@@ -222,8 +229,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         # every candidate type's clip search on ONE read of the tensor (antq_search_sse_multi); the search on the grid
         # that is installed afterwards is one of them and is not repeated (search_mse looks it up)
         per_channel = self.is_perchannel and (not self.is_input)
-        lb = int(self.w_low) if per_channel else int(self.a_low)
-        ub = int(self.w_up) if per_channel else int(self.a_up)
+        lb, ub = self._search_window(per_channel)
         uniq = list({g.tobytes(): g for g in type_grids}.values())          # (-float1..4 all search float_value(1))
         plans = [_lib.plan_for(g) for g in uniq]
         with np.errstate(all="ignore"):
@@ -231,8 +237,8 @@ class Quantizer(HostMirrorMixin, nn.Module):
         x_max = core.row_absmax(data, per_channel)
         res = core.clip_search_types(data, x_max, per_channel, lb, ub, 1, plans, gmaxs) if len(uniq) > 1 else None
         if res is not None:
-            self._type_search = {g.tobytes(): r for g, r in zip(uniq, res)}
-            mse_list = [self._type_search[g.tobytes()][0].sum().reshape(()) for g in type_grids]
+            self._type_search = {(g.tobytes(), lb, ub): r for g, r in zip(uniq, res)}
+            mse_list = [self._type_search[(g.tobytes(), lb, ub)][0].sum().reshape(()) for g in type_grids]
         else:
             for t, g in zip(modes, type_grids):
                 self.mode = t

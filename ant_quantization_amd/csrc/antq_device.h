@@ -61,6 +61,7 @@ struct f16_tag {};
 // (v_cvt_pk_bf16_f32 / v_cvt_f16_f32), which is what `tensor.to(dtype)` does.
 template <typename T> struct IO;
 template <> struct IO<float> {
+    static constexpr int DTYPE = ANTQ_F32;
     static constexpr int EPL = 4;
     static constexpr int ESIZE = 4;
     __device__ __forceinline__ static void unpack(const uint4 &v, float (&f)[4])
@@ -81,6 +82,7 @@ template <> struct IO<float> {
     __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return m; }
 };
 template <> struct IO<bf16_tag> {
+    static constexpr int DTYPE = ANTQ_BF16;
     static constexpr int EPL = 8;
     static constexpr int ESIZE = 2;
     __device__ __forceinline__ static void unpack(const uint4 &v, float (&f)[8])
@@ -123,6 +125,7 @@ template <> struct IO<bf16_tag> {
     __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return max(m & 0xffffu, m >> 16) << 16; }
 };
 template <> struct IO<f16_tag> {
+    static constexpr int DTYPE = ANTQ_F16;
     static constexpr int EPL = 8;
     static constexpr int ESIZE = 2;
     __device__ __forceinline__ static float h2f(uint32_t bits16)

@@ -12,7 +12,7 @@ namespace antq {
 // round-half-to-even like torch.round.  Expression order follows the reference exactly:
 //   scale*x - zp  (linear_quantize :39), (q + zp) / scale  (linear_dequantize :62).
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_affine(const float *__restrict__ x, float *__restrict__ out, int32_t *__restrict__ qout,
          size_t n, size_t row_len, int k,
          const float *__restrict__ xmin, const float *__restrict__ xmax, int per_row)
@@ -41,7 +41,7 @@ k_affine(const float *__restrict__ x, float *__restrict__ out, int32_t *__restri
 #define ANTQ_AFFINE_U 2
 #endif
 constexpr int kAffineU = ANTQ_AFFINE_U;   // vectors per lane (2 measured best for one-launch-per-tensor kernels)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_affine_vec(const uint4 *__restrict__ x, uint4 *__restrict__ out, int4 *__restrict__ qout, size_t n_vec, size_t vpr, int k,
              const float *__restrict__ xmin, const float *__restrict__ xmax, int per_row)
 {
@@ -96,7 +96,7 @@ k_affine_vec(const uint4 *__restrict__ x, uint4 *__restrict__ out, int4 *__restr
 }
 
 // 16 B per lane streaming copy: the empirical HBM ceiling for this access pattern.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec)
 {
     const size_t first = ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 256u + (threadIdx.x & 63u);
@@ -113,7 +113,7 @@ k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec)
     }
 }
 
-__global__ void __launch_bounds__(256) k_scale_inplace(float *__restrict__ a, size_t n, float ratio)
+static __global__ void __launch_bounds__(256) k_scale_inplace(float *__restrict__ a, size_t n, float ratio)
 {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (i < n) a[i] = a[i] * ratio;
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_scale_inplace(float *__restrict__ a, si
 // float's bit pattern (non-negative floats order like unsigned ints; NaN sorts above Inf,
 // so a NaN anywhere yields NaN like torch.max).
 // ------------------------------------------------------------------------------------
-__global__ void k_zero_f32(float *p) { if (threadIdx.x == 0) *p = 0.0f; }      // (cheaper than hipMemsetAsync of 4 bytes)
+static __global__ void k_zero_f32(float *p) { if (threadIdx.x == 0) *p = 0.0f; }      // (cheaper than hipMemsetAsync of 4 bytes)
 
 template <typename T>
 __global__ void __launch_bounds__(256)

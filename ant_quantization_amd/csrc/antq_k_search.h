@@ -33,7 +33,7 @@ struct WaveAcc {
 };
 
 // out[f] = sum over the n_wg workgroup partials of candidate f, in a fixed order (strided per thread, then a tree)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_sum_partials(const double *__restrict__ ws, uint32_t n_wg, int chunk, double *__restrict__ out)
 {
     const int f = (int)blockIdx.x;
@@ -323,7 +323,7 @@ k_search_sse_scalar(const void *__restrict__ x, size_t rows, size_t row_len, con
 }
 
 // search_mse's selection loop, one thread per row (AQ:299-306): strict '<' keeps the earliest best.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_search_pick(const double *__restrict__ sse, const float *__restrict__ xmax, const float *__restrict__ ratios,
               int ncand, size_t na, double row_len, float *__restrict__ best_score, float *__restrict__ best_alpha)
 {

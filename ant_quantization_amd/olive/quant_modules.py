@@ -190,7 +190,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         lb = int(self.w_low) if per_channel else int(self.a_low)
         ub = int(self.w_up) if per_channel else int(self.a_up)
         plan = self._ensure_plan()
-        hit = self._type_search.get(plan.grid.tobytes()) if self._type_search else None
+        hit = self._type_search.get((plan.grid.tobytes(), lb, ub)) if self._type_search else None
         if hit is not None:
             best_score, alpha, ratios = hit       # this very search was part of the type selection's single pass
         else:
@@ -220,7 +220,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
                                      ovp=not self._no_outlier)
         mse_list = []
         if res is not None:
-            self._type_search = {f.tobytes(): r for f, r in zip(fulls, res)}
+            self._type_search = {(f.tobytes(), lb, ub): r for f, r in zip(fulls, res)}
             mse_list = [r[0].sum().reshape(()) for r in res]
         else:
             for t, n in zip(modes, normals):

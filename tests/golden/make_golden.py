@@ -30,6 +30,37 @@ sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 
 
+def scan_numpy(x, grid):
+    """A SECOND stand-in for quant_cuda.quant, written independently of oracle/antq_oracle.c and in a different form:
+    not the step loop of quant_kernel.cu:29-35 but what that loop computes -- with d_i = fl32|fl32(x) - fl32(y_i)|
+    (:23 narrows the grid into `float y_shared[]`, :28 narrows x, :30 subtracts in float), the running `<=` test keeps
+    the LAST index attaining the smallest d_i among those with d_i <= 102400 (:25 initial sub_min; a NaN distance
+    compares false); z is that grid entry itself, or :26's 0.0 when no entry qualifies.  Every call the reference makes
+    while the fixtures are generated is answered by the C scan AND checked against this function (`_install_shim`), so the
+    fixtures do not pin the oracle's scan with itself."""
+    x = np.asarray(x)
+    xf = x.astype(np.float32).reshape(-1)
+    y = np.asarray(grid).astype(np.float32).reshape(-1)
+    m = y.size
+    z = np.zeros(xf.shape, dtype=np.float32)
+    idx = np.full(xf.shape, -1, dtype=np.int32)
+    for lo in range(0, xf.size, 1 << 16):
+        xc = xf[lo:lo + (1 << 16)]
+        with np.errstate(all="ignore"):
+            d = np.abs(xc[:, None] - y[None, :])                  # float32 throughout
+        ok = d <= np.float32(102400.0)                              # False for NaN
+        dm = np.where(ok, d, np.float32(np.inf))
+        best = dm.min(axis=1)
+        last = (m - 1) - np.argmax((dm == best[:, None])[:, ::-1], axis=1)     # last index attaining the minimum
+        hit = ok.any(axis=1)
+        idx[lo:lo + xc.size] = np.where(hit, last, -1)
+        z[lo:lo + xc.size] = np.where(hit, y[np.where(hit, last, 0)], np.float32(0.0))
+    return z.astype(x.dtype).reshape(x.shape), idx.reshape(x.shape)
+
+
+SCAN_CHECKS = [0, 0]      # calls / elements cross-checked between the two stand-ins in this process
+
+
 def _install_shim():
     import torch
     from oracle import antq_oracle as orc
@@ -41,6 +72,12 @@ def _install_shim():
         xn = x.detach().contiguous().cpu().numpy()
         gn = grid.detach().contiguous().cpu().numpy()
         z, idx = orc.nearest(xn, gn)
+        z2, idx2 = scan_numpy(xn, gn)
+        zb, z2b = np.ascontiguousarray(z).view(np.uint8), np.ascontiguousarray(z2).view(np.uint8)
+        if not (np.array_equal(zb, z2b) and np.array_equal(idx, idx2)):
+            raise AssertionError("the two stand-ins for quant_cuda.quant disagree (C scan vs numpy restatement)")
+        SCAN_CHECKS[0] += 1
+        SCAN_CHECKS[1] += int(xn.size)
         shim.last_idx = idx
         return torch.from_numpy(z).to(x.dtype), torch.zeros_like(x)
 
@@ -658,9 +695,123 @@ def gen_long(outdir, tree):
     np.savez_compressed(os.path.join(outdir, "%s_select_long_traces.npz" % tree), **tr)
 
 
+# ----------------------------------------------------------------------------
+# Round 3: CHECKPOINTS WRITTEN BY THE REFERENCE'S OWN CODE and one MultiheadAttentionQuantizer forward (N4).
+# The reference's quant_model.py / quant_utils.py are imported unmodified (torchvision is absent from the image and is
+# only used by get_model(): an empty stand-in module satisfies the import), a small network is rewritten by ITS
+# quantize_model, calibrated by ITS first forward, and ITS state_dict() is stored the way ImageNet/main.py saves it from a
+# DistributedDataParallel model (every key prefixed "module.", main.py:151-157 strips 7 characters on load).  Every
+# TensorQuantizer's (input, output) of the recorded forward is stored beside it: the quantisers are bit-exact across
+# devices, F.conv2d / F.linear are not, so the wire test compares quantiser by quantiser and the model output with a
+# tolerance.
+# ----------------------------------------------------------------------------
+def _stub_torchvision():
+    import importlib.machinery
+    tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+    tv.__spec__ = importlib.machinery.ModuleSpec("torchvision", None)      # (transformers probes find_spec("torchvision"))
+    tvm.__spec__ = importlib.machinery.ModuleSpec("torchvision.models", None)
+    tv.models = tvm
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tvm
+
+
+def _record_model(prefix, model, x, fx, qm, call=None, sd="all"):
+    """Run model(x) with a hook on every TensorQuantizer; store state_dict (DDP-prefixed), x, y and the hooks' tensors.
+    sd: "all", "quant" (only the quantisers' entries: the weights are those of an earlier record) or None.  A weight
+    quantiser's input is the layer's weight (in the state dict), so only activation inputs are stored."""
+    import torch
+    recs, hooks = {}, []
+    for name, mod in model.named_modules():
+        if isinstance(mod, qm.TensorQuantizer):
+            def hook(m, inp, out, name=name):
+                recs[name] = (inp[0].detach().clone().numpy(), out.detach().clone().numpy())
+            hooks.append(mod.register_forward_hook(hook))
+    with torch.no_grad():
+        y = call(model, x) if call else model(x)
+    for h in hooks:
+        h.remove()
+    fx[prefix + "x"] = x.numpy()
+    fx[prefix + "y"] = y.detach().numpy()
+    for k, v in (model.state_dict().items() if sd else ()):
+        if sd == "all" or "quant_" in k:
+            fx[prefix + "sd__module." + k] = v.detach().numpy()
+    for name, (i, o) in recs.items():
+        if "quant_input" in name:
+            fx[prefix + "q__" + name + "__in"] = i
+        fx[prefix + "q__" + name + "__out"] = o
+    fx[prefix + "quantizers"] = np.array(sorted(recs.keys()))
+
+
+def gen_ckpt(outdir, tree):
+    import torch
+    import torch.nn as nn
+
+    _install_shim()
+    _stub_torchvision()
+    fx = {}
+    if tree == "ant":
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29536")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        sys.path.insert(0, os.path.join(REF, "ant_quantization", "antquant"))
+        import quant_modules as qm
+        import quant_model
+        import quant_utils
+        args = _args(mode="ant-int-pot-flint", wbit=4, abit=4)
+        quant_utils.set_quantizer(args)
+        torch.manual_seed(51)
+        net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Flatten(), nn.Linear(512, 32), nn.ReLU(),
+                            nn.Linear(32, 10))
+        x = torch.randn(4, 3, 8, 8)
+        model = quant_model.quantize_model(net)
+        quant_utils.enable_quantization(model)
+        _record_model("a__", model, x, fx, qm)            # first forward = calibration; the state dict is the calibrated one
+        x2 = torch.randn(4, 3, 8, 8)
+        _record_model("a2__", model, x2, fx, qm, sd=None)          # steady state on new data, same state dict
+        # mixed precision the reference's way: pair 1 (the 512 -> 32 Linear) to 8 bit, every quantiser re-armed,
+        # the next forward recalibrates -- that layer's quant_grid is 256 entries long in the checkpoint
+        quant_model.set_8_bit_layer_l(model, "1")
+        _record_model("b__", model, x, fx, qm, sd="quant")
+        # N4: one MultiheadAttentionQuantizer (multihead_attention.py:486-686), (seq, batch, embed) and batch_first
+        for tag, bf in (("m__", False), ("mb__", True)):
+            torch.manual_seed(52)
+            ma = nn.Sequential(nn.MultiheadAttention(64, 4, batch_first=bf)).eval()
+            qma = quant_model.quantize_model(ma).eval()
+            quant_utils.enable_quantization(qma)
+            xm = torch.randn(3, 10, 64) if bf else torch.randn(10, 3, 64)
+            _record_model(tag, qma, xm, fx, qm, call=lambda m, t: m[0](t, t, t)[0])
+            with torch.no_grad():
+                fx[tag + "attn_weights"] = qma[0](xm, xm, xm)[1].numpy()
+        dist.destroy_process_group()
+    else:
+        sys.path.insert(0, os.path.join(REF, "olive_quantization", "antquant"))
+        import quant_modules as qm
+        import quant_model
+        import quant_utils
+        from transformers import pytorch_utils
+        args = _args(mode="ant-int-flint", wbit=4, abit=4, w_up=250, a_up=250)
+        quant_utils.set_quantizer(args)
+        torch.manual_seed(53)
+        net = nn.Sequential(nn.Linear(64, 128), nn.GELU(), nn.Linear(128, 64), pytorch_utils.Conv1D(32, 64))
+        with torch.no_grad():
+            for m in net:
+                if hasattr(m, "weight"):
+                    w = m.weight
+                    mask = torch.rand_like(w) < 0.01
+                    w[mask] *= torch.empty(int(mask.sum())).uniform_(8, 40)
+        x = torch.randn(8, 64)
+        x.view(-1)[::37] *= 12
+        model = quant_model.quantize_model(net)
+        quant_utils.enable_quantization(model)
+        _record_model("a__", model, x, fx, qm)
+        x2 = torch.randn(8, 64)
+        x2.view(-1)[::29] *= 10
+        _record_model("a2__", model, x2, fx, qm, sd=None)
+    np.savez_compressed(os.path.join(outdir, "%s_ckpt.npz" % tree), **fx)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long", "all"], default="all")
+    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long", "ant_ckpt", "olive_ckpt", "all"], default="all")
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--traces-only", action="store_true",
                     help="write only the *_traces.npz files (per-candidate MSE of the complete calibrations)")
@@ -670,7 +821,7 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
     if a.tree == "all":
-        for t in ("ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long"):
+        for t in ("ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long") + (() if a.traces_only else ("ant_ckpt", "olive_ckpt")):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", t, "--out", a.out] +
                                   (["--traces-only"] if a.traces_only else []))
         return
@@ -678,6 +829,8 @@ def main():
     torch.set_num_threads(1)   # deterministic reductions for the recorded MSE traces
     if a.tree in ("ant_long", "olive_long"):
         gen_long(a.out, a.tree[:-5])
+    elif a.tree in ("ant_ckpt", "olive_ckpt"):
+        gen_ckpt(a.out, a.tree[:-5])
     elif a.tree == "ant":
         gen_ant(a.out)
     elif a.tree == "ant_wide":
@@ -686,6 +839,8 @@ def main():
         gen_olive_wide(a.out)
     else:
         gen_olive(a.out)
+    print("[make_golden] %s: quant_cuda.quant answered %d times, %d elements, C scan == independent numpy restatement on all"
+          % (a.tree, SCAN_CHECKS[0], SCAN_CHECKS[1]))
 
 
 if __name__ == "__main__":

@@ -254,6 +254,46 @@ def test_module_surface_and_state_dict_keys(tree):
     assert m.features[0].quant_weight.quant_grid.numel() == 256
 
 
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_reference_written_checkpoint_strict_loads_on_the_host(tree):
+    """The wire format of N2 without a GPU: the state dict the REFERENCE wrote (tests/golden/*_ckpt.npz, from its own
+    quantize_model + calibration, keys with the DDP 'module.' prefix) strict-loads into this package's rewrite of the
+    same network after load_ant_state_dict -- same key set, same shapes (OliVe: the 14-entry `outliers` and 15-entry
+    `quant_grid` of a calibrated 4-bit layer, a Conv1D layer's per-channel alpha; ANT: a 256-entry grid after
+    set_8_bit_layer_l), and nothing is left out.  (The forward needs the GPU: tests/test_gpu_parity.py.)"""
+    import importlib
+    import torch
+    import torch.nn as nn
+    if tree == "olive":
+        pytest.importorskip("transformers")
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    fx = golden("%s_ckpt.npz" % tree)
+    if tree == "ant":
+        qutil.set_quantizer(_args(mode="ant-int-pot-flint", wbit=4, abit=4))
+        net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Flatten(), nn.Linear(512, 32), nn.ReLU(),
+                            nn.Linear(32, 10))
+    else:
+        from transformers import pytorch_utils
+        qutil.set_quantizer(_args(mode="ant-int-flint", wbit=4, abit=4, w_up=250, a_up=250))
+        net = nn.Sequential(nn.Linear(64, 128), nn.GELU(), nn.Linear(128, 64), pytorch_utils.Conv1D(32, 64))
+    for prefixes in (["a__"], ["a__", "b__"]) if tree == "ant" else (["a__"],):
+        check = {}
+        for pre in prefixes:
+            for k in fx.files:
+                if k.startswith(pre + "sd__"):
+                    assert k[len(pre) + 4:].startswith("module.")
+                    check[k[len(pre) + 4 + 7:]] = torch.from_numpy(np.array(fx[k]))
+        model = qmod.quantize_model(net)
+        assert set(model.state_dict().keys()) == set(check.keys())
+        qmod.load_ant_state_dict(model, check)
+        res = model.load_state_dict(check, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        for k, v in model.state_dict().items():
+            assert v.shape == check[k].shape and torch.equal(v, check[k]), k
+        assert all(float(v) == 1.0 for k, v in check.items() if k.endswith("has_inited_quant_para"))
+
+
 def test_quant_affine_helpers_match_reference_formulas():
     import torch
     from ant_quantization_amd.ant import quant_affine as qa
