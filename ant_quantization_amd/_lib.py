@@ -15,9 +15,11 @@ import torch  # must be imported before libantq.so so that ONE libamdhip64 is sh
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ANTQ_LIB") or os.path.join(_HERE, "libantq.so")   # ANTQ_LIB: A/B builds (dev)
 
+ABI_VERSION = 2         # include/antq.h ANTQ_ABI_VERSION this binding was written against
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_OVP = 1
 FLAG_DYNAMIC = 2
+FLAG_UNORDERED = 4     # antq_fakequant: the launch may start while earlier launches of the stream drain (inputs at rest)
 IDX_NONE = -1
 IDX_VICTIM = -2
 MAX_GRID = 1024
@@ -44,6 +46,10 @@ def lib():
                         "libantq.so not found at %s -- build it with `make -C %s/csrc` "
                         "(or __graft_entry__.build()); there is no CPU fallback" % (LIB_PATH, _HERE))
                 L = ctypes.CDLL(LIB_PATH)
+                L.antq_abi_version.restype = ctypes.c_int
+                if L.antq_abi_version() != ABI_VERSION:
+                    raise AntqError("%s speaks C ABI version %d, this binding version %d: the argument lists differ -- "
+                                    "rebuild it (make -C %s/csrc)" % (LIB_PATH, L.antq_abi_version(), ABI_VERSION, _HERE))
                 L.antq_strerror.restype = ctypes.c_char_p
                 for name in ("antq_abi_version", "antq_nearest", "antq_plan_build", "antq_plan_kind",
                              "antq_plan_bytes", "antq_plan_eval_host", "antq_fakequant",
@@ -53,8 +59,7 @@ def lib():
                              "antq_search_sse_multi", "antq_plan_eval_host_a"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
-                if hasattr(L, "antq_search_workspace_bytes"):      # (absent from older builds loaded through ANTQ_LIB for A/B runs)
-                    L.antq_search_workspace_bytes.restype = ctypes.c_size_t
+                L.antq_search_workspace_bytes.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
                 vp, sz, ci, cf, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_uint
                 L.antq_fakequant.argtypes = [vp, vp, vp, sz, sz, vp, ci, cf, vp, vp, cu, ci, vp]
@@ -249,8 +254,10 @@ def nearest_hinted(x, grid, plan, stale=None, want_idx=False):
     return (z, idx) if want_idx else z
 
 
-def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=False, out=None):
-    """Fused Quantizer._forward on a contiguous tensor viewed as [rows, row_len]."""
+def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=False, out=None, unordered=False):
+    """Fused Quantizer._forward on a contiguous tensor viewed as [rows, row_len].
+    unordered: the caller promises that x / alpha are not produced by work still in flight on the stream (weights at rest);
+    the launch may then overlap the tail of the launches queued before it (ANTQ_FLAG_UNORDERED)."""
     _require_gpu(x, "x")
     _require_gpu(alpha, "alpha")
     dt = _DTYPES.get(x.dtype)
@@ -269,7 +276,8 @@ def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=
     with _on_device(x.device):
         rc = lib().antq_fakequant(x.data_ptr(), out.data_ptr(), _ptr(idx), rows, row_len, alpha.data_ptr(),
                                   1 if per_row else 0, gmax, plan.host_addr, pd.data_ptr(),
-                                  FLAG_OVP if ovp else 0, dt, _stream_int(x.device))
+                                  (FLAG_OVP if ovp else 0) | (FLAG_UNORDERED if unordered else 0), dt,
+                                  _stream_int(x.device))
     if rc:
         _check(rc, "antq_fakequant")
     return (out, idx) if want_idx else out
@@ -325,7 +333,7 @@ def alpha_grad(x, out, gout, rows, row_len, per_row=True):
     if dt is None or dt == F64 or out.dtype != x.dtype or gout.dtype != x.dtype:
         raise AntqError("alpha_grad: x / out / gout must share one of float32 / bfloat16 / float16")
     gsum = torch.empty(rows if per_row else 1, dtype=torch.float64, device=x.device)
-    ws = None if per_row else torch.empty(int(lib().antq_search_workspace_bytes()), dtype=torch.uint8, device=x.device)
+    ws = None if per_row else _workspace(x.device)
     with _on_device(x.device):
         _check(lib().antq_alpha_grad(_vp(x), _vp(out), _vp(gout), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
                                      ctypes.c_int(1 if per_row else 0), _vp(gsum), _vp(ws), ctypes.c_int(dt),
@@ -333,12 +341,30 @@ def alpha_grad(x, out, gout, rows, row_len, per_row=True):
     return gsum
 
 
+_workspaces = {}            # (device index, raw stream) -> 8 MiB scratch; launches on one stream are ordered, so they may share it
+
+
+def _workspace(device):
+    """Scratch for the workgroup partials of a whole-tensor sum (antq_search_workspace_bytes), ONE per (device, stream):
+    kernels that use it on the same stream run one after the other, so a QAT backward does not ask the caching allocator
+    for a fresh 8 MiB block per quantiser and step; different streams never share one."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _stream_int(device))
+    ws = _workspaces.get(key)
+    if ws is None:
+        with _lock:
+            ws = _workspaces.get(key)
+            if ws is None:
+                if len(_workspaces) >= 64:           # streams come and go: do not grow without bound
+                    _workspaces.clear()
+                ws = _workspaces[key] = torch.empty(int(lib().antq_search_workspace_bytes()), dtype=torch.uint8, device=device)
+    return ws
+
+
 def _search_workspace(device, rows, per_row):
-    """Scratch for the workgroup partials of a whole-tensor sum (antq_search_workspace_bytes; a fresh block from torch's
-    stream-ordered allocator per call, so calls on different streams never share one)."""
     if per_row and rows > 1:
         return None
-    return torch.empty(int(lib().antq_search_workspace_bytes()), dtype=torch.uint8, device=device)
+    return _workspace(device)
 
 
 def search_sse(x, rows, row_len, xmax, per_row, ratios, plan, gmax, ovp=False):

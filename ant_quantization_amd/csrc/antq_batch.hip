@@ -162,7 +162,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         fam_blocks[fam[(size_t)i]] += nblk[(size_t)i];
         total_blocks += nblk[(size_t)i];
     }
-    if (total_blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+    if (total_blocks > 0x1fffffffull) return ANTQ_ERR_UNSUPPORTED;      // (x 4: one-wavefront workgroups)
     if (cap < h.map_offset + 4 * total_blocks) return ANTQ_ERR_PLAN;
     size_t off[kBatchFamilies], acc = 0;
     for (int f = 0; f < kBatchFamilies; f++) { off[f] = acc; acc += fam_blocks[f]; h.fam_blocks[f] = (uint32_t)fam_blocks[f]; }
@@ -209,8 +209,14 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
             break;                                                                                                \
         }                                                                                                         \
         if (h->fam_blocks[0]) {                                                                                   \
-            if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true>), dim3(h->fam_blocks[0]), block, 0, st, descs, fmap[0]);   \
-            else hipLaunchKernelGGL((k_fq_batch<TT, false>), dim3(h->fam_blocks[0]), block, 0, st, descs, fmap[0]);      \
+            const int w_ = g_knob_waves == 4 || g_knob_waves == 2 ? g_knob_waves : 1;    /* knob 6 (A/B); default 1 */   \
+            const dim3 g_(h->fam_blocks[0] * (4u / w_)), b_(64u * w_);                                           \
+            if (w_ == 1) { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 1>), g_, b_, 0, st, descs, fmap[0]);        \
+                           else hipLaunchKernelGGL((k_fq_batch<TT, false, 1>), g_, b_, 0, st, descs, fmap[0]); }         \
+            else if (w_ == 2) { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 2>), g_, b_, 0, st, descs, fmap[0]);   \
+                           else hipLaunchKernelGGL((k_fq_batch<TT, false, 2>), g_, b_, 0, st, descs, fmap[0]); }         \
+            else { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 4>), g_, b_, 0, st, descs, fmap[0]);                \
+                   else hipLaunchKernelGGL((k_fq_batch<TT, false, 4>), g_, b_, 0, st, descs, fmap[0]); }                 \
         }                                                                                                         \
         if (h->fam_blocks[1]) { if (ovp) ANTQ_LAUNCH_D(TT, true, true); else ANTQ_LAUNCH_D(TT, false, true); }    \
         if (h->fam_blocks[2]) { if (ovp) ANTQ_LAUNCH_D(TT, true, false); else ANTQ_LAUNCH_D(TT, false, false); }  \

@@ -35,17 +35,30 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 // Streaming (nontemporal) 16-byte accesses: x is read once and out written once, so the
 // lines are marked evict-first instead of thrashing L2 / MALL.  Measured on MI355X
 // (tools/ubench.hip): a 4 KiB-per-wave copy runs 5.4 TB/s with nt, 2.9 TB/s without.
+// Every pointer these kernels dereference is device (global) memory.  Pointers that arrive through a descriptor in
+// memory (the batched launch) are "generic" to the compiler, which then emits FLAT instructions -- those tick BOTH the
+// vector-memory and the LDS counters, so every wait for a table read also waits for them.  Saying "address space 1"
+// turns them into global_load / global_store (round 3: the batched kernels had 45 flat loads and no global one).
+#define ANTQ_GLOBAL __attribute__((address_space(1)))
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 {
-    u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    u32x4_t v = __builtin_nontemporal_load((const ANTQ_GLOBAL u32x4_t *)(p));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v)
 {
     u32x4_t w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
+    __builtin_nontemporal_store(w, (ANTQ_GLOBAL u32x4_t *)(p));
 }
+// plain (cached) global loads: tables, scales
+__device__ __forceinline__ uint4 ld_global(const uint4 *p)
+{
+    u32x4_t v = *(const ANTQ_GLOBAL u32x4_t *)(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ld_global(const float *p) { return *(const ANTQ_GLOBAL float *)(p); }
+__device__ __forceinline__ void st_global(float *p, float v) { *(ANTQ_GLOBAL float *)(p) = v; }
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float floatx2_t __attribute__((ext_vector_type(2)));
@@ -178,14 +191,15 @@ template <> struct IO<f16_tag> {
     __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return f2u(h2f(max(m & 0xffffu, m >> 16))); }
 };
 
-// floor(o / opr) without an integer division: one f64 multiply by the reciprocal (inv = 1.0 / opr) and a +-1 fix-up
-// (o < 2^32, exact).
+// floor(o / opr) without an integer division: one f64 multiply by the reciprocal (inv = 1.0 / opr) and a +-1 fix-up.
+// Exact for every o < 2^32: the estimate is off by at most one, and the fix-up compares in 64 bits (q * opr can exceed
+// 2^32 when the estimate is one too high and o is close to 2^32).
 __device__ __forceinline__ uint32_t oct_row(uint32_t o, uint32_t opr, double inv)
 {
     uint32_t q = (uint32_t)((double)o * inv);
-    const uint32_t qo = q * opr;
+    const uint64_t qo = (uint64_t)q * opr;
     if (qo > o) q--;
-    else if (o - qo >= opr) q++;
+    else if ((uint64_t)o - qo >= opr) q++;
     return q;
 }
 
@@ -230,7 +244,7 @@ __device__ __forceinline__ PlanLds stage_plan(const PlanArgs &pa, const uint4 *_
         smem[(i < grid_units) ? (pa.n_entries + i) : (i - grid_units)] = first;
     }
     for (uint32_t i = threadIdx.x + blockDim.x; i < pa.tab_units; i += blockDim.x)
-        smem[(i < grid_units) ? (pa.n_entries + i) : (i - grid_units)] = plan_tab[i];
+        smem[(i < grid_units) ? (pa.n_entries + i) : (i - grid_units)] = ld_global(plan_tab + i);
     PlanLds L;
     L.lut = reinterpret_cast<const LutEntry *>(smem);
     L.grid = reinterpret_cast<const float *>(smem + pa.n_entries);

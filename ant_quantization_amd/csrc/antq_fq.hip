@@ -23,7 +23,22 @@
 #include "antq_k_fakequant.h"
 #include "antq_k_aux.h"
 
+#include <hip/hip_ext.h>
+
 namespace antq {
+
+// ANTQ_FLAG_UNORDERED of the call being dispatched (set by the entry point, read by the launch helpers of this file)
+static thread_local bool t_unordered = false;
+
+// One launch.  `unordered`: the dispatch packet goes out without the barrier bit (hipExtAnyOrderLaunch), so the kernel may
+// start while the launches queued before it on the same stream are still draining -- the caller has promised that it
+// does not depend on them (weights at rest).  Later ordinary launches still wait for it.
+template <typename... KArgs, typename... Args>
+static inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args)
+{
+    if (t_unordered) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, static_cast<KArgs>(args)...);
+    else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, static_cast<KArgs>(args)...);
+}
 
 template <typename T, bool OVP, bool IDX, bool DYN>
 static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, size_t vpr, const float *alpha,
@@ -59,8 +74,24 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
         const float *grid = reinterpret_cast<const float *>(tab);
         const dim3 grid_dim((unsigned)((total + 3) / 4)), block(256);
 #define ANTQ_LAUNCH_X(UU)                                                                                           \
-    hipLaunchKernelGGL((k_fq_xrow<T, OVP, IDX, UU, DYN>), grid_dim, block, 0, st, xv, ov, idx, (uint32_t)total,     \
-                       (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries, grid)
+    launch_k(k_fq_xrow<T, OVP, IDX, UU, DYN>, grid_dim, block, 0, st, xv, ov, idx, (uint32_t)total,                 \
+             (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries, grid)
+        // static rows, no index output: ONE wavefront per workgroup when the launch is unordered (or knob 6 = 1) -- the
+        // tables are wave-private, there is no workgroup barrier, and wavefronts that start and retire one by one keep
+        // the memory system busy across the launch boundary (tools/exp_lane.hip: 73.7 -> 74.7 % unordered, U = 4)
+        if constexpr (!DYN && !IDX) {
+            const int wpb = g_knob_waves ? g_knob_waves : (t_unordered ? 1 : 4);
+            if (wpb == 1 && U >= 2 && U <= 4) {
+                const dim3 g1((unsigned)total), b1(64);
+                if (total > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+#define ANTQ_LAUNCH_X1(UU)                                                                                          \
+    launch_k(k_fq_xrow<T, OVP, false, UU, false, 1, 1>, g1, b1, 0, st, xv, ov, idx, (uint32_t)total,                \
+             (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ratio, alpha_out, xa, entries, grid)
+                if (U == 4) ANTQ_LAUNCH_X1(4); else if (U == 3) ANTQ_LAUNCH_X1(3); else ANTQ_LAUNCH_X1(2);
+#undef ANTQ_LAUNCH_X1
+                return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+            }
+        }
         if (wpr16) {
             const dim3 g16((unsigned)rows), b16(1024);
             if (U == 8)
@@ -159,7 +190,13 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
         // the row index (f64 reciprocal + fix-up) and still gain: fp32 1-3.5 points (4608 / 11008 / 28672 wide: 70.7 -> 71.8,
         // 68.6 -> 72.1, 69.0 -> 71.9 %), bf16 0-3.5 on three boxes (57.3 -> 60.0, 58.2 -> 59.9, 58.9 -> 60.4 % on the last;
         // 768-wide rows: equal) -- tools/probe_lane_rows_np2.py
-        const bool lane_rows = pa.adom && g_knob_lane_rows != 0;
+        // Unordered launches overlap their neighbours, i.e. run in something like the batched kernels' steady state, where
+        // the per-row table kernel's leaner element loop wins (tools/exp_lane.hip: 74.7 % against 71.1 %): they take it
+        // whenever the plan has the x-domain form (knob 5 = 2 keeps the lane kernel)
+        const PlanHeader *ph_ = static_cast<const PlanHeader *>(plan_host);
+        const bool rows_unordered = t_unordered && !IDX && g_knob_lane_rows == 1 && g_knob_x != 0 && pa.kind == kPlanLut &&
+                                    ph_->xdom && vpr >= kRowKernelMinVpr;
+        const bool lane_rows = pa.adom && g_knob_lane_rows != 0 && !rows_unordered;
         if (vpr >= kRowKernelMinVpr && !lane_rows) {
             if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
             return launch_uniform<T, OVP, IDX, false>(x, out, idx, rows, vpr, alpha, per_row, gmax, 1.0f, nullptr, pa,
@@ -168,17 +205,28 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
             const size_t n_vec = n / EPL;
             int vshift = -1;
             if ((vpr & (vpr - 1)) == 0) { vshift = 0; while (((size_t)1 << vshift) < vpr) vshift++; }
-            constexpr int U = 2;
-            const size_t blocks = (n_vec + 256 * U - 1) / (256 * U);
+            // Launch shape of the exact-decision lane kernel (tools/exp_lane.hip, same-box A/B on 16 x 4096^2 bf16): an
+            // ordinary launch 4 wavefronts per workgroup, 2 vectors per lane (62.5 %; one-wavefront workgroups re-stage the
+            // table four times as often: 59-61 %); an unordered one 1 wavefront per workgroup, 4 vectors per lane (71.1 %
+            // against 69.7 %).  Knobs 6 / 7 force wavefronts per workgroup / vectors per lane (A/B).
+            int W = IDX ? 4 : (g_knob_waves ? g_knob_waves : (t_unordered ? 1 : 4));
+            int U = IDX ? 2 : (g_knob_lane_u ? g_knob_lane_u : (t_unordered ? 4 : 2));
+            if (!pa.adom) { W = 4; U = 2; }
+            if (W != 1 && W != 4) W = 4;
+            if (U != 1 && U != 2 && U != 4) U = 2;
+            const size_t per_wg = (size_t)64 * W * U;
+            const size_t blocks = (n_vec + per_wg - 1) / per_wg;
             if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
-            if (pa.adom)
-                hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, false, true>), dim3((unsigned)blocks), dim3(256), lds, st,
-                                   static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
-                                   vshift, alpha, per_row, gmax, 1.0f, (float *)nullptr, pa, tab);
-            else
-                hipLaunchKernelGGL((k_fq_lane<T, OVP, IDX, U, false, false>), dim3((unsigned)blocks), dim3(256), lds, st,
-                                   static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
-                                   vshift, alpha, per_row, gmax, 1.0f, (float *)nullptr, pa, tab);
+            const uint4 *xv = static_cast<const uint4 *>(x);
+            uint4 *ov = static_cast<uint4 *>(out);
+#define ANTQ_LANE(UU, WW, AA)                                                                                          \
+    launch_k(k_fq_lane<T, OVP, IDX, UU, false, AA, WW>, dim3((unsigned)blocks), dim3(64 * WW), lds, st, xv, ov, idx, n_vec,  \
+             (uint32_t)vpr, vshift, alpha, per_row, gmax, 1.0f, (float *)nullptr, pa, tab)
+            if (!pa.adom) ANTQ_LANE(2, 4, false);
+            else if constexpr (IDX) ANTQ_LANE(2, 4, true);
+            else if (W == 1) { if (U == 1) ANTQ_LANE(1, 1, true); else if (U == 2) ANTQ_LANE(2, 1, true); else ANTQ_LANE(4, 1, true); }
+            else             { if (U == 1) ANTQ_LANE(1, 4, true); else if (U == 2) ANTQ_LANE(2, 4, true); else ANTQ_LANE(4, 4, true); }
+#undef ANTQ_LANE
         }
     } else if (aligned && !per_row && n >= (size_t)64 * EPL) {
         // per-tensor scale with a ragged tail: vector body + element tail
@@ -289,6 +337,10 @@ extern "C" int antq_fakequant(const void *x, void *out, int16_t *idx, size_t row
     if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int per_row = alpha_per_row ? 1 : 0;
+    struct Unordered {       // scoped: the flag never outlives the call
+        explicit Unordered(bool on) { t_unordered = on; }
+        ~Unordered() { t_unordered = false; }
+    } scope((flags & ANTQ_FLAG_UNORDERED) != 0);
     switch (dtype) {
     case ANTQ_F32:
         if (reinterpret_cast<uintptr_t>(x) % 4 || reinterpret_cast<uintptr_t>(out) % 4) return ANTQ_ERR_ALIGN;

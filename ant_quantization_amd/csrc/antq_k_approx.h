@@ -87,7 +87,7 @@ __device__ __forceinline__ uint4 atab_src(const PlanArgs &pa, const uint4 *__res
     // plan_tab: [grid m_pad/4 units][entries n_entries units][atab slots units][aidx]
     const uint32_t gu = pa.m_pad >> 2, s = pa.atab_slots;
     const uint4 *at = plan_tab + gu + pa.n_entries;
-    return i < s ? at[i] : (i < s + gu ? plan_tab[i - s] : at[i - gu]);
+    return ld_global(i < s ? at + i : (i < s + gu ? plan_tab + (i - s) : at + (i - gu)));
 }
 template <bool IDX>
 __device__ __forceinline__ ATab stage_atab(const PlanArgs &pa, const uint4 *__restrict__ plan_tab, uint4 *smem, uint4 first)

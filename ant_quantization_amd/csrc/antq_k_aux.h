@@ -304,6 +304,113 @@ k_alpha_grad(const void *__restrict__ x, const void *__restrict__ out, const voi
     }
 }
 
+// ------------------------------------------------------------------------------------
+// OliVe's clip statistic (OQ/quant_modules.py:193-197, :213-218): x_max = max(|mean + 3 std|, |mean - 3 std|) per row or
+// per tensor, unbiased std.  The reference runs t.mean() and t.std() (two reductions, >= 3 reads of the tensor) before a
+// search that itself needs one read; here ONE read-only pass leaves (sum x, sum x^2) in double per row / tensor --
+// x^2 is exact in double, every sum is formed in one fixed order (a wavefront owns a row; whole-tensor sums from
+// workgroup partials through k_sum_partials) -- and k_xmax_3sigma turns them into the fp32 x_max with the roundings the
+// reference's dtype would apply (fp32: mean / std rounded to float; bf16 / fp16: mean, std, 3 * std, the sum and the
+// difference each rounded to the tensor's dtype, as torch's element-wise kernels do).  The sums themselves are what a
+// row-sharded per-tensor quantiser all-reduces across ranks ((sum x, sum x^2, n)).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_moments(const void *__restrict__ x, double *__restrict__ sums, double *__restrict__ ws, size_t rows, size_t row_len,
+          int per_row, int vec_ok)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const uint32_t lane = threadIdx.x & 63u;
+    double s1 = 0.0, s2 = 0.0;
+    auto acc_vec = [&](const uint4 &v) {
+        float f[EPL];
+        IO<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const double d = (double)f[e];
+            s1 += d;
+            s2 = __builtin_fma(d, d, s2);
+        }
+    };
+    auto acc_one = [&](size_t i) {
+        const double d = (double)IO<T>::load1(x, i);
+        s1 += d;
+        s2 = __builtin_fma(d, d, s2);
+    };
+    if (per_row) {
+        const size_t wave = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+        const size_t nwaves = (size_t)gridDim.x * 4u;
+        for (size_t r = wave; r < rows; r += nwaves) {
+            s1 = 0.0;
+            s2 = 0.0;
+            if (vec_ok) {
+                const size_t vpr = row_len / EPL;
+                const uint4 *p = static_cast<const uint4 *>(x) + r * vpr;
+                size_t i = lane;
+                for (; i + 192 < vpr; i += 256) {          // four 16-byte loads in flight per lane
+                    const uint4 a0 = p[i], a1 = p[i + 64], a2 = p[i + 128], a3 = p[i + 192];
+                    acc_vec(a0); acc_vec(a1); acc_vec(a2); acc_vec(a3);
+                }
+                for (; i < vpr; i += 64) acc_vec(p[i]);
+            } else {
+                for (size_t i = lane; i < row_len; i += 64) acc_one(r * row_len + i);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+            if (lane == 0) { sums[2 * r] = s1; sums[2 * r + 1] = s2; }
+        }
+    } else {
+        const size_t n = rows * row_len;
+        const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, stride = (size_t)gridDim.x * 256u;
+        if (vec_ok) {
+            const size_t nv = n / EPL;
+            const uint4 *p = static_cast<const uint4 *>(x);
+            size_t i = tid;
+            for (; i + 3 * stride < nv; i += 4 * stride) {
+                const uint4 a0 = p[i], a1 = p[i + stride], a2 = p[i + 2 * stride], a3 = p[i + 3 * stride];
+                acc_vec(a0); acc_vec(a1); acc_vec(a2); acc_vec(a3);
+            }
+            for (; i < nv; i += stride) acc_vec(p[i]);
+            for (size_t k = nv * EPL + tid; k < n; k += stride) acc_one(k);
+        } else {
+            for (size_t k = tid; k < n; k += stride) acc_one(k);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+        __shared__ double w1[4], w2[4];
+        if (lane == 0) { w1[threadIdx.x >> 6] = s1; w2[threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ws[(size_t)blockIdx.x * kPartialStride] = (w1[0] + w1[1]) + (w1[2] + w1[3]);
+            ws[(size_t)blockIdx.x * kPartialStride + 1] = (w2[0] + w2[1]) + (w2[2] + w2[3]);
+        }
+    }
+}
+
+// x_max[r] from (sum x, sum x^2) of n elements.  T: the dtype whose roundings the reference would apply.
+template <typename T> struct RoundTo { __device__ __forceinline__ static float r(float v) { return v; } };
+template <> struct RoundTo<bf16_tag> {
+    __device__ __forceinline__ static float r(float v) { return u2f(IO<bf16_tag>::pk(v, 0.0f) << 16); }
+};
+template <> struct RoundTo<f16_tag> {
+    __device__ __forceinline__ static float r(float v) { return IO<f16_tag>::h2f(IO<f16_tag>::f2h(v)); }
+};
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_xmax_3sigma(const double *__restrict__ sums, size_t na, double n, float *__restrict__ xmax)
+{
+    const size_t r = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= na) return;
+    const double s1 = sums[2 * r], s2 = sums[2 * r + 1];
+    const double mean = s1 / n;
+    double var = (s2 - s1 * mean) / (n - 1.0);           // unbiased (torch.std default); n == 1: 0 / 0 = NaN, like torch
+    if (var < 0.0) var = 0.0;                            // (cancellation on a constant row)
+    const float m = RoundTo<T>::r((float)mean), sd = RoundTo<T>::r((float)__builtin_sqrt(var));
+    const float t3 = RoundTo<T>::r(3.0f * sd);
+    const float a = fabsf(RoundTo<T>::r(m + t3)), b = fabsf(RoundTo<T>::r(m - t3));
+    xmax[r] = (a != a || b != b) ? __builtin_nanf("") : __builtin_fmaxf(a, b);     // torch.maximum propagates NaN
+}
+
 }  // namespace antq
 
 #endif  // ANTQ_K_AUX_H

@@ -35,7 +35,7 @@ __device__ __forceinline__ void task_load(const uint4 *__restrict__ x, const flo
 #pragma unroll
     for (int u = 0; u < U; u++) v[u] = ld_stream(p + min(v0 + 64u * u, vpr - 1u));
     a = 1.0f;
-    if (!dyn) a = alpha[per_row ? row : 0];
+    if (!dyn) a = ld_global(alpha + (per_row ? row : 0));
 }
 
 // max over aligned groups of g = 1, 2, 4, ... 64 adjacent lanes (g wave-uniform): DPP lane exchanges up to 16 lanes
@@ -96,7 +96,7 @@ __device__ __forceinline__ void task_run(uint4 *__restrict__ out, int16_t *__res
         m = IO<T>::amax_bits(m);
         m = wave_max_u32(m);
         a = u2f(m) * ratio;
-        if (alpha_out && lane == 0) alpha_out[row] = a;
+        if (alpha_out && lane == 0) st_global(alpha_out + row, a);
     }
     // plans with `adom` (every ANT / OliVe codebook whose table is too big for a per-row copy: int-8, flint-5..8, ...):
     // approximate quotient + margin test instead of the exact division per element (wave-uniform choice)
@@ -135,7 +135,7 @@ k_fq_uniform(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__re
     // also wait for the HBM loads of the task, which are issued right behind it
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (pa.adom) tab0 = atab_prefetch<IDX>(pa, plan_tab);
-    else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    else if (threadIdx.x < pa.tab_units) tab0 = ld_global(plan_tab + threadIdx.x);
 
     uint4 v[U];
     float a;
@@ -375,14 +375,19 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
     constexpr int EPL = IO<T>::EPL;
     // static bucket entries of this lane (L2 hits), issued ahead of the HBM loads; tables of
     // 65..128 buckets (e.g. unsigned int-4) give every lane a second entry
-    uint4 ent = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u), ent2 = ent;
-    if (lane < xa.n_entries) ent = entries[lane];
+    // (unconditional, clamped addresses: a load under an exec mask makes the compiler wait for it before the mask is
+    //  restored -- i.e. BEFORE the HBM loads below are even issued, a serial L2 round trip per wavefront)
+    const uint4 none = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u);
     const bool two = xa.n_entries > 64u;
-    if (two && lane + 64u < xa.n_entries) ent2 = entries[lane + 64u];
+    uint4 ent = ld_global(entries + min(lane, xa.n_entries - 1u)), ent2 = none;
+    if (two) ent2 = ld_global(entries + min(lane + 64u, xa.n_entries - 1u));
 
     uint4 v[U];
     float a;
     task_load<T, U>(x, alpha, per_row, task, vpr, tpr, lane, DYN, v, a);
+    __builtin_amdgcn_sched_barrier(0);                 // nothing that consumes a load is scheduled above this line
+    if (lane >= xa.n_entries) ent = none;
+    if (lane + 64u >= xa.n_entries) ent2 = none;
 
     uint32_t row = task, g = 0;
     if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
@@ -404,7 +409,7 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
             for (int w = 1; w < WPR; w++) m = max(m, wmax[w]);
         }
         a = u2f(m) * ratio;
-        if (alpha_out && lane == 0 && (WPR == 1 || wv == 0)) alpha_out[row] = a;
+        if (alpha_out && lane == 0 && (WPR == 1 || wv == 0)) st_global(alpha_out + row, a);
     }
     const Scale sc = make_scale(a, gmax);
 
@@ -427,15 +432,15 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
 
 // WPR = 16 (DYN only): rows of up to 64 * U * 16 = 4096 / 8192 vectors (C4's 28 672-wide rows: 3584 bf16 / 7168 fp32
 // vectors) held in the registers of ONE 1024-thread workgroup -- abs-max and quantisation on a single HBM read.
-template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR = 1>
-__global__ void __launch_bounds__(WPR > 4 ? 64 * WPR : 256)
+template <typename T, bool OVP, bool IDX, int U, bool DYN, int WPR = 1, int WPB = 4>
+__global__ void __launch_bounds__(WPR > 4 ? 64 * WPR : 64 * WPB)
 k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
           uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
           const float *__restrict__ alpha, int per_row, float gmax, float ratio,
           float *__restrict__ alpha_out, XArgs xa, const uint4 *__restrict__ entries,
           const float *__restrict__ grid)
 {
-    constexpr uint32_t WAVES = WPR > 4 ? WPR : 4;
+    constexpr uint32_t WAVES = WPR > 4 ? WPR : WPB;      // wavefronts per workgroup (WPR > 1: a row spans them, WPB = 4)
     __shared__ __attribute__((aligned(16))) uint4 wtab_all[WAVES][256];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
@@ -455,7 +460,10 @@ k_fq_xrow(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restr
 // DYN: alpha = max|group| * ratio from a butterfly over the group's lanes (vpr a power of two <= 256; beyond 64 lanes the
 // wavefronts of the workgroup exchange their maxima through LDS).
 // Body shared by k_fq_lane and the batched d-domain kernel (k_fq_batch_d).
-template <typename T, bool OVP, bool IDX, int U, bool DYN, bool AD, bool XW = false>
+// TPB: threads per workgroup (the U vectors of a lane are TPB vectors apart).  64 = one wavefront per workgroup: the
+// wavefronts of a launch then start and retire one by one instead of four at a time, which measured +1.5 ... +5 points on a
+// plain copy of 1 GiB (tools/stream_shapes.hip) and more on one launch per 33.5 MB tensor.
+template <typename T, bool OVP, bool IDX, int U, bool DYN, bool AD, bool XW = false, int TPB = 256>
 __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
                                           size_t n_vec, uint32_t vpr, int vshift, const float *__restrict__ alpha, int per_row,
                                           float gmax, float ratio, float *__restrict__ alpha_out, const PlanArgs &pa,
@@ -464,13 +472,13 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
     constexpr int EPL = IO<T>::EPL;
     uint4 tab0 = make_uint4(0, 0, 0, 0);
     if (AD) tab0 = atab_prefetch<IDX>(pa, plan_tab);
-    else if (threadIdx.x < pa.tab_units) tab0 = plan_tab[threadIdx.x];
+    else if (threadIdx.x < pa.tab_units) tab0 = ld_global(plan_tab + threadIdx.x);
     uint4 v[U];
     float a[U];
     const double inv_vpr = 1.0 / (double)vpr;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const size_t vi = first + (size_t)u * 256u;
+        const size_t vi = first + (size_t)u * (size_t)TPB;
         v[u] = make_uint4(0, 0, 0, 0);
         a[u] = 1.0f;
         if (vi < n_vec) {
@@ -480,7 +488,7 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
                 if (per_row)   // a shift; else the f64-reciprocal quotient (exact below 2^32 vectors); else a 64-bit division
                     row = (vshift >= 0) ? (vi >> vshift)
                                         : (n_vec <= 0xffffffffull ? (size_t)oct_row((uint32_t)vi, vpr, inv_vpr) : vi / vpr);
-                a[u] = alpha[row];
+                a[u] = ld_global(alpha + row);
             }
         }
     }
@@ -521,14 +529,14 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const size_t vi = first + (size_t)u * 256u;
+            const size_t vi = first + (size_t)u * (size_t)TPB;
             a[u] = u2f(m[u]) * ratio;             // AQ:474 (x_max), :300 (x_max * ratio)
-            if (alpha_out && vi < n_vec && (vi & (vpr - 1)) == 0) alpha_out[vi >> vshift] = a[u];
+            if (alpha_out && vi < n_vec && (vi & (vpr - 1)) == 0) st_global(alpha_out + (vi >> vshift), a[u]);
         }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const size_t vi = first + (size_t)u * 256u;
+        const size_t vi = first + (size_t)u * (size_t)TPB;
         float xf[EPL];
         IO<T>::unpack(v[u], xf);
         if (vi < n_vec) {
@@ -547,20 +555,21 @@ __device__ __forceinline__ void lane_task(const uint4 *__restrict__ x, uint4 *__
     }
 }
 
-template <typename T, bool OVP, bool IDX, int U, bool DYN, bool AD>
-__global__ void __launch_bounds__(256)
+template <typename T, bool OVP, bool IDX, int U, bool DYN, bool AD, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES)
 k_fq_lane(const uint4 *__restrict__ x, uint4 *__restrict__ out, int16_t *__restrict__ idx,
           size_t n_vec, uint32_t vpr, int vshift,
           const float *__restrict__ alpha, int per_row, float gmax, float ratio,
           float *__restrict__ alpha_out, PlanArgs pa, const uint4 *__restrict__ plan_tab)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-    if (DYN && AD && vpr > 64u)                          // 16-bit rows of 128 vectors: groups of 2 wavefronts
+    constexpr uint32_t TPB = 64u * WAVES;
+    if (WAVES == 4 && DYN && AD && vpr > 64u)            // 16-bit rows of 128 vectors: groups of 2 wavefronts
         lane_task<T, OVP, IDX, U, DYN, AD, true>(x, out, idx, n_vec, vpr, vshift, alpha, per_row, gmax, ratio, alpha_out, pa,
                                                  plan_tab, smem, ((size_t)blockIdx.x * U) * 256u + threadIdx.x);
     else
-        lane_task<T, OVP, IDX, U, DYN, AD>(x, out, idx, n_vec, vpr, vshift, alpha, per_row, gmax, ratio, alpha_out, pa, plan_tab,
-                                           smem, ((size_t)blockIdx.x * U) * 256u + threadIdx.x);
+        lane_task<T, OVP, IDX, U, DYN, AD, false, (int)TPB>(x, out, idx, n_vec, vpr, vshift, alpha, per_row, gmax, ratio, alpha_out,
+                                                            pa, plan_tab, smem, ((size_t)blockIdx.x * U) * TPB + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------

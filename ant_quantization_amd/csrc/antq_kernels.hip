@@ -206,6 +206,8 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 3) g_knob_nearest_fast = value;
     else if (key == 4) g_knob_a = value;
     else if (key == 5) g_knob_lane_rows = value;
+    else if (key == 6) g_knob_waves = value;
+    else if (key == 7) g_knob_lane_u = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }
@@ -277,6 +279,54 @@ extern "C" int antq_alpha_grad(const void *x, const void *out, const void *gout,
     case ANTQ_F16: return launch_alpha_grad<f16_tag>(x, out, gout, gsum, ws, rows, row_len, per_row ? 1 : 0, st);
     default: return ANTQ_ERR_UNSUPPORTED;
     }
+}
+
+namespace antq {
+template <typename T>
+static int launch_moments(const void *x, double *sums, double *ws, size_t rows, size_t row_len, int per_row, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const bool al = reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    const int vec_ok = per_row ? (al && row_len % EPL == 0) : al;
+    size_t waves = per_row ? rows : (rows * row_len + 64 * EPL * 4 - 1) / (64 * EPL * 4);
+    size_t blocks = (waves + 3) / 4;
+    const size_t cap = per_row ? 4096 : 1024;            // (per tensor: <= kWsSlots partials)
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_moments<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, sums, ws, rows, row_len, per_row, vec_ok);
+    if (!per_row) hipLaunchKernelGGL(k_sum_partials, dim3(2), dim3(256), 0, st, ws, (uint32_t)blocks, 2, sums);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+}  // namespace antq
+
+extern "C" int antq_moments(const void *x, size_t rows, size_t row_len, int per_row, int dtype, double *sums, void *workspace,
+                            void *stream)
+{
+    if (rows == 0 || row_len == 0) return ANTQ_OK;
+    if (!x || !sums || (!per_row && !workspace)) return ANTQ_ERR_ARG;
+    double *ws = static_cast<double *>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case ANTQ_F32: return launch_moments<float>(x, sums, ws, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_BF16: return launch_moments<bf16_tag>(x, sums, ws, rows, row_len, per_row ? 1 : 0, st);
+    case ANTQ_F16: return launch_moments<f16_tag>(x, sums, ws, rows, row_len, per_row ? 1 : 0, st);
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int antq_xmax_3sigma(const double *sums, size_t na, size_t n_per, int dtype, float *xmax, void *stream)
+{
+    if (na == 0) return ANTQ_OK;
+    if (!sums || !xmax || n_per == 0) return ANTQ_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 g((unsigned)((na + 255) / 256)), b(256);
+    switch (dtype) {
+    case ANTQ_F32: hipLaunchKernelGGL((k_xmax_3sigma<float>), g, b, 0, st, sums, na, (double)n_per, xmax); break;
+    case ANTQ_BF16: hipLaunchKernelGGL((k_xmax_3sigma<bf16_tag>), g, b, 0, st, sums, na, (double)n_per, xmax); break;
+    case ANTQ_F16: hipLaunchKernelGGL((k_xmax_3sigma<f16_tag>), g, b, 0, st, sums, na, (double)n_per, xmax); break;
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
 extern "C" int antq_absmax(const void *x, float *amax, size_t rows, size_t row_len, int per_row, int dtype, void *stream)

@@ -29,6 +29,7 @@ except the one read-back that builds a plan for a buffer seen twice.
 import collections
 import os
 import sys
+import threading
 
 import torch
 
@@ -55,27 +56,49 @@ class _Hint:
 
 
 _hints = collections.OrderedDict()      # (data_ptr, numel, device index) -> _Hint, LRU
+_hints_lock = threading.Lock()          # nn.DataParallel calls quant() from one thread per GPU (ABERT/run_glue.py:570)
+
+# The flag a kernel raises when its hint was wrong lives in pinned host memory, and a launch that may still write to it
+# can be in flight on any stream when its _Hint is evicted or re-planned.  So the flags are NEVER returned to torch's pinned
+# allocator: they are 4-byte slots of one pool that lives as long as the module, handed out round-robin.  A slot reused
+# after _STALE_SLOTS newer plans can at worst receive a late "stale" from a long-gone launch -- which costs its new owner
+# one unnecessary re-plan, never a wrong result (the kernel's own comparison with the device grid decides the values).
+_STALE_SLOTS = 4096
+_stale_pool = None
+_stale_next = 0
+
+
+def _new_stale_flag():
+    global _stale_pool, _stale_next
+    if _stale_pool is None:
+        _stale_pool = torch.zeros(_STALE_SLOTS, dtype=torch.int32).pin_memory()
+    i = _stale_next % _STALE_SLOTS
+    _stale_next += 1
+    flag = _stale_pool[i:i + 1]
+    flag.zero_()
+    return flag
 
 
 def _hint_for(grid):
     key = (grid.data_ptr(), grid.numel(), grid.device.index)
-    h = _hints.get(key)
-    if h is None:
-        h = _hints[key] = _Hint()
-        if len(_hints) > _MAX_HINTS:
-            _hints.popitem(last=False)
-    else:
-        _hints.move_to_end(key)
-    if h.plan is not None and int(h.stale[0]) != 0:
-        # an earlier launch found other values at this address: forget, and be slower to believe again
-        h.plan, h.seen, h.strikes = None, 0, h.strikes + 1
-        h.need = min(2 << h.strikes, 256)
-    if h.plan is None:
-        h.seen += 1
-        if h.seen >= h.need:
-            h.plan = _lib.plan_for(grid.detach().float().cpu().numpy())     # the one read-back per long-lived buffer
-            h.stale = torch.zeros(1, dtype=torch.int32).pin_memory()
-    return h
+    with _hints_lock:
+        h = _hints.get(key)
+        if h is None:
+            h = _hints[key] = _Hint()
+            if len(_hints) > _MAX_HINTS:
+                _hints.popitem(last=False)
+        else:
+            _hints.move_to_end(key)
+        if h.plan is not None and int(h.stale[0]) != 0:
+            # an earlier launch found other values at this address: forget, and be slower to believe again
+            h.plan, h.seen, h.strikes = None, 0, h.strikes + 1
+            h.need = min(2 << h.strikes, 256)
+        if h.plan is None:
+            h.seen += 1
+            if h.seen >= h.need:
+                h.plan = _lib.plan_for(grid.detach().float().cpu().numpy())     # the one read-back per long-lived buffer
+                h.stale = _new_stale_flag()
+        return h
 
 
 def quant(x, y):

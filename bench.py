@@ -17,6 +17,7 @@ Inputs are resident in HBM before the timed region.  Weak scaling: every rank ow
 bracket the timed region and at the MAX-reduction of the elapsed time.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N ...                       (no launcher: starts the N ranks itself, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -63,8 +64,9 @@ class Harness:
         self.selftest = selftest
         if self.world != gpus:
             sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch N ranks with `python -m torch.distributed.run "
-                     "--nnodes=1 --nproc-per-node N ... bench.py --gpus N` (one process per GPU); refusing to report "
-                     "a number for a job of another size" % (gpus, self.world))
+                     "--nnodes=1 --nproc-per-node N ... bench.py --gpus N` (one process per GPU) or run `python bench.py "
+                     "--gpus N` without WORLD_SIZE set (it then starts the N ranks itself); refusing to report a number "
+                     "for a job of another size" % (gpus, self.world))
         import torch
         self.torch = torch
         if selftest:
@@ -225,6 +227,28 @@ def cpu_baseline_torch(seconds_budget=6.0):
 
 
 # ------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves -- one fresh process per GPU, the same
+    command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, exactly what
+    `torch.distributed.run --nnodes=1 --nproc-per-node N` would have set -- and wait for them.  Rank 0 prints the JSON
+    line on the inherited stdout.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def selftest_main(args):
     """Stub workload for the CPU test of the rank harness: rank r sleeps (r + 1) ms per step."""
     h = Harness(args.gpus, selftest=True)
@@ -249,6 +273,8 @@ def main():
     ap.add_argument("--nbuf", type=int, default=32, help="distinct 4096x4096 bf16 tensors per GPU (one step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))             # no launcher around us: one process per GPU, started here
     if os.environ.get("ANTQ_BENCH_SELFTEST") == "1":
         return selftest_main(args)
 

@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define ANTQ_ABI_VERSION 1
+/* 2 (round 3): antq_search_sse / antq_alpha_grad take a caller workspace before `stream`, antq_absmax initialises its
+ * output, the batch blob changed (plan version 8), ANTQ_FLAG_UNORDERED.  A caller built against another version must not
+ * call in: the argument lists differ. */
+#define ANTQ_ABI_VERSION 2
 
 /* element types of x / out */
 #define ANTQ_F32  0
@@ -54,6 +57,11 @@ extern "C" {
 /* flags of antq_fakequant* */
 #define ANTQ_FLAG_OVP        1u    /* OliVe outlier-victim pair masking (OQ:311-320) */
 #define ANTQ_FLAG_DYNAMIC    2u    /* antq_batch_build only: alpha computed in the kernel */
+#define ANTQ_FLAG_UNORDERED  4u    /* antq_fakequant only: this launch does not depend on the launches queued before it on
+                                    * the stream (its inputs are at rest: calibrated weights), so it may START while they are
+                                    * still draining -- the dispatch packet goes out without the barrier bit
+                                    * (hipExtAnyOrderLaunch).  Ordinary launches queued after it still wait for it.  Worth
+                                    * 2-3 us per 33.5 MB tensor when many weight tensors are quantised one launch each. */
 
 /* values written to the optional int16 index output */
 #define ANTQ_IDX_NONE    (-1)      /* no grid entry within 102400 (NaN/Inf/huge)     */
@@ -282,6 +290,22 @@ int antq_decode4(const uint8_t *codes_dev, void *out_dev, size_t rows, size_t ro
                  const float *alpha_dev, int alpha_per_row, float gmax,
                  const void *plan_host, const void *plan_dev, int n_normal,
                  unsigned flags, int dtype, void *stream);
+
+/* -------------------------------------------------------------------------
+ * OliVe's clip statistic on ONE read (replaces t.mean() + t.std() of olive_quantization/antquant/quant_modules.py:193-197
+ * and :213-218, which read the tensor at least three times before the clip search reads it again).
+ * antq_moments: sums_dev[2 r] = sum of x, sums_dev[2 r + 1] = sum of x^2 over row r (alpha_per_row) or over the whole
+ *   tensor (one pair), in double, formed in one fixed order (bit-reproducible; no atomics).  workspace_dev: required for
+ *   the whole-tensor form, antq_search_workspace_bytes() bytes.  These are also the numbers a row-sharded per-tensor
+ *   quantiser all-reduces across ranks (sum x, sum x^2, n).
+ * antq_xmax_3sigma: xmax_dev[r] = max(|mean + 3 std|, |mean - 3 std|) from na pairs of sums over n_per elements each,
+ *   unbiased std, with the roundings of `dtype` applied where the reference's tensor ops round (fp32: mean and std to
+ *   float; bf16 / fp16: mean, std, 3 * std, sum and difference each rounded to the tensor's dtype).  Agrees with the
+ *   reference's torch reductions to their own summation-order noise (relative 1e-6 in fp32).
+ * ------------------------------------------------------------------------- */
+int antq_moments(const void *x_dev, size_t rows, size_t row_len, int alpha_per_row, int dtype,
+                 double *sums_dev, void *workspace_dev, void *stream);
+int antq_xmax_3sigma(const double *sums_dev, size_t na, size_t n_per, int dtype, float *xmax_dev, void *stream);
 
 /* Plain device copy with the fake-quant kernels' access pattern (16 B per lane):
  * used by bench.py to measure the empirical HBM ceiling on the same buffers. */

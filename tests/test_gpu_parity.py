@@ -858,6 +858,56 @@ def test_hf_models_end_to_end_and_checkpoint_roundtrip(antq_lib, dev, capsys):
         assert torch.equal(y3, y1)
 
 
+def test_launch_shapes_and_unordered_launches_are_bit_identical(antq_lib, oracle, dev):
+    """Round 3 launch shapes: wavefronts per workgroup (knob 6) and vectors per lane (knob 7) of the lane kernel, the
+    batched row-table kernel with 4 / 2 / 1 wavefronts per workgroup, ordinary and unordered launches
+    (ANTQ_FLAG_UNORDERED: no barrier bit on the dispatch packet) -- every combination against the oracle."""
+    import torch
+    rng = np.random.default_rng(77)
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    gol = np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])
+    knob = antq_lib.lib().antq_debug_set
+    try:
+        for bf16 in (True, False):
+            for rows, K in ((48, 4096), (40, 1000), (3, 8200)):
+                x = make_x(rng, rows, K, specials=False)
+                x.reshape(-1)[::41] *= 25
+                xh = oracle.f32_to_bf16(x) if bf16 else x
+                xf = oracle.bf16_to_f32(xh) if bf16 else xh
+                xt = to_dev(xh, dev, bf16)
+                for ovp, g, gmax in ((False, G["flint_b4_s"], 10.0), (True, gol, 32.0)):
+                    alpha = (np.abs(xf).max(1) * np.float32(0.3 if ovp else 0.9)).astype(np.float32)
+                    ref, _ = oracle.forward(xh, alpha, g, gmax, ovp)
+                    plan, a_t = antq_lib.plan_for(g), torch.from_numpy(alpha).to(dev)
+                    for w in (0, 1, 4):
+                        for u in (0, 1, 2, 4):
+                            knob(6, w)
+                            knob(7, u)
+                            for unordered in (False, True):
+                                # several back-to-back launches into distinct outputs: unordered ones may overlap
+                                outs = [antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, True, ovp=ovp, unordered=unordered)
+                                        for _ in range(3)]
+                                for o in outs:
+                                    ok = bf16_same(bf16_bits(o), ref, oracle) if bf16 else f32_same(o.cpu().numpy(), ref)
+                                    assert ok, (bf16, rows, K, ovp, w, u, unordered)
+                    knob(7, 0)
+                    if K * (2 if bf16 else 4) // 16 >= 128:
+                        for w in (4, 2, 1):
+                            knob(6, w)
+                            out = torch.zeros_like(xt)
+                            out2 = torch.zeros_like(xt)
+                            bt = antq_lib.Batch([(xt, out, a_t, plan, gmax, rows, K, True), (xt, out2, a_t, plan, gmax, rows, K, True)],
+                                                ovp=ovp)
+                            bt.run()
+                            for o in (out, out2):
+                                ok = bf16_same(bf16_bits(o), ref, oracle) if bf16 else f32_same(o.cpu().numpy(), ref)
+                                assert ok, ("batch", bf16, rows, K, ovp, w)
+                    knob(6, 0)
+    finally:
+        knob(6, 0)
+        knob(7, 0)
+
+
 def _ref_checkpoint(fx, prefixes, dev, strip):
     """The state dict the reference wrote (tests/golden/*_ckpt.npz, keys 'module.'-prefixed as ImageNet/main.py saves a
     DistributedDataParallel model); later prefixes override earlier ones.  strip: drop the 7 characters the way

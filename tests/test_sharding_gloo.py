@@ -150,7 +150,75 @@ def test_bench_refuses_a_world_size_other_than_gpus(tmp_path):
     r = _run_bench(tmp_path, 2, 4)
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in (r.stderr + r.stdout)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
-    env = dict(os.environ, ANTQ_BENCH_SELFTEST="1")
+    env = dict(os.environ, ANTQ_BENCH_SELFTEST="1", WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (no WORLD_SIZE in the environment): bench.py starts the two
+    ranks itself -- one process per GPU, the environment torch.distributed.run would have set -- and the same harness
+    produces the same single JSON line (gloo, stub workload)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["ANTQ_BENCH_SELFTEST"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 10 and res["selftest"] is True
+    assert 2.0 <= res["ms_per_step"] < 20.0                              # the slower rank's time
+
+
+def test_c3_shaped_list_lpt_split_and_odd_numel_fix_world2():
+    """The sharded driver's host logic (tools/bench_sharded.py) for a C3-shaped list at world 2: LPT by bytes gives every
+    tensor to exactly one rank with equal loads, and `fix_odd_numel_wrap` is a no-op for every C3 / C4 tensor (even
+    element counts) -- checked by calling it with a process group of 2 over gloo on a small even tensor."""
+    import torch.multiprocessing as mp
+    from ant_quantization_amd import sharding
+    shapes = []
+    for _ in range(4):                                                   # 4 OPT-6.7B layers (SURVEY 8a C3)
+        shapes += [(4096, 4096)] * 4 + [(16384, 4096), (4096, 16384)]
+    sizes = [r * c for r, c in shapes]
+    parts = sharding.lpt_assign(sizes, 2)
+    assert sorted(i for p in parts for i in p) == list(range(len(shapes)))
+    assert sum(sizes[i] for i in parts[0]) == sum(sizes[i] for i in parts[1])
+    assert all((r * c) % 2 == 0 for r, c in shapes)                      # no odd element count: no wrap bit needed
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_even_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res)
+
+
+def _even_worker(rank, world, port, q):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ant_quantization_amd import _lib, grids, sharding
+    from oracle import antq_oracle as orc
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grid = np.concatenate([grids.olive_flint(4, True), grids.olive_outliers(4, True)])
+    plan = _lib.plan_for(grid)
+    rng = np.random.default_rng(5)
+    rows, K = 8, 64
+    x = (rng.standard_normal((rows, K)) * 0.02).astype(np.float32)
+    x[0, 0] = 1.9                                                         # element 0 an outlier: irrelevant for an even count
+    alpha = np.full(rows, 0.06, dtype=np.float32)
+    b, e = sharding.row_block(rows, rank, world, pair_safe_row_len=K)
+    full, _ = orc.forward(x, alpha, grid, gmax=32.0, ovp=True)
+    part, _ = orc.forward(x[b:e], alpha[b:e], grid, gmax=32.0, ovp=True)
+    ob = torch.from_numpy(part.copy())
+    sharding.fix_odd_numel_wrap(torch.from_numpy(x[b:e].copy()), ob, torch.from_numpy(alpha[b:e].copy()), plan, 32.0, rows, K,
+                                rank, world, plain_fn=None)
+    q.put(bool(np.array_equal(ob.numpy().view(np.uint32), full[b:e].view(np.uint32))))
+    dist.destroy_process_group()
