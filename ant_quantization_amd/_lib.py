@@ -56,7 +56,7 @@ def lib():
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
                              "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
-                             "antq_search_sse_multi", "antq_plan_eval_host_a"):
+                             "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 L.antq_search_workspace_bytes.restype = ctypes.c_size_t
@@ -323,6 +323,37 @@ def absmax(x, rows, row_len, per_row=True):
     if rc:
         _check(rc, "antq_absmax")
     return amax
+
+
+def moments(x, rows, row_len, per_row=True):
+    """[rows or 1, 2] float64: (sum x, sum x^2) per row or for the whole tensor, on ONE read, in a fixed order."""
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    if rows * row_len != x.numel():
+        raise AntqError("rows*row_len != numel")
+    sums = torch.empty((rows if per_row else 1, 2), dtype=torch.float64, device=x.device)
+    ws = None if per_row else _workspace(x.device)
+    with _on_device(x.device):
+        _check(lib().antq_moments(_vp(x), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), ctypes.c_int(1 if per_row else 0),
+                                  ctypes.c_int(dt), _vp(sums), _vp(ws), _stream(x.device)), "antq_moments")
+    return sums
+
+
+def xmax_3sigma(x, rows, row_len, per_row=True, sums=None):
+    """OliVe's clip statistic max(|mean + 3 std|, |mean - 3 std|) (OQ:193-197, :213-218; unbiased std) per row or per
+    tensor as float32, with the roundings of x's dtype: one read of x (`sums`: already reduced moments, e.g. all-reduced
+    across the ranks of a row-sharded tensor -- then x is not read at all)."""
+    dt = _DTYPES.get(x.dtype)
+    if sums is None:
+        sums = moments(x, rows, row_len, per_row)
+    na = sums.shape[0]
+    out = torch.empty(na, dtype=torch.float32, device=x.device)
+    with _on_device(x.device):
+        _check(lib().antq_xmax_3sigma(_vp(sums), ctypes.c_size_t(na), ctypes.c_size_t(row_len if per_row else rows * row_len),
+                                      ctypes.c_int(dt), _vp(out), _stream(x.device)), "antq_xmax_3sigma")
+    return out
 
 
 def alpha_grad(x, out, gout, rows, row_len, per_row=True):

@@ -11,8 +11,8 @@ extern "C" size_t antq_batch_capacity(const antq_job *jobs, int n, int dtype)
     if (!jobs || n < 1 || !epl) return 0;
     size_t blocks = 0;
     // (the dynamic variant gives rows of 257..1024 vectors a workgroup each: never more than max(static, rows))
-    // (x-domain rows may be cut into tasks of 2 or 3 vectors per lane instead of 4: at most twice the blocks)
-    for (int i = 0; i < n; i++) blocks += std::max(2 * job_blocks(jobs[i], epl, nullptr) + 1, jobs[i].rows);
+    // (x-domain rows may be cut into tasks of 1, 2 or 3 vectors per lane instead of 4: at most four times the blocks)
+    for (int i = 0; i < n; i++) blocks += std::max(4 * job_blocks(jobs[i], epl, nullptr) + 1, jobs[i].rows);
     return sizeof(BatchHeader) + sizeof(BatchDesc) * (size_t)n + 4 * blocks;
 }
 
@@ -64,7 +64,8 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             if (d.kind == 0 && xdom) {
                 // x-domain rows: the task size that leaves the fewest idle lanes for this row length
                 d.kind = 2;
-                d.u = row_task_u(d.vpr);
+                d.u = row_task_u_small(d.vpr);
+                if (g_knob_u >= 1 && g_knob_u <= 4) d.u = (uint32_t)g_knob_u;     // knob 0 (A/B): vectors per lane and task
                 d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
                 const size_t total = (J.alpha_per_row ? J.rows : (size_t)1) * (size_t)d.tpr;   // per tensor: ONE row
                 if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;

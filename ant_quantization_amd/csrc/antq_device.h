@@ -24,6 +24,20 @@ __host__ __device__ inline uint32_t row_task_u(uint32_t vpr)
     }
     return best_u;
 }
+// The same with ties going to the SMALLER task: the batched launch's one-wavefront workgroups stream best with 2 KiB per
+// wavefront (32 x 4096^2 bf16, same box: 2 vectors per lane 81.4 %, 4: 79.7 %, 3: 80.8 % at 89 % lane use, 1: 70.4 % --
+// the per-task table build then costs more than the finer granularity gains; profiles/r03_launch_shapes_*.log)
+__host__ __device__ inline uint32_t row_task_u_small(uint32_t vpr)
+{
+    uint32_t best_u = 2;
+    double best = -1.0;
+    for (uint32_t u = 2; u <= 4; u++) {
+        const uint32_t span = 64u * u, tasks = (vpr + span - 1u) / span;
+        const double util = (double)vpr / (double)(tasks * span);
+        if (util > best + 1e-9) { best = util; best_u = u; }
+    }
+    return best_u;
+}
 
 
 // ------------------------------------------------------------------------------------

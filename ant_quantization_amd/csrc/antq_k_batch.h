@@ -101,7 +101,7 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
     xrow_task<T, OVP, false, UU, false, 1>(D.x, D.out, nullptr, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, 1.0f, nullptr, \
                                            xa, plan_tab + (D.pa.m_pad >> 2), reinterpret_cast<const float *>(plan_tab),        \
                                            wtab_all[wv], lane, wv)
-    if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else ANTQ_XROW(2);
+    if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else if (D.u == 1u) ANTQ_XROW(1); else ANTQ_XROW(2);
 #undef ANTQ_XROW
 }
 

@@ -29,13 +29,15 @@ __device__ __forceinline__ void task_load(const uint4 *__restrict__ x, const flo
     if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
     const uint32_t v0 = g * (64u * U) + lane;
     const uint4 *p = x + (size_t)row * vpr;
+    // The scale FIRST: loads return in order, so whoever needs only the scale (the per-row table build) waits for it with
+    // the U data loads still in flight behind it instead of for everything.
+    a = 1.0f;
+    if (!dyn) a = ld_global(alpha + (per_row ? row : 0));
     // Unconditional loads (lanes past the row end re-read the row's last vector and are
     // masked at the store): no exec-mask branches between the loads, so all U of them are
     // in flight together.
 #pragma unroll
     for (int u = 0; u < U; u++) v[u] = ld_stream(p + min(v0 + 64u * u, vpr - 1u));
-    a = 1.0f;
-    if (!dyn) a = ld_global(alpha + (per_row ? row : 0));
 }
 
 // max over aligned groups of g = 1, 2, 4, ... 64 adjacent lanes (g wave-uniform): DPP lane exchanges up to 16 lanes

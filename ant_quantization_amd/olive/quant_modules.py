@@ -168,20 +168,21 @@ class Quantizer(HostMirrorMixin, nn.Module):
         return (quant_tensor - source_tensor).abs().pow(p).mean()
 
     def _three_sigma(self, tensor, per_channel):
-        """OQ:193-197 / :213-218: x_max = max(|mean + 3 std|, |mean - 3 std|) (unbiased std), or the
-        abs-max when outliers are disabled.  O(N) statistics stay in torch (mean / std are the
-        reference's own reductions; they run once per calibration), in the TENSOR'S OWN dtype as the reference
-        computes them (fp16 for its LLM scripts: torch accumulates in fp32 and rounds mean / std to the dtype),
-        without a full-size fp32 copy; only the `rows` results are widened for the kernels."""
+        """OQ:193-197 / :213-218: x_max = max(|mean + 3 std|, |mean - 3 std|) (unbiased std), or the abs-max when
+        outliers are disabled.  The reference runs t.mean() and t.std() -- at least three reads of the tensor before the
+        search reads it again; here ONE read leaves (sum x, sum x^2) in double per row / tensor (antq_moments, fixed
+        summation order) and antq_xmax_3sigma applies the roundings the reference's dtype would (fp32: mean / std to
+        float; fp16 / bf16 as its LLM scripts run: mean, std, 3 * std, sum and difference each rounded to the tensor's
+        dtype).  Agrees with torch's own reductions to their summation-order noise (tests: rtol 2e-6 in fp32)."""
         if self._no_outlier:
             return core.row_absmax(tensor, per_channel)
         t = tensor.detach()
-        if per_channel:
-            t2 = t.reshape(t.shape[0], -1)
-            mean, std = t2.mean(dim=-1), t2.std(dim=-1)
-        else:
-            mean, std = t.mean(), t.std()
-        return torch.maximum((mean + 3 * std).abs(), (mean - 3 * std).abs()).reshape(-1).float()
+        if not t.is_contiguous():
+            t = t.contiguous()
+        rows = t.shape[0] if (per_channel and t.dim() > 0) else 1
+        if t.dtype not in (torch.float32, torch.bfloat16, torch.float16) or t.numel() == 0:
+            raise _lib.AntqError("OliVe calibration: unsupported tensor dtype %s" % t.dtype)
+        return _lib.xmax_3sigma(t, rows, t.numel() // rows, per_row=per_channel)
 
     @torch.no_grad()
     def search_mse(self, tensor):

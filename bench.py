@@ -308,6 +308,10 @@ def main():
         for i in range(args.nbuf):
             _lib.fakequant(xs[i], alphas[i], plan, 10.0, ROWS, COLS, True, out=outs[i])
 
+    def step_per_tensor_unordered():    # the same launches marked independent of their predecessors (weights at rest):
+        for i in range(args.nbuf):      # ANTQ_FLAG_UNORDERED, no barrier bit on the dispatch packet
+            _lib.fakequant(xs[i], alphas[i], plan, 10.0, ROWS, COLS, True, out=outs[i], unordered=True)
+
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def event_time(fn, min_seconds, per_call):
@@ -327,6 +331,7 @@ def main():
     # which is what it takes for an idle MI355X to reach steady clocks (the first ~50 ms of load run
     # up to 20 % slower: tools/probe_clock_ramp.py).
     pt_launch_s = event_time(step_per_tensor, 0.3, 5) / args.nbuf
+    ptu_launch_s = event_time(step_per_tensor_unordered, 0.15, 5) / args.nbuf
 
     # ---- the timed region: HIP events on the launch stream (= torch's current stream) inside the barriers
     elapsed = h.timed(step, args.steps, args.warmup, on_start=ev0.record, on_stop=ev1.record)
@@ -367,14 +372,22 @@ def main():
                    "io_dtype": "bf16", "elements_per_step_per_gpu": args.nbuf * ROWS * COLS,
                    "sharding": "independent tensors per rank, no data-path collective",
                    "idempotence_check": ok,
-                   "per_tensor_launches": {"kernel": "antq::k_fq_lane<bf16,...,U=2,AD> (antq_fakequant, one launch per tensor)",
-                                           "launch_us": round(pt_launch_s * 1e6, 2),
-                                           "gelem_per_s": round(ROWS * COLS / pt_launch_s / 1e9, 1),
-                                           "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9, 1),
-                                           "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}},
+                   "per_tensor_launches": {"what": "the same pass as ONE LAUNCH PER TENSOR (antq_fakequant, the reference's "
+                                                   "granularity), %d independent weight tensors back to back on one stream, "
+                                                   "each launch marked ANTQ_FLAG_UNORDERED (inputs at rest: its dispatch "
+                                                   "packet carries no barrier bit, so it may start while its predecessor "
+                                                   "drains); `ordered` = the same launches without the flag" % args.nbuf,
+                                           "kernel": "antq::k_fq_xrow<bf16,...,U=4,WPB=1> (per-row table, one wavefront per workgroup)",
+                                           "launch_us": round(ptu_launch_s * 1e6, 2),
+                                           "gelem_per_s": round(ROWS * COLS / ptu_launch_s / 1e9, 1),
+                                           "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9, 1),
+                                           "frac": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9 / HBM_PEAK_GBPS, 4),
+                                           "ordered": {"kernel": "antq::k_fq_lane<bf16,...,U=2,AD>",
+                                                       "launch_us": round(pt_launch_s * 1e6, 2),
+                                                       "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": "antq::k_fq_batch<bf16,false>", "launch_us": round(launch_s * 1e6, 2),
+                     "kernel": "antq::k_fq_batch<bf16,false,1>", "launch_us": round(launch_s * 1e6, 2),
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "copy_ceiling": {"antq_copy_GBps": round(algo_bytes / copy_s / 1e9, 1),
                                       "hipMemcpyDtoD_GBps": round(algo_bytes / d2d_s / 1e9, 1),

@@ -135,6 +135,25 @@ def absmax(x2d, per_row=True, ratio=1.0):
     return alpha
 
 
+def three_sigma(x2d, per_row=True):
+    """OliVe's clip statistic (OQ/quant_modules.py:193-197 per channel, :213-218 per tensor):
+    x_max = max(|mean + 3 std|, |mean - 3 std|), std unbiased (torch.std default).  x2d float32, or uint16 holding bf16
+    bits: the reference then computes in the tensor's own dtype -- mean, std, 3 * std, the sum and the difference are each
+    rounded to bf16 (torch's element-wise kernels compute in fp32 and round the result).  Sums in float64 here; torch's
+    fp32 reductions agree to their summation-order noise."""
+    bf16 = x2d.dtype == np.uint16
+    xf = (bf16_to_f32(x2d) if bf16 else np.asarray(x2d, dtype=np.float32)).astype(np.float64)
+    if not per_row:
+        xf = xf.reshape(1, -1)
+    rnd = (lambda v: bf16_to_f32(f32_to_bf16(np.asarray(v, dtype=np.float32)))) if bf16 else (lambda v: np.asarray(v, dtype=np.float32))
+    with np.errstate(all="ignore"):
+        mean = rnd(xf.mean(axis=1).astype(np.float32))
+        std = rnd(xf.std(axis=1, ddof=1).astype(np.float32))
+        t3 = rnd(np.float32(3.0) * std)
+        a, b = np.abs(rnd(mean + t3)), np.abs(rnd(mean - t3))
+    return np.maximum(a, b).astype(np.float32)
+
+
 def mse(q2d, x2d, per_row=True):
     q2d = _f32(q2d)
     x2d = _f32(x2d)

@@ -908,6 +908,48 @@ def test_launch_shapes_and_unordered_launches_are_bit_identical(antq_lib, oracle
         knob(7, 0)
 
 
+def test_olive_three_sigma_statistic_on_one_read(antq_lib, oracle, dev):
+    """antq_moments + antq_xmax_3sigma (OQ:193-197, :213-218): the sums against float64 numpy, x_max against the oracle's
+    restatement and against torch's own mean / std on the GPU (the reference's ops), per row and per tensor, fp32 and
+    bf16, ragged / unaligned rows, a constant row (std 0) and a one-element row (NaN, like torch.std); bit-reproducible."""
+    import torch
+    rng = np.random.default_rng(31)
+    for rows, K in ((64, 4096), (7, 33), (3, 8200), (1, 1), (5, 1), (128, 64)):
+        x = (rng.standard_normal((rows, K)) * 0.05 + 0.01).astype(np.float32)
+        x.reshape(-1)[::37] *= 12
+        if rows > 2 and K > 1:
+            x[2] = 0.75                                     # constant row: std exactly 0
+        for bf16 in (False, True):
+            xh = oracle.f32_to_bf16(x) if bf16 else x
+            xf = (oracle.bf16_to_f32(xh) if bf16 else xh).astype(np.float64)
+            xt = to_dev(xh, dev, bf16)
+            for per_row in (True, False):
+                sums = antq_lib.moments(xt, rows, K, per_row)
+                ref = xf if per_row else xf.reshape(1, -1)
+                np.testing.assert_allclose(sums[:, 0].cpu().numpy(), ref.sum(1), rtol=1e-12, atol=1e-13)
+                np.testing.assert_allclose(sums[:, 1].cpu().numpy(), (ref * ref).sum(1), rtol=1e-12, atol=1e-15)
+                assert torch.equal(sums, antq_lib.moments(xt, rows, K, per_row))          # fixed order: same bits
+                got = antq_lib.xmax_3sigma(xt, rows, K, per_row).cpu().numpy()
+                want = oracle.three_sigma(xh, per_row)
+                t2 = xt.reshape(rows, -1) if per_row else xt.reshape(1, -1)
+                mean, std = t2.mean(dim=-1), t2.std(dim=-1)
+                tor = torch.maximum((mean + 3 * std).abs(), (mean - 3 * std).abs()).float().cpu().numpy()
+                assert got.shape == want.shape == tor.shape
+                nan = np.isnan(want)
+                assert np.array_equal(np.isnan(got), nan) and np.array_equal(np.isnan(tor), nan)
+                assert nan.all() == (ref.shape[1] == 1)                    # one element: unbiased std is 0 / 0
+                tol = 2.0 ** -7 if bf16 else 2e-6            # bf16: one rounding step of the tensor's dtype at most
+                np.testing.assert_allclose(got[~nan], want[~nan], rtol=tol)
+                np.testing.assert_allclose(got[~nan], tor[~nan], rtol=tol, atol=1e-30)
+                if bf16 and (~nan).any():                    # ... and that only where torch's fp32 sum sits on a rounding boundary
+                    assert (got[~nan] == tor[~nan]).mean() >= 0.9
+    # an unaligned view (storage offset 1 element) goes through the element path: same sums
+    base = torch.randn(4097, device=dev)
+    v = base[1:]
+    s1 = antq_lib.moments(v, 1, 4096, False)
+    np.testing.assert_allclose(s1[0, 0].item(), v.double().sum().item(), rtol=1e-12)
+
+
 def _ref_checkpoint(fx, prefixes, dev, strip):
     """The state dict the reference wrote (tests/golden/*_ckpt.npz, keys 'module.'-prefixed as ImageNet/main.py saves a
     DistributedDataParallel model); later prefixes override earlier ones.  strip: drop the 7 characters the way

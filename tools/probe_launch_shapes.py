@@ -50,6 +50,12 @@ for rnd in range(rounds):
         note("batched plain, %d wavefront(s) per workgroup" % w, timed(b_plain.run, 20))
         note("batched OVP,   %d wavefront(s) per workgroup" % w, timed(b_ovp.run, 20))
     knob(6, 0)
+    for u in (2, 1):                       # (the descriptors fix the task size at build time: rebuild the batches)
+        knob(0, u)
+        bu_plain, bu_ovp = batch(False), batch(True)
+        knob(0, 0)
+        note("batched plain, 1 wavefront per workgroup, %d vectors per lane" % u, timed(bu_plain.run, 20))
+        note("batched OVP,   1 wavefront per workgroup, %d vectors per lane" % u, timed(bu_ovp.run, 20))
     # one launch per tensor: (knob 5: 1 default / 0 row-table kernel / 2 lane kernel, knob 6, knob 7)
     for unordered in (False, True):
         for k5, w, u in ((1, 0, 0), (2, 4, 2), (2, 1, 4), (2, 1, 2), (0, 4, 0), (0, 1, 0)):
