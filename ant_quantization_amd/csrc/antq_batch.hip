@@ -71,6 +71,8 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                 if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
                 d.total_tasks = (uint32_t)total;
                 blocks = (total + 3) / 4;
+                // a partial last task + tasks per row sharing a factor with the 8 XCDs: rotate this job's workgroup -> task map
+                d.rot = (d.vpr % (64u * d.u) != 0u && (d.tpr % 2u) == 0u) ? 1u : 0u;
             }
             // (groups of 16 / 32 / 64 vectors: a per-group x-domain table was round 1's answer for bf16 group-128 ... 512; the
             //  lane kernel with the exact per-element decision matches it for 16-bit data -- 75.2-76.7 vs 76.5-77.5 % -- and
@@ -157,6 +159,15 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             for (int i = 0; i < n; i++) fam[(size_t)i] = 0;
         }
     }
+    {
+        // Wavefronts per workgroup of the row-table launch (family 0): 1 when most of its bytes sit in rows of >= 256 vectors
+        // (same-box A/B, bf16: 512 ... 3584-vector rows 80.3-81.0 -> 81.4-82.5 %; rows of 128 vectors 79.3-80.7 -> 78.6 %;
+        // profiles/r03_batch_rotation.log), 4 otherwise.  Stored in bits 8.. of `pad` (bit 0: mixed batch).
+        double long_b = 0.0, short_b = 0.0;
+        for (int i = 0; i < n; i++)
+            if (descs[i].kind == 2) (descs[i].vpr >= 256u ? long_b : short_b) += (double)descs[i].total_tasks * descs[i].u;
+        h.pad |= (long_b >= short_b ? 1u : 4u) << 8;
+    }
     size_t total_blocks = 0;
     for (int i = 0; i < n; i++) {
         descs[i].first_block = (uint32_t)fam_blocks[fam[(size_t)i]];
@@ -204,20 +215,22 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
     } while (0)
 #define ANTQ_LAUNCH_B(TT)                                                                                         \
     do {                                                                                                          \
-        if (h->pad) {      /* mixed static batch: the all-in-one kernel */                                       \
+        if (h->pad & 1u) {      /* mixed static batch: the all-in-one kernel */                                       \
             if (ovp) hipLaunchKernelGGL((k_fq_batch_all<TT, true>), dim3(h->fam_blocks[0]), block, h->lds_bytes, st, descs, fmap[0]);  \
             else hipLaunchKernelGGL((k_fq_batch_all<TT, false>), dim3(h->fam_blocks[0]), block, h->lds_bytes, st, descs, fmap[0]);     \
             break;                                                                                                \
         }                                                                                                         \
         if (h->fam_blocks[0]) {                                                                                   \
-            const int w_ = g_knob_waves == 4 || g_knob_waves == 2 ? g_knob_waves : 1;    /* knob 6 (A/B); default 1 */   \
+            const int hw_ = (int)((h->pad >> 8) & 7u);                                                           \
+            const int w_ = (g_knob_waves == 4 || g_knob_waves == 2 || g_knob_waves == 1) ? g_knob_waves : (hw_ == 1 ? 1 : 4);   \
             const dim3 g_(h->fam_blocks[0] * (4u / w_)), b_(64u * w_);                                           \
-            if (w_ == 1) { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 1>), g_, b_, 0, st, descs, fmap[0]);        \
-                           else hipLaunchKernelGGL((k_fq_batch<TT, false, 1>), g_, b_, 0, st, descs, fmap[0]); }         \
-            else if (w_ == 2) { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 2>), g_, b_, 0, st, descs, fmap[0]);   \
-                           else hipLaunchKernelGGL((k_fq_batch<TT, false, 2>), g_, b_, 0, st, descs, fmap[0]); }         \
-            else { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 4>), g_, b_, 0, st, descs, fmap[0]);                \
-                   else hipLaunchKernelGGL((k_fq_batch<TT, false, 4>), g_, b_, 0, st, descs, fmap[0]); }                 \
+            const uint32_t rot_ = (uint32_t)g_knob_rot;                                                          \
+            if (w_ == 1) { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 1>), g_, b_, 0, st, descs, fmap[0], rot_);        \
+                           else hipLaunchKernelGGL((k_fq_batch<TT, false, 1>), g_, b_, 0, st, descs, fmap[0], rot_); }         \
+            else if (w_ == 2) { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 2>), g_, b_, 0, st, descs, fmap[0], rot_);   \
+                           else hipLaunchKernelGGL((k_fq_batch<TT, false, 2>), g_, b_, 0, st, descs, fmap[0], rot_); }         \
+            else { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 4>), g_, b_, 0, st, descs, fmap[0], rot_);                \
+                   else hipLaunchKernelGGL((k_fq_batch<TT, false, 4>), g_, b_, 0, st, descs, fmap[0], rot_); }                 \
         }                                                                                                         \
         if (h->fam_blocks[1]) { if (ovp) ANTQ_LAUNCH_D(TT, true, true); else ANTQ_LAUNCH_D(TT, false, true); }    \
         if (h->fam_blocks[2]) { if (ovp) ANTQ_LAUNCH_D(TT, true, false); else ANTQ_LAUNCH_D(TT, false, false); }  \

@@ -27,6 +27,7 @@ extern thread_local int g_knob_nearest_fast;  // 0: antq_nearest always runs the
 extern thread_local int g_knob_lane_rows;     // 0: rows of a power of two of vectors through the per-row table kernels (A/B)
 extern thread_local int g_knob_a;             // 0 disables the approximate-quotient element path (quant_vec_a): exact division
 extern thread_local int g_knob_waves;         // wavefronts per workgroup of the streaming kernels: 0 = the measured default, 1 / 2 / 4 (A/B)
+extern thread_local int g_knob_rot;            // 1: rotate the workgroup -> task map of the batched row kernel per group of 8 (XCD balance)
 extern thread_local int g_knob_lane_u;        // vectors per lane of the one-launch-per-tensor lane kernel: 0 = default (A/B)
 
 static inline bool plan_args_from_host(const void *plan_host, PlanArgs &pa)

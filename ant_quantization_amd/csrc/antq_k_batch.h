@@ -10,7 +10,7 @@ namespace antq {
 constexpr uint32_t kBatchMagic = 0x32544E41u;  // "ANT2"
 constexpr int kBatchU = 4;                      // vectors per lane per task (4 KiB per wavefront: best measured)
 
-struct BatchDesc {   // 152 bytes, device-visible
+struct BatchDesc {   // 160 bytes, device-visible
     const uint4 *x;
     uint4 *out;
     const float *alpha;    // ANTQ_FLAG_DYNAMIC: an OUTPUT
@@ -34,8 +34,14 @@ struct BatchDesc {   // 152 bytes, device-visible
     float ratio;           // ANTQ_FLAG_DYNAMIC: alpha = max|row| * ratio
     uint32_t u;            // x-domain row kinds (2, 4): vectors per lane and task, 2 / 3 / 4 -- the value that leaves the fewest
                            // idle lanes for this row length (rows of 128 vectors: 2; ResNet's 3x3 rows of 144 / 288 / 576: 3)
+    uint32_t rot;          // x-domain rows, one- / two-wavefront workgroups: rotate the workgroup -> task map of every group of 8
+                           // workgroups by the group's number.  Workgroup b runs on XCD b % 8; when a row's last task is a
+                           // partial one and the tasks per row share a factor with 8, task fullness would line up with the XCD
+                           // number (4096 x 2048 bf16 in 192-vector tasks: 71 % instead of 81 %).  Only set for such jobs:
+                           // full tasks stream 1-4 points better on the fixed map (profiles/r03_batch_rotation.log)
+    uint32_t pad_;
 };
-static_assert(sizeof(BatchDesc) == 152, "BatchDesc must be 152 bytes");
+static_assert(sizeof(BatchDesc) == 160, "BatchDesc must be 160 bytes");
 
 // A batch is up to four launches, one per kernel FAMILY, so that no kernel carries the registers of code paths its
 // jobs never take (the headline x-domain row kernel keeps its 80 VGPRs whatever else a batch may contain):
@@ -81,10 +87,22 @@ __device__ __forceinline__ XArgs xargs_of(const BatchDesc &D)
 // of 8 TB/s on two boxes with 64-thread workgroups, profiles/r03_stream_shapes_*.log).
 template <typename T, bool OVP, int WAVES = 4>
 __global__ void __launch_bounds__(64 * WAVES, OVP ? ANTQ_OVP_WAVES : ANTQ_PLAIN_WAVES)
-k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
+k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map, uint32_t rotate)
 {
     constexpr uint32_t SPLIT = 4u / WAVES;                  // workgroups per map entry
-    const uint32_t b4 = blockIdx.x / SPLIT, sub = blockIdx.x % SPLIT;
+    // Workgroup b runs on XCD b % 8.  When a row's last task is a partial one and the tasks per row divide 8 (or share a
+    // factor with it), task "fullness" would line up with the XCD number -- half the XCDs get the full tasks, the others
+    // the nearly empty ones (measured: 4096 x 2048 bf16 in 192-vector tasks 71 % instead of 82 %).  Rotating the eight
+    // workgroups of every group of eight by the group's number keeps each group on the same eight tasks (same locality)
+    // and gives every XCD every residue in turn.
+    uint32_t blk = blockIdx.x;
+    if (WAVES < 4) {
+        const uint32_t g8 = blk >> 3;
+        // (the decision belongs to the GROUP -- all eight of its workgroups must take the same one: the job of its first task)
+        if ((g8 << 3) + 8u <= gridDim.x && (rotate == 1u || (rotate == 0u && descs[block_map[(g8 << 3) / SPLIT]].rot)))
+            blk = (g8 << 3) + ((blk + g8) & 7u);
+    }
+    const uint32_t b4 = blk / SPLIT, sub = blk % SPLIT;
     const uint32_t j = block_map[b4];
     const BatchDesc &D = descs[j];
     const uint32_t lb = b4 - D.first_block;

@@ -36,6 +36,7 @@ thread_local int g_knob_lane_rows = 1;
 thread_local int g_knob_a = 1;
 thread_local int g_knob_waves = 0;
 thread_local int g_knob_lane_u = 0;
+thread_local int g_knob_rot = 0;
 
 }  // namespace antq
 
@@ -208,6 +209,7 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 5) g_knob_lane_rows = value;
     else if (key == 6) g_knob_waves = value;
     else if (key == 7) g_knob_lane_u = value;
+    else if (key == 8) g_knob_rot = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }

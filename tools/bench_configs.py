@@ -204,6 +204,8 @@ def main():
         outs = [torch.empty_like(w) for w in ws]
         report("C3 OPT-6.7B W (%d tensors), OliVe flint4 OVP, %s" % (len(ws), str(dt)[6:]), elems, bpe,
                timed(lambda: [_lib.fakequant(w, a, pol, 32.0, w.shape[0], w.shape[1], True, ovp=True, out=o) for w, a, o in zip(ws, al, outs)], 5), len(ws))
+        report("C3 the same, launches marked UNORDERED (weights at rest)", elems, bpe,
+               timed(lambda: [_lib.fakequant(w, a, pol, 32.0, w.shape[0], w.shape[1], True, ovp=True, out=o, unordered=True) for w, a, o in zip(ws, al, outs)], 5), len(ws))
         bt = _lib.Batch([(w, o, a, pol, 32.0, w.shape[0], w.shape[1], True) for w, a, o in zip(ws, al, outs)], ovp=True)
         report("C3 OPT-6.7B W (%d tensors), OliVe flint4 OVP, %s, BATCHED" % (len(ws), str(dt)[6:]), elems, bpe,
                timed(bt.run, 5), 1)
@@ -229,6 +231,8 @@ def main():
            elems, 4, timed(bt.run, 5), 1)
     report("C4 same share, one launch per tensor", elems, 4,
            timed(lambda: [_lib.fakequant(w, a, pol, 32.0, w.shape[0], w.shape[1], True, ovp=True, out=o) for w, a, o in zip(ws, al, outs)], 3), len(ws))
+    report("C4 same share, one launch per tensor, UNORDERED", elems, 4,
+           timed(lambda: [_lib.fakequant(w, a, pol, 32.0, w.shape[0], w.shape[1], True, ovp=True, out=o, unordered=True) for w, a, o in zip(ws, al, outs)], 3), len(ws))
     del ws, outs, al, bt
     torch.cuda.empty_cache()
 
@@ -240,6 +244,8 @@ def main():
         outs = [torch.empty_like(x) for x in xs]
         report("headline 4096x4096 %s flint4 per-row (static)" % str(dt)[6:], nb * 4096 * 4096, bpe,
                timed(lambda: [_lib.fakequant(x, a, plan, 10.0, 4096, 4096, True, out=o) for x, a, o in zip(xs, al, outs)], 10), nb)
+        report("headline 4096x4096 %s flint4 per-row (static), UNORDERED launches" % str(dt)[6:], nb * 4096 * 4096, bpe,
+               timed(lambda: [_lib.fakequant(x, a, plan, 10.0, 4096, 4096, True, out=o, unordered=True) for x, a, o in zip(xs, al, outs)], 10), nb)
         report("headline 4096x4096 %s flint4 per-row (dynamic abs-max)" % str(dt)[6:], nb * 4096 * 4096, bpe,
                timed(lambda: [_lib.fakequant_dynamic(x, plan, 10.0, 4096, 4096, out=o, want_alpha=False) for x, o in zip(xs, outs)], 10), nb)
         bt = _lib.Batch([(x, o, a, plan, 10.0, 4096, 4096, True) for x, a, o in zip(xs, al, outs)])
