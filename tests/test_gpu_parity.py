@@ -2076,6 +2076,107 @@ def test_bench_workload_batched_kernel_vs_oracle(antq_lib, oracle, dev):
         antq_lib.lib().antq_debug_set(5, 1)
 
 
+def _resnet50_weight_shapes():
+    s = [(64, 3, 7, 7)]
+    inp = 64
+    for planes, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
+        for b in range(blocks):
+            s += [(planes, inp, 1, 1), (planes, planes, 3, 3), (planes * 4, planes, 1, 1)]
+            if b == 0:
+                s.append((planes * 4, inp, 1, 1))
+            inp = planes * 4
+    s.append((1000, 2048))
+    return s
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_c1_resnet50_all_weight_tensors_sampled_against_the_oracle(antq_lib, oracle, dev, bf16):
+    """configs[1] at its real size against the ORACLE (not against another HIP launch): all 54 ResNet-50 weight tensors
+    (randn * sqrt(2 / fan_out), seed 1), signed flint-4, alpha = abs-max, (a) per output channel -- the
+    reference's grouping -- and (b) groups of 16 on the flattened tensor, each as ONE batched launch; >= 64 rows / groups
+    of every tensor (all of them when it has fewer) are compared with oracle.forward bit for bit, the rest of the batched
+    output with the per-tensor launches."""
+    import torch
+    from ant_quantization_amd import grids
+    g = grids.ant_flint(4, True)
+    plan = antq_lib.plan_for(g)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    ws = []
+    for sh in _resnet50_weight_shapes():
+        fan_out = sh[0] * int(np.prod(sh[2:], dtype=np.int64))
+        w = torch.randn(*sh, device=dev, generator=gen) * float(np.sqrt(2.0 / fan_out))
+        ws.append(w.to(torch.bfloat16) if bf16 else w)
+    assert len(ws) == 54
+    rng = np.random.default_rng(101)
+    for group in (None, 16):
+        views = [w.reshape(w.shape[0], -1) if group is None else w.reshape(-1, group) for w in ws]
+        alphas = [antq_lib.absmax(v, v.shape[0], v.shape[1], per_row=True) for v in views]
+        outs = [torch.empty_like(v) for v in views]
+        bt = antq_lib.Batch([(v, o, a, plan, 10.0, v.shape[0], v.shape[1], True) for v, o, a in zip(views, outs, alphas)])
+        bt.run()
+        n_checked = 0
+        for v, o, a in zip(views, outs, alphas):
+            R = v.shape[0]
+            rows = np.arange(R) if R <= 256 else np.unique(np.concatenate([[0, 1, R - 2, R - 1], rng.choice(R, 96, replace=False)]))
+            rt = torch.from_numpy(rows).to(dev)
+            xa = bf16_bits(v[rt]) if bf16 else v[rt].cpu().numpy()
+            an = a[rt].cpu().numpy()
+            xf = oracle.bf16_to_f32(xa) if bf16 else xa
+            assert np.array_equal(an, oracle.absmax(xf, True, 1.0))
+            ref, _ = oracle.forward(xa, an, g, 10.0, False)
+            got = o[rt]
+            ok = bf16_same(bf16_bits(got), ref, oracle) if bf16 else f32_same(got.cpu().numpy(), ref)
+            assert ok, (tuple(v.shape), group)
+            assert rows.size >= min(R, 64)
+            n_checked += rows.size
+            o1 = antq_lib.fakequant(v, a, plan, 10.0, v.shape[0], v.shape[1], True)
+            assert torch.equal(o1.view(torch.int16) if bf16 else o1.view(torch.int32), o.view(torch.int16) if bf16 else o.view(torch.int32))
+        assert n_checked >= 54 * 64
+
+
+@pytest.mark.parametrize("shape", [(16384, 4096), (4096, 16384), (4096, 4096)])
+def test_c3_opt67b_weight_shapes_static_ovp_sampled_against_the_oracle(antq_lib, oracle, dev, shape):
+    """configs[3] at its real sizes against the ORACLE: the three OPT-6.7B weight shapes (randn * 0.02 with
+    0.1 % of the entries multiplied by U(8, 64), seed 4), OliVe flint-4 + outlier codebook with the outlier-victim pair
+    rule, STATIC alpha = the 3-sigma statistic (antq_xmax_3sigma, compared with the oracle's restatement), bf16 and fp32:
+    batched launch, ordinary and unordered per-tensor launches; 96 rows of each against oracle.forward (values and -- per
+    tensor -- indices incl. victims), everything else against the per-tensor launch."""
+    import torch
+    O = golden("olive_grids.npz")
+    gn, go = O["flint_b4_s"], O["outlier_b4_s"]
+    gg, gmax = np.concatenate([gn, go]), float(gn.max())
+    plan = antq_lib.plan_for(gg)
+    R, K = shape
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4)
+    w32 = torch.randn(R, K, device=dev, generator=gen) * 0.02
+    m = torch.rand(R, K, device=dev, generator=gen) < 0.001
+    w32[m] *= torch.empty(int(m.sum()), device=dev).uniform_(8, 64, generator=gen)
+    rng = np.random.default_rng(104)
+    for bf16 in (True, False):
+        w = w32.to(torch.bfloat16) if bf16 else w32
+        alpha = antq_lib.xmax_3sigma(w, R, K, per_row=True)
+        rows = np.unique(np.concatenate([[0, 1, R - 2, R - 1], rng.choice(R, 96, replace=False)]))
+        rt = torch.from_numpy(rows).to(dev)
+        xa = bf16_bits(w[rt]) if bf16 else w[rt].cpu().numpy()
+        an = alpha[rt].cpu().numpy()
+        np.testing.assert_allclose(an, oracle.three_sigma(xa, True), rtol=2.0 ** -7 if bf16 else 2e-6)
+        ref, ridx = oracle.forward(xa, an, gg, gmax, True)
+        assert (ridx == oracle.IDX_VICTIM).any() and (ridx >= gn.size).any()
+        out_b = torch.empty_like(w)
+        antq_lib.Batch([(w, out_b, alpha, plan, gmax, R, K, True)], ovp=True).run()
+        o1, idx = antq_lib.fakequant(w, alpha, plan, gmax, R, K, True, ovp=True, want_idx=True)
+        o2 = antq_lib.fakequant(w, alpha, plan, gmax, R, K, True, ovp=True)
+        o3 = antq_lib.fakequant(w, alpha, plan, gmax, R, K, True, ovp=True, unordered=True)
+        for o in (out_b, o1, o2, o3):
+            ok = bf16_same(bf16_bits(o[rt]), ref, oracle) if bf16 else f32_same(o[rt].cpu().numpy(), ref)
+            assert ok, (shape, bf16)
+        assert np.array_equal(idx[rt].cpu().numpy().astype(np.int32), ridx)
+        iv = (lambda t: t.view(torch.int16)) if bf16 else (lambda t: t.view(torch.int32))
+        assert torch.equal(iv(out_b), iv(o2)) and torch.equal(iv(o1), iv(o2)) and torch.equal(iv(o3), iv(o2))
+
+
 def test_bert_base_real_shapes_weights_and_activations(antq_lib, oracle, dev, capsys):
     """C2 at its real sizes: the 74 nn.Linear weights of BERT-base (49 x [768,768] incl. the pooler,
     12 x [3072,768], 12 x [768,3072], the [2,768] classifier; randn * 0.02, seed 2) calibrated with `ant-int-pot-flint`
