@@ -28,7 +28,7 @@ PLAN_MAX_BYTES = 96 + 4 * MAX_GRID + 16 * 3072 + 20 * 1024
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.float64: F64}
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()        # (re-entrant: ext() loads the library under it)
 
 
 class AntqError(RuntimeError):
@@ -69,6 +69,35 @@ def lib():
                 L.antq_copy.argtypes = [vp, vp, sz, vp]
                 _lib = L
     return _lib
+
+
+_ext_mod = False          # False: not tried yet; None: unavailable
+
+
+def ext():
+    """The compiled torch extension (csrc/antq_torch.cpp -> _antq_ext*.so: the counterpart of the reference's pybind11
+    `quant_cuda` module plus compiled fast paths of the fused entry points), or None: not built, switched off with
+    ANTQ_NO_EXT=1, or ANTQ_LIB points at another library build (the extension is linked against the in-tree one).  Every
+    caller falls back to the ctypes binding of the same C ABI -- same kernels, ~4 us more host time per call."""
+    global _ext_mod
+    if _ext_mod is False:
+        with _lock:
+            if _ext_mod is False:
+                mod = None
+                if os.environ.get("ANTQ_NO_EXT") != "1" and not os.environ.get("ANTQ_LIB"):
+                    lib()                                   # the library first: ONE libantq / libamdhip64 in the process
+                    try:
+                        from . import _antq_ext as mod
+                    except ImportError:
+                        try:
+                            import importlib
+                            mod = importlib.import_module("ant_quantization_amd._antq_ext")
+                        except ImportError:
+                            mod = None
+                    if mod is not None and mod.abi_version() != ABI_VERSION:
+                        mod = None
+                _ext_mod = mod
+    return _ext_mod
 
 
 def _check(rc, what):
@@ -143,6 +172,7 @@ class Plan:
         self.host_addr = self.host.ctypes.data          # stays valid: self.host is never reallocated
         self.kind = int(lib().antq_plan_kind(self.host.ctypes.data_as(ctypes.c_void_p)))
         self._dev = {}
+        self._dev_ptr = {}       # device index -> address of the device copy (the extension's fast path)
 
     @property
     def is_table(self):
@@ -157,6 +187,7 @@ class Plan:
         if t is None:
             t = torch.from_numpy(self.host).to(device)
             self._dev[key] = t
+            self._dev_ptr[key] = t.data_ptr()
         return t
 
     def eval_host(self, d):
@@ -258,6 +289,21 @@ def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=
     """Fused Quantizer._forward on a contiguous tensor viewed as [rows, row_len].
     unordered: the caller promises that x / alpha are not produced by work still in flight on the stream (weights at rest);
     the launch may then overlap the tail of the launches queued before it (ANTQ_FLAG_UNORDERED)."""
+    flags = (FLAG_OVP if ovp else 0) | (FLAG_UNORDERED if unordered else 0)
+    e = _ext_mod
+    if e is False:
+        e = ext()
+    if e is not None:
+        # the compiled path: every check below is made by the extension as well (TORCH_CHECK -> AntqError)
+        pd = plan._dev_ptr.get(x.device.index)
+        if pd is None:
+            if not x.is_cuda:
+                raise AntqError("x must live on a HIP device (got %s); libantq has no CPU path" % x.device)
+            pd = plan.dev(x.device).data_ptr()
+        try:
+            return e.fakequant(x, alpha, plan.host_addr, pd, gmax, rows, row_len, per_row, flags, out, want_idx)
+        except RuntimeError as err:
+            raise AntqError(str(err).split("\n")[0]) from None
     _require_gpu(x, "x")
     _require_gpu(alpha, "alpha")
     dt = _DTYPES.get(x.dtype)
@@ -269,14 +315,13 @@ def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=
         raise AntqError("rows*row_len != numel")
     if alpha.numel() != (rows if per_row else 1):
         raise AntqError("alpha has %d entries, expected %d" % (alpha.numel(), rows if per_row else 1))
+    pd = plan.dev(x.device)
     if out is None:
         out = torch.empty_like(x)
     idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
-    pd = plan.dev(x.device)
     with _on_device(x.device):
         rc = lib().antq_fakequant(x.data_ptr(), out.data_ptr(), _ptr(idx), rows, row_len, alpha.data_ptr(),
-                                  1 if per_row else 0, gmax, plan.host_addr, pd.data_ptr(),
-                                  (FLAG_OVP if ovp else 0) | (FLAG_UNORDERED if unordered else 0), dt,
+                                  1 if per_row else 0, gmax, plan.host_addr, pd.data_ptr(), flags, dt,
                                   _stream_int(x.device))
     if rc:
         _check(rc, "antq_fakequant")
@@ -569,7 +614,10 @@ class Batch:
             self.dev = torch.from_numpy(self.host).to(self.device)
 
     def run(self):
-        if self.host is not None:
+        e = _ext_mod if _ext_mod is not False else ext()
+        if self.host is not None and e is not None:
+            e.batch_run(self.host.ctypes.data, self.dev)
+        elif self.host is not None:
             with _on_device(self.device):
                 rc = lib().antq_fakequant_batch(ctypes.c_void_p(self.host.ctypes.data), ctypes.c_void_p(self.dev.data_ptr()),
                                                 ctypes.c_void_p(_stream_int(self.device)))
