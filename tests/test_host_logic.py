@@ -471,7 +471,8 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
             return n, None
         assert n <= cap
         h = host[:56].view(np.uint32)
-        total, fam, mixed = int(h[7]), [int(v) for v in h[8:13]], int(h[13])
+        total, fam, mixed, waves = int(h[7]), [int(v) for v in h[8:13]], int(h[13]) & 1, (int(h[13]) >> 8) & 7
+        assert waves in (1, 4)          # wavefronts per workgroup the row-table launch will use (bits 8.. of the last word)
         assert sum(fam) == total and int(h[6]) == n == int(h[5]) + 4 * total
         bmap = host[int(h[5]):n].view(np.uint32)
         descs = []
