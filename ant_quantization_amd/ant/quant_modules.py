@@ -100,6 +100,9 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._grid_key = None
         self._searched = False    # the last search_mse had at least one candidate
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
+        self.weights_at_rest = False   # opt-in (quant_utils.set_weights_at_rest): this WEIGHT quantiser's tensor and alpha are
+                                       # not written by anything still in flight when forward runs (inference on frozen
+                                       # weights), so its launch may start while earlier work on the stream drains
         self._type_search = None  # during one calibration: grid bytes -> clip search result of the type selection's pass
 
     # ---------------------------------------------------------------- bookkeeping
@@ -353,7 +356,8 @@ class Quantizer(HostMirrorMixin, nn.Module):
     def _forward(self, data):
         """AQ:535-551 as one fused kernel."""
         plan = self._ensure_plan()
-        return core.fake_quant(data, self.alpha, plan, self._gmax, self.is_perchannel)
+        return core.fake_quant(data, self.alpha, plan, self._gmax, self.is_perchannel,
+                               unordered=self.weights_at_rest and not self.is_input)
 
     def tensor_forward(self, tensor, input_tensor=None):
         if self.mode == "base":

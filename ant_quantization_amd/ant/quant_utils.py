@@ -4,8 +4,8 @@ import os  # noqa: F401
 
 import torch  # noqa: F401
 
-from .._utils import (get_ckpt_filename, get_ckpt_path, get_model, logger, make_walkers,  # noqa: F401
-                      set_util_logging, tag_info)
+from .._utils import (get_ckpt_filename, get_ckpt_path, get_model, logger, make_set_weights_at_rest,  # noqa: F401
+                      make_walkers, set_util_logging, tag_info)
 from .quant_modules import Quantizer as Q
 
 quant_args = {}
@@ -17,3 +17,4 @@ def set_quantizer(args):
 
 
 disable_input_quantization, enable_quantization, disable_quantization = make_walkers(Q)
+set_weights_at_rest = make_set_weights_at_rest(Q)       # ours, opt-in: unordered launches for frozen weights

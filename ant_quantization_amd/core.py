@@ -54,14 +54,17 @@ class FakeQuantSTE(torch.autograd.Function):
         return gx, ga, None, None, None, None
 
 
-def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False):
-    """Steady-state Quantizer._forward.  Uses autograd only when a gradient is wanted."""
+def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False, unordered=False):
+    """Steady-state Quantizer._forward.  Uses autograd only when a gradient is wanted.
+    unordered (inference only): x and alpha are at rest -- nothing still in flight on the stream writes them -- so the
+    launch may overlap the tail of the launches queued before it (ANTQ_FLAG_UNORDERED; see Quantizer.weights_at_rest)."""
     if torch.is_grad_enabled() and (x.requires_grad or alpha.requires_grad):
         return FakeQuantSTE.apply(x, alpha, plan, gmax, per_channel, ovp)
     xc = x.detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)
     a = alpha.detach().reshape(-1).to(torch.float32).contiguous()
-    return _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp)
+    return _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp,
+                          unordered=unordered and xc.data_ptr() == x.data_ptr())
 
 
 def clip_search(x, x_max, per_channel, lo, hi, step, plan, gmax, ovp=False):

@@ -182,6 +182,135 @@ k_encode4(const void *__restrict__ x, uint32_t *__restrict__ codes, size_t n_oct
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Row-table encoder (round 3): rows of >= 128 vectors with an x-domain plan (every ANT / OliVe 4-bit codebook).  The exact-
+// decision encoder above spends ~23 instructions per element (f64 decision, per-octet scale, table of 16-byte entries with
+// 42 % bank conflicts) and is VALU-bound at 46-50 % of HBM for bf16.  Here a wavefront owns a task of ONE row, as in
+// k_fq_xrow: lane b moves threshold T_b into the x domain once (x_threshold) and stores {U_b, code_lo | code_hi << 16} --
+// an 8-byte slot, the codes already mapped (outlier -> index in the outlier list, bit 8 = the pair rule's outlier test) --
+// into a wave-private table; per element: slot from x * rcp(s), one ds_read_b64, one compare, one SDWA select of the
+// 16-bit half.  No division, no f64, no dequantised value.  One wavefront per workgroup, no barrier.
+// fp32: a lane's vector is half an octet; the two halves of an octet sit in adjacent lanes and meet through one DPP move.
+// ------------------------------------------------------------------------------------
+// (x >= u) ? w >> 16 : w & 0xffff -- compare + one SDWA select that reads the 16-bit half directly (no shift, no mask)
+__device__ __forceinline__ uint32_t select_half_ge(uint32_t w, float x, float u)
+{
+    uint32_t r;
+    asm("v_cmp_ge_f32 vcc, %1, %2\n\t"
+        "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+        : "=v"(r) : "v"(x), "v"(u), "v"(w) : "vcc");
+    return r;
+}
+
+template <bool OVP>
+__device__ __forceinline__ uint32_t pack_codes4(uint32_t (&c)[4])          // 4 codes (2 pairs) -> 16 bits of nibbles
+{
+    uint32_t pr[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        uint32_t c0 = c[2 * p], c1 = c[2 * p + 1];
+        if (OVP) {
+            const bool me = c0 >= kOutlierBit, mo = c1 >= kOutlierBit;
+            const bool ve = mo && !me;
+            c0 = ve ? 15u : c0;
+            c1 = me ? 15u : c1;
+        }
+        pr[p] = ((c1 & 15u) << 4) | (c0 & 15u);
+    }
+    return pr[0] | (pr[1] << 8);
+}
+
+template <typename T, bool OVP, int U>
+__global__ void __launch_bounds__(64)
+k_encode4_xrow(const uint4 *__restrict__ x, uint32_t *__restrict__ codes, uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
+               const float *__restrict__ alpha, int per_row, float gmax, XArgs xa, const uint4 *__restrict__ entries,
+               const float *__restrict__ grid, int n_normal, int zero_code, float flim)
+{
+    constexpr int EPL = IO<T>::EPL;
+    __shared__ __attribute__((aligned(16))) uint2 wtab[256];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t task = blockIdx.x;
+    if (task >= total_tasks) return;
+    const uint4 none = make_uint4(f2u(__builtin_inff()), 0u, 0u, 0u);
+    const bool two = xa.n_entries > 64u;
+    uint4 ent = ld_global(entries + min(lane, xa.n_entries - 1u)), ent2 = none;
+    if (two) ent2 = ld_global(entries + min(lane + 64u, xa.n_entries - 1u));
+    uint4 v[U];
+    float a;
+    task_load<T, U>(x, alpha, per_row, task, vpr, tpr, lane, false, v, a);
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane >= xa.n_entries) ent = none;
+    if (lane + 64u >= xa.n_entries) ent2 = none;
+    uint32_t row = task, g = 0;
+    if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+    const uint32_t v0 = g * (64u * U) + lane;
+    const size_t base = (size_t)row * vpr + v0;
+    const Scale sc = make_scale(a, gmax);
+    const bool rowfast = sc.ok && (sc.s > 0.0f);
+    {
+        // the wave-private code table: thresholds into the x domain, the two indices of an entry as final codes
+        const uint32_t nbp = xa.n_entries - xa.nbneg;
+        const bool lin = xa.linear != 0u;
+        auto put = [&](uint32_t i, const uint4 &e) {
+            bool ok = true;
+            float Ux = u2f(e.x);
+            if (rowfast && i < xa.n_entries && Ux < __builtin_inff()) Ux = x_threshold(Ux, sc.s, sc.rs, ok);
+            const uint32_t cl = code_of<OVP>(e.w & kIdxMask, u2f(e.y), n_normal), ch = code_of<OVP>((e.w >> 16) & kIdxMask, u2f(e.z), n_normal);
+            const uint2 w = make_uint2(f2u(Ux), cl | (ch << 16));
+            if (i < xa.n_entries) wtab[lin ? i : (i < nbp ? 2u * i : 2u * (i - nbp) + 1u)] = w;
+            return w;
+        };
+        const uint2 w0 = put(lane, ent);
+        if (!lin && xa.nbneg == 0u && lane == 0u) wtab[1] = w0;
+        if (two) put(lane + 64u, ent2);
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+    }
+    const char *t0 = reinterpret_cast<const char *>(wtab) - (xa.linear ? 0 : ((int32_t)xa.kmin << 4));
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        float xf[EPL];
+        IO<T>::unpack(v[u], xf);
+        uint32_t c[EPL];
+        bool fast = rowfast;
+        float dt[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            dt[e] = xf[e] * sc.rs;
+            // (codes only need the table's DECISION, which holds over its whole domain -- not just below xlim, where the
+            //  straight-through arithmetic of the dequantised value is exact too: clipped elements stay on this path)
+            fast = fast && (fabsf(dt[e]) < flim);
+        }
+        if (fast) {
+            uint32_t slots[EPL];
+            x_slots<EPL>(xa, dt, slots);
+            uint2 ents[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; e++) ents[e] = *reinterpret_cast<const uint2 *>(t0 + (slots[e] << 3));
+#pragma unroll
+            for (int e = 0; e < EPL; e++) c[e] = select_half_ge(ents[e].y, xf[e], u2f(ents[e].x));
+        } else {
+            // clipped far beyond the grid, NaN / Inf, or a scale outside the table path's range: the literal sequence
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                int jj;
+                const float q = scan_lds(xf[e] / sc.s, grid, (int)xa.m, jj);
+                c[e] = jj == ANTQ_IDX_NONE ? (uint32_t)zero_code : code_of<OVP>((uint32_t)jj, q, n_normal);
+            }
+        }
+        const bool live = v0 + 64u * u < vpr;
+        if constexpr (EPL == 8) {
+            const uint32_t word = pack_codes<OVP>(c);
+            if (live) __builtin_nontemporal_store(word, codes + base + 64u * u);
+        } else {
+            const uint32_t half = pack_codes4<OVP>(c);
+            const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)half, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+            // vectors 2k / 2k + 1 of the tensor are octet k: the even lane stores both halves (vpr even: row_len % 8 == 0)
+            if (live && (lane & 1u) == 0u) __builtin_nontemporal_store(half | (other << 16), codes + ((base + 64u * u) >> 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Decoder.  VEC: one 16-byte vector of output per thread and access (EPL = 4 fp32 / 8 bf16 elements = 2 / 4 bytes of
 // codes), 4 in flight: every store instruction of a wavefront covers 1 KiB contiguous.  Otherwise 8 elements per thread
 // with element stores.
@@ -261,6 +390,30 @@ static int launch_codec(bool enc, const void *x, void *codes_or_out, const uint8
     int zero_code = 0;
     for (int i = 0; i < (ovp ? n_normal : m); i++) if (grid_host[i] == 0.0f) zero_code = i;
     const dim3 gd((unsigned)blocks), bd(256);
+    if (enc && vec && g_knob_x != 0 && g_knob_lane_rows != 2) {
+        // rows of >= 128 vectors with an x-domain plan: the row-table encoder (knob 2 = 0 or knob 5 = 2: the element encoder, A/B)
+        const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
+        const size_t rl = per_row ? row_len : n;
+        const size_t vpr = rl / IO<T>::EPL;
+        if (pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr && vpr <= 0xffffffffull && rl % 8 == 0) {
+            const uint32_t U = 2;
+            const size_t tpr = (vpr + 64 * U - 1) / (64 * U), total = (per_row ? rows : 1) * tpr;
+            if (total <= 0x7fffffffull) {
+                XArgs xa;
+                xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+                xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
+                xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+                const uint4 *tab = plan_tab_ptr(plan_dev);
+#define ANTQ_ENCX(O) hipLaunchKernelGGL((k_encode4_xrow<T, O, 2>), dim3((unsigned)total), dim3(64), 0, st, static_cast<const uint4 *>(x),    \
+                                        static_cast<uint32_t *>(codes_or_out), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, \
+                                        gmax, xa, tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(tab), n_normal, zero_code,    \
+                                        pa.fastlim * 0.99999f)
+                if (ovp) ANTQ_ENCX(true); else ANTQ_ENCX(false);
+#undef ANTQ_ENCX
+                return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+            }
+        }
+    }
     if (enc) {
         const size_t lds = lds_table(pa, true);
         uint32_t *codes = static_cast<uint32_t *>(codes_or_out);

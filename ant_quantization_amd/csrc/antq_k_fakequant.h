@@ -227,6 +227,43 @@ __device__ __forceinline__ float x_threshold(float T, float s, float rs, bool &o
     return take ? xf : f_up(xf);
 }
 
+// Slot of the per-row table for EPL approximate quotients dt = x * rcp(s) (all |dt| < xlim).
+//   slot = 2 * clamp(key) + sign: positive and negative buckets interleaved, so that the sign costs one v_alignbit and the
+//   clamp one v_med3 (an unsigned grid keeps a negative key: it clamps to kmin, slot 1); linear-key plans: the bucket number.
+// (slots of a float-bits table are 2 * kmin too high: the caller folds that into the table's base address)
+template <int EPL>
+__device__ __forceinline__ void x_slots(const XArgs &xa, const float (&dt)[EPL], uint32_t (&slots)[EPL])
+{
+    const uint32_t sh = xa.shift, wd = 31u - xa.shift;
+    const bool mag = xa.keymask != 0xffffffffu;     // key = magnitude bits [shift, 31) (v_bfe_u32); unsigned grid: arithmetic shift
+    const int32_t lo = (int32_t)xa.kmin, hi = (int32_t)xa.kmax;
+    const bool lin = xa.linear != 0u;               // wave-uniform
+    const float khi = (float)xa.kmax;
+    if (lin) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++)
+            slots[e] = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(dt[e], xa.lin_scale, xa.lin_bias), 0.0f, khi);
+    } else if (mag) {                                 // (a branch per loop, not a select per element)
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const uint32_t u = f2u(dt[e]);
+            const int32_t t = (int32_t)__builtin_amdgcn_ubfe(u, sh, wd);
+            int32_t ck;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+            slots[e] = __builtin_amdgcn_alignbit((uint32_t)ck, u, 31);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int32_t u = (int32_t)f2u(dt[e]);
+            const int32_t t = u >> sh;
+            int32_t ck;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
+            slots[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);
+        }
+    }
+}
+
 template <int EPL, bool OVP, bool IDX>
 __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, const float *__restrict__ grid,
                                             const Scale &sc, bool rowfast, const float (&x)[EPL], float (&o)[EPL],
@@ -240,40 +277,12 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
         fast = fast && (fabsf(dt[e]) < xa.xlim);
     }
     if (fast) {
-        // slot = 2 * clamp(key) + sign: positive and negative buckets interleaved, so that the sign costs one
-        // v_alignbit and the clamp one v_med3 (an unsigned grid keeps a negative key: it clamps to kmin, slot 1)
-        const uint32_t sh = xa.shift, wd = 31u - xa.shift;
-        const bool mag = xa.keymask != 0xffffffffu;     // key = magnitude bits [shift, 31) (v_bfe_u32); unsigned grid: arithmetic shift
-        const int32_t lo = (int32_t)xa.kmin, hi = (int32_t)xa.kmax;
         const bool lin = xa.linear != 0u;               // wave-uniform
-        const char *t0 = reinterpret_cast<const char *>(wtab) - (lin ? 0 : (lo << 5));
-        const float khi = (float)xa.kmax;
+        const char *t0 = reinterpret_cast<const char *>(wtab) - (lin ? 0 : ((int32_t)xa.kmin << 5));
         bool isout[EPL];
         const float othr = xa.vout * sc.s;
         uint32_t slots[EPL];
-        if (lin) {
-#pragma unroll
-            for (int e = 0; e < EPL; e++)
-                slots[e] = (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(dt[e], xa.lin_scale, xa.lin_bias), 0.0f, khi);
-        } else if (mag) {                                 // (a branch per loop, not a select per element)
-#pragma unroll
-            for (int e = 0; e < EPL; e++) {
-                const uint32_t u = f2u(dt[e]);
-                const int32_t t = (int32_t)__builtin_amdgcn_ubfe(u, sh, wd);
-                int32_t ck;
-                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
-                slots[e] = __builtin_amdgcn_alignbit((uint32_t)ck, u, 31);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < EPL; e++) {
-                const int32_t u = (int32_t)f2u(dt[e]);
-                const int32_t t = u >> sh;
-                int32_t ck;
-                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ck) : "v"(t), "v"(lo), "v"(hi));
-                slots[e] = __builtin_amdgcn_alignbit((uint32_t)ck, (uint32_t)u, 31);
-            }
-        }
+        x_slots<EPL>(xa, dt, slots);
         // {U, O_lo, O_hi, idx pair}: one ds_read_b128 each, NB of them in flight before the first use (all 8 would cost
         // the one-launch-per-tensor kernel its 8th wave per SIMD: 72 registers)
         constexpr int NB = EPL < 4 ? EPL : 4;

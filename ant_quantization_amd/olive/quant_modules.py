@@ -80,6 +80,9 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._grid_key = None
         self._searched = False
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
+        self.weights_at_rest = False   # opt-in (quant_utils.set_weights_at_rest): this WEIGHT quantiser's tensor and alpha are
+                                       # not written by anything still in flight when forward runs (inference on frozen
+                                       # weights), so its launch may start while earlier work on the stream drains
         self._type_search = None  # during one calibration: grid bytes -> clip search result of the type selection's pass
 
     # ---------------------------------------------------------------- bookkeeping
@@ -279,7 +282,8 @@ class Quantizer(HostMirrorMixin, nn.Module):
     def _forward(self, data, display=False):
         """OQ:294-330 as one fused kernel (nearest over normal||outliers + victim masking)."""
         plan = self._ensure_plan()
-        return core.fake_quant(data, self.alpha, plan, self._gmax, self.is_perchannel, ovp=not self._no_outlier)
+        return core.fake_quant(data, self.alpha, plan, self._gmax, self.is_perchannel, ovp=not self._no_outlier,
+                               unordered=self.weights_at_rest and not self.is_input)
 
     @torch.no_grad()
     def tensor_forward(self, tensor, input_tensor=None):

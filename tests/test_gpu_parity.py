@@ -950,6 +950,37 @@ def test_olive_three_sigma_statistic_on_one_read(antq_lib, oracle, dev):
     np.testing.assert_allclose(s1[0, 0].item(), v.double().sum().item(), rtol=1e-12)
 
 
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
+    """quant_utils.set_weights_at_rest(model): the weight quantisers' launches go out unordered (ANTQ_FLAG_UNORDERED); a
+    calibrated model's forward must produce the same bits with the flag on and off, also right after other kernels were
+    queued on the stream (the activations it does NOT apply to are produced by them)."""
+    import importlib
+    import torch
+    import torch.nn as nn
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qutil.set_quantizer(_args(mode="ant-int-flint", wbit=4, abit=4, w_up=150, a_up=150))
+    torch.manual_seed(3)
+    net = nn.Sequential(nn.Linear(1024, 2048), nn.GELU(), nn.Linear(2048, 1024), nn.GELU(), nn.Linear(1024, 64))
+    model = qmod.quantize_model(net).to(dev).eval()
+    qutil.enable_quantization(model)
+    x = torch.randn(32, 1024, device=dev)
+    with torch.no_grad():
+        y0 = model(x)                       # calibration
+        y1 = model(x)
+        qutil.set_weights_at_rest(model, True)
+        assert all(m.weights_at_rest for m in model.modules() if hasattr(m, "weights_at_rest"))
+        for _ in range(5):
+            junk = torch.randn(4096, 4096, device=dev) @ torch.randn(4096, 64, device=dev)      # work in flight on the stream
+            y2 = model(x)
+            assert torch.equal(y2, y1)
+        qutil.set_weights_at_rest(model, False)
+        assert torch.equal(model(x), y1) and torch.equal(y0, y1)
+    capsys.readouterr()
+    del junk
+
+
 def _ref_checkpoint(fx, prefixes, dev, strip):
     """The state dict the reference wrote (tests/golden/*_ckpt.npz, keys 'module.'-prefixed as ImageNet/main.py saves a
     DistributedDataParallel model); later prefixes override earlier ones.  strip: drop the 7 characters the way
