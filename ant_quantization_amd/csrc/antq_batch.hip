@@ -32,6 +32,13 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     uint32_t *map = reinterpret_cast<uint32_t *>(p + h.map_offset);
     std::vector<uint8_t> fam((size_t)n);
     std::vector<size_t> nblk((size_t)n);
+    // bytes the launch will move (in + out).  Whole models (OPT-6.7B: 25.8 GB, the 70 B stack: 137 GB in place) stream with
+    // a longer average memory latency than a few GB do (address translation), and then want more bytes in flight per
+    // wavefront: 4 vectors per lane instead of 2 (same-process A/B, tools/probe_sharded_ab.py: OPT-6.7B 75.1 -> 79.2 %,
+    // 70 B 76.0 -> 78.8 %; below ~8 GB it is the other way round: 81.4 against 79.7 %, tools/probe_footprint.py)
+    double batch_bytes = 0.0;
+    for (int i = 0; i < n; i++) batch_bytes += 2.0 * (double)jobs[i].rows * (double)jobs[i].row_len * (dtype == ANTQ_F32 ? 4.0 : 2.0);
+    const bool big_footprint = batch_bytes >= 8.0 * 1073741824.0;
     size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0, 0}, lds = 0;
     bool any_da = false;
     for (int i = 0; i < n; i++) {
@@ -47,6 +54,10 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         const PlanHeader *ph = static_cast<const PlanHeader *>(J.plan_host);
         const bool xdom = g_knob_x && d.pa.kind == kPlanLut && ph->xdom;
         d.vout = ph->vout;
+        {
+            const XArgs xe = xargs_from_plan(J.plan_host, d.pa);
+            d.vmin = xe.vmin; d.vmax = xe.vmax;
+        }
         d.ratio = 1.0f;
         int f;
         d.u = (uint32_t)kBatchU;
@@ -64,7 +75,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             if (d.kind == 0 && xdom) {
                 // x-domain rows: the task size that leaves the fewest idle lanes for this row length
                 d.kind = 2;
-                d.u = row_task_u_small(d.vpr);
+                d.u = big_footprint ? row_task_u(d.vpr) : row_task_u_small(d.vpr);
                 if (g_knob_u >= 1 && g_knob_u <= 4) d.u = (uint32_t)g_knob_u;     // knob 0 (A/B): vectors per lane and task
                 d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
                 const size_t total = (J.alpha_per_row ? J.rows : (size_t)1) * (size_t)d.tpr;   // per tensor: ONE row

@@ -66,10 +66,7 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
         const size_t tpr = wpr16 ? 16 : wpr4 ? 4 : (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
         const size_t total = rows * tpr;
         if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
-        XArgs xa;
-        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
-        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+        const XArgs xa = xargs_from_plan(plan_host, pa);
         const uint4 *entries = tab + (pa.m_pad >> 2);
         const float *grid = reinterpret_cast<const float *>(tab);
         const dim3 grid_dim((unsigned)((total + 3) / 4)), block(256);

@@ -399,10 +399,7 @@ static int launch_codec(bool enc, const void *x, void *codes_or_out, const uint8
             const uint32_t U = 2;
             const size_t tpr = (vpr + 64 * U - 1) / (64 * U), total = (per_row ? rows : 1) * tpr;
             if (total <= 0x7fffffffull) {
-                XArgs xa;
-                xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-                xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
-                xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+                const XArgs xa = xargs_from_plan(plan_host, pa);
                 const uint4 *tab = plan_tab_ptr(plan_dev);
 #define ANTQ_ENCX(O) hipLaunchKernelGGL((k_encode4_xrow<T, O, 2>), dim3((unsigned)total), dim3(64), 0, st, static_cast<const uint4 *>(x),    \
                                         static_cast<uint32_t *>(codes_or_out), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, \

@@ -197,7 +197,24 @@ struct XArgs {
     uint32_t linear;     // PlanHeader::linear: slot = trunc(clamp(fma(x * rcp(s), lin_scale, lin_bias), 0, kmax)), no sign slots
     float lin_scale;
     float lin_bias;
+    float flim;          // |x * rcp(s)| below this: the table's DECISION is right (its whole domain, PlanHeader::fastlim)
+    float vmin, vmax;    // the grid's extreme values: what an element clipped beyond xlim quantises to (by sign)
 };
+
+// host: XArgs of a plan (every launcher of an x-domain kernel goes through this)
+static inline XArgs xargs_from_plan(const void *plan_host, const PlanArgs &pa)
+{
+    const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
+    XArgs xa;
+    xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
+    xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
+    xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+    xa.flim = pa.fastlim * 0.99999f;                        // (the approximate quotient is within 2^-22 of fl(x / s))
+    const float *g = plan_grid(plan_host);
+    xa.vmin = xa.vmax = g[0];
+    for (uint32_t i = 1; i < pa.m; i++) { xa.vmin = g[i] < xa.vmin ? g[i] : xa.vmin; xa.vmax = g[i] > xa.vmax ? g[i] : xa.vmax; }
+    return xa;
+}
 
 __device__ __forceinline__ float f_up(float c)   // next float towards +inf (c != 0)
 {
@@ -269,12 +286,18 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
                                             const Scale &sc, bool rowfast, const float (&x)[EPL], float (&o)[EPL],
                                             int (&j)[EPL])
 {
+    // fast: the table decides (|d| inside its domain).  Elements clipped beyond xlim (twice the outermost values: OliVe's
+    // planted outliers at a 3-sigma alpha, activations far above a calibrated clip) keep the table's decision -- they
+    // quantise to the grid's extreme value of their sign -- and only redo the straight-through arithmetic with the true
+    // quotient (round 2 sent the whole lane through the literal scan: C3 / C4 lost 2-4 points to one lane in a thousand).
     bool fast = rowfast;
     float dt[EPL];
+    float dmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
         dt[e] = x[e] * sc.rs;
-        fast = fast && (fabsf(dt[e]) < xa.xlim);
+        fast = fast && (fabsf(dt[e]) < xa.flim);         // false for NaN / Inf / beyond the table's domain
+        dmax = __builtin_fmaxf(dmax, fabsf(dt[e]));
     }
     if (fast) {
         const bool lin = xa.linear != 0u;               // wave-uniform
@@ -300,6 +323,19 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
                 o[e] = c ? u2f(ent.v.z) : u2f(ent.v.y);
                 if (OVP) isout[e] = fabsf(o[e]) >= othr;      // |v| > 32 (PlanHeader::vout)
                 if (IDX) j[e] = (int)((c ? (ent.v.w >> 16) : ent.v.w) & kIdxMask);
+            }
+        }
+        if (dmax >= xa.xlim) {
+            // (rare) far-clipped elements: q is the extreme grid value of the element's sign; (q - d) + d is not q out here
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                if (fabsf(dt[e]) >= xa.xlim) {
+                    const float d = x[e] / sc.s;
+                    const float q = (d > 0.0f ? xa.vmax : xa.vmin) + 0.0f;
+                    const float t = (q - d) + d;
+                    o[e] = t * sc.s;
+                    if (OVP) isout[e] = fabsf(q) > 32.0f;
+                }
             }
         }
         if (OVP) {

@@ -51,10 +51,7 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     }
     const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
     const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr;
-    XArgs xa;
-    xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-    xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
-        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+    const XArgs xa = xargs_from_plan(plan_host, pa);
     const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
     const uint4 *xv = static_cast<const uint4 *>(x);
 #define ANTQ_LAUNCH_S(PT_, XD_)                                                                                    \
@@ -87,10 +84,7 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
         if (!plan_args_from_host(plan_host[t], pa)) return ANTQ_ERR_PLAN;
         const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host[t]);
         if (!(g_knob_x != 0 && pa.kind == kPlanLut && ph->xdom)) return ANTQ_ERR_UNSUPPORTED;
-        XArgs &xa = ma.xa[t];
-        xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-        xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
-        xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+        ma.xa[t] = xargs_from_plan(plan_host[t], pa);
         const uint4 *tab = plan_tab_ptr(plan_dev[t]);
         ma.entries[t] = tab + (pa.m_pad >> 2);
         ma.grid[t] = reinterpret_cast<const float *>(tab);

@@ -981,6 +981,37 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
     del junk
 
 
+def test_far_clipped_elements_keep_the_tables_decision(antq_lib, oracle, dev):
+    """Elements clipped beyond twice the outermost grid value (|x / s| >= xlim): the straight-through arithmetic
+    ((q - d) + d) * s is no longer q * s out there, but the table's decision still is right -- the row-table kernels redo
+    only the arithmetic for them (round 3; the lane kernel since round 2).  Small alphas put 1 ... 60 % of the elements
+    there, of both signs, next to NaN / Inf / 1e30 (which must still take the literal scan): per tensor through both
+    kernels (knob 5), batched, unordered; ANT signed / unsigned and OliVe with the pair rule; fp32 and bf16."""
+    import torch
+    rng = np.random.default_rng(41)
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    gol = np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])
+    for rows, K in ((24, 4096), (6, 8200), (40, 1024)):
+        for div in (2.5, 8.0, 40.0, 900.0):
+            x = make_x(rng, rows, K, specials=True)
+            for bf16 in (False, True):
+                for g, gmax, ovp, uns in ((G["flint_b4_s"], 10.0, False, False), (G["flint_b4_u"], 10.0, False, True),
+                                          (G["int_b4_s"], 10.0, False, False), (gol, 32.0, True, False)):
+                    xx = np.abs(x) if uns else x
+                    alpha = (safe_absmax(xx).max(1) / np.float32(div)).astype(np.float32)
+                    run_case(antq_lib, oracle, dev, xx, alpha, g, gmax, True, ovp, bf16)
+                    # batched + unordered
+                    xh = oracle.f32_to_bf16(xx) if bf16 else xx
+                    ref, _ = oracle.forward(xh, alpha, g, gmax, ovp)
+                    xt, a_t, plan = to_dev(xh, dev, bf16), torch.from_numpy(alpha).to(dev), antq_lib.plan_for(g)
+                    ob = torch.zeros_like(xt)
+                    antq_lib.Batch([(xt, ob, a_t, plan, gmax, rows, K, True)], ovp=ovp).run()
+                    ou = antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, True, ovp=ovp, unordered=True)
+                    for o in (ob, ou):
+                        ok = bf16_same(bf16_bits(o), ref, oracle) if bf16 else f32_same(o.cpu().numpy(), ref)
+                        assert ok, (rows, K, div, bf16, ovp, uns)
+
+
 def _ref_checkpoint(fx, prefixes, dev, strip):
     """The state dict the reference wrote (tests/golden/*_ckpt.npz, keys 'module.'-prefixed as ImageNet/main.py saves a
     DistributedDataParallel model); later prefixes override earlier ones.  strip: drop the 7 characters the way

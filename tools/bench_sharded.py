@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--model", choices=["opt6.7b", "llama70b"], default="opt6.7b")
     ap.add_argument("--inplace", action="store_true", help="out = x (halves the footprint)")
     ap.add_argument("--passes", type=int, default=5)
+    ap.add_argument("--knobs", default="", help="dev: comma-separated key=value pairs for antq_debug_set before the batch is built")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -52,7 +53,9 @@ def main():
         w[m] *= torch.empty(int(m.sum()), device=dev, dtype=torch.bfloat16).uniform_(8, 64, generator=gen)
         del m
         ws.append(w)
-        alphas.append((3 * w.float().std(1)).contiguous())
+        alphas.append(_lib.xmax_3sigma(w, w.shape[0], w.shape[1], per_row=True))      # OQ:193-197 on one read (antq_moments)
+    for kv in [k for k in args.knobs.split(",") if k]:
+        _lib.lib().antq_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
     outs = ws if args.inplace else [torch.empty_like(w) for w in ws]
     elems = sum(w.numel() for w in ws)
     bt = _lib.Batch([(w, o, a, plan, 32.0, w.shape[0], w.shape[1], True) for w, o, a in zip(ws, outs, alphas)], ovp=True)
@@ -76,7 +79,7 @@ def main():
                           "elements_total": int(tot.item()), "GB_resident_rank0": round(elems * (2 if args.inplace else 4) / 1e9, 1),
                           "ms_per_pass": round(tmax.item() * 1e3, 3), "Gelem_per_s": round(tot.item() / tmax.item() / 1e9, 1),
                           "frac_of_8TBps_per_gpu": round(tot.item() * 4 / tmax.item() / world / 8e12, 4),
-                          "inplace": bool(args.inplace), "launches_per_pass_per_gpu": 1}), flush=True)
+                          "inplace": bool(args.inplace), "launches_per_pass_per_gpu": 1, "knobs": args.knobs}), flush=True)
     if multi:
         dist.destroy_process_group()
 

@@ -182,10 +182,7 @@ int main()
         if (ANY) hipExtLaunchKernelGGL((k_persist<U, W, P>), g, b, lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, (const uint4 *)in[i], (uint4 *)out[i], n_vec, vpr, vshift, (const float *)alpha_dev, 10.0f, pa, tab); \
         else hipLaunchKernelGGL((k_persist<U, W, P>), g, b, lds, st, (const uint4 *)in[i], (uint4 *)out[i], n_vec, vpr, vshift, (const float *)alpha_dev, 10.0f, pa, tab); }
     const PlanHeader *ph = reinterpret_cast<const PlanHeader *>(plan.data());
-    XArgs xa;
-    xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
-    xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
-    xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
+    const XArgs xa = xargs_from_plan(plan.data(), pa);
     const uint4 *entries = tab + (pa.m_pad >> 2);
     const float *grid_dev = reinterpret_cast<const float *>(tab);
 #define XROW(U, W, ANY) [&](int i) {                                                                                            \
