@@ -77,7 +77,7 @@ __device__ __forceinline__ XArgs xargs_of(const BatchDesc &D)
 //  6 / 7 / 8 waves all within 79.4-80.3 % -- since the d-domain paths left this kernel its occupancy no longer matters;
 //  7 for the pair rule is the highest value that does not spill (8 needed 44 bytes of scratch).)
 #ifndef ANTQ_OVP_WAVES
-#define ANTQ_OVP_WAVES 7
+#define ANTQ_OVP_WAVES 8
 #endif
 #ifndef ANTQ_PLAIN_WAVES
 #define ANTQ_PLAIN_WAVES 6

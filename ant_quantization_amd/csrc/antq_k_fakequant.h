@@ -302,7 +302,6 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
     if (fast) {
         const bool lin = xa.linear != 0u;               // wave-uniform
         const char *t0 = reinterpret_cast<const char *>(wtab) - (lin ? 0 : ((int32_t)xa.kmin << 5));
-        bool isout[EPL];
         const float othr = xa.vout * sc.s;
         uint32_t slots[EPL];
         x_slots<EPL>(xa, dt, slots);
@@ -321,7 +320,6 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
                 ent.pin();
                 const bool c = x[e] >= u2f(ent.v.x);
                 o[e] = c ? u2f(ent.v.z) : u2f(ent.v.y);
-                if (OVP) isout[e] = fabsf(o[e]) >= othr;      // |v| > 32 (PlanHeader::vout)
                 if (IDX) j[e] = (int)((c ? (ent.v.w >> 16) : ent.v.w) & kIdxMask);
             }
         }
@@ -334,14 +332,16 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
                     const float q = (d > 0.0f ? xa.vmax : xa.vmin) + 0.0f;
                     const float t = (q - d) + d;
                     o[e] = t * sc.s;
-                    if (OVP) isout[e] = fabsf(q) > 32.0f;
                 }
             }
         }
         if (OVP) {
+            // |q| > 32 (OQ:314) read off the output: |o| >= fl(vout * s), vout = the smallest magnitude above 32 in the grid
+            // (PlanHeader::vout) -- also for a far-clipped element, whose output is within a few ulps of an outlier's.  The
+            // two flags of a pair are formed right where they are used (eight live masks cost the pair kernel a wave per SIMD).
 #pragma unroll
             for (int p = 0; p < EPL / 2; p++) {
-                const bool me = isout[2 * p], mo = isout[2 * p + 1];
+                const bool me = fabsf(o[2 * p]) >= othr, mo = fabsf(o[2 * p + 1]) >= othr;
                 const bool ve = mo && !me;
                 o[2 * p] = ve ? 0.0f : o[2 * p];          // ((q*0 - d) + d) * s == +0 for s > 0
                 o[2 * p + 1] = me ? 0.0f : o[2 * p + 1];

@@ -3,7 +3,7 @@
 #   gpurun --timeout 1500 -- 'bash tools/profile_counters.sh r02'
 # Writes gpurun_out/<tag>_pmc_kernels.txt (mean per launch and kernel); copy it into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"

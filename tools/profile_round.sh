@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box.  Run from the repo root through gpurun:
-#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r03'
 # Everything is written under gpurun_out/<tag>/ (small text files only); copy what should be judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -44,6 +44,13 @@ $PY tools/probe_codec.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_codec.log"
 ( $PY tools/probe_absmax.py; $PY tools/probe_affine.py ) 2>&1 | grep -v amdgpu > "$OUT/${TAG}_aux_kernels.log"
 ( $PY tools/probe_lane_rows.py; $PY tools/probe_lane_rows_np2.py; $PY tools/probe_batch_lane.py ) 2>&1 | grep -v amdgpu > "$OUT/${TAG}_lane_rows.log"
 ( $PY tools/bench_sharded.py --model opt6.7b; $PY tools/bench_sharded.py --model llama70b --inplace ) 2>&1 | grep "^{" > "$OUT/${TAG}_sharded.log"
+# round 3: launch shapes (wavefronts per workgroup, task size, unordered launches), footprint, call overhead
+$PY tools/probe_launch_shapes.py 3 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > "$OUT/${TAG}_launch_shapes.log"
+$PY tools/probe_footprint.py 2 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > "$OUT/${TAG}_footprint.log"
+( $PY tools/probe_call_overhead.py; ANTQ_NO_EXT=1 $PY tools/probe_call_overhead.py ) 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > "$OUT/${TAG}_call_overhead.log"
+$PY tools/probe_box.py 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > "$OUT/${TAG}_box.log"
+[ -x tools/exp_lane ] && ./tools/exp_lane > "$OUT/${TAG}_exp_lane.log" 2>&1
+[ -x tools/stream_shapes ] && ./tools/stream_shapes all > "$OUT/${TAG}_stream_shapes.log" 2>&1
 [ -x tools/launch_anatomy ] && ./tools/launch_anatomy 2>&1 | cut -c1-70 > "$OUT/${TAG}_launch_anatomy.log"
 [ -x tools/valu_rates ] && ./tools/valu_rates > "$OUT/${TAG}_valu_rates.log" 2>&1
 [ -x tools/ubench ] && ( cd tools && ./ubench 2>&1 | head -38; $PY probe_lane_rows.py 2>&1 | grep -v "amdgpu\|OliVe" | head -5 ) > "$OUT/${TAG}_ubench_copy_variants.log"

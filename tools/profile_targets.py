@@ -35,6 +35,9 @@ def main():
     b, al = batch(xs, outs, 4096, flint, 10.0)
     runs.append(b.run)                                                                   # k_fq_batch<bf16,false>: headline
     runs.append(lambda: [_lib.fakequant(x, a, flint, 10.0, 4096, 4096, True, out=o) for x, a, o in zip(xs, al, outs)])   # k_fq_lane
+    runs.append(lambda: [_lib.fakequant(x, a, flint, 10.0, 4096, 4096, True, out=o, unordered=True) for x, a, o in zip(xs, al, outs)])   # k_fq_xrow, 1 wavefront / workgroup (unordered launches)
+    runs.append(lambda: [_lib.moments(x, 4096, 4096, True) for x in xs])                # k_moments (OliVe 3-sigma statistic), per row
+    runs.append(lambda: [_lib.moments(x, 4096, 4096, False) for x in xs])               # ... per tensor
     # rows that are not a power of two of vectors (ResNet's 3x3 rows: 4608 = 576 bf16 vectors): the per-row table kernels
     x46 = [x.view(-1)[:3640 * 4608].view(3640, 4608) for x in xs]
     o46 = [o.view(-1)[:3640 * 4608].view(3640, 4608) for o in outs]
