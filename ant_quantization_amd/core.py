@@ -54,10 +54,51 @@ class FakeQuantSTE(torch.autograd.Function):
         return gx, ga, None, None, None, None
 
 
+_grid64_cache = {}
+
+
+def fake_quant_f64(x, alpha, plan, gmax, per_channel, ovp=False):
+    """float64 tensors (a `.double()` model).  The reference's operator is dispatched for double and narrows to float
+    INSIDE the kernel (KQ/quant_kernel.cu:51, :28), everything around it runs in double: that is exactly what happens
+    here -- the reference's own op sequence (AQ:535-551 / OQ:294-330) in torch float64 around `antq_nearest` (F64: same
+    narrowing), seven launches instead of one fused kernel.  Double precision is not a throughput path; autograd flows
+    through the torch ops as it does in the reference (ANT's straight-through graph)."""
+    key = (plan.grid.tobytes(), x.device.index)
+    grid = _grid64_cache.get(key)
+    if grid is None:
+        grid = _grid64_cache[key] = torch.from_numpy(plan.grid.astype(np.float64)).to(x.device)
+    gkey = ("gmax", float(gmax), x.device.index)
+    gm = _grid64_cache.get(gkey)
+    if gm is None:                                 # a 0-dim DEVICE tensor, like the reference's torch.max(quant_grid): a python
+        gm = _grid64_cache[gkey] = torch.tensor(float(gmax), dtype=torch.float64, device=x.device)   # scalar would be multiplied by its reciprocal
+    scale = alpha.to(torch.float64) / gm
+    data = (x.view(x.shape[0], -1) / scale).view(x.shape) if per_channel else x / scale
+    with torch.no_grad():
+        q = _lib.nearest(data.detach().reshape(-1).contiguous(), grid)
+        if ovp:                                   # OQ:311-320 on the flat tensor
+            mask = q.abs() > 32
+            victim_odd = torch.roll(mask, 1, -1)
+            victim_odd[::2] = 0
+            victim_even = torch.roll(mask & (~victim_odd), -1, -1)
+            victim_even[1::2] = 0
+            q = q * (~(victim_even | victim_odd))
+        q = q.view(data.shape)
+    t = (q - data).detach() + data
+    return (t.view(t.shape[0], -1) * scale).view(x.shape) if per_channel else t * scale
+
+
+def _calib_view(x):
+    """Calibration kernels take fp32 / bf16 / fp16: a float64 tensor is calibrated on its float32 image (the statistics and
+    the MSE scores of the clip search in single precision; the forward itself then runs in double, fake_quant_f64)."""
+    return x.detach().float() if x.dtype == torch.float64 else x
+
+
 def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False, unordered=False):
     """Steady-state Quantizer._forward.  Uses autograd only when a gradient is wanted.
     unordered (inference only): x and alpha are at rest -- nothing still in flight on the stream writes them -- so the
     launch may overlap the tail of the launches queued before it (ANTQ_FLAG_UNORDERED; see Quantizer.weights_at_rest)."""
+    if x.dtype == torch.float64:
+        return fake_quant_f64(x, alpha, plan, gmax, per_channel, ovp)
     if torch.is_grad_enabled() and (x.requires_grad or alpha.requires_grad):
         return FakeQuantSTE.apply(x, alpha, plan, gmax, per_channel, ovp)
     xc = x.detach().contiguous()
@@ -75,7 +116,7 @@ def clip_search(x, x_max, per_channel, lo, hi, step, plan, gmax, ovp=False):
     Candidates i in range(lo, hi, step) use alpha_i = x_max * fl32(i * 0.01); the first
     strict minimum wins, per row for weights and per tensor for activations.
     """
-    xc = x.detach().contiguous()
+    xc = _calib_view(x).detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)
     cand = list(range(int(lo), int(hi), int(step)))
     if not cand:
@@ -96,7 +137,7 @@ def clip_search_types(x, x_max, per_channel, lo, hi, step, plans, gmaxs, ovp=Fal
     single-read path for this shape / these plans (the caller then searches type by type)."""
     if len(plans) < 2 or not list(range(int(lo), int(hi), int(step))):
         return None
-    xc = x.detach().contiguous()
+    xc = _calib_view(x).detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)
     ratios = _ratios(int(lo), int(hi), int(step), x.device)
     xm = x_max.reshape(-1).to(torch.float32).contiguous()
@@ -142,6 +183,6 @@ def device_grid(values, device):
 
 
 def row_absmax(x, per_channel):
-    xc = x.detach().contiguous()
+    xc = _calib_view(x).detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)
     return _lib.absmax(xc, rows, row_len, per_row=per_channel)

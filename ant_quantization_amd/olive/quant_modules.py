@@ -179,7 +179,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         dtype).  Agrees with torch's own reductions to their summation-order noise (tests: rtol 2e-6 in fp32)."""
         if self._no_outlier:
             return core.row_absmax(tensor, per_channel)
-        t = tensor.detach()
+        t = core._calib_view(tensor).detach()
         if not t.is_contiguous():
             t = t.contiguous()
         rows = t.shape[0] if (per_channel and t.dim() > 0) else 1

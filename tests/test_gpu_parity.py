@@ -738,7 +738,8 @@ def test_packed_4bit_codec_roundtrip_equals_fakequant(antq_lib, oracle, dev, dty
 
 
 def test_ant_outlier_mode_vs_reference(antq_lib, dev, capsys):
-    """mode='outlier' (int4 body + int16 outliers by percentile, AQ:417-465) against the reference's outputs."""
+    """mode='outlier' (int4 body + int16 outliers by percentile, AQ:417-465) against the reference's outputs: the two
+    percentile ends to 1e-6 (np.percentile on the host), the dequantised tensors BIT FOR BIT (round 3: was rtol 2e-6)."""
     import torch
     from ant_quantization_amd.ant import quant_modules as qm
     o = golden("ant_outlier.npz")
@@ -753,8 +754,8 @@ def test_ant_outlier_mode_vs_reference(antq_lib, dev, capsys):
             out = q(xx)
             np.testing.assert_allclose(q.percent_value_int4.item(), o[k + "_p4"], rtol=1e-6)
             np.testing.assert_allclose(q.percent_value_int16.item(), o[k + "_p16"], rtol=1e-6)
-            np.testing.assert_allclose(out.detach().cpu().numpy(), o[k + "_out"], rtol=2e-6, atol=1e-9)
-            np.testing.assert_allclose(q(xx * 0.5).detach().cpu().numpy(), o[k + "_out2"], rtol=2e-6, atol=1e-9)
+            assert f32_same(out.detach().cpu().numpy(), o[k + "_out"]), k            # bit for bit (north_star: <= 1 ULP)
+            assert f32_same(q(xx * 0.5).detach().cpu().numpy(), o[k + "_out2"]), k
     capsys.readouterr()
 
 
@@ -1010,6 +1011,58 @@ def test_far_clipped_elements_keep_the_tables_decision(antq_lib, oracle, dev):
                     for o in (ob, ou):
                         ok = bf16_same(bf16_bits(o), ref, oracle) if bf16 else f32_same(o.cpu().numpy(), ref)
                         assert ok, (rows, K, div, bf16, ovp, uns)
+
+
+def test_float64_forward_is_the_reference_sequence_around_the_operator(antq_lib, oracle, dev, capsys):
+    """A float64 tensor through the module surface: the reference's kernel is dispatched for double and narrows to float
+    inside (KQ/quant_kernel.cu:51, :28) while the ops around it stay in double; `core.fake_quant` does the same -- the
+    reference's op sequence (AQ:535-551 / OQ:294-330) in float64 around `antq_nearest` -- checked bit for bit against that
+    sequence restated in numpy float64 on the oracle's scan, per channel and per tensor, ANT and OliVe with the pair rule;
+    then a TensorQuantizer fed a double tensor calibrates (on the float32 image) and returns float64."""
+    import torch
+    from ant_quantization_amd import core
+    rng = np.random.default_rng(64)
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    gol = np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])
+    for shape in ((16, 256), (7, 33), (64, 3, 7, 7)):
+        x = rng.standard_normal(shape) * 0.05
+        x.reshape(-1)[::19] *= 25
+        xt = torch.from_numpy(x).to(dev)
+        for g, gmax, ovp in ((G["flint_b4_s"], 10.0, False), (G["int_b4_s"], 10.0, False), (gol, 32.0, True)):
+            plan = antq_lib.plan_for(g)
+            for per_channel in (True, False):
+                x2 = x.reshape(shape[0], -1)
+                alpha = (np.abs(x2).max(1) * 0.8 if per_channel else np.array(np.abs(x).max() * 0.8)).astype(np.float32)
+                a_t = torch.from_numpy(alpha.reshape(-1, 1) if per_channel else alpha.reshape(())).to(dev)
+                out = core.fake_quant(xt, a_t, plan, gmax, per_channel, ovp=ovp)
+                assert out.dtype == torch.float64 and out.shape == xt.shape
+                scale = alpha.astype(np.float64).reshape(-1, 1) / gmax if per_channel else alpha.astype(np.float64) / gmax
+                d = (x2 / scale).reshape(shape) if per_channel else x / scale
+                q = oracle.nearest(d.reshape(-1), g.astype(np.float64))[0]
+                if ovp:                                          # OQ:311-320
+                    mask = np.abs(q) > 32
+                    vo = np.roll(mask, 1)
+                    vo[::2] = False
+                    ve = np.roll(mask & ~vo, -1)
+                    ve[1::2] = False
+                    q = q * (~(ve | vo))
+                q = q.reshape(shape)
+                t = (q - d) + d
+                ref = (t.reshape(shape[0], -1) * scale).reshape(shape) if per_channel else t * scale
+                got = out.cpu().numpy()
+                assert np.array_equal(got.view(np.uint64), np.ascontiguousarray(ref).view(np.uint64)), (shape, ovp, per_channel)
+    from ant_quantization_amd.ant import quant_modules as qm
+    from ant_quantization_amd.olive import quant_modules as oqm
+    w = torch.from_numpy(rng.standard_normal((32, 512)) * 0.03).to(dev)
+    for mod, mode, kw in ((qm, "ant-int-flint", {}), (oqm, "ant-int-flint", dict(w_up=250, a_up=250))):
+        q = mod.TensorQuantizer(mode=mode, bit=4, is_signed=True, is_enable=True, args=_args(**kw)).to(dev)
+        q.name = "f64"
+        q.alpha.data = torch.ones(32, 1, device=dev)
+        y = q(w)
+        assert y.dtype == torch.float64 and torch.isfinite(y).all()
+        y32 = q(w.float())                                       # same calibrated state, float32 input: the fused kernel
+        np.testing.assert_allclose(y.detach().cpu().numpy(), y32.detach().double().cpu().numpy(), rtol=1e-6, atol=1e-12)
+    capsys.readouterr()
 
 
 def _ref_checkpoint(fx, prefixes, dev, strip):
