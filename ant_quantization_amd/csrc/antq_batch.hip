@@ -135,6 +135,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         d.plan_tab = plan_tab_ptr(J.plan_dev);
         d.per_row = J.alpha_per_row ? 1 : 0;
         d.gmax = J.gmax;
+        d.inv_gmax = 1.0 / (double)J.gmax;
         descs[i] = d;
         fam[(size_t)i] = (uint8_t)(f < 0 ? 255 : f);
         nblk[(size_t)i] = blocks;

@@ -66,7 +66,8 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
         const size_t tpr = wpr16 ? 16 : wpr4 ? 4 : (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
         const size_t total = rows * tpr;
         if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
-        const XArgs xa = xargs_from_plan(plan_host, pa);
+        XArgs xa = xargs_from_plan(plan_host, pa);
+        xa.inv_gmax = 1.0 / (double)gmax;
         const uint4 *entries = tab + (pa.m_pad >> 2);
         const float *grid = reinterpret_cast<const float *>(tab);
         const dim3 grid_dim((unsigned)((total + 3) / 4)), block(256);

@@ -10,7 +10,7 @@ namespace antq {
 constexpr uint32_t kBatchMagic = 0x32544E41u;  // "ANT2"
 constexpr int kBatchU = 4;                      // vectors per lane per task (4 KiB per wavefront: best measured)
 
-struct BatchDesc {   // 168 bytes, device-visible
+struct BatchDesc {   // 176 bytes, device-visible
     const uint4 *x;
     uint4 *out;
     const float *alpha;    // ANTQ_FLAG_DYNAMIC: an OUTPUT
@@ -41,8 +41,9 @@ struct BatchDesc {   // 168 bytes, device-visible
                            // full tasks stream 1-4 points better on the fixed map (profiles/r03_batch_rotation.log)
     float vmin, vmax;      // the grid's extreme values (XArgs::vmin / vmax: what far-clipped elements quantise to)
     uint32_t pad_;
+    double inv_gmax;       // 1.0 / (double)gmax (XArgs::inv_gmax: the row's scale without a division)
 };
-static_assert(sizeof(BatchDesc) == 168, "BatchDesc must be 168 bytes");
+static_assert(sizeof(BatchDesc) == 176, "BatchDesc must be 176 bytes");
 
 // A batch is up to four launches, one per kernel FAMILY, so that no kernel carries the registers of code paths its
 // jobs never take (the headline x-domain row kernel keeps its 80 VGPRs whatever else a batch may contain):
@@ -68,7 +69,7 @@ __device__ __forceinline__ XArgs xargs_of(const BatchDesc &D)
     xa.m = pa.m; xa.shift = pa.shift; xa.kmin = pa.kmin; xa.kmax = pa.kmax; xa.keymask = pa.keymask;
     xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = pa.xlim; xa.vout = D.vout;
     xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
-    xa.flim = pa.fastlim * 0.99999f; xa.vmin = D.vmin; xa.vmax = D.vmax;
+    xa.flim = pa.fastlim * 0.99999f; xa.vmin = D.vmin; xa.vmax = D.vmax; xa.inv_gmax = D.inv_gmax;
     return xa;
 }
 

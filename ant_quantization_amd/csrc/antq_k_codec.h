@@ -245,7 +245,7 @@ k_encode4_xrow(const uint4 *__restrict__ x, uint32_t *__restrict__ codes, uint32
     if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
     const uint32_t v0 = g * (64u * U) + lane;
     const size_t base = (size_t)row * vpr + v0;
-    const Scale sc = make_scale(a, gmax);
+    const Scale sc = row_scale(a, gmax, xa.inv_gmax);
     const bool rowfast = sc.ok && (sc.s > 0.0f);
     {
         // the wave-private code table: thresholds into the x domain, the two indices of an entry as final codes
@@ -399,7 +399,8 @@ static int launch_codec(bool enc, const void *x, void *codes_or_out, const uint8
             const uint32_t U = 2;
             const size_t tpr = (vpr + 64 * U - 1) / (64 * U), total = (per_row ? rows : 1) * tpr;
             if (total <= 0x7fffffffull) {
-                const XArgs xa = xargs_from_plan(plan_host, pa);
+                XArgs xa = xargs_from_plan(plan_host, pa);
+                xa.inv_gmax = 1.0 / (double)gmax;
                 const uint4 *tab = plan_tab_ptr(plan_dev);
 #define ANTQ_ENCX(O) hipLaunchKernelGGL((k_encode4_xrow<T, O, 2>), dim3((unsigned)total), dim3(64), 0, st, static_cast<const uint4 *>(x),    \
                                         static_cast<uint32_t *>(codes_or_out), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, \

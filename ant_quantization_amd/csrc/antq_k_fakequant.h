@@ -199,7 +199,27 @@ struct XArgs {
     float lin_bias;
     float flim;          // |x * rcp(s)| below this: the table's DECISION is right (its whole domain, PlanHeader::fastlim)
     float vmin, vmax;    // the grid's extreme values: what an element clipped beyond xlim quantises to (by sign)
+    double inv_gmax;     // 1.0 / (double)gmax of THIS launch (set by the launcher, 0: unknown): scale without a division
 };
+
+// The scale of a row task.  s = fl32(alpha / gmax) (AQ:536: a true division) as fl32((double)alpha * (1 / (double)gmax)):
+// the double product is within 2^-52 of the quotient and a quotient of two floats is never that close to a float
+// rounding boundary without lying on the same side of it (make_scale_a, antq_k_approx.h); scales outside the table
+// path's range (denormal, zero, negative, Inf, NaN) are divided literally.  The reciprocal only steers the bucket choice
+// (thresholds keep 2^-20 clear of bucket edges): v_rcp_f32.  ~6 instructions instead of two IEEE divisions (~24).
+__device__ __forceinline__ Scale row_scale(float alpha, float gmax, double inv_gmax)
+{
+    Scale sc;
+    sc.s = (float)((double)alpha * inv_gmax);
+    sc.ok = (inv_gmax != 0.0) && (sc.s >= kScaleLo) && (sc.s <= kScaleHi);
+    if (!sc.ok) {
+        sc.s = alpha / gmax;
+        const float as = fabsf(sc.s);
+        sc.ok = (as >= kScaleLo) && (as <= kScaleHi);
+    }
+    sc.rs = __builtin_amdgcn_rcpf(sc.s);
+    return sc;
+}
 
 // host: XArgs of a plan (every launcher of an x-domain kernel goes through this)
 static inline XArgs xargs_from_plan(const void *plan_host, const PlanArgs &pa)
@@ -210,6 +230,7 @@ static inline XArgs xargs_from_plan(const void *plan_host, const PlanArgs &pa)
     xa.nbneg = pa.nbneg; xa.n_entries = pa.n_entries; xa.xlim = ph->xlim; xa.vout = ph->vout;
     xa.linear = pa.linear; xa.lin_scale = pa.lin_scale; xa.lin_bias = pa.lin_bias;
     xa.flim = pa.fastlim * 0.99999f;                        // (the approximate quotient is within 2^-22 of fl(x / s))
+    xa.inv_gmax = 0.0;
     const float *g = plan_grid(plan_host);
     xa.vmin = xa.vmax = g[0];
     for (uint32_t i = 1; i < pa.m; i++) { xa.vmin = g[i] < xa.vmin ? g[i] : xa.vmin; xa.vmax = g[i] > xa.vmax ? g[i] : xa.vmax; }
@@ -458,7 +479,7 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
         a = u2f(m) * ratio;
         if (alpha_out && lane == 0 && (WPR == 1 || wv == 0)) st_global(alpha_out + row, a);
     }
-    const Scale sc = make_scale(a, gmax);
+    const Scale sc = row_scale(a, gmax, xa.inv_gmax);
 
     // per-row table: thresholds into the x domain, outputs pre-multiplied by the scale
     const bool rowfast = build_row_table(xa, ent, ent2, sc, wtab, lane);

@@ -477,7 +477,7 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
         bmap = host[int(h[5]):n].view(np.uint32)
         descs = []
         for k in range(len(jobs)):
-            d = host[56 + 168 * k:56 + 168 * (k + 1)]
+            d = host[56 + 176 * k:56 + 176 * (k + 1)]
             w = d[40:72].view(np.uint32)          # total_tasks vpr tpr vshift first_block kind per_row gmax
             descs.append(dict(n_vec=int(d[32:40].view(np.uint64)[0]), total_tasks=int(w[0]), vpr=int(w[1]), tpr=int(w[2]),
                               first_block=int(w[4]), kind=int(w[5]), u=int(d[148:152].view(np.uint32)[0])))
