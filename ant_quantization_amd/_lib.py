@@ -290,6 +290,10 @@ def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=
     unordered: the caller promises that x / alpha are not produced by work still in flight on the stream (weights at rest);
     the launch may then overlap the tail of the launches queued before it (ANTQ_FLAG_UNORDERED)."""
     flags = (FLAG_OVP if ovp else 0) | (FLAG_UNORDERED if unordered else 0)
+    if unordered and (out is None or want_idx):
+        # torch's caching allocator recycles blocks in STREAM ORDER: a fresh tensor may sit on memory that a kernel still
+        # in flight is reading or writing -- harmless for an ordered launch, fatal for one that may start early
+        raise AntqError("an unordered launch needs a caller-owned output buffer (out=...) that nothing in flight touches")
     e = _ext_mod
     if e is False:
         e = ext()

@@ -102,7 +102,11 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
         self.weights_at_rest = False   # opt-in (quant_utils.set_weights_at_rest): this WEIGHT quantiser's tensor and alpha are
                                        # not written by anything still in flight when forward runs (inference on frozen
-                                       # weights), so its launch may start while earlier work on the stream drains
+                                       # weights), so its launch may start while earlier work on the stream drains.  The
+                                       # output then lives in ONE buffer owned by the quantiser (a fresh tensor from the
+                                       # stream-ordered allocator could sit on memory an in-flight kernel still uses):
+                                       # every forward returns the same storage, like WeightBank's resident outputs
+        self._rest_out = None
         self._type_search = None  # during one calibration: grid bytes -> clip search result of the type selection's pass
 
     # ---------------------------------------------------------------- bookkeeping
@@ -353,11 +357,21 @@ class Quantizer(HostMirrorMixin, nn.Module):
             self._type_search = None
 
     # ---------------------------------------------------------------- steady state
+    def _rest_buffer(self, data):
+        """The quantiser-owned output buffer of the weights-at-rest mode (None otherwise)."""
+        if not (self.weights_at_rest and not self.is_input) or torch.is_grad_enabled() and data.requires_grad:
+            return None
+        b = self._rest_out
+        if b is None or b.shape != data.shape or b.dtype != data.dtype or b.device != data.device:
+            b = self._rest_out = torch.empty_like(data, memory_format=torch.contiguous_format)
+            torch.cuda.current_stream(data.device).synchronize()      # (once: nothing in flight may still own this block)
+        return b
+
     def _forward(self, data):
         """AQ:535-551 as one fused kernel."""
         plan = self._ensure_plan()
         return core.fake_quant(data, self.alpha, plan, self._gmax, self.is_perchannel,
-                               unordered=self.weights_at_rest and not self.is_input)
+                               unordered=self.weights_at_rest and not self.is_input, out=self._rest_buffer(data))
 
     def tensor_forward(self, tensor, input_tensor=None):
         if self.mode == "base":

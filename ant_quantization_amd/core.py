@@ -93,10 +93,11 @@ def _calib_view(x):
     return x.detach().float() if x.dtype == torch.float64 else x
 
 
-def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False, unordered=False):
+def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False, unordered=False, out=None):
     """Steady-state Quantizer._forward.  Uses autograd only when a gradient is wanted.
-    unordered (inference only): x and alpha are at rest -- nothing still in flight on the stream writes them -- so the
-    launch may overlap the tail of the launches queued before it (ANTQ_FLAG_UNORDERED; see Quantizer.weights_at_rest)."""
+    unordered (inference only, needs `out`): x and alpha are at rest -- nothing still in flight on the stream writes them --
+    and `out` is a buffer nothing in flight touches, so the launch may overlap the tail of the launches queued before it
+    (ANTQ_FLAG_UNORDERED; see Quantizer.weights_at_rest)."""
     if x.dtype == torch.float64:
         return fake_quant_f64(x, alpha, plan, gmax, per_channel, ovp)
     if torch.is_grad_enabled() and (x.requires_grad or alpha.requires_grad):
@@ -104,8 +105,9 @@ def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False, unordered=False):
     xc = x.detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)
     a = alpha.detach().reshape(-1).to(torch.float32).contiguous()
-    return _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp,
-                          unordered=unordered and xc.data_ptr() == x.data_ptr())
+    unordered = unordered and out is not None and xc.data_ptr() == x.data_ptr()
+    return _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp, unordered=unordered,
+                          out=out if unordered else None)
 
 
 def clip_search(x, x_max, per_channel, lo, hi, step, plan, gmax, ovp=False):

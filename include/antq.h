@@ -61,7 +61,10 @@ extern "C" {
                                     * the stream (its inputs are at rest: calibrated weights), so it may START while they are
                                     * still draining -- the dispatch packet goes out without the barrier bit
                                     * (hipExtAnyOrderLaunch).  Ordinary launches queued after it still wait for it.  Worth
-                                    * 2-3 us per 33.5 MB tensor when many weight tensors are quantised one launch each. */
+                                    * 2-3 us per 33.5 MB tensor when many weight tensors are quantised one launch each.
+                                    * The OUTPUT buffer must be at rest too: not one a stream-ordered allocator has just
+                                    * recycled from a kernel that may still be running (torch's caching allocator does that:
+                                    * the Python binding refuses the flag without a caller-owned `out`). */
 
 /* values written to the optional int16 index output */
 #define ANTQ_IDX_NONE    (-1)      /* no grid entry within 102400 (NaN/Inf/huge)     */

@@ -880,14 +880,16 @@ def test_launch_shapes_and_unordered_launches_are_bit_identical(antq_lib, oracle
                     alpha = (np.abs(xf).max(1) * np.float32(0.3 if ovp else 0.9)).astype(np.float32)
                     ref, _ = oracle.forward(xh, alpha, g, gmax, ovp)
                     plan, a_t = antq_lib.plan_for(g), torch.from_numpy(alpha).to(dev)
+                    bufs = [torch.empty_like(xt) for _ in range(3)]     # (unordered launches write caller-owned buffers)
+                    torch.cuda.synchronize()
                     for w in (0, 1, 4):
                         for u in (0, 1, 2, 4):
                             knob(6, w)
                             knob(7, u)
                             for unordered in (False, True):
                                 # several back-to-back launches into distinct outputs: unordered ones may overlap
-                                outs = [antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, True, ovp=ovp, unordered=unordered)
-                                        for _ in range(3)]
+                                outs = [antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, True, ovp=ovp, unordered=unordered,
+                                                           out=bufs[i]) for i in range(3)]
                                 for o in outs:
                                     ok = bf16_same(bf16_bits(o), ref, oracle) if bf16 else f32_same(o.cpu().numpy(), ref)
                                     assert ok, (bf16, rows, K, ovp, w, u, unordered)
@@ -1007,7 +1009,7 @@ def test_far_clipped_elements_keep_the_tables_decision(antq_lib, oracle, dev):
                     xt, a_t, plan = to_dev(xh, dev, bf16), torch.from_numpy(alpha).to(dev), antq_lib.plan_for(g)
                     ob = torch.zeros_like(xt)
                     antq_lib.Batch([(xt, ob, a_t, plan, gmax, rows, K, True)], ovp=ovp).run()
-                    ou = antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, True, ovp=ovp, unordered=True)
+                    ou = antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, True, ovp=ovp, unordered=True, out=torch.empty_like(xt))
                     for o in (ob, ou):
                         ok = bf16_same(bf16_bits(o), ref, oracle) if bf16 else f32_same(o.cpu().numpy(), ref)
                         assert ok, (rows, K, div, bf16, ovp, uns)
@@ -2283,7 +2285,9 @@ def test_c3_opt67b_weight_shapes_static_ovp_sampled_against_the_oracle(antq_lib,
         antq_lib.Batch([(w, out_b, alpha, plan, gmax, R, K, True)], ovp=True).run()
         o1, idx = antq_lib.fakequant(w, alpha, plan, gmax, R, K, True, ovp=True, want_idx=True)
         o2 = antq_lib.fakequant(w, alpha, plan, gmax, R, K, True, ovp=True)
-        o3 = antq_lib.fakequant(w, alpha, plan, gmax, R, K, True, ovp=True, unordered=True)
+        o3 = antq_lib.fakequant(w, alpha, plan, gmax, R, K, True, ovp=True, unordered=True, out=torch.empty_like(w))
+        with pytest.raises(antq_lib.AntqError):           # an unordered launch into a buffer the allocator may just have recycled
+            antq_lib.fakequant(w, alpha, plan, gmax, R, K, True, ovp=True, unordered=True)
         for o in (out_b, o1, o2, o3):
             ok = bf16_same(bf16_bits(o[rt]), ref, oracle) if bf16 else f32_same(o[rt].cpu().numpy(), ref)
             assert ok, (shape, bf16)
