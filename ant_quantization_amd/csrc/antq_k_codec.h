@@ -323,7 +323,8 @@ k_decode4(const uint32_t *__restrict__ codes, void *__restrict__ out, size_t n_o
     constexpr int EPL = VEC ? IO<T>::EPL : 8;          // elements per thread and access
     constexpr int U = VEC ? 4 : 1;
     __shared__ float g[32];
-    if (threadIdx.x < 32) g[threadIdx.x] = ((int)threadIdx.x < m) ? grid[threadIdx.x] : 0.0f;
+    // (+ 0.0f: a codebook's -0 decodes to +0, which is what the reference's (q - d) + d makes of it for every finite d)
+    if (threadIdx.x < 32) g[threadIdx.x] = ((int)threadIdx.x < m) ? grid[threadIdx.x] + 0.0f : 0.0f;
     const size_t n_units = n_oct * (8 / EPL);
     const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
     uint32_t word[U];

@@ -2632,3 +2632,130 @@ def test_empty_inputs(antq_lib, dev):
         assert antq_lib.decode4(codes, a, plan, 10.0, 0, 64, True, dt).numel() == 0
     with pytest.raises(antq_lib.AntqError):
         antq_lib.Batch([(torch.empty(0, 64, device=dev), torch.empty(0, 64, device=dev), torch.empty(0, device=dev), plan, 10.0, 0, 64, True)])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ANTQ_FUZZ_SEEDS", 3))))
+def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
+    """Rows long enough for the per-row table kernels (and a few that are not), every reference codebook, random
+    lengths / scales (heavy clipping, scales down to 2^-60 and up to 2^40, zero and negative alphas) / outliers /
+    specials, fp32 and bf16 -- through EVERY launch form of the same arithmetic: ordinary launch (+ indices), unordered
+    launch into a caller-owned buffer, one batched launch of all tensors of a dtype (mixed task sizes, rotated and fixed
+    maps in one grid), the in-kernel abs-max form, and the packed 4-bit codec where a 4-bit code exists.  Each against
+    the ORACLE.  ANTQ_FUZZ_SEEDS widens it (tools/fuzz_campaign.sh)."""
+    import torch
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    rng = np.random.default_rng(31000 + seed)
+    names = [k for k in G.files if not k.startswith("INVALID")]
+    groups = {}
+    for case in range(10):
+        bf16 = bool(rng.random() < 0.6)
+        if rng.random() < 0.5:
+            gname = names[rng.integers(0, len(names))]
+            g, ovp, n_normal = G[gname], False, 0
+            gmax = float(g.max())
+        else:
+            t, b, s = ["int", "flint"][rng.integers(0, 2)], int(rng.choice([3, 4, 4, 4, 5, 8])), "su"[rng.integers(0, 2)]
+            gn = O["%s_b%d_%s" % (t, b, s)]
+            g, gmax, ovp, gname, n_normal = np.concatenate([gn, O["outlier_b%d_%s" % (b, s)]]), float(gn.max()), True, "olive_" + s, gn.size
+        epv = 8 if bf16 else 4
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            K = epv * int(rng.choice([128, 192, 256, 384, 512, 1024, 1376, 2048, 3584]))        # whole tasks
+        elif kind == 1:
+            K = epv * int(rng.integers(128, 2100))                                              # partial last task
+        elif kind == 2:
+            K = epv * int(rng.integers(1, 128))                                                 # short rows
+        elif kind == 3:
+            K = int(rng.integers(1, 9000))                                                      # ragged
+        else:
+            K = epv * int(rng.choice([16, 32, 64, 100, 127, 129, 255, 257]))
+        rows = int(rng.choice([1, 2, 3, 7, 8, 9, 16, 33, 64]))
+        rows = max(1, min(rows, 600_000 // K))
+        x = make_x(rng, rows, K, unsigned=gname.endswith("_u"), specials=bool(rng.random() < 0.3)) * np.float32(rng.uniform(0.2, 40))
+        m = rng.random((rows, K)) < 0.02
+        x[m] *= rng.uniform(8, 200, int(m.sum())).astype(np.float32)
+        xh = oracle.f32_to_bf16(x) if bf16 else x
+        xf = oracle.bf16_to_f32(xh) if bf16 else xh
+        am = safe_absmax(xf).max(1)
+        akind = rng.integers(0, 6)
+        if akind == 0:
+            alpha = am * np.float32(rng.uniform(0.01, 0.08))                                    # most elements clipped
+        elif akind == 1:
+            alpha = am * np.float32(2.0 ** rng.integers(-60, 40))                               # outside the table path's range
+        else:
+            alpha = am * rng.uniform(0.2, 1.3, rows)
+        alpha = (alpha + 1e-6).astype(np.float32)
+        if akind == 2 and rows > 2:
+            alpha[1], alpha[2] = 0.0, -alpha[2]
+        per_row = bool(rng.random() < 0.75)
+        a_np = alpha if per_row else np.float32(alpha.mean())
+        tag = (seed, case, gname, rows, K, bf16, ovp, per_row, int(akind))
+        with np.errstate(all="ignore"):
+            ref, ridx = oracle.forward(xh, a_np, g, gmax, ovp)
+        plan = antq_lib.plan_for(g)
+        xt = to_dev(xh, dev, bf16)
+        a_t = torch.from_numpy(np.atleast_1d(a_np).astype(np.float32)).to(dev)
+
+        def same(t, r=ref, xh=xh, a_np=a_np, K=K):
+            if bf16_same(bf16_bits(t), r, oracle) if bf16 else f32_same(t.cpu().numpy(), r):
+                return True
+            got = bf16_bits(t).reshape(-1) if bf16 else t.cpu().numpy().reshape(-1).view(np.uint32)
+            want = r.reshape(-1) if bf16 else r.reshape(-1).view(np.uint32)
+            bad = np.flatnonzero(got != want)
+            print("MISMATCH %d of %d; first at %s: x bits %s alpha %s got %s want %s" % (
+                bad.size, got.size, bad[:6], [hex(int(v)) for v in xh.reshape(-1).view(np.uint16 if bf16 else np.uint32)[bad[:6]]],
+                np.atleast_1d(a_np)[np.minimum(bad[:6] // K, np.atleast_1d(a_np).size - 1)],
+                [hex(int(v)) for v in got[bad[:6]]], [hex(int(v)) for v in want[bad[:6]]]))
+            return False
+
+        out, idx = antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, per_row, ovp=ovp, want_idx=True)
+        assert same(out), ("ordered", tag)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int32), ridx), ("indices", tag)
+        bufs = [torch.empty_like(xt) for _ in range(2)]
+        torch.cuda.synchronize()
+        for b in bufs:
+            antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, per_row, ovp=ovp, unordered=True, out=b)
+        for b in bufs:
+            assert same(b), ("unordered", tag)
+        groups.setdefault((bf16, ovp), []).append((xt, torch.zeros_like(xt), a_t, plan, gmax, rows, K, per_row, ref, tag))
+        # in-kernel abs-max (rows only; the reference's dynamic scale is ratio * max|x|, no specials in it)
+        if per_row and not np.isnan(xf).any() and not np.isinf(xf).any():
+            ratio = float(np.float32(rng.uniform(0.3, 1.1)))
+            a_dyn = oracle.absmax(xf, True, ratio)
+            with np.errstate(all="ignore"):
+                ref_d, _ = oracle.forward(xh, a_dyn, g, gmax, ovp)
+            out_d, a_dev, _ = antq_lib.fakequant_dynamic(xt, plan, gmax, rows, K, ratio=ratio, ovp=ovp)
+            assert np.array_equal(a_dev.cpu().numpy(), a_dyn), ("dynamic alpha", tag)
+            assert same(out_d, ref_d), ("dynamic", tag)
+        # packed 4-bit codes: exist for <= 16 codes (ANT) / 8 + 8 with the identifier (OliVe 4-bit), whole 32-bit words
+        four_bit = (g.size <= 16 and not ovp) or (ovp and n_normal <= 15 and g.size - n_normal <= 8)
+        if four_bit and K % 8 == 0 and (per_row or True):
+            try:
+                codes = antq_lib.encode4(xt, a_t, plan, gmax, rows, K, per_row, n_normal=n_normal, ovp=ovp)
+            except antq_lib.AntqError:
+                codes = None                       # no 4-bit code for this codebook: refused, not guessed
+            if codes is not None:
+                # the codes are the oracle's indices (an element the scan never reaches -- NaN, beyond its horizon -- takes
+                # the zero code); the decoder returns value * scale, which is the reference's ((q - d) + d) * s wherever that
+                # is finite and the element is not clipped beyond twice the outermost value (DESIGN 4)
+                zc = np.flatnonzero((g[:n_normal] if ovp else g) == 0)
+                want = _oracle_codes(oracle, ridx, n_normal, ovp, int(zc[-1]) if zc.size else None)
+                nib = _nibbles(codes, rows, K)
+                scanned = (ridx != oracle.IDX_NONE) | bool(zc.size)
+                assert np.array_equal(nib[scanned], want[scanned]), ("codes", tag)
+                dec = antq_lib.decode4(codes, a_t, plan, gmax, rows, K, per_row, torch.bfloat16 if bf16 else torch.float32,
+                                       n_normal=n_normal, ovp=ovp)
+                reff = oracle.bf16_to_f32(ref) if bf16 else ref
+                a_rows = np.broadcast_to(np.atleast_1d(a_np).astype(np.float32)[:, None], (rows, K)) if per_row else np.float32(a_np)
+                with np.errstate(all="ignore"):
+                    near = np.isfinite(reff) & (np.abs(xf) <= 1.9 * np.abs(a_rows) * float(np.abs(g).max()) / gmax)
+                got = bf16_bits(dec) if bf16 else dec.cpu().numpy().view(np.uint32)
+                wantb = ref if bf16 else ref.view(np.uint32)
+                bad = np.flatnonzero((got != wantb) & near)
+                assert bad.size == 0, ("codec", tag, bad[:8], got.reshape(-1)[bad[:8]], wantb.reshape(-1)[bad[:8]])
+    for (bf16, ovp), jobs in groups.items():
+        antq_lib.Batch([j[:8] for j in jobs], ovp=ovp).run()
+        for j in jobs:
+            ref = j[8]
+            ok = bf16_same(bf16_bits(j[1]), ref, oracle) if bf16 else f32_same(j[1].cpu().numpy(), ref)
+            assert ok, ("batched", j[9])
