@@ -1,0 +1,16 @@
+#!/bin/bash
+# Wide fuzz run on an MI355X (the -m gpu suite runs the same tests with a handful of seeds):
+#   gpurun -- 'bash tools/fuzz_campaign.sh 1500 120'
+# $1 seeds for test_fuzz_every_launch_form_long_rows (10 tensors each, every launch form against the oracle),
+# $2 seeds for the arbitrary-codebook / arbitrary-shape fuzz tests.  Summary -> gpurun_out/fuzz_campaign.log
+set -u
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+{
+  echo "== test_fuzz_every_launch_form_long_rows, ${1:-1500} seeds"
+  ANTQ_FUZZ_SEEDS=${1:-1500} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line -s \
+      -k fuzz_every_launch_form 2>&1 | grep -E "MISMATCH|Error|passed|failed" | cut -c1-900 | head -60
+  echo "== test_random_grids_fuzz, test_random_grids_fuzz_other_entry_points, test_random_shapes_fuzz, ${2:-120} seeds each"
+  ANTQ_FUZZ_SEEDS=${2:-120} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k "random_grids_fuzz or random_shapes_fuzz" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+} | tee gpurun_out/fuzz_campaign.log
