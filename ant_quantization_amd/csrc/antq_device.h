@@ -107,6 +107,10 @@ template <> struct IO<float> {
         return max(max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, v.z & 0x7fffffffu)), v.w & 0x7fffffffu);
     }
     __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return m; }
+    // "every magnitude of the vector is below lim" on the raw words: amax_acc(0, v) against lim_key(lim).  NaN / Inf are
+    // never below (their magnitude bits exceed every finite value's).
+    __device__ __forceinline__ static uint32_t lim_key(float lim) { return f2u(lim); }
+    __device__ __forceinline__ static bool all_below(uint32_t acc, uint32_t key) { return acc < key; }
 };
 template <> struct IO<bf16_tag> {
     static constexpr int DTYPE = ANTQ_BF16;
@@ -150,6 +154,12 @@ template <> struct IO<bf16_tag> {
         return as_u32(a);
     }
     __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return max(m & 0xffffu, m >> 16) << 16; }
+    // both 16-bit magnitudes <= (lim's bf16 bits, truncated) - 1, i.e. strictly below lim: one v_pk_max_u16 + one compare
+    __device__ __forceinline__ static uint32_t lim_key(float lim) { return (max(f2u(lim) >> 16, 1u) - 1u) * 0x10001u; }
+    __device__ __forceinline__ static bool all_below(uint32_t acc, uint32_t key)
+    {
+        return as_u32(__builtin_elementwise_max(as_u16x2(acc), as_u16x2(key))) == key;
+    }
 };
 template <> struct IO<f16_tag> {
     static constexpr int DTYPE = ANTQ_F16;
@@ -203,6 +213,16 @@ template <> struct IO<f16_tag> {
     }
     // half magnitude bits -> fp32 magnitude bits (exact widening)
     __device__ __forceinline__ static uint32_t amax_bits(uint32_t m) { return f2u(h2f(max(m & 0xffffu, m >> 16))); }
+    // half magnitudes order like their bits too; lim rounded to half (nearest), one step taken off: strictly below lim
+    __device__ __forceinline__ static uint32_t lim_key(float lim)
+    {
+        _Float16 h = (_Float16)lim;                    // beyond 65504 -> Inf (0x7c00): every finite half passes
+        return (max((uint32_t) * reinterpret_cast<uint16_t *>(&h), 2u) - 2u) * 0x10001u;
+    }
+    __device__ __forceinline__ static bool all_below(uint32_t acc, uint32_t key)
+    {
+        return as_u32(__builtin_elementwise_max(as_u16x2(acc), as_u16x2(key))) == key;
+    }
 };
 
 // floor(o / opr) without an integer division: one f64 multiply by the reciprocal (inv = 1.0 / opr) and a +-1 fix-up.

@@ -116,7 +116,7 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
                         float xf[EPL], of[EPL];
                         int j[EPL];
                         IO<T>::unpack(v[u], xf);
-                        if (XD) quant_vec_x<EPL, OVP, false>(xa, wtab, grid_g, sc, rowfast, xf, of, j);
+                        if (XD) quant_vec_x<EPL, OVP, false>(xa, wtab, grid_g, sc, rowfast, false, xf, of, j);
                         else quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
                         float part = 0.0f;
 #pragma unroll
@@ -219,7 +219,7 @@ k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t v
                         float xf[EPL], of[EPL];
                         int j[EPL];
                         IO<T>::unpack(v[u], xf);
-                        quant_vec_x<EPL, OVP, false>(xa, wtab, grid_t, sc, rowfast, xf, of, j);
+                        quant_vec_x<EPL, OVP, false>(xa, wtab, grid_t, sc, rowfast, false, xf, of, j);
                         float part = 0.0f;
 #pragma unroll
                         for (int e = 0; e < EPL; e++) {
