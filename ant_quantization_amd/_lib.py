@@ -145,6 +145,13 @@ class _on_device:
             self.ctx.__exit__(*a)
 
 
+def _require_out(out, x):
+    """A caller-supplied output buffer: same device, dtype and element count as x, contiguous."""
+    if not (out.is_cuda and out.device == x.device and out.dtype == x.dtype and out.numel() == x.numel()
+            and out.is_contiguous()):
+        raise AntqError("out must be a contiguous tensor of x's dtype, element count and device")
+
+
 def _require_gpu(t, name):
     if not t.is_cuda:
         raise AntqError("%s must live on a HIP device (got %s); libantq has no CPU path" % (name, t.device))
@@ -322,6 +329,8 @@ def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=
     pd = plan.dev(x.device)
     if out is None:
         out = torch.empty_like(x)
+    else:
+        _require_out(out, x)
     idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
     with _on_device(x.device):
         rc = lib().antq_fakequant(x.data_ptr(), out.data_ptr(), _ptr(idx), rows, row_len, alpha.data_ptr(),
@@ -342,6 +351,8 @@ def fakequant_dynamic(x, plan, gmax, rows, row_len, ratio=1.0, ovp=False, want_i
         raise AntqError("rows*row_len != numel")
     if out is None:
         out = torch.empty_like(x)
+    else:
+        _require_out(out, x)
     idx = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_idx else None
     pd = plan.dev(x.device)
     alpha, rc = None, -1
@@ -595,6 +606,12 @@ class Batch:
         self.singles, batched = [], []
         for j in jobs:
             x, out, alpha, plan, gmax, rows, row_len, per_row = j
+            _require_gpu(x, "x")
+            if x.device != x0.device:
+                raise AntqError("every tensor of a batch must live on one device")
+            _require_out(out, x)
+            if rows * row_len != x.numel():
+                raise AntqError("rows*row_len != numel")
             if x.dtype != x0.dtype:
                 self.singles.append(j)
             else:

@@ -81,12 +81,17 @@ struct KeyHash {
 constexpr size_t kMaxHints = 64;
 constexpr int kStaleSlots = 4096;
 
-std::mutex g_mu;                                             // nn.DataParallel calls quant() from one thread per GPU
+// nn.DataParallel calls quant() from one thread per GPU.  Every entry point of this module runs with the GIL held from
+// start to end (nothing here releases it), so a Hint returned by hint_for is not modified by another thread while quant()
+// uses it; the mutex keeps the cache itself consistent should a caller ever release the GIL around these calls.
+std::mutex g_mu;
 std::list<std::pair<Key, std::shared_ptr<Hint>>> g_lru;      // front = most recent
 std::unordered_map<Key, decltype(g_lru)::iterator, KeyHash> g_map;
 at::Tensor g_stale_pool;                                     // pinned int32[kStaleSlots]: never returned to the allocator, so a
 int g_stale_next = 0;                                        // late write of a long-gone launch can only cost a re-plan
 
+// (after kStaleSlots beliefs a slot is handed out again: two live beliefs may then share a flag, and one going stale
+//  makes the other re-plan once -- slower, never wrong)
 int *new_stale_flag()
 {
     if (!g_stale_pool.defined())
@@ -210,6 +215,17 @@ py::object fakequant(const at::Tensor &x, const at::Tensor &alpha, uintptr_t pla
     TORCH_CHECK(alpha.scalar_type() == at::kFloat, "alpha must be float32");
     TORCH_CHECK(rows * row_len == x.numel(), "rows*row_len != numel");
     TORCH_CHECK(alpha.numel() == (per_row ? rows : 1), "alpha has ", alpha.numel(), " entries, expected ", per_row ? rows : 1);
+    TORCH_CHECK(alpha.device() == x.device(), "alpha lives on ", alpha.device(), ", x on ", x.device());
+    if (out_opt.has_value()) {
+        const at::Tensor &o = *out_opt;
+        TORCH_CHECK(o.is_cuda() && o.device() == x.device() && o.is_contiguous() && o.scalar_type() == x.scalar_type() &&
+                        o.numel() == x.numel(),
+                    "out must be a contiguous tensor of x's dtype, element count and device");
+    }
+    // an unordered launch may overlap whatever the stream ran last: its output must be a buffer the CALLER owns (a block the
+    // caching allocator just recycled can still be in use by a kernel in flight), and the index tensor would be such a block
+    TORCH_CHECK(!(flags & ANTQ_FLAG_UNORDERED) || (out_opt.has_value() && !want_idx),
+                "ANTQ_FLAG_UNORDERED needs a caller-owned `out` and no index output");
     c10::hip::OptionalHIPGuard guard;
     if (x.device().index() != c10::hip::current_device()) guard.set_device(x.device());
     at::Tensor out = out_opt.has_value() ? *out_opt : at::empty_like(x);

@@ -2759,3 +2759,34 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
             ref = j[8]
             ok = bf16_same(bf16_bits(j[1]), ref, oracle) if bf16 else f32_same(j[1].cpu().numpy(), ref)
             assert ok, ("batched", j[9])
+
+
+def test_caller_supplied_output_buffers_are_validated(antq_lib, dev):
+    """out= of the wrong dtype / size / layout is refused by both bindings (compiled extension and ctypes), by the batch
+    builder too; an unordered launch without a caller-owned buffer (or with an index output) is refused."""
+    import torch
+    g = golden("ant_grids.npz")["flint_b4_s"]
+    plan = antq_lib.plan_for(g)
+    x = torch.randn(8, 1024, device=dev)
+    a = x.abs().amax(1).contiguous()
+    bad = [torch.empty(8, 1024, device=dev, dtype=torch.bfloat16), torch.empty(8, 512, device=dev),
+           torch.empty(1024, 8, device=dev).t(), torch.empty(8, 1024)]
+    for o in bad:
+        with pytest.raises(antq_lib.AntqError):
+            antq_lib.fakequant(x, a, plan, 10.0, 8, 1024, True, out=o)
+        with pytest.raises(antq_lib.AntqError):
+            antq_lib.Batch([(x, o, a, plan, 10.0, 8, 1024, True)])
+    with pytest.raises(antq_lib.AntqError):
+        antq_lib.fakequant_dynamic(x, plan, 10.0, 8, 1024, out=bad[0])
+    with pytest.raises(antq_lib.AntqError):
+        antq_lib.fakequant(x, a, plan, 10.0, 8, 1024, True, unordered=True)
+    with pytest.raises(antq_lib.AntqError):
+        antq_lib.fakequant(x, a, plan, 10.0, 8, 1024, True, unordered=True, out=torch.empty_like(x), want_idx=True)
+    e = antq_lib.ext()
+    if e is not None:                    # the extension on its own refuses the same (it may be called directly)
+        with pytest.raises(RuntimeError):
+            e.fakequant(x, a, plan.host_addr, plan.dev(x.device).data_ptr(), 10.0, 8, 1024, True, antq_lib.FLAG_UNORDERED)
+        with pytest.raises(RuntimeError):
+            e.fakequant(x, a, plan.host_addr, plan.dev(x.device).data_ptr(), 10.0, 8, 1024, True, 0, bad[1])
+    ok = torch.empty_like(x)
+    assert antq_lib.fakequant(x, a, plan, 10.0, 8, 1024, True, out=ok) is ok
