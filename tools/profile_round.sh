@@ -13,6 +13,11 @@ PY="python"
 $PY bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"
 tail -1 "$OUT/${TAG}_bench.json" | cut -c1-400
 
+# the launch form the driver uses for N > 1 (one rank per GPU over RCCL), on the one GPU of this box
+$PY -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 \
+    --no-cpu-baseline 2> "$OUT/bench_torchrun.stderr" | tail -1 > "$OUT/${TAG}_bench_torchrun_n1.json"
+cut -c1-200 "$OUT/${TAG}_bench_torchrun_n1.json"
+
 # kernel trace of the same command (no PMC in this pass)
 ( cd /tmp && rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- \
     $PY "$REPO/bench.py" --no-cpu-baseline > "$OUT/bench_profiled.json" 2> /tmp/prof_kt.err )
