@@ -15,7 +15,7 @@ import torch  # must be imported before libantq.so so that ONE libamdhip64 is sh
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ANTQ_LIB") or os.path.join(_HERE, "libantq.so")   # ANTQ_LIB: A/B builds (dev)
 
-ABI_VERSION = 2         # include/antq.h ANTQ_ABI_VERSION this binding was written against
+ABI_VERSION = 3         # include/antq.h ANTQ_ABI_VERSION this binding was written against
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_OVP = 1
 FLAG_DYNAMIC = 2
@@ -56,10 +56,12 @@ def lib():
                              "antq_fakequant_dynamic", "antq_absmax", "antq_search_sse", "antq_affine",
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
                              "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
-                             "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma"):
+                             "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma",
+                             "antq_calibrate"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 L.antq_search_workspace_bytes.restype = ctypes.c_size_t
+                L.antq_calibrate_workspace_bytes.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
                 vp, sz, ci, cf, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_uint
                 L.antq_fakequant.argtypes = [vp, vp, vp, sz, sz, vp, ci, cf, vp, vp, cu, ci, vp]
@@ -505,6 +507,55 @@ def search_sse_multi(x, rows, row_len, xmax, per_row, ratios, plans, gmaxs, ovp=
         return None
     _check(rc, "antq_search_sse_multi")
     return sse
+
+
+XMAX_GIVEN, XMAX_ABSMAX, XMAX_3SIGMA = 0, 1, 2
+
+
+def calibrate(x, rows, row_len, per_row, plans, gmaxs, lb, ub, step, xmax="absmax", ovp=False):
+    """One quantiser's whole first-call calibration in one C call (antq_calibrate): the clip statistic, every candidate
+    codebook's clip search, the per-row choice and the type choice -- no device->host sync.
+    xmax: "absmax" (ANT), "3sigma" (OliVe) or a float32 device tensor with rows (per_row) / 1 entries.
+    Returns (alpha [ntypes, na] float32, score [ntypes] float32, type int32[1], xmax [na] float32), all on x's device."""
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x.dtype)
+    if rows * row_len != x.numel():
+        raise AntqError("rows*row_len != numel")
+    nt = len(plans)
+    if nt < 1 or len(gmaxs) != nt:
+        raise AntqError("one gmax per plan, at least one plan")
+    na = rows if per_row else 1
+    if isinstance(xmax, str):
+        mode = {"absmax": XMAX_ABSMAX, "3sigma": XMAX_3SIGMA}.get(xmax)
+        if mode is None:
+            raise AntqError("xmax must be 'absmax', '3sigma' or a tensor")
+        xm = torch.empty(na, dtype=torch.float32, device=x.device)
+    else:
+        mode = XMAX_GIVEN
+        _require_gpu(xmax, "xmax")
+        xm = xmax.reshape(-1)
+        if xm.dtype != torch.float32 or xm.numel() != na or xm.device != x.device:
+            raise AntqError("xmax must hold %d float32 values on x's device" % na)
+    nbytes = lib().antq_calibrate_workspace_bytes(ctypes.c_size_t(rows), ctypes.c_int(1 if per_row else 0), ctypes.c_int(lb),
+                                                  ctypes.c_int(ub), ctypes.c_int(step), ctypes.c_int(nt))
+    if nbytes == 0:
+        raise AntqError("antq_calibrate: bad candidate range / type count")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    alpha = torch.empty(nt, na, dtype=torch.float32, device=x.device)
+    score = torch.empty(nt, dtype=torch.float32, device=x.device)
+    typ = torch.empty(1, dtype=torch.int32, device=x.device)
+    ph = (ctypes.c_void_p * nt)(*[p.host_addr for p in plans])
+    pd = (ctypes.c_void_p * nt)(*[p.dev(x.device).data_ptr() for p in plans])
+    gm = (ctypes.c_float * nt)(*[float(g) for g in gmaxs])
+    with _on_device(x.device):
+        rc = lib().antq_calibrate(_vp(x), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), ctypes.c_int(1 if per_row else 0),
+                                  ctypes.c_int(dt), ctypes.c_int(mode), _vp(xm), ctypes.c_int(lb), ctypes.c_int(ub),
+                                  ctypes.c_int(step), ctypes.c_int(nt), gm, ph, pd, ctypes.c_uint(FLAG_OVP if ovp else 0),
+                                  _vp(alpha), _vp(score), _vp(typ), _vp(ws), ctypes.c_size_t(nbytes), _stream(x.device))
+    _check(rc, "antq_calibrate")
+    return alpha, score, typ, xm
 
 
 def search_pick(sse, xmax, ratios, row_len):

@@ -340,6 +340,54 @@ k_search_pick(const double *__restrict__ sse, const float *__restrict__ xmax, co
     best_alpha[r] = alpha;
 }
 
+// antq_calibrate's small steps.  The candidate ratios: fl32(i * 0.01), i * 0.01 evaluated in double as Python does (AQ:296).
+static __global__ void __launch_bounds__(256)
+k_calib_ratios(float *__restrict__ ratios, int lb, int step, int ncand)
+{
+    const int c = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (c < ncand) ratios[c] = (float)((double)(lb + c * step) * 0.01);
+}
+
+// no candidate at all (range(lb, ub, step) empty): the reference's loop body never runs -- best = 1e10, alpha = x_max
+static __global__ void __launch_bounds__(256)
+k_calib_none(const float *__restrict__ xmax, size_t na, int ntypes, float *__restrict__ best_score, float *__restrict__ alpha)
+{
+    const size_t r = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= na) return;
+    for (int t = 0; t < ntypes; t++) { best_score[(size_t)t * na + r] = 1e10f; alpha[(size_t)t * na + r] = xmax[r]; }
+}
+
+// score of a type = the sum of its rows' best MSE (search_mse returns best_score.sum(), AQ:326): one workgroup per type,
+// double accumulators, one fixed order (thread-strided partials, then a tree over the 256 threads)
+static __global__ void __launch_bounds__(256)
+k_calib_type_score(const float *__restrict__ best_score, size_t na, float *__restrict__ score)
+{
+    __shared__ double part[256];
+    const float *p = best_score + (size_t)blockIdx.x * na;
+    double s = 0.0;
+    for (size_t r = threadIdx.x; r < na; r += 256u) s += (double)p[r];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t w = 128u; w > 0u; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) score[blockIdx.x] = (float)part[0];
+}
+
+// the type with the smallest score, the first one on ties, NaN last (np.argsort(mse)[0], AQ:413-415)
+static __global__ void k_calib_type_pick(const float *__restrict__ score, int ntypes, int32_t *__restrict__ type)
+{
+    int best = 0;
+    bool have = false;
+    for (int t = 0; t < ntypes; t++) {
+        const float v = score[t];
+        if (v != v) continue;
+        if (!have || v < score[best]) { best = t; have = true; }
+    }
+    type[0] = best;
+}
+
 }  // namespace antq
 
 #endif  // ANTQ_K_SEARCH_H

@@ -1,4 +1,4 @@
-// antq_search.hip -- calibration entry points of libantq: antq_search_sse, antq_search_sse_multi, antq_search_pick
+// antq_search.hip -- calibration entry points of libantq: antq_search_sse, antq_search_sse_multi, antq_search_pick, antq_calibrate
 // (reference: search_mse AQ/quant_modules.py:287-326, search_adaptive_numeric_type :328-415; OQ:189-256).  gfx950 only.
 #include "antq_host.h"
 #include "antq_k_fakequant.h"
@@ -193,3 +193,101 @@ extern "C" int antq_search_pick(const double *sse, const float *xmax, const floa
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+
+
+// ------------------------------------------------------------------------------------------------
+// antq_calibrate: one call = x_max, every candidate type's clip search, the per-row choice and the type choice
+// ------------------------------------------------------------------------------------------------
+namespace {
+inline size_t up256(size_t v) { return (v + 255u) & ~(size_t)255u; }
+struct CalibLayout {
+    size_t search, ratios, sse, score, sums, total;
+};
+inline CalibLayout calib_layout(size_t na, int ncand, int ntypes)
+{
+    CalibLayout L;
+    L.search = 0;
+    L.ratios = up256(antq_search_workspace_bytes());
+    L.sse = L.ratios + up256((size_t)std::max(ncand, 1) * sizeof(float));
+    L.score = L.sse + up256((size_t)ntypes * (size_t)std::max(ncand, 1) * na * sizeof(double));
+    L.sums = L.score + up256((size_t)ntypes * na * sizeof(float));
+    L.total = L.sums + up256(2 * na * sizeof(double));
+    return L;
+}
+inline int calib_ncand(int lb, int ub, int step) { return (step > 0 && ub > lb) ? (ub - lb + step - 1) / step : 0; }
+}  // namespace
+
+extern "C" size_t antq_calibrate_workspace_bytes(size_t rows, int alpha_per_row, int lb, int ub, int step, int ntypes)
+{
+    if (ntypes < 1 || step < 1) return 0;
+    return calib_layout(alpha_per_row ? rows : 1, calib_ncand(lb, ub, step), ntypes).total;
+}
+
+extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int alpha_per_row, int dtype, int xmax_mode,
+                              float *xmax, int lb, int ub, int step, int ntypes, const float *gmax_host,
+                              const void *const *plan_host, const void *const *plan_dev, unsigned flags, float *alpha,
+                              float *score, int32_t *type, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (rows == 0 || row_len == 0) return ANTQ_OK;
+    if (!x || !xmax || !gmax_host || !plan_host || !plan_dev || !alpha || !score || !type || !workspace || ntypes < 1 || step < 1)
+        return ANTQ_ERR_ARG;
+    if (dtype != ANTQ_F32 && dtype != ANTQ_BF16 && dtype != ANTQ_F16) return ANTQ_ERR_UNSUPPORTED;
+    for (int t = 0; t < ntypes; t++)
+        if (!plan_host[t] || !plan_dev[t]) return ANTQ_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return ANTQ_ERR_ALIGN;
+    const size_t na = alpha_per_row ? rows : 1;
+    const size_t n_per = alpha_per_row ? row_len : rows * row_len;
+    const int ncand = calib_ncand(lb, ub, step);
+    const CalibLayout L = calib_layout(na, ncand, ntypes);
+    if (workspace_bytes < L.total) return ANTQ_ERR_ARG;
+    char *w = static_cast<char *>(workspace);
+    void *ws_search = w + L.search;
+    float *ratios = reinterpret_cast<float *>(w + L.ratios);
+    double *sse = reinterpret_cast<double *>(w + L.sse);
+    float *best = reinterpret_cast<float *>(w + L.score);
+    double *sums = reinterpret_cast<double *>(w + L.sums);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int pr = alpha_per_row ? 1 : 0;
+    int rc = ANTQ_OK;
+    // 1. the clip statistic: abs-max (ANT, AQ:289 / :308), mean +- 3 sigma (OliVe, OQ:193-197 / :213-218), or the caller's
+    if (xmax_mode == ANTQ_XMAX_ABSMAX) rc = antq_absmax(x, xmax, rows, row_len, pr, dtype, stream);
+    else if (xmax_mode == ANTQ_XMAX_3SIGMA) {
+        rc = antq_moments(x, rows, row_len, pr, dtype, sums, ws_search, stream);
+        if (rc == ANTQ_OK) rc = antq_xmax_3sigma(sums, na, n_per, dtype, xmax, stream);
+    } else if (xmax_mode != ANTQ_XMAX_GIVEN) return ANTQ_ERR_ARG;
+    if (rc != ANTQ_OK) return rc;
+    const unsigned nab = (unsigned)std::min<size_t>((na + 255) / 256, 0x7fffffffu);
+    if ((na + 255) / 256 > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+    if (ncand == 0) {
+        hipLaunchKernelGGL(k_calib_none, dim3(nab), dim3(256), 0, st, xmax, na, ntypes, best, alpha);
+    } else {
+        hipLaunchKernelGGL(k_calib_ratios, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ratios, lb, step, ncand);
+        // 2. sum of squared errors of every (type, candidate) per row: kMaxTypes types per read of the tensor where the
+        //    single-read kernel applies, one read per type otherwise
+        const size_t per_type = (size_t)ncand * na;
+        for (int b = 0; b < ntypes; b += kMaxTypes) {
+            const int nt = std::min(kMaxTypes, ntypes - b);
+            rc = nt > 1 ? antq_search_sse_multi(x, rows, row_len, xmax, pr, ratios, ncand, nt, gmax_host + b, plan_host + b,
+                                                plan_dev + b, flags, dtype, sse + (size_t)b * per_type, ws_search, stream)
+                        : ANTQ_ERR_UNSUPPORTED;
+            if (rc == ANTQ_ERR_UNSUPPORTED) {
+                for (int t = b; t < b + nt; t++) {
+                    rc = antq_search_sse(x, rows, row_len, xmax, pr, ratios, ncand, gmax_host[t], plan_host[t], plan_dev[t], flags,
+                                         dtype, sse + (size_t)t * per_type, ws_search, stream);
+                    if (rc != ANTQ_OK) return rc;
+                }
+            }
+            if (rc != ANTQ_OK) return rc;
+        }
+        // 3. per row: the first strict minimum (AQ:299-306)
+        for (int t = 0; t < ntypes; t++) {
+            rc = antq_search_pick(sse + (size_t)t * per_type, xmax, ratios, ncand, na, n_per, best + (size_t)t * na,
+                                  alpha + (size_t)t * na, stream);
+            if (rc != ANTQ_OK) return rc;
+        }
+    }
+    // 4. per tensor: the type with the smallest sum of best MSEs (AQ:326, :413-415)
+    hipLaunchKernelGGL(k_calib_type_score, dim3((unsigned)ntypes), dim3(256), 0, st, best, na, score);
+    hipLaunchKernelGGL(k_calib_type_pick, dim3(1), dim3(1), 0, st, score, ntypes, type);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}

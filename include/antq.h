@@ -38,7 +38,7 @@ extern "C" {
 /* 2 (round 3): antq_search_sse / antq_alpha_grad take a caller workspace before `stream`, antq_absmax initialises its
  * output, the batch blob changed (plan version 8), ANTQ_FLAG_UNORDERED.  A caller built against another version must not
  * call in: the argument lists differ. */
-#define ANTQ_ABI_VERSION 2
+#define ANTQ_ABI_VERSION 3
 
 /* element types of x / out */
 #define ANTQ_F32  0
@@ -224,6 +224,36 @@ int antq_search_sse_multi(const void *x_dev, size_t rows, size_t row_len, const 
  * na = rows (per-channel) or 1.  Keeps the whole calibration free of device->host syncs. */
 int antq_search_pick(const double *sse_dev, const float *xmax_dev, const float *ratios_dev, int ncand,
                      size_t na, size_t row_len, float *best_score_dev, float *best_alpha_dev, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * The whole first-call calibration of one quantiser in ONE call, stream-ordered, without a device->host sync
+ * (Quantizer._init_quant_para's search: search_mse AQ:287-326 per candidate type, the type choice of
+ * search_adaptive_numeric_type AQ:328-415; OliVe OQ:189-256) -- the composition of the entry points above that
+ * ant/quant_modules.py and olive/quant_modules.py perform step by step:
+ *   x_max      ANTQ_XMAX_ABSMAX: row / tensor abs-max (ANT, AQ:289 / :308) written to xmax_dev;
+ *              ANTQ_XMAX_3SIGMA: max(|mean + 3 std|, |mean - 3 std|) (OliVe, OQ:193-197 / :213-218) written to xmax_dev;
+ *              ANTQ_XMAX_GIVEN : xmax_dev is an input (a statistic all-reduced over ranks, `no_outlier`, ...)
+ *   candidates i = lb, lb + step, ... < ub:  alpha_i[r] = fl32(xmax[r] * fl32(i * 0.01))   (ANT: step 1; OliVe: step 2)
+ *   per type t (ntypes codebooks: plan_host / plan_dev / gmax_host arrays), per row r (alpha_per_row) or for the tensor:
+ *              alpha_dev[t * na + r] = the candidate with the smallest mean squared error, the first one on ties, x_max
+ *              when the candidate list is empty or no error is below 1e10 (AQ:299-306)
+ *   score_dev[t] = sum over rows of the best mean squared error (what search_mse returns, AQ:326), summed in double in
+ *              one fixed order and rounded to float
+ *   type_dev[0]  = the t with the smallest score, the first on ties, NaN scores last (np.argsort(mse)[0], AQ:413-415)
+ * na = rows (alpha_per_row) or 1.  flags: ANTQ_FLAG_OVP searches with OliVe's outlier-victim pairs applied.
+ * workspace_dev: antq_calibrate_workspace_bytes(...) bytes of caller-owned scratch, 16-byte aligned, not shared with a
+ * call running concurrently on another stream.  The host decides lb / ub (ANT: lb = 95 when bit > 6, AQ:291-292) and which
+ * codebooks are candidates (the `-float1..4` quirk of AQ:370-397 included: pass float_value(1)'s plan for each).
+ * ------------------------------------------------------------------------- */
+#define ANTQ_XMAX_GIVEN  0
+#define ANTQ_XMAX_ABSMAX 1
+#define ANTQ_XMAX_3SIGMA 2
+size_t antq_calibrate_workspace_bytes(size_t rows, int alpha_per_row, int lb, int ub, int step, int ntypes);
+int antq_calibrate(const void *x_dev, size_t rows, size_t row_len, int alpha_per_row, int dtype,
+                   int xmax_mode, float *xmax_dev, int lb, int ub, int step,
+                   int ntypes, const float *gmax_host, const void *const *plan_host, const void *const *plan_dev,
+                   unsigned flags, float *alpha_dev, float *score_dev, int32_t *type_dev,
+                   void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * AsymmetricQuantFunction.forward (ant_quantization/antquant/quant_affine.py:95-115)

@@ -5,7 +5,7 @@
 // upload it, call the fused entry points on its own stream and buffers.  Covers antq_nearest (the quant_cuda.quant
 // replacement, KQ/quant_kernel.cu:11-62), antq_fakequant (AQ:535-551), the OliVe victim rule (OQ:311-320),
 // antq_fakequant_dynamic + antq_absmax, antq_fakequant_batch, the packed 4-bit codec, antq_nearest_hinted, group-16 and the
-// calibration entry points (antq_search_sse with its workspace, antq_search_pick).
+// calibration entry points (antq_search_sse with its workspace, antq_search_pick, and antq_calibrate: all of it in one call).
 // Exit code 0 = every comparison bit-exact; prints one line per check.
 #include <hip/hip_runtime.h>
 
@@ -275,6 +275,65 @@ int main()
                                                                        : "antq_search_sse + antq_search_pick, per tensor",
                bad ? "MISMATCH" : "ok", flips, na);
         if (bad) failures++;
+    }
+
+    // 7e. the same calibration as ONE call (antq_calibrate): abs-max, two candidate codebooks (flint-4 and a 4-bit int
+    //     grid), per-row picks and the type pick, no host step in between.  Checked against the step-by-step entry points
+    //     (bit for bit: same kernels) and against the oracle's per-type sums for the type.
+    {
+        std::vector<float> int4;
+        for (int k = -8; k <= 7; k++) int4.push_back((float)k * (10.0f / 7.0f));
+        std::vector<uint8_t> plan_i(ANTQ_PLAN_MAX_BYTES);
+        const int pbi = antq_plan_build(int4.data(), (int)int4.size(), plan_i.data(), plan_i.size());
+        if (pbi <= 0) { printf("int-4 plan build failed\n"); return 5; }
+        DevBuf<uint8_t> dplan_i(ANTQ_PLAN_MAX_BYTES);
+        HIP_OK(hipMemcpyAsync(dplan_i.p, plan_i.data(), pbi, hipMemcpyHostToDevice, st));
+        const int lb = 75, ub = 150, ncand = ub - lb;
+        const void *ph[2] = {plan_i.data(), plan.data()}, *pd[2] = {dplan_i.p, dplan.p};
+        const float gm[2] = {10.0f, 10.0f};
+        const std::vector<float> *grids2[2] = {&int4, &flint};
+        for (int per_row = 1; per_row >= 0; per_row--) {
+            const size_t na = per_row ? rows : 1;
+            const size_t wsb = antq_calibrate_workspace_bytes(rows, per_row, lb, ub, 1, 2);
+            DevBuf<uint8_t> dws(wsb), dws2(antq_search_workspace_bytes());
+            DevBuf<float> dxm(na), dal(2 * na), dsc(2), dratios((size_t)ncand), dscore(na), dbest(na);
+            DevBuf<int32_t> dty(1);
+            DevBuf<double> dsse((size_t)ncand * na);
+            ANTQ_OK_(antq_calibrate(dxf.p, rows, K, per_row, ANTQ_F32, ANTQ_XMAX_ABSMAX, dxm.p, lb, ub, 1, 2, gm, ph, pd, 0, dal.p,
+                                    dsc.p, dty.p, dws.p, wsb, st));
+            const std::vector<float> al = dal.down(st), sc = dsc.down(st), xm = dxm.down(st);
+            const int ty = dty.down(st)[0];
+            std::vector<float> ratios((size_t)ncand);
+            for (int i = 0; i < ncand; i++) ratios[(size_t)i] = (float)((double)(lb + i) * 0.01);
+            dratios.up(ratios, st);
+            int bad = 0;
+            double osum[2];
+            for (int t = 0; t < 2; t++) {
+                ANTQ_OK_(antq_search_sse(dxf.p, rows, K, dxm.p, per_row, dratios.p, ncand, 10.0f, ph[t], pd[t], 0, ANTQ_F32, dsse.p,
+                                         dws2.p, st));
+                ANTQ_OK_(antq_search_pick(dsse.p, dxm.p, dratios.p, ncand, na, per_row ? K : n, dscore.p, dbest.p, st));
+                const std::vector<float> step_alpha = dbest.down(st), step_score = dscore.down(st);
+                double ssum = 0.0;
+                for (size_t r = 0; r < na; r++) {
+                    if (std::memcmp(&step_alpha[r], &al[(size_t)t * na + r], 4) != 0) bad++;
+                    ssum += (double)step_score[r];
+                }
+                if (std::fabs(ssum - (double)sc[t]) > 1e-6 * ssum) bad++;
+                std::vector<float> o_score(na), o_alpha(na), trace((size_t)ncand * na);
+                antq_oracle_search_mse_f32(xf.data(), rows, K, per_row, xm.data(), lb, ub, 1, grids2[t]->data(),
+                                           (int)grids2[t]->size(), 10.0f, 0, o_score.data(), o_alpha.data(), trace.data());
+                osum[t] = 0.0;
+                for (size_t r = 0; r < na; r++) osum[t] += (double)o_score[r];
+            }
+            const int want = osum[1] < osum[0] ? 1 : 0;
+            const bool tie = std::fabs(osum[0] - osum[1]) <= 1e-4 * std::min(osum[0], osum[1]);
+            if (ty != want && !tie) bad++;
+            if (ty != (sc[1] < sc[0] ? 1 : 0)) bad++;
+            printf("%-62s %s (type %d, oracle sums %.6g / %.6g)\n", per_row ? "antq_calibrate (abs-max, 2 types, picks, type), per row"
+                                                                             : "antq_calibrate (abs-max, 2 types, picks, type), per tensor",
+                   bad ? "MISMATCH" : "ok", ty, osum[0], osum[1]);
+            if (bad) failures++;
+        }
     }
 
     // 8. error behaviour: codes, not exceptions

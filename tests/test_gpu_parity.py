@@ -2790,3 +2790,71 @@ def test_caller_supplied_output_buffers_are_validated(antq_lib, dev):
             e.fakequant(x, a, plan.host_addr, plan.dev(x.device).data_ptr(), 10.0, 8, 1024, True, 0, bad[1])
     ok = torch.empty_like(x)
     assert antq_lib.fakequant(x, a, plan, 10.0, 8, 1024, True, out=ok) is ok
+
+
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_calibrate_one_call_equals_the_stepwise_calibration_and_the_oracle(antq_lib, oracle, dev, tree):
+    """antq_calibrate (clip statistic + every type's clip search + per-row pick + type pick in ONE C call, no host sync)
+    against (a) the step-by-step composition the modules use -- bit for bit -- and (b) the ORACLE's search_mse per type
+    (same candidate except for reference near-ties; the type with the smallest oracle sum unless two sums are within 1e-4).
+    Per channel and per tensor, fp32 and bf16, long rows (single-read kernel), short / ragged rows (per-type kernels),
+    an empty candidate range, a caller-supplied x_max."""
+    import torch
+    from ant_quantization_amd import core
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    rng = np.random.default_rng(11)
+    if tree == "ant":
+        grids_ = [G["int_b4_s"], G["flint_b4_s"], G["pot_b4_s"], G["float_b4_s"], G["apot_b4_s"]]
+        gmaxs, ovp, step, stat = [10.0] * 5, False, 1, "absmax"
+        lb, ub = 75, 150
+    else:
+        grids_ = [np.concatenate([O["int_b4_s"], O["outlier_b4_s"]]), np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])]
+        gmaxs, ovp, step, stat = [float(O["int_b4_s"].max()), float(O["flint_b4_s"].max())], True, 2, "3sigma"
+        lb, ub = 75, 250
+    plans = [antq_lib.plan_for(g) for g in grids_]
+    for (rows, K), per_row, bf16 in [((32, 1024), True, False), ((16, 2048), True, True), ((24, 147), True, False),
+                                     ((8, 4096), False, False), ((4, 2048), False, True), ((40, 64), True, True)]:
+        x = (rng.standard_normal((rows, K)) * 0.05).astype(np.float32)
+        x[rng.random((rows, K)) < 0.01] *= 12
+        xh = oracle.f32_to_bf16(x) if bf16 else x
+        xf = oracle.bf16_to_f32(xh) if bf16 else xh
+        xt = to_dev(xh, dev, bf16)
+        r_, k_ = (rows, K) if per_row else (1, rows * K)
+        alpha, score, typ, xm = antq_lib.calibrate(xt, rows, K, per_row, plans, gmaxs, lb, ub, step, xmax=stat, ovp=ovp)
+        na = rows if per_row else 1
+        assert alpha.shape == (len(plans), na) and score.shape == (len(plans),) and typ.numel() == 1
+        # (a) the stepwise path: same kernels, same order -> identical bits
+        if tree == "ant":
+            xm_step = antq_lib.absmax(xt, r_, k_, per_row=per_row) if per_row else antq_lib.absmax(xt, rows, K, per_row=False)
+        else:
+            xm_step = antq_lib.xmax_3sigma(xt, rows, K, per_row=per_row)
+        assert torch.equal(xm, xm_step.reshape(-1)), (tree, rows, K, per_row)
+        ratios = core._ratios(lb, ub, step, xt.device)
+        sums = []
+        for t, (p, gm) in enumerate(zip(plans, gmaxs)):
+            sse = antq_lib.search_sse(xt, r_, k_, xm, per_row, ratios, p, gm, ovp=ovp)
+            best, al = antq_lib.search_pick(sse, xm, ratios, k_)
+            assert torch.equal(al.reshape(-1), alpha[t]), (tree, rows, K, per_row, t)
+            sums.append(best.double().sum().item())
+            np.testing.assert_allclose(score[t].item(), sums[-1], rtol=1e-6)
+        # (b) the oracle
+        osum = []
+        for t, (g, gm) in enumerate(zip(grids_, gmaxs)):
+            rb, ra, trace = oracle.search_mse(xf.reshape(r_, k_) if not per_row else xf, xm.cpu().numpy(), lb, ub, step, g, gm,
+                                              ovp, per_row)
+            check_alpha_picks("%s_%d" % (tree, t), alpha[t].cpu().numpy(), ra, trace, ratios_of(lb, ub, step), xmax_rtol=0.0)
+            osum.append(float(rb.astype(np.float64).sum()))
+        order = np.argsort(osum)
+        if (osum[order[1]] - osum[order[0]]) > 1e-4 * osum[order[0]]:
+            assert int(typ.item()) == int(order[0]), (tree, rows, K, per_row, osum, score.cpu().numpy())
+        assert int(typ.item()) == int(np.argsort(score.cpu().numpy(), kind="stable")[0])
+    # empty candidate range: alpha = x_max, score = rows * 1e10 for every type, type 0; and a caller-supplied x_max
+    xt = to_dev((rng.standard_normal((8, 1024)) * 0.05).astype(np.float32), dev)
+    given = torch.full((8,), 0.2, device=dev)
+    alpha, score, typ, xm = antq_lib.calibrate(xt, 8, 1024, True, plans, gmaxs, 100, 100, step, xmax=given, ovp=ovp)
+    assert torch.equal(alpha, given.expand(len(plans), 8)) and int(typ.item()) == 0
+    np.testing.assert_allclose(score.cpu().numpy(), 8e10, rtol=1e-6)
+    alpha, score, typ, xm = antq_lib.calibrate(xt, 8, 1024, True, plans[:1], gmaxs[:1], lb, ub, step, xmax=given, ovp=ovp)
+    ratios = core._ratios(lb, ub, step, xt.device)
+    best, al = antq_lib.search_pick(antq_lib.search_sse(xt, 8, 1024, given, True, ratios, plans[0], gmaxs[0], ovp=ovp), given, ratios, 1024)
+    assert torch.equal(al, alpha[0]) and int(typ.item()) == 0
