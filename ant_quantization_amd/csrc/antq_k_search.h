@@ -104,11 +104,17 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
             float xm;
             task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
             const uint32_t v0 = g * (64u * U) + lane;
+            // the vectors' magnitude maxima, once for all candidates: per candidate ONE comparison per vector then says
+            // whether the per-element domain checks of the table path can be skipped (see quant_vec_x)
+            uint32_t vamax[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) vamax[u] = IO<T>::amax_acc(0u, v[u]);
             for (int c = c_begin; c < c_end; c++) {
                 const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
                 const Scale sc = make_scale(a, gmax);
                 bool rowfast = false;
                 if (XD) rowfast = build_row_table(xa, ent, ent2, sc, wtab, lane);
+                const uint32_t lkey = IO<T>::lim_key(fminf(xa.flim, xa.xlim) * sc.s * 0.999f);
                 double acc = 0.0;
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -116,7 +122,7 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
                         float xf[EPL], of[EPL];
                         int j[EPL];
                         IO<T>::unpack(v[u], xf);
-                        if (XD) quant_vec_x<EPL, OVP, false>(xa, wtab, grid_g, sc, rowfast, false, xf, of, j);
+                        if (XD) quant_vec_x<EPL, OVP, false>(xa, wtab, grid_g, sc, rowfast, rowfast && IO<T>::all_below(vamax[u], lkey), xf, of, j);
                         else quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
                         float part = 0.0f;
 #pragma unroll
@@ -200,6 +206,9 @@ k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t v
             float xm;
             task_load<T, U>(x, xmax, per_row, task, vpr, tpr, lane, false, v, xm);
             const uint32_t v0 = g * (64u * U) + lane;
+            uint32_t vamax[U];             // (as in k_search_sse: one domain comparison per vector and candidate)
+#pragma unroll
+            for (int u = 0; u < U; u++) vamax[u] = IO<T>::amax_acc(0u, v[u]);
             // the flattened list [f_begin, f_end) type by type: a type's bucket entries and plan fields are fetched once
             int f = f_begin;
             for (int t = f_begin / ncand; f < f_end; t++) {
@@ -212,6 +221,7 @@ k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t v
                 const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
                 const Scale sc = make_scale(a, gmax_t);
                 const bool rowfast = build_row_table(xa, ent, ent2, sc, wtab, lane);
+                const uint32_t lkey = IO<T>::lim_key(fminf(xa.flim, xa.xlim) * sc.s * 0.999f);
                 double acc = 0.0;
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -219,7 +229,7 @@ k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t v
                         float xf[EPL], of[EPL];
                         int j[EPL];
                         IO<T>::unpack(v[u], xf);
-                        quant_vec_x<EPL, OVP, false>(xa, wtab, grid_t, sc, rowfast, false, xf, of, j);
+                        quant_vec_x<EPL, OVP, false>(xa, wtab, grid_t, sc, rowfast, rowfast && IO<T>::all_below(vamax[u], lkey), xf, of, j);
                         float part = 0.0f;
 #pragma unroll
                         for (int e = 0; e < EPL; e++) {

@@ -31,7 +31,10 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     if (!per_row) { row_len = rows * row_len; rows = 1; }
     const size_t vpr = row_len / EPL;
     if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
-    constexpr int U = 4;
+    // vectors per lane and task: the per-candidate work of a task that does not depend on its size (the row table for this
+    // scale, ~60 instructions incl. the exact f64 threshold moves; the scale's division; the 64-lane sum of the squared
+    // errors) is shared by twice the elements with 8 (tools/probe_search.py); short rows keep 4 (fewer idle lanes)
+    const int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : (vpr >= 512 ? 8 : 4);
     const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
@@ -54,12 +57,14 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     const XArgs xa = xargs_from_plan(plan_host, pa);
     const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
     const uint4 *xv = static_cast<const uint4 *>(x);
-#define ANTQ_LAUNCH_S(PT_, XD_)                                                                                    \
-    hipLaunchKernelGGL((k_search_sse<T, OVP, U, PT_, XD_>), gdim, bdim, (XD_) ? 0 : lds, st, xv, (uint32_t)total,    \
+#define ANTQ_LAUNCH_S(PT_, XD_, U_)                                                                                \
+    hipLaunchKernelGGL((k_search_sse<T, OVP, U_, PT_, XD_>), gdim, bdim, (XD_) ? 0 : lds, st, xv, (uint32_t)total,   \
                        (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, gmax, sse, ws, pa,          \
                        plan_tab_ptr(plan_dev), cand_chunk, xa)
-    if (pt) { if (xd) ANTQ_LAUNCH_S(true, true); else ANTQ_LAUNCH_S(true, false); }
-    else    { if (xd) ANTQ_LAUNCH_S(false, true); else ANTQ_LAUNCH_S(false, false); }
+#define ANTQ_LAUNCH_SU(PT_, XD_) do { if (U == 8) ANTQ_LAUNCH_S(PT_, XD_, 8); else ANTQ_LAUNCH_S(PT_, XD_, 4); } while (0)
+    if (pt) { if (xd) ANTQ_LAUNCH_SU(true, true); else ANTQ_LAUNCH_SU(true, false); }
+    else    { if (xd) ANTQ_LAUNCH_SU(false, true); else ANTQ_LAUNCH_SU(false, false); }
+#undef ANTQ_LAUNCH_SU
 #undef ANTQ_LAUNCH_S
     if (pt) hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)blocks, cand_chunk, sse);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
@@ -90,7 +95,7 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
         ma.grid[t] = reinterpret_cast<const float *>(tab);
         ma.gmax[t] = gmax[t];
     }
-    constexpr int U = 4;
+    const int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : (vpr >= 512 ? 8 : 4);      // (as in launch_search)
     const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
@@ -110,13 +115,16 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
     }
     const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
     const uint4 *xv = static_cast<const uint4 *>(x);
+#define ANTQ_LAUNCH_M(PT_, U_)                                                                                            \
+    hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U_, PT_>), gdim, bdim, 0, st, xv, (uint32_t)total, (uint32_t)vpr,      \
+                       (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, flat_chunk)
     if (pt) {
-        hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U, true>), gdim, bdim, 0, st, xv, (uint32_t)total, (uint32_t)vpr,
-                           (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, flat_chunk);
+        if (U == 8) ANTQ_LAUNCH_M(true, 8); else ANTQ_LAUNCH_M(true, 4);
         hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nflat), dim3(256), 0, st, ws, (uint32_t)blocks, flat_chunk, sse);
-    } else
-        hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U, false>), gdim, bdim, 0, st, xv, (uint32_t)total, (uint32_t)vpr,
-                           (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, flat_chunk);
+    } else {
+        if (U == 8) ANTQ_LAUNCH_M(false, 8); else ANTQ_LAUNCH_M(false, 4);
+    }
+#undef ANTQ_LAUNCH_M
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
