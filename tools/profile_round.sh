@@ -46,6 +46,7 @@ $PY tools/probe_size_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_size_sweep.lo
 $PY tools/probe_group_sweep.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_group_sweep.log"
 $PY tools/probe_lane_u.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_lane_task_u.log"
 $PY tools/probe_codec.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_codec.log"
+$PY tools/probe_search.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_search.log"
 ( $PY tools/probe_absmax.py; $PY tools/probe_affine.py ) 2>&1 | grep -v amdgpu > "$OUT/${TAG}_aux_kernels.log"
 ( $PY tools/probe_lane_rows.py; $PY tools/probe_lane_rows_np2.py; $PY tools/probe_batch_lane.py ) 2>&1 | grep -v amdgpu > "$OUT/${TAG}_lane_rows.log"
 ( $PY tools/bench_sharded.py --model opt6.7b; $PY tools/bench_sharded.py --model llama70b --inplace ) 2>&1 | grep "^{" > "$OUT/${TAG}_sharded.log"
