@@ -499,7 +499,9 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
         if (v0 + 64u * u < vpr) {
             float xf[EPL], of[EPL];
             int j[EPL];
-            const bool pre = rowfast && IO<T>::all_below(IO<T>::amax_acc(0u, v[u]), lkey);
+            // (not in the pair kernel: it runs at 64 registers for 8 waves per SIMD, the extra live values spill, and whole
+            //  models lost up to 12 points with 4-vector tasks -- OPT-6.7B 78 -> 66 % -- for +0.4 with 2-vector tasks)
+            const bool pre = OVP ? false : (rowfast && IO<T>::all_below(IO<T>::amax_acc(0u, v[u]), lkey));
             IO<T>::unpack(v[u], xf);
             quant_vec_x<EPL, OVP, IDX>(xa, wtab, grid, sc, rowfast, pre, xf, of, j);
             st_stream(out + base + 64u * u, IO<T>::pack(of));
