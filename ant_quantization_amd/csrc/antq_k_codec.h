@@ -397,17 +397,21 @@ static int launch_codec(bool enc, const void *x, void *codes_or_out, const uint8
         const size_t rl = per_row ? row_len : n;
         const size_t vpr = rl / IO<T>::EPL;
         if (pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr && vpr <= 0xffffffffull && rl % 8 == 0) {
-            const uint32_t U = 2;
+            // 4 vectors per lane for rows of >= 256 vectors (the encoder is VALU-bound: the per-task table build is then shared
+            // by twice the elements: +3 ... +5 points, tools/probe_codec_u.py; knob 0 = 2 / 4 / 8 forces a size for A/B)
+            const uint32_t U = (g_knob_u == 2 || g_knob_u == 4 || g_knob_u == 8) ? (uint32_t)g_knob_u : (vpr >= 256 ? 4u : 2u);
             const size_t tpr = (vpr + 64 * U - 1) / (64 * U), total = (per_row ? rows : 1) * tpr;
             if (total <= 0x7fffffffull) {
                 XArgs xa = xargs_from_plan(plan_host, pa);
                 xa.inv_gmax = 1.0 / (double)gmax;
                 const uint4 *tab = plan_tab_ptr(plan_dev);
-#define ANTQ_ENCX(O) hipLaunchKernelGGL((k_encode4_xrow<T, O, 2>), dim3((unsigned)total), dim3(64), 0, st, static_cast<const uint4 *>(x),    \
+#define ANTQ_ENCX(O, U_) hipLaunchKernelGGL((k_encode4_xrow<T, O, U_>), dim3((unsigned)total), dim3(64), 0, st, static_cast<const uint4 *>(x), \
                                         static_cast<uint32_t *>(codes_or_out), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, \
                                         gmax, xa, tab + (pa.m_pad >> 2), reinterpret_cast<const float *>(tab), n_normal, zero_code,    \
                                         pa.fastlim * 0.99999f)
-                if (ovp) ANTQ_ENCX(true); else ANTQ_ENCX(false);
+                if (U == 8) { if (ovp) ANTQ_ENCX(true, 8); else ANTQ_ENCX(false, 8); }
+                else if (U == 4) { if (ovp) ANTQ_ENCX(true, 4); else ANTQ_ENCX(false, 4); }
+                else        { if (ovp) ANTQ_ENCX(true, 2); else ANTQ_ENCX(false, 2); }
 #undef ANTQ_ENCX
                 return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
             }
