@@ -2687,6 +2687,8 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
         alpha = (alpha + 1e-6).astype(np.float32)
         if akind == 2 and rows > 2:
             alpha[1], alpha[2] = 0.0, -alpha[2]
+        if akind == 3 and rows > 3:
+            alpha[0], alpha[1], alpha[3] = np.inf, np.nan, np.float32(1e-42)       # (a denormal scale)
         per_row = bool(rng.random() < 0.75)
         a_np = alpha if per_row else np.float32(alpha.mean())
         tag = (seed, case, gname, rows, K, bf16, ovp, per_row, int(akind))
