@@ -217,6 +217,10 @@ int main(int argc, char **argv)
             line("any-order, oneshot wg=64 U=4, 96 ops/vec", [&]() { for (int i = 0; i < NT; i++) T_ANY(4, 24, 1, i); });
             line("any-order, oneshot wg=128 U=2, 96 ops/vec", [&]() { for (int i = 0; i < NT; i++) T_ANY(2, 24, 2, i); });
             line("any-order, oneshot wg=64 U=2, 0 ops", [&]() { for (int i = 0; i < NT; i++) T_ANY(2, 0, 1, i); });
+#define T_ANYS(U, N, WV, STREAM, I) hipExtLaunchKernelGGL((k_oneshot<U, 2, 2, N, 0, WV>), dim3((n_vec + 64u * WV * U - 1) / (64u * WV * U)), dim3(64 * WV), 0, STREAM, nullptr, nullptr, hipExtAnyOrderLaunch, src(I), dst(I), n_vec, c1, c2)
+            line("any-order on 2 streams, oneshot wg=64 U=4, 96 ops/vec", [&]() { fork(2); for (int i = 0; i < NT; i++) T_ANYS(4, 24, 1, C.st[i % 2], i); join(2); });
+            line("any-order on 2 streams, oneshot wg=64 U=2, 96 ops/vec", [&]() { fork(2); for (int i = 0; i < NT; i++) T_ANYS(2, 24, 1, C.st[i % 2], i); join(2); });
+            line("any-order on 4 streams, oneshot wg=64 U=4, 96 ops/vec", [&]() { fork(4); for (int i = 0; i < NT; i++) T_ANYS(4, 24, 1, C.st[i % 4], i); join(4); });
             line("any-order then ONE ordered launch per pass (wg=64 U=2, 96 ops)", [&]() { for (int i = 0; i < NT - 1; i++) T_ANY(2, 24, 1, i); T_ONEW(2, 24, 1, C.st[0], NT - 1); });
         }
         // a hipGraph whose NT kernel nodes have no edges between them (captured from forked streams)
