@@ -1399,6 +1399,20 @@ def test_entry_points_capture_into_a_hip_graph(antq_lib, dev):
     for x, a, o in zip(xs, al, outs):
         assert torch.equal(o, antq_lib.fakequant(x, a, plan, 10.0, 256, 1024, True))
     assert torch.equal(one, outs[0])
+    # unordered launches (ANTQ_FLAG_UNORDERED) inside a capture: whatever the runtime makes of the any-order flag in a graph
+    # node, the replay must produce the same bits (weights at rest: x / alpha are not written by the graph)
+    bufs = [torch.zeros_like(x) for x in xs]
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        for x, a, b in zip(xs, al, bufs):
+            antq_lib.fakequant(x, a, plan, 10.0, 256, 1024, True, out=b, unordered=True)
+    for b in bufs:
+        b.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    for b, o in zip(bufs, outs):
+        assert torch.equal(b, o)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("ANTQ_FUZZ_SEEDS", 12))))
