@@ -107,6 +107,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
                                        # stream-ordered allocator could sit on memory an in-flight kernel still uses):
                                        # every forward returns the same storage, like WeightBank's resident outputs
         self._rest_out = None
+        self._rest_stamp = None
         self._type_search = None  # during one calibration: grid bytes -> clip search result of the type selection's pass
 
     # ---------------------------------------------------------------- bookkeeping
@@ -367,11 +368,25 @@ class Quantizer(HostMirrorMixin, nn.Module):
             torch.cuda.current_stream(data.device).synchronize()      # (once: nothing in flight may still own this block)
         return b
 
+    def _at_rest(self, data):
+        """Whether THIS call may launch unordered: the weight and alpha are the very tensors (same storage, same version
+        counter) the previous call saw -- so whatever wrote them (calibration a moment ago, load_state_dict, an optimiser
+        step, a dtype / device move) is at least one ordinary, ordered launch of this quantiser in the past.  The first call
+        after any such change launches ordered.  (`.data` edits do not bump the counter: those stay the caller's promise.)"""
+        if not (self.weights_at_rest and not self.is_input):
+            return False
+        a = self.alpha
+        stamp = (data.data_ptr(), data._version, a.data_ptr(), a._version)
+        if stamp != self._rest_stamp:
+            self._rest_stamp = stamp
+            return False
+        return True
+
     def _forward(self, data):
         """AQ:535-551 as one fused kernel."""
         plan = self._ensure_plan()
         return core.fake_quant(data, self.alpha, plan, self._gmax, self.is_perchannel,
-                               unordered=self.weights_at_rest and not self.is_input, out=self._rest_buffer(data))
+                               unordered=self._at_rest(data), out=self._rest_buffer(data))
 
     def tensor_forward(self, tensor, input_tensor=None):
         if self.mode == "base":

@@ -106,8 +106,7 @@ def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False, unordered=False, ou
     rows, row_len = view_rows(xc, per_channel)
     a = alpha.detach().reshape(-1).to(torch.float32).contiguous()
     unordered = unordered and out is not None and xc.data_ptr() == x.data_ptr()
-    return _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp, unordered=unordered,
-                          out=out if unordered else None)
+    return _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp, unordered=unordered, out=out)
 
 
 def clip_search(x, x_max, per_channel, lo, hi, step, plan, gmax, ovp=False):

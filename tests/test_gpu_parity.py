@@ -980,6 +980,34 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
             assert torch.equal(y2, y1)
         qutil.set_weights_at_rest(model, False)
         assert torch.equal(model(x), y1) and torch.equal(y0, y1)
+        # weights rewritten by work STILL IN FLIGHT (an in-place update, a device-side load_state_dict): the version counter
+        # moves, so the first forward afterwards launches ordered -- and later ones, unordered again, agree with it
+        qutil.set_weights_at_rest(model, True)
+        model(x)
+        lins = [m for m in model.modules() if isinstance(getattr(m, "weight", None), torch.Tensor) and hasattr(m, "quant_weight")]
+        new_w = [torch.randn_like(m.weight) * 0.05 for m in lins]
+        ref_model_out = None
+        for rep in range(3):
+            big = torch.randn(8192, 8192, device=dev)
+            for m, w in zip(lins, new_w):
+                big = big * 1.0001                                  # a few ms of queued work ahead of the copies
+                m.weight.copy_(w * (1.0 + 0.1 * rep))
+            y_a = model(x)                                          # first forward after the change: ordered launches
+            y_b = model(x)                                          # unordered again
+            qutil.set_weights_at_rest(model, False)
+            y_ref = model(x)
+            qutil.set_weights_at_rest(model, True)
+            assert torch.equal(y_a, y_ref) and torch.equal(y_b, y_ref), rep
+    # the flag set BEFORE the first (calibrating) forward: calibration writes alpha a moment before the launch
+    net2 = nn.Sequential(nn.Linear(1024, 512), nn.GELU(), nn.Linear(512, 64))
+    m2 = qmod.quantize_model(net2).to(dev).eval()
+    qutil.enable_quantization(m2)
+    qutil.set_weights_at_rest(m2, True)
+    with torch.no_grad():
+        z0 = m2(x)
+        z1 = m2(x)
+        qutil.set_weights_at_rest(m2, False)
+        assert torch.equal(m2(x), z1) and torch.equal(z0, z1)
     capsys.readouterr()
     del junk
 
