@@ -36,8 +36,8 @@ extern "C" {
 #endif
 
 /* 2 (round 3): antq_search_sse / antq_alpha_grad take a caller workspace before `stream`, antq_absmax initialises its
- * output, the batch blob changed (plan version 8), ANTQ_FLAG_UNORDERED.  A caller built against another version must not
- * call in: the argument lists differ. */
+ * output, the batch blob changed (plan version 8), ANTQ_FLAG_UNORDERED.  3: antq_calibrate / antq_calibrate_workspace_bytes
+ * added (nothing else changed).  A caller built against another version must not call in: the argument lists differ. */
 #define ANTQ_ABI_VERSION 3
 
 /* element types of x / out */
