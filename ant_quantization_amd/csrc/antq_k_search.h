@@ -55,6 +55,37 @@ k_sum_partials(const double *__restrict__ ws, uint32_t n_wg, int chunk, double *
 // wavefront rebuilds its row table for THAT scale (closed-form thresholds, ~14 ops per lane) and the element loop is
 // the one of k_fq_xrow -- no division, no straight-through arithmetic, no multiply: ~12 instead of ~20 VALU ops per
 // candidate evaluation.
+// Sums over the 64 lanes of FOUR per-lane doubles at once (the squared-error sums of four consecutive candidates): two
+// transposing exchanges (lanes 32 apart, then 16 apart: each lane gives away the half it does not keep) leave row r of 16
+// lanes with candidate r's partial sums, which four DPP steps (no LDS crossbar) add up -- 3 crossbar exchanges of a double
+// per FOUR candidates instead of 6 per candidate (the reduction was 7-10 % of the calibration kernels' time).  Returns, in
+// every lane of row r (lanes 16 r .. 16 r + 15), the total of value r.  One fixed order: bit-reproducible.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum4(double a0, double a1, double a2, double a3, uint32_t lane)
+{
+    const bool up = (lane & 32u) != 0u;              // lanes 32..63 keep values 2, 3 and give away 0, 1
+    double k0 = up ? a2 : a0, k1 = up ? a3 : a1;
+    const double s0 = up ? a0 : a2, s1 = up ? a1 : a3;
+    k0 += __shfl_xor(s0, 32, 64);
+    k1 += __shfl_xor(s1, 32, 64);
+    const bool odd = (lane & 16u) != 0u;             // rows 1, 3 keep the second value of their pair
+    double k = odd ? k1 : k0;
+    const double s = odd ? k0 : k1;
+    k += __shfl_xor(s, 16, 64);
+    k += dpp_f64<0xB1>(k);                           // quad_perm [1,0,3,2]
+    k += dpp_f64<0x4E>(k);                           // quad_perm [2,3,0,1]
+    k += dpp_f64<0x141>(k);                          // row_half_mirror
+    k += dpp_f64<0x140>(k);                          // row_mirror
+    return k;
+}
+
 template <typename T, bool OVP, int U, bool PT, bool XD>
 __global__ void __launch_bounds__(256)
 k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
@@ -109,6 +140,8 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
             uint32_t vamax[U];
 #pragma unroll
             for (int u = 0; u < U; u++) vamax[u] = IO<T>::amax_acc(0u, v[u]);
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;      // the last four candidates' per-lane sums (q3 the newest)
+            int filled = 0;
             for (int c = c_begin; c < c_end; c++) {
                 const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
                 const Scale sc = make_scale(a, gmax);
@@ -133,11 +166,17 @@ k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, ui
                         acc += (double)part;
                     }
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-                if (lane == 0) {
-                    if (!PT && tpr == 1) sse[(size_t)c * na + row] = acc;
-                    else wacc[wv][c - c_begin] += acc;
+                q0 = q1; q1 = q2; q2 = q3; q3 = acc;
+                if (++filled == 4 || c == c_end - 1) {
+                    // four (or the last few) candidates summed over the lanes together: row r of lanes holds slot r
+                    const double tot = wave_sum4(q0, q1, q2, q3, lane);
+                    const int slot = (int)(lane >> 4), cc = c - 3 + slot;
+                    if ((lane & 15u) == 0u && slot >= 4 - filled) {
+                        if (!PT && tpr == 1) sse[(size_t)cc * na + row] = tot;
+                        else wacc[wv][cc - c_begin] += tot;
+                    }
+                    q0 = q1 = q2 = q3 = 0.0;
+                    filled = 0;
                 }
             }
         }
@@ -169,8 +208,10 @@ struct MultiArgs {
     int ntypes;
 };
 
+// (16-bit data, 4-vector tasks: held to 128 registers = 4 waves per SIMD; the four-candidate lane sum's eight extra
+//  registers would otherwise cost the kernel a wave per SIMD and 3.5 %)
 template <typename T, bool OVP, int U, bool PT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (IO<T>::EPL == 8 && U == 4) ? 4 : 1)
 k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
                    const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand,
                    double *__restrict__ sse, double *__restrict__ ws, MultiArgs ma, int flat_chunk)
@@ -217,6 +258,8 @@ k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t v
             const float gmax_t = ma.gmax[t];
             const float *grid_t = ma.grid[t];
             const int c_first = f - t * ncand, c_last = min(ncand, f_end - t * ncand);
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;      // (as in k_search_sse: four candidates per lane reduction)
+            int filled = 0;
             for (int c = c_first; c < c_last; c++, f++) {
                 const float a = xm * ratios[c];  // AQ:300  new_alpha = base_alpha * fl32(i*0.01)
                 const Scale sc = make_scale(a, gmax_t);
@@ -239,11 +282,16 @@ k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t v
                         acc += (double)part;
                     }
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-                if (lane == 0) {
-                    if (!PT && tpr == 1) sse[((size_t)t * ncand + c) * na + row] = acc;
-                    else wacc[wv][f - f_begin] += acc;
+                q0 = q1; q1 = q2; q2 = q3; q3 = acc;
+                if (++filled == 4 || c == c_last - 1) {
+                    const double tot = wave_sum4(q0, q1, q2, q3, lane);
+                    const int slot = (int)(lane >> 4), back = 3 - slot;          // candidate c - back, flat index f - back
+                    if ((lane & 15u) == 0u && slot >= 4 - filled) {
+                        if (!PT && tpr == 1) sse[((size_t)t * ncand + (c - back)) * na + row] = tot;
+                        else wacc[wv][f - back - f_begin] += tot;
+                    }
+                    q0 = q1 = q2 = q3 = 0.0;
+                    filled = 0;
                 }
             }
             }

@@ -34,7 +34,7 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     // vectors per lane and task: the per-candidate work of a task that does not depend on its size (the row table for this
     // scale, ~60 instructions incl. the exact f64 threshold moves; the scale's division; the 64-lane sum of the squared
     // errors) is shared by twice the elements with 8 (tools/probe_search.py); short rows keep 4 (fewer idle lanes)
-    const int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : (vpr >= 512 ? 8 : 4);
+    const int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : ((vpr >= 512 && EPL == 4) ? 8 : 4);   // (16-bit: 4 measured faster)
     const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
@@ -95,7 +95,8 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
         ma.grid[t] = reinterpret_cast<const float *>(tab);
         ma.gmax[t] = gmax[t];
     }
-    const int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : (vpr >= 512 ? 8 : 4);      // (as in launch_search)
+    // (as in launch_search; 16-bit data stays at 4: with 8 the kernel needs 169 registers -- 2 waves per SIMD instead of 3)
+    const int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : ((vpr >= 512 && EPL == 4) ? 8 : 4);
     const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
