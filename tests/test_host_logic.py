@@ -84,6 +84,17 @@ def test_cabi_argument_errors_without_gpu(antq_lib):
     assert L.antq_fakequant(None, None, None, ctypes.c_size_t(0), ctypes.c_size_t(4), None, 0, ctypes.c_float(1),
                             None, None, 0, 0, None) == 0       # empty tensor: nothing to do
     assert L.antq_nearest(None, None, None, ctypes.c_size_t(0), None, 0, 0, None) == 0
+    # antq_calibrate: nothing to do for an empty tensor, argument errors before any launch, workspace size arithmetic
+    sz, ci = ctypes.c_size_t, ctypes.c_int
+    cal = lambda rows, step, ntypes: L.antq_calibrate(None, sz(rows), sz(64), ci(1), ci(0), ci(1), None, ci(75), ci(150), ci(step),
+                                                      ci(ntypes), None, None, None, ctypes.c_uint(0), None, None, None, None,
+                                                      sz(0), None)
+    assert cal(0, 1, 1) == 0 and cal(8, 1, 1) == -1 and cal(8, 0, 1) == -1 and cal(8, 1, 0) == -1
+    wsb = lambda rows, per_row, lb, ub, step, nt: L.antq_calibrate_workspace_bytes(sz(rows), ci(per_row), ci(lb), ci(ub), ci(step), ci(nt))
+    assert wsb(8, 1, 75, 150, 1, 0) == 0 and wsb(8, 1, 75, 150, 0, 2) == 0
+    base = L.antq_search_workspace_bytes()
+    assert wsb(8, 1, 100, 100, 1, 2) > base                       # an empty candidate range still needs the fixed parts
+    assert wsb(4096, 1, 75, 150, 1, 3) - wsb(4096, 0, 75, 150, 1, 3) >= 3 * 75 * 4095 * 8      # sse: [types][cands][rows] doubles
 
 
 # ---------------------------------------------------------------- plans
