@@ -209,6 +209,30 @@ def main():
         bt = _lib.Batch([(w, o, a, pol, 32.0, w.shape[0], w.shape[1], True) for w, a, o in zip(ws, al, outs)], ovp=True)
         report("C3 OPT-6.7B W (%d tensors), OliVe flint4 OVP, %s, BATCHED" % (len(ws), str(dt)[6:]), elems, bpe,
                timed(bt.run, 5), 1)
+        if dt == torch.bfloat16:
+            # OliVe's calibration of these tensors (OQ:189-256): x_max = max|mean +- 3 std| per row, then for int and flint
+            # (+ outliers, pair rule) the clip search over range(75, 250, 2) -- 88 candidates x 2 types -- and the type pick.
+            # "reference statistic": t.mean(1) / t.std(1) as torch ops (what OQ:193-197 runs: >= 3 reads of the tensor);
+            # "one read": antq_moments + antq_xmax_3sigma.  The search is ours in both (the reference's: 176 full passes).
+            gi = np.concatenate([grids.olive_int(4, True), go])
+            pls, gms = [_lib.plan_for(gi), pol], [float(grids.olive_int(4, True).max()), 32.0]
+            def stat_ref():
+                for w in ws:
+                    mu, sd = w.mean(1), w.std(1)
+                    torch.maximum((mu + 3 * sd).abs(), (mu - 3 * sd).abs())
+            def stat_one():
+                for w in ws:
+                    _lib.xmax_3sigma(w, w.shape[0], w.shape[1], per_row=True)
+            def full():
+                for w in ws:
+                    _lib.calibrate(w, w.shape[0], w.shape[1], True, pls, gms, 75, 250, 2, xmax="3sigma", ovp=True)
+            t_ref, t_one, t_full = timed(stat_ref, 3), timed(stat_one, 3), timed(full, 2)
+            evals = elems * 88 * 2
+            scale = 192 / len(ws)
+            print("%-58s %8.2f ms reference statistic (torch mean / std), %6.2f ms on one read (antq_moments)" % (
+                "C3 OPT-6.7B calibration, clip statistic, %d tensors" % len(ws), t_ref * 1e3, t_one * 1e3), flush=True)
+            print("%-58s %8.1f ms = %6.1f G candidate-evals/s (statistic + 2 types x 88 ratios + picks, antq_calibrate); x %d for the 192 tensors: %.0f ms" % (
+                "C3 OPT-6.7B calibration, whole (these %d tensors)" % len(ws), t_full * 1e3, evals / t_full / 1e9, int(scale), t_full * 1e3 * scale), flush=True)
         del ws, outs, al, bt
 
     # ---------------- C4: 70B-parameter bf16 Linear stack, OliVe flint4 OVP: this rank's 1/8 share (LPT by bytes)
