@@ -302,7 +302,7 @@ __device__ __forceinline__ void x_slots(const XArgs &xa, const float (&dt)[EPL],
     }
 }
 
-template <int EPL, bool OVP, bool IDX>
+template <int EPL, bool OVP, bool IDX, bool PRE = true>
 __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, const float *__restrict__ grid,
                                             const Scale &sc, bool rowfast, bool pre, const float (&x)[EPL],
                                             float (&o)[EPL], int (&j)[EPL])
@@ -317,14 +317,23 @@ __device__ __forceinline__ void quant_vec_x(const XArgs &xa, const uint4 *wtab, 
     bool fast = rowfast;
     float dt[EPL];
     float dmax = 0.0f;
+    if constexpr (PRE) {
 #pragma unroll
-    for (int e = 0; e < EPL; e++) {
-        dt[e] = x[e] * sc.rs;
-    }
-    if (!pre) {
+        for (int e = 0; e < EPL; e++) dt[e] = x[e] * sc.rs;
+        if (!pre) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                fast = fast && (fabsf(dt[e]) < xa.flim);     // false for NaN / Inf / beyond the table's domain
+                dmax = __builtin_fmaxf(dmax, fabsf(dt[e]));
+            }
+        }
+    } else {
+        // (PRE = false: the callers that never pass pre -- the pair kernel, compiled for 64 registers -- keep the loop they
+        //  were tuned with: checks fused with the products)
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
-            fast = fast && (fabsf(dt[e]) < xa.flim);     // false for NaN / Inf / beyond the table's domain
+            dt[e] = x[e] * sc.rs;
+            fast = fast && (fabsf(dt[e]) < xa.flim);
             dmax = __builtin_fmaxf(dmax, fabsf(dt[e]));
         }
     }
@@ -503,7 +512,7 @@ __device__ __forceinline__ void xrow_task(const uint4 *__restrict__ x, uint4 *__
             //  models lost up to 12 points with 4-vector tasks -- OPT-6.7B 78 -> 66 % -- for +0.4 with 2-vector tasks)
             const bool pre = OVP ? false : (rowfast && IO<T>::all_below(IO<T>::amax_acc(0u, v[u]), lkey));
             IO<T>::unpack(v[u], xf);
-            quant_vec_x<EPL, OVP, IDX>(xa, wtab, grid, sc, rowfast, pre, xf, of, j);
+            quant_vec_x<EPL, OVP, IDX, !OVP>(xa, wtab, grid, sc, rowfast, pre, xf, of, j);
             st_stream(out + base + 64u * u, IO<T>::pack(of));
             if (IDX) store_idx<EPL>(idx, base + 64u * u, j);
         }
