@@ -346,12 +346,17 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
 
 /* Development / benchmark tuning knobs (thread-local: only the calling thread's later calls are affected; not part of
  * the stable surface):
- *   key 0: force the per-task unroll U of the row kernels (0 = heuristic)
- *   key 1: number of persistent workgroups of antq_encode4 (0 = default, 2048)
+ *   key 0: force the vectors per lane and task (U) of the row kernels -- batched launch 1..4, row-table encoder 2 / 4 / 8,
+ *          calibration kernels 4 / 8 (0 = heuristic)
+ *   key 1: number of persistent workgroups of antq_encode4's element encoder (0 = default, 2048)
  *   key 2: 0 disables the per-row (x-domain) table kernels, the d-domain kernels run instead (A/B measurements)
  *   key 3: 0 disables the binary-search path of antq_nearest (literal scan only)
+ *   key 4: 0 makes the element encoder divide exactly instead of using the approximate-quotient decision
  *   key 5: 0 sends long rows through the per-row table kernels, 2 through the lane kernel in batches too (1 = the measured
- *          default: lane kernel for one-launch-per-tensor calls and fp32 batches) */
+ *          default: lane kernel for one-launch-per-tensor calls and fp32 batches)
+ *   key 6: wavefronts per workgroup (1 / 2 / 4) of the batched row-table launch and of the one-launch lane kernel (0 = heuristic)
+ *   key 7: vectors per lane of the one-launch lane kernel (0 = heuristic)
+ *   key 8: workgroup -> task map rotation of the batched row-table launch: 0 per job (default), 1 always, 2 never */
 int antq_debug_set(int key, int value);
 
 #ifdef __cplusplus
