@@ -33,20 +33,15 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     std::vector<uint8_t> fam((size_t)n);
     std::vector<size_t> nblk((size_t)n);
     // bytes the launch will move (in + out).  Whole models (OPT-6.7B: 25.8 GB, the 70 B stack: 137 GB in place) stream with
-    // a longer average memory latency than a few GB do (address translation), and the best launch shape moves with it.
-    // Below ~8 GB: one-wavefront workgroups, 2-vector tasks (81.4 against 79.7 % with 4, tools/probe_footprint.py).  Beyond,
-    // by row length (tools/bench_sharded.py --knobs, same box): rows of 512 vectors (OPT-6.7B: two thirds of its bytes) want
-    // 4-vector tasks in one-wavefront workgroups (77.2 % against 73.6-74.3 with 2-vector tasks), rows of >= 1024 vectors
-    // (the 70 B stack, its per-rank share) 2-vector tasks in 4-wavefront workgroups (78.6 against 76.4 %).
-    double batch_bytes = 0.0, long_row_bytes = 0.0;
-    for (int i = 0; i < n; i++) {
-        const double b = 2.0 * (double)jobs[i].rows * (double)jobs[i].row_len * (dtype == ANTQ_F32 ? 4.0 : 2.0);
-        batch_bytes += b;
-        const double rl = jobs[i].alpha_per_row ? (double)jobs[i].row_len : (double)jobs[i].rows * (double)jobs[i].row_len;
-        if (rl / epl >= 1024.0) long_row_bytes += b;
-    }
+    // a longer average memory latency than a few GB do (address translation), and the best launch shape moves with it: below
+    // ~8 GB one-wavefront workgroups win (81.4 against 80.5 %, tools/probe_footprint.py); beyond, 4 wavefronts per workgroup
+    // with the same 2-vector tasks: OPT-6.7B 79.4 against 78.3 % (one wavefront, 2 or 4 vectors), the 70 B stack 77.9
+    // against 77.3 % (tools/bench_sharded.py --knobs in steady state; tools/probe_sharded_ab.py on five boxes: +1.0 ... +1.6).
+    // (An earlier choice -- 4-vector tasks in one-wavefront workgroups -- came from a harness that timed 5 passes after 2:
+    //  before the clocks had settled, where fewer, longer tasks look better.)
+    double batch_bytes = 0.0;
+    for (int i = 0; i < n; i++) batch_bytes += 2.0 * (double)jobs[i].rows * (double)jobs[i].row_len * (dtype == ANTQ_F32 ? 4.0 : 2.0);
     const bool big_footprint = batch_bytes >= 8.0 * 1073741824.0;
-    const bool big_long = big_footprint && 2.0 * long_row_bytes >= batch_bytes;
     size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0, 0}, lds = 0;
     bool any_da = false;
     for (int i = 0; i < n; i++) {
@@ -83,7 +78,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             if (d.kind == 0 && xdom) {
                 // x-domain rows: the task size that leaves the fewest idle lanes for this row length
                 d.kind = 2;
-                d.u = (big_footprint && !big_long) ? row_task_u(d.vpr) : row_task_u_small(d.vpr);
+                d.u = row_task_u_small(d.vpr);
                 if (g_knob_u >= 1 && g_knob_u <= 4) d.u = (uint32_t)g_knob_u;     // knob 0 (A/B): vectors per lane and task
                 d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
                 const size_t total = (J.alpha_per_row ? J.rows : (size_t)1) * (size_t)d.tpr;   // per tensor: ONE row
@@ -186,7 +181,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         double long_b = 0.0, short_b = 0.0;
         for (int i = 0; i < n; i++)
             if (descs[i].kind == 2) (descs[i].vpr >= 256u ? long_b : short_b) += (double)descs[i].total_tasks * descs[i].u;
-        h.pad |= ((long_b >= short_b && !big_long) ? 1u : 4u) << 8;               // (big footprints: see batch_bytes above)
+        h.pad |= ((long_b >= short_b && !big_footprint) ? 1u : 4u) << 8;          // (big footprints: see batch_bytes above)
     }
     size_t total_blocks = 0;
     for (int i = 0; i < n; i++) {

@@ -59,16 +59,25 @@ def main():
     outs = ws if args.inplace else [torch.empty_like(w) for w in ws]
     elems = sum(w.numel() for w in ws)
     bt = _lib.Batch([(w, o, a, plan, 32.0, w.shape[0], w.shape[1], True) for w, o, a in zip(ws, outs, alphas)], ovp=True)
-    for _ in range(2):
+    # warm-up: at least 2 passes and at least 100 ms of them (an MI355X that was idle -- or busy with the short kernels of the
+    # data generation above -- needs ~50 ms of load to reach steady clocks: tools/probe_clock_ramp.py); then at least
+    # `--passes` passes and at least 200 ms of them
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bt.run()
+    torch.cuda.synchronize()
+    once = max(time.perf_counter() - t0, 1e-6)
+    for _ in range(max(1, int(0.1 / once) + 1)):
         bt.run()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
+    passes = max(args.passes, int(0.2 / once) + 1)
     t0 = time.perf_counter()
-    for _ in range(args.passes):
+    for _ in range(passes):
         bt.run()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.passes
+    dt = (time.perf_counter() - t0) / passes
     tot = torch.tensor([float(elems)], dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if multi:

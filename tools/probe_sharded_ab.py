@@ -21,6 +21,9 @@ shapes = opt67_shapes(32) if model.startswith("opt6.7b") else opt67_shapes(int(m
 if ":" in model:                      # e.g. opt6.7b:4096x4096 -- only the tensors of that shape
     want = tuple(int(v) for v in model.split(":")[1].split("x"))
     shapes = [s_ for s_ in shapes if tuple(s_) == want]
+if os.environ.get("PROBE_LPT") == "1":           # the order tools/bench_sharded.py uses (largest tensors first)
+    from ant_quantization_amd import sharding
+    shapes = [shapes[i] for i in sharding.lpt_assign([2 * a * b for a, b in shapes], 1)[0]]
 ovp = os.environ.get("PROBE_OVP", "1") == "1"
 plan = _lib.plan_for(np.concatenate([grids.olive_flint(4, True), grids.olive_outliers(4, True)]) if ovp else grids.ant_flint(4, True))
 gmax = 32.0 if ovp else 10.0
