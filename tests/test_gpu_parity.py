@@ -2902,3 +2902,33 @@ def test_calibrate_one_call_equals_the_stepwise_calibration_and_the_oracle(antq_
     ratios = core._ratios(lb, ub, step, xt.device)
     best, al = antq_lib.search_pick(antq_lib.search_sse(xt, 8, 1024, given, True, ratios, plans[0], gmaxs[0], ovp=ovp), given, ratios, 1024)
     assert torch.equal(al, alpha[0]) and int(typ.item()) == 0
+
+
+def test_bench_line_contract_on_the_gpu(antq_lib, dev):
+    """`python bench.py` prints ONE JSON line with the driver's keys, the roofline object of the dominant kernel (live launch
+    time, algorithmic bytes, copy ceiling of the same process) and -- unless switched off -- the CPU baseline; K steps are timed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--nbuf", "8"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "Gelem/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
+    assert r["algorithmic_bytes_per_launch"] == 8 * 4096 * 4096 * 4
+    # value = elements per step / time per step, and the live launch time is (nearly) the step time of a one-launch step
+    assert abs(d["value"] - 8 * 4096 * 4096 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    assert abs(r["launch_us"] - d["ms_per_step"] * 1e3) < 0.25 * r["launch_us"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Gelem/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
