@@ -105,7 +105,9 @@ def fake_quant(x, alpha, plan, gmax, per_channel, ovp=False, unordered=False, ou
     xc = x.detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)
     a = alpha.detach().reshape(-1).to(torch.float32).contiguous()
-    unordered = unordered and out is not None and xc.data_ptr() == x.data_ptr()
+    # (x or alpha converted on the way -- a non-contiguous weight, an alpha that model.bfloat16() turned into bf16 -- are
+    #  tensors a kernel still in flight is writing: that launch must stay ordered)
+    unordered = unordered and out is not None and xc.data_ptr() == x.data_ptr() and a.data_ptr() == alpha.data_ptr()
     return _lib.fakequant(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp, unordered=unordered, out=out)
 
 

@@ -88,6 +88,8 @@ class Quantizer(HostMirrorMixin, nn.Module):
                                        # every forward returns the same storage, like WeightBank's resident outputs
         self._rest_out = None
         self._rest_stamp = None
+        self._alpha32 = None
+        self._alpha32_stamp = None
         self._type_search = None  # during one calibration: grid bytes -> clip search result of the type selection's pass
 
     # ---------------------------------------------------------------- bookkeeping
@@ -293,6 +295,20 @@ class Quantizer(HostMirrorMixin, nn.Module):
             torch.cuda.current_stream(data.device).synchronize()      # (once: nothing in flight may still own this block)
         return b
 
+    def _rest_alpha(self):
+        """alpha as the kernels take it (float32).  A model moved to bf16 / fp16 carries a 16-bit alpha Parameter; converting
+        it on every forward would put a kernel in flight right in front of the launch (which then has to stay ordered), so
+        the weights-at-rest mode keeps a float32 copy, refreshed when the Parameter's storage or version changes."""
+        a = self.alpha
+        if a.dtype == torch.float32 or not (self.weights_at_rest and not self.is_input) or (
+                torch.is_grad_enabled() and a.requires_grad):
+            return a
+        st = (a.data_ptr(), a._version)
+        if self._alpha32_stamp != st:
+            self._alpha32 = a.detach().to(torch.float32).reshape(-1).contiguous()
+            self._alpha32_stamp = st
+        return self._alpha32
+
     def _at_rest(self, data):
         """Whether THIS call may launch unordered: the weight and alpha are the very tensors (same storage, same version
         counter) the previous call saw -- so whatever wrote them (calibration a moment ago, load_state_dict, an optimiser
@@ -300,7 +316,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         after any such change launches ordered.  (`.data` edits do not bump the counter: those stay the caller's promise.)"""
         if not (self.weights_at_rest and not self.is_input):
             return False
-        a = self.alpha
+        a = self._rest_alpha()
         stamp = (data.data_ptr(), data._version, a.data_ptr(), a._version)
         if stamp != self._rest_stamp:
             self._rest_stamp = stamp
@@ -311,7 +327,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
     def _forward(self, data, display=False):
         """OQ:294-330 as one fused kernel (nearest over normal||outliers + victim masking)."""
         plan = self._ensure_plan()
-        return core.fake_quant(data, self.alpha, plan, self._gmax, self.is_perchannel, ovp=not self._no_outlier,
+        return core.fake_quant(data, self._rest_alpha(), plan, self._gmax, self.is_perchannel, ovp=not self._no_outlier,
                                unordered=self._at_rest(data), out=self._rest_buffer(data))
 
     @torch.no_grad()

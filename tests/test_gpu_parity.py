@@ -998,6 +998,28 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
             y_ref = model(x)
             qutil.set_weights_at_rest(model, True)
             assert torch.equal(y_a, y_ref) and torch.equal(y_b, y_ref), rep
+    # a model moved to bf16 AFTER calibration: alpha is a bf16 Parameter now and is converted to float32 on every forward
+    # (a kernel in flight right before the launch) -- such launches stay ordered
+    mb = qmod.quantize_model(nn.Sequential(nn.Linear(1024, 2048), nn.GELU(), nn.Linear(2048, 64))).to(dev).eval()
+    qutil.enable_quantization(mb)
+    with torch.no_grad():
+        mb(x)
+        mb = mb.bfloat16()
+        xb = x.bfloat16()
+        ref_b = mb(xb)
+        qutil.set_weights_at_rest(mb, True)
+        for _ in range(4):
+            junk = torch.randn(4096, 4096, device=dev) @ torch.randn(4096, 64, device=dev)
+            assert torch.equal(mb(xb), ref_b)
+        qw = [m.quant_weight for m in mb.modules() if hasattr(m, "quant_weight")]
+        assert all(q._alpha32 is not None and q._alpha32.dtype == torch.float32 for q in qw)     # (the cached scales are in use)
+        for q in qw:                                   # an alpha edit is noticed: copy refreshed, that launch ordered
+            q.alpha.mul_(1.25)
+        y_new = mb(xb)
+        qutil.set_weights_at_rest(mb, False)
+        assert torch.equal(mb(xb), y_new) and not torch.equal(y_new, ref_b)
+        qutil.set_weights_at_rest(mb, True)
+        assert torch.equal(mb(xb), y_new)
     # the flag set BEFORE the first (calibrating) forward: calibration writes alpha a moment before the launch
     net2 = nn.Sequential(nn.Linear(1024, 512), nn.GELU(), nn.Linear(512, 64))
     m2 = qmod.quantize_model(net2).to(dev).eval()
