@@ -356,6 +356,15 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         }
         h.adom = ok ? 1u : 0u;                          // (the d-domain path reads the outlier flags of the entries)
         if (vout < INFINITY && !((double)vout >= (double)vnorm * (1.0 + 0x1p-20))) ok = false;
+        // ... and an element clipped beyond xlim keeps the table's decision (the extreme value of its sign) but redoes the
+        // straight-through step, t = (q - d) + d = q -+ ulp(d) / 2: if that extreme value is an outlier, t has to stay
+        // recognisable as one, |t| >= vout.  True of every reference codebook (384 against 48); a value list whose only
+        // outlier magnitude IS its extreme (found by the 600-seed fuzz run of round 3: {-0, 35.8}, {-120.9, -0}) keeps the
+        // d-domain kernels, whose entries carry the flag.
+        for (const float ve : {dv[0].v, dv[k - 1].v}) {
+            const double a = fabs((double)ve);
+            if (a > 32.0 && !(a - (double)vout >= 0x1p-22 * (double)h.fastlim)) ok = false;
+        }
         h.vout = vout;
         h.xdom = (ok && h.n_entries <= 128) ? 1u : 0u;
     }
