@@ -2713,7 +2713,15 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
     groups = {}
     for case in range(10):
         bf16 = bool(rng.random() < 0.6)
-        if rng.random() < 0.5:
+        pick = rng.random()
+        if pick < 0.2:
+            # an ARBITRARY value list (random size, order, duplicates, -0, entries beyond 32), with or without the pair rule
+            g = _random_grid(rng, int(rng.choice([2, 3, 5, 8, 15, 16, 29, 64])))
+            if not (g.max() > 0):
+                g[-1] = np.float32(1.5)
+            gname, n_normal, ovp = "random", 0, bool(rng.random() < 0.5)
+            gmax = float(np.abs(g).max()) if rng.random() < 0.5 else float(max(g.max(), 0.5))
+        elif pick < 0.6:
             gname = names[rng.integers(0, len(names))]
             g, ovp, n_normal = G[gname], False, 0
             gmax = float(g.max())
@@ -2794,7 +2802,7 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
             assert np.array_equal(a_dev.cpu().numpy(), a_dyn), ("dynamic alpha", tag)
             assert same(out_d, ref_d), ("dynamic", tag)
         # packed 4-bit codes: exist for <= 16 codes (ANT) / 8 + 8 with the identifier (OliVe 4-bit), whole 32-bit words
-        four_bit = (g.size <= 16 and not ovp) or (ovp and n_normal <= 15 and g.size - n_normal <= 8)
+        four_bit = gname != "random" and ((g.size <= 16 and not ovp) or (ovp and n_normal <= 15 and g.size - n_normal <= 8))
         if four_bit and K % 8 == 0 and (per_row or True):
             try:
                 codes = antq_lib.encode4(xt, a_t, plan, gmax, rows, K, per_row, n_normal=n_normal, ovp=ovp)
