@@ -2802,7 +2802,7 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
             assert np.array_equal(a_dev.cpu().numpy(), a_dyn), ("dynamic alpha", tag)
             assert same(out_d, ref_d), ("dynamic", tag)
         # packed 4-bit codes: exist for <= 16 codes (ANT) / 8 + 8 with the identifier (OliVe 4-bit), whole 32-bit words
-        four_bit = gname != "random" and ((g.size <= 16 and not ovp) or (ovp and n_normal <= 15 and g.size - n_normal <= 8))
+        four_bit = (g.size <= 16 and not ovp) or (gname != "random" and ovp and n_normal <= 15 and g.size - n_normal <= 8)
         if four_bit and K % 8 == 0 and (per_row or True):
             try:
                 codes = antq_lib.encode4(xt, a_t, plan, gmax, rows, K, per_row, n_normal=n_normal, ovp=ovp)
@@ -2826,7 +2826,9 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
                 got = bf16_bits(dec) if bf16 else dec.cpu().numpy().view(np.uint32)
                 wantb = ref if bf16 else ref.view(np.uint32)
                 bad = np.flatnonzero((got != wantb) & near)
-                assert bad.size == 0, ("codec", tag, bad[:8], got.reshape(-1)[bad[:8]], wantb.reshape(-1)[bad[:8]])
+                # (an arbitrary value list has no exact straight-through step -- (q - d) + d is q only when neighbouring
+                #  magnitudes lie within a factor of two, as in every reference codebook: there the CODES are the contract)
+                assert bad.size == 0 or gname == "random", ("codec", tag, bad[:8], got.reshape(-1)[bad[:8]], wantb.reshape(-1)[bad[:8]])
     for (bf16, ovp), jobs in groups.items():
         antq_lib.Batch([j[:8] for j in jobs], ovp=ovp).run()
         for j in jobs:
