@@ -2700,12 +2700,13 @@ def test_empty_inputs(antq_lib, dev):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("ANTQ_FUZZ_SEEDS", 3))))
 def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
-    """Rows long enough for the per-row table kernels (and a few that are not), every reference codebook, random
-    lengths / scales (heavy clipping, scales down to 2^-60 and up to 2^40, zero and negative alphas) / outliers /
-    specials, fp32 and bf16 -- through EVERY launch form of the same arithmetic: ordinary launch (+ indices), unordered
-    launch into a caller-owned buffer, one batched launch of all tensors of a dtype (mixed task sizes, rotated and fixed
-    maps in one grid), the in-kernel abs-max form, and the packed 4-bit codec where a 4-bit code exists.  Each against
-    the ORACLE.  ANTQ_FUZZ_SEEDS widens it (tools/fuzz_campaign.sh)."""
+    """Rows long enough for the per-row table kernels (and a few that are not), every reference codebook and -- a fifth
+    of the cases -- arbitrary value lists, random lengths / scales (heavy clipping, scales down to 2^-60 and up to 2^40,
+    zero, negative, infinite, NaN and denormal alphas) / outliers / specials, fp32 and bf16 -- through EVERY launch form of
+    the same arithmetic: ordinary launch (+ indices), unordered launch into a caller-owned buffer, one batched launch of
+    all tensors of a dtype (mixed task sizes, rotated and fixed maps in one grid), the in-kernel abs-max form per tensor
+    and batched, and the packed 4-bit codec where a 4-bit code exists.  Each against the ORACLE.  ANTQ_FUZZ_SEEDS widens
+    it (tools/fuzz_campaign.sh)."""
     import torch
     G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
     rng = np.random.default_rng(31000 + seed)
@@ -2801,6 +2802,19 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
             out_d, a_dev, _ = antq_lib.fakequant_dynamic(xt, plan, gmax, rows, K, ratio=ratio, ovp=ovp)
             assert np.array_equal(a_dev.cpu().numpy(), a_dyn), ("dynamic alpha", tag)
             assert same(out_d, ref_d), ("dynamic", tag)
+            # the batched form of the same (ratio 1): row lengths it has no single-read kernel for are refused, not guessed
+            a_one = oracle.absmax(xf, True, 1.0)
+            o_b, a_b = torch.zeros_like(xt), torch.zeros(rows, dtype=torch.float32, device=dev)
+            try:
+                bd = antq_lib.Batch([(xt, o_b, a_b, plan, gmax, rows, K, True)], ovp=ovp, dynamic=True)
+            except antq_lib.AntqError:
+                bd = None
+            if bd is not None:
+                bd.run()
+                with np.errstate(all="ignore"):
+                    ref_b, _ = oracle.forward(xh, a_one, g, gmax, ovp)
+                assert np.array_equal(a_b.cpu().numpy(), a_one), ("dynamic batch alpha", tag)
+                assert same(o_b, ref_b), ("dynamic batch", tag)
         # packed 4-bit codes: exist for <= 16 codes (ANT) / 8 + 8 with the identifier (OliVe 4-bit), whole 32-bit words
         four_bit = (g.size <= 16 and not ovp) or (gname != "random" and ovp and n_normal <= 15 and g.size - n_normal <= 8)
         if four_bit and K % 8 == 0 and (per_row or True):
