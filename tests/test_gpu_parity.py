@@ -2978,3 +2978,66 @@ def test_bench_line_contract_on_the_gpu(antq_lib, dev):
     assert abs(r["launch_us"] - d["ms_per_step"] * 1e3) < 0.25 * r["launch_us"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Gelem/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ANTQ_FUZZ_SEEDS", 2))))
+def test_calibration_fuzz_random_shapes_vs_oracle(antq_lib, oracle, dev, seed):
+    """The calibration kernels on random shapes -- rows of one partial task, of many tasks with a partial last one (4- and
+    8-vector tasks), ragged and unaligned rows (element kernel), per row and per tensor, fp32 / bf16, ANT types and OliVe's
+    pair rule: every candidate's mean squared error against the oracle's trace (summation-order tolerance), the picks
+    against the oracle's (near-ties excepted), through antq_search_sse, antq_search_sse_multi and antq_calibrate."""
+    import torch
+    from ant_quantization_amd import core
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    rng = np.random.default_rng(77000 + seed)
+    for case in range(5):
+        olive = bool(rng.random() < 0.4)
+        if olive:
+            grids_ = [np.concatenate([O["int_b4_s"], O["outlier_b4_s"]]), np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])]
+            gmaxs, ovp, step, lb, ub = [float(O["int_b4_s"].max()), float(O["flint_b4_s"].max())], True, 2, 75, 140
+        else:
+            names = list(rng.choice(["int_b4_s", "flint_b4_s", "pot_b4_s", "float_b4_s", "apot_b4_s", "flint_b3_s", "int_b6_s"], 3, replace=False))
+            grids_ = [G[n] for n in names]
+            gmaxs, ovp, step, lb, ub = [float(g.max()) for g in grids_], False, 1, 80, 115
+        bf16 = bool(rng.random() < 0.5)
+        epv = 8 if bf16 else 4
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            K = epv * int(rng.integers(128, 2200))              # long rows: 4- / 8-vector tasks, partial last task
+        elif kind == 1:
+            K = epv * int(rng.integers(1, 128))                 # short rows
+        elif kind == 2:
+            K = int(rng.integers(3, 3000))                      # ragged
+        else:
+            K = epv * int(rng.choice([128, 256, 512, 1024, 2048]))
+        rows = max(1, min(int(rng.choice([1, 2, 5, 16, 40])), 200_000 // K))
+        per_row = bool(rng.random() < 0.6)
+        if ovp and not per_row and (rows * K) % 2:
+            K += 1                                              # (pairs of a flat tensor: keep the element count even)
+        x = (rng.standard_normal((rows, K)) * 0.05).astype(np.float32)
+        x[rng.random((rows, K)) < 0.01] *= 12
+        xh = oracle.f32_to_bf16(x) if bf16 else x
+        xf = oracle.bf16_to_f32(xh) if bf16 else xh
+        xt = to_dev(xh, dev, bf16)
+        r_, k_ = (rows, K) if per_row else (1, rows * K)
+        tag = (seed, case, olive, rows, K, per_row, bf16)
+        plans = [antq_lib.plan_for(g) for g in grids_]
+        alpha, score, typ, xm = antq_lib.calibrate(xt, rows, K, per_row, plans, gmaxs, lb, ub, step,
+                                                  xmax="3sigma" if olive else "absmax", ovp=ovp)
+        ratios = core._ratios(lb, ub, step, xt.device)
+        xm_np = xm.cpu().numpy()
+        osum = []
+        for t, (g, gm) in enumerate(zip(grids_, gmaxs)):
+            rb, ra, trace = oracle.search_mse(xf.reshape(r_, k_), xm_np, lb, ub, step, g, gm, ovp, per_row)
+            sse = antq_lib.search_sse(xt, r_, k_, xm, per_row, ratios, plans[t], gm, ovp=ovp)
+            np.testing.assert_allclose((sse / k_).float().cpu().numpy(), trace, rtol=3e-5, atol=1e-12, err_msg=str(tag + (t,)))
+            check_alpha_picks("fuzz_%d_%d_%d" % (seed, case, t), alpha[t].cpu().numpy(), ra, trace, ratios_of(lb, ub, step), xmax_rtol=0.0)
+            osum.append(float(rb.astype(np.float64).sum()))
+        multi = antq_lib.search_sse_multi(xt, r_, k_, xm, per_row, ratios, plans, gmaxs, ovp=ovp)
+        if multi is not None:
+            for t, (p, gm) in enumerate(zip(plans, gmaxs)):
+                one = antq_lib.search_sse(xt, r_, k_, xm, per_row, ratios, p, gm, ovp=ovp)
+                np.testing.assert_allclose(multi[t].cpu().numpy(), one.cpu().numpy(), rtol=1e-12, err_msg=str(tag + (t, "multi")))
+        order = np.argsort(osum)
+        if len(osum) > 1 and (osum[order[1]] - osum[order[0]]) > 1e-4 * max(osum[order[0]], 1e-30):
+            assert int(typ.item()) == int(order[0]), (tag, osum, score.cpu().numpy())

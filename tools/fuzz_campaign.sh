@@ -1,8 +1,8 @@
 #!/bin/bash
 # Wide fuzz run on an MI355X (the -m gpu suite runs the same tests with a handful of seeds):
-#   gpurun -- 'bash tools/fuzz_campaign.sh 1500 120'
+#   gpurun -- 'bash tools/fuzz_campaign.sh 1500 120 300'
 # $1 seeds for test_fuzz_every_launch_form_long_rows (10 tensors each, every launch form against the oracle),
-# $2 seeds for the arbitrary-codebook / arbitrary-shape fuzz tests.  Summary -> gpurun_out/fuzz_campaign.log
+# $2 seeds for the arbitrary-codebook / arbitrary-shape fuzz tests, $3 seeds (5 calibrations each) for the calibration fuzz.  Summary -> gpurun_out/fuzz_campaign.log
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -13,4 +13,7 @@ mkdir -p gpurun_out
   echo "== test_random_grids_fuzz, test_random_grids_fuzz_other_entry_points, test_random_shapes_fuzz, ${2:-120} seeds each"
   ANTQ_FUZZ_SEEDS=${2:-120} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k "random_grids_fuzz or random_shapes_fuzz" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+  echo "== test_calibration_fuzz_random_shapes_vs_oracle, ${3:-300} seeds"
+  ANTQ_FUZZ_SEEDS=${3:-300} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k calibration_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
 } | tee gpurun_out/fuzz_campaign.log
