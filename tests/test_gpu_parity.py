@@ -3041,3 +3041,82 @@ def test_calibration_fuzz_random_shapes_vs_oracle(antq_lib, oracle, dev, seed):
         order = np.argsort(osum)
         if len(osum) > 1 and (osum[order[1]] - osum[order[0]]) > 1e-4 * max(osum[order[0]], 1e-30):
             assert int(typ.item()) == int(order[0]), (tag, osum, score.cpu().numpy())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ANTQ_FUZZ_SEEDS", 2))))
+def test_fp16_io_fuzz_every_launch_form(antq_lib, oracle, dev, seed):
+    """fp16 tensors (what model.half() hands the quantisers): the kernels compute the fp32 path on the widened input and
+    round the result to half ONCE -- i.e. half(oracle(float(x))) -- through every launch form: ordinary (+ indices),
+    unordered, batched, in-kernel abs-max, 4-bit codec.  Reference codebooks, random row lengths, planted outliers."""
+    import torch
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    rng = np.random.default_rng(91000 + seed)
+    names = [k for k in G.files if not k.startswith("INVALID")]
+    jobs = {}
+    for case in range(8):
+        if rng.random() < 0.5:
+            gname = names[rng.integers(0, len(names))]
+            g, ovp, n_normal = G[gname], False, 0
+            gmax = float(g.max())
+        else:
+            t, b, sg = ["int", "flint"][rng.integers(0, 2)], int(rng.choice([3, 4, 4, 5])), "su"[rng.integers(0, 2)]
+            gn = O["%s_b%d_%s" % (t, b, sg)]
+            g, gmax, ovp, gname, n_normal = np.concatenate([gn, O["outlier_b%d_%s" % (b, sg)]]), float(gn.max()), True, "olive_" + sg, gn.size
+        K = int(rng.choice([8 * int(rng.integers(128, 1500)), 8 * int(rng.integers(1, 128)), int(rng.integers(1, 5000)), 1024, 4096]))
+        rows = max(1, min(int(rng.choice([1, 3, 8, 33])), 300_000 // K))
+        x = make_x(rng, rows, K, unsigned=gname.endswith("_u"), specials=False) * np.float32(rng.uniform(0.2, 20))
+        m = rng.random((rows, K)) < 0.02
+        x[m] *= rng.uniform(8, 100, int(m.sum())).astype(np.float32)
+        xh = x.astype(np.float16)
+        xf = xh.astype(np.float32)
+        alpha = (np.abs(xf).max(1) * rng.uniform(0.05, 1.2, rows) + 1e-4).astype(np.float32)
+        per_row = bool(rng.random() < 0.75)
+        a_np = alpha if per_row else np.float32(alpha.mean())
+        with np.errstate(all="ignore"):
+            ref32, ridx = oracle.forward(xf, a_np, g, gmax, ovp)
+            ref = ref32.astype(np.float16)
+        tag = (seed, case, gname, rows, K, ovp, per_row)
+        plan = antq_lib.plan_for(g)
+        xt = torch.from_numpy(xh).to(dev)
+        a_t = torch.from_numpy(np.atleast_1d(a_np).astype(np.float32)).to(dev)
+
+        def same(t, r=ref):
+            got = t.cpu().numpy().view(np.uint16).reshape(-1)
+            want = r.view(np.uint16).reshape(-1)
+            return bool(np.all((got == want) | (np.isnan(t.cpu().numpy().reshape(-1)) & np.isnan(r.reshape(-1)))))
+
+        out, idx = antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, per_row, ovp=ovp, want_idx=True)
+        assert same(out), ("ordered", tag)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int32), ridx), ("indices", tag)
+        buf = torch.empty_like(xt)
+        torch.cuda.synchronize()
+        antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, per_row, ovp=ovp, unordered=True, out=buf)
+        assert same(buf), ("unordered", tag)
+        jobs.setdefault(ovp, []).append((xt, torch.zeros_like(xt), a_t, plan, gmax, rows, K, per_row, ref, tag))
+        if per_row:
+            a_dyn = oracle.absmax(xf, True, 1.0)
+            with np.errstate(all="ignore"):
+                ref_d = oracle.forward(xf, a_dyn, g, gmax, ovp)[0].astype(np.float16)
+            out_d, a_dev, _ = antq_lib.fakequant_dynamic(xt, plan, gmax, rows, K, ovp=ovp)
+            assert np.array_equal(a_dev.cpu().numpy(), a_dyn) and same(out_d, ref_d), ("dynamic", tag)
+        four_bit = (g.size <= 16 and not ovp) or (ovp and n_normal <= 15 and g.size - n_normal <= 8)
+        if four_bit and K % 8 == 0:
+            try:
+                codes = antq_lib.encode4(xt, a_t, plan, gmax, rows, K, per_row, n_normal=n_normal, ovp=ovp)
+            except antq_lib.AntqError:
+                codes = None
+            if codes is not None:
+                zc = np.flatnonzero((g[:n_normal] if ovp else g) == 0)
+                want = _oracle_codes(oracle, ridx, n_normal, ovp, int(zc[-1]) if zc.size else None)
+                scanned = (ridx != oracle.IDX_NONE) | bool(zc.size)
+                assert np.array_equal(_nibbles(codes, rows, K)[scanned], want[scanned]), ("codes", tag)
+                dec = antq_lib.decode4(codes, a_t, plan, gmax, rows, K, per_row, torch.float16, n_normal=n_normal, ovp=ovp)
+                a_rows = np.broadcast_to(np.atleast_1d(a_np).astype(np.float32)[:, None], (rows, K)) if per_row else np.float32(a_np)
+                near = np.isfinite(ref32) & (np.abs(xf) <= 1.9 * np.abs(a_rows) * float(np.abs(g).max()) / gmax)
+                bad = np.flatnonzero((dec.cpu().numpy().view(np.uint16) != ref.view(np.uint16)) & near)
+                assert bad.size == 0, ("codec", tag, bad[:8])
+    for ovp, js in jobs.items():
+        antq_lib.Batch([j[:8] for j in js], ovp=ovp).run()
+        for j in js:
+            got = j[1].cpu().numpy()
+            assert bool(np.all((got.view(np.uint16) == j[8].view(np.uint16)) | (np.isnan(got) & np.isnan(j[8])))), ("batched", j[9])

@@ -13,6 +13,9 @@ mkdir -p gpurun_out
   echo "== test_random_grids_fuzz, test_random_grids_fuzz_other_entry_points, test_random_shapes_fuzz, ${2:-120} seeds each"
   ANTQ_FUZZ_SEEDS=${2:-120} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k "random_grids_fuzz or random_shapes_fuzz" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+  echo "== test_fp16_io_fuzz_every_launch_form, ${2:-120} seeds"
+  ANTQ_FUZZ_SEEDS=${2:-120} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k fp16_io_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
   echo "== test_calibration_fuzz_random_shapes_vs_oracle, ${3:-300} seeds"
   ANTQ_FUZZ_SEEDS=${3:-300} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k calibration_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
