@@ -2770,6 +2770,19 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
         plan = antq_lib.plan_for(g)
         xt = to_dev(xh, dev, bf16)
         a_t = torch.from_numpy(np.atleast_1d(a_np).astype(np.float32)).to(dev)
+        unaligned = bool(rng.random() < 0.15)          # tensors that start 2 / 4 bytes into a 16-byte line: the element kernels
+
+        def like(t):                                   # an output buffer laid out like the input (aligned or not)
+            if not unaligned:
+                return torch.zeros_like(t)
+            base = torch.zeros(t.numel() + 8, dtype=t.dtype, device=dev)
+            return base[1:1 + t.numel()].view(t.shape)
+
+        if unaligned:
+            x_un = like(xt)
+            x_un.copy_(xt)
+            xt = x_un
+            assert xt.data_ptr() % 16 != 0
 
         def same(t, r=ref, xh=xh, a_np=a_np, K=K):
             if bf16_same(bf16_bits(t), r, oracle) if bf16 else f32_same(t.cpu().numpy(), r):
@@ -2786,13 +2799,13 @@ def test_fuzz_every_launch_form_long_rows(antq_lib, oracle, dev, seed):
         out, idx = antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, per_row, ovp=ovp, want_idx=True)
         assert same(out), ("ordered", tag)
         assert np.array_equal(idx.cpu().numpy().astype(np.int32), ridx), ("indices", tag)
-        bufs = [torch.empty_like(xt) for _ in range(2)]
+        bufs = [like(xt) for _ in range(2)]
         torch.cuda.synchronize()
         for b in bufs:
             antq_lib.fakequant(xt, a_t, plan, gmax, rows, K, per_row, ovp=ovp, unordered=True, out=b)
         for b in bufs:
             assert same(b), ("unordered", tag)
-        groups.setdefault((bf16, ovp), []).append((xt, torch.zeros_like(xt), a_t, plan, gmax, rows, K, per_row, ref, tag))
+        groups.setdefault((bf16, ovp), []).append((xt, like(xt), a_t, plan, gmax, rows, K, per_row, ref, tag))
         # in-kernel abs-max (rows only; the reference's dynamic scale is ratio * max|x|, no specials in it)
         if per_row and not np.isnan(xf).any() and not np.isinf(xf).any():
             ratio = float(np.float32(rng.uniform(0.3, 1.1)))
