@@ -3025,8 +3025,6 @@ def test_calibration_fuzz_random_shapes_vs_oracle(antq_lib, oracle, dev, seed):
             K = epv * int(rng.choice([128, 256, 512, 1024, 2048]))
         rows = max(1, min(int(rng.choice([1, 2, 5, 16, 40])), 200_000 // K))
         per_row = bool(rng.random() < 0.6)
-        if ovp and not per_row and (rows * K) % 2:
-            K += 1                                              # (pairs of a flat tensor: keep the element count even)
         x = (rng.standard_normal((rows, K)) * 0.05).astype(np.float32)
         x[rng.random((rows, K)) < 0.01] *= 12
         xh = oracle.f32_to_bf16(x) if bf16 else x
