@@ -14,6 +14,9 @@ code that edits `bit` / `has_inited_quant_para` / `quant_grid` that way must cal
 (INTEGRATION.md, section 2).  The operator-level drop-in (`quant_cuda.quant`) does not rely on keys at all: its kernel
 verifies the grid on the device.
 """
+import weakref
+
+import torch
 
 
 class HostMirrorMixin:
@@ -46,3 +49,77 @@ class HostMirrorMixin:
             if ok:
                 self._hm[name][0] = self._hm_key(name)
         return out
+
+
+class WeightsAtRestMixin:
+    """The weights-at-rest launch mode of a WEIGHT quantiser (quant_utils.set_weights_at_rest), shared by the ANT and the
+    OliVe Quantizer: the steady-state launch may start while earlier work on the stream drains (ANTQ_FLAG_UNORDERED) when
+    its inputs are provably not being written by anything in flight.  Needs: weights_at_rest, is_input, alpha, _plan, _gmax
+    and the four _rest_* / _alpha32* slots set to None in the constructor."""
+
+    def _rest_on(self):
+        return self.weights_at_rest and not self.is_input
+
+    def __getstate__(self):
+        """torch.save(model) pickles the module: the launch-mode caches (a weak reference among them) are not state."""
+        st = self.__dict__.copy()
+        for k in ("_rest_src", "_rest_stamp", "_rest_out", "_alpha32", "_alpha32_stamp"):
+            if k in st:
+                st[k] = None
+        return st
+
+    def _rest_buffer(self, data):
+        """The quantiser-owned output buffer of the weights-at-rest mode (None otherwise)."""
+        if not self._rest_on() or torch.is_grad_enabled() and data.requires_grad:
+            return None
+        b = self._rest_out
+        if b is None or b.shape != data.shape or b.dtype != data.dtype or b.device != data.device:
+            with torch.inference_mode(False):      # an ordinary tensor even when the forward runs under inference_mode
+                b = self._rest_out = torch.empty_like(data, memory_format=torch.contiguous_format)
+            torch.cuda.current_stream(data.device).synchronize()      # (once: nothing in flight may still own this block)
+        return b
+
+    def _rest_alpha(self):
+        """alpha as the kernels take it (float32).  A model moved to bf16 / fp16 carries a 16-bit alpha Parameter; converting
+        it on every forward would put a kernel in flight right in front of the launch (which then has to stay ordered), so
+        the weights-at-rest mode keeps a float32 copy, refreshed when the Parameter's storage or version changes."""
+        a = self.alpha
+        if a.dtype == torch.float32 or not self._rest_on() or (torch.is_grad_enabled() and a.requires_grad):
+            return a
+        st = _tensor_stamp(a)
+        if st is None:                             # an inference tensor: no version counter, nothing to key a cache on
+            return a
+        if self._alpha32_stamp != st:
+            self._alpha32 = a.detach().to(torch.float32).reshape(-1).contiguous()
+            self._alpha32_stamp = st
+        return self._alpha32
+
+    def _at_rest(self, data):
+        """Whether THIS call may launch unordered: the weight is the very tensor OBJECT the previous call saw (held by a weak
+        reference: a temporary -- w.t().contiguous(), a slice copy, a dequantised weight -- is a new object every forward even
+        when the caching allocator hands it a recycled address, and never qualifies), with the same storage and version
+        counter; alpha likewise; and the codebook (plan, gmax) is the one the previous call used, so nothing may still be
+        writing or re-planning what this launch reads.  Whatever changed them (calibration a moment ago, load_state_dict, an
+        optimiser step, a dtype / device move, a new grid) is then at least one ordinary, ordered launch of this quantiser in
+        the past.  The first call after any such change launches ordered; so does every call on a tensor without a version
+        counter (created under torch.inference_mode).  (`.data` edits do not bump the counter: those stay the caller's promise.)"""
+        if not self._rest_on():
+            return False
+        ds, as_ = _tensor_stamp(data), _tensor_stamp(self.alpha)
+        if ds is None or as_ is None:
+            self._rest_stamp = self._rest_src = None
+            return False
+        stamp = (ds, as_, id(self._plan), self._gmax)
+        src = self._rest_src() if self._rest_src is not None else None
+        if src is not data or stamp != self._rest_stamp:
+            self._rest_stamp = stamp
+            self._rest_src = weakref.ref(data)
+            return False
+        return True
+
+
+def _tensor_stamp(t):
+    """(storage address, version counter) of a tensor, None for an inference tensor (torch raises on its _version)."""
+    if torch.is_inference(t):
+        return None
+    return (t.data_ptr(), t._version)

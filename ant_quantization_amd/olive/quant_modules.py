@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, core, grids
-from .._mirror import HostMirrorMixin
+from .._mirror import HostMirrorMixin, WeightsAtRestMixin
 
 
 class QuantBase():
@@ -42,7 +42,7 @@ class QuantBase():
             return QuantBase._quantization(real_val, quant_grid, plan)
 
 
-class Quantizer(HostMirrorMixin, nn.Module):
+class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
     def __init__(self, mode="base", bit=8, is_signed=True, is_enable=False, is_input=False, args=None, operator=None):
         super(Quantizer, self).__init__()
         self.mode = mode
@@ -88,6 +88,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
                                        # every forward returns the same storage, like WeightBank's resident outputs
         self._rest_out = None
         self._rest_stamp = None
+        self._rest_src = None
         self._alpha32 = None
         self._alpha32_stamp = None
         self._type_search = None  # during one calibration: grid bytes -> clip search result of the type selection's pass
@@ -285,43 +286,7 @@ class Quantizer(HostMirrorMixin, nn.Module):
         self._type_search = None
 
     # ---------------------------------------------------------------- steady state
-    def _rest_buffer(self, data):
-        """The quantiser-owned output buffer of the weights-at-rest mode (None otherwise)."""
-        if not (self.weights_at_rest and not self.is_input) or torch.is_grad_enabled() and data.requires_grad:
-            return None
-        b = self._rest_out
-        if b is None or b.shape != data.shape or b.dtype != data.dtype or b.device != data.device:
-            b = self._rest_out = torch.empty_like(data, memory_format=torch.contiguous_format)
-            torch.cuda.current_stream(data.device).synchronize()      # (once: nothing in flight may still own this block)
-        return b
-
-    def _rest_alpha(self):
-        """alpha as the kernels take it (float32).  A model moved to bf16 / fp16 carries a 16-bit alpha Parameter; converting
-        it on every forward would put a kernel in flight right in front of the launch (which then has to stay ordered), so
-        the weights-at-rest mode keeps a float32 copy, refreshed when the Parameter's storage or version changes."""
-        a = self.alpha
-        if a.dtype == torch.float32 or not (self.weights_at_rest and not self.is_input) or (
-                torch.is_grad_enabled() and a.requires_grad):
-            return a
-        st = (a.data_ptr(), a._version)
-        if self._alpha32_stamp != st:
-            self._alpha32 = a.detach().to(torch.float32).reshape(-1).contiguous()
-            self._alpha32_stamp = st
-        return self._alpha32
-
-    def _at_rest(self, data):
-        """Whether THIS call may launch unordered: the weight and alpha are the very tensors (same storage, same version
-        counter) the previous call saw -- so whatever wrote them (calibration a moment ago, load_state_dict, an optimiser
-        step, a dtype / device move) is at least one ordinary, ordered launch of this quantiser in the past.  The first call
-        after any such change launches ordered.  (`.data` edits do not bump the counter: those stay the caller's promise.)"""
-        if not (self.weights_at_rest and not self.is_input):
-            return False
-        a = self._rest_alpha()
-        stamp = (data.data_ptr(), data._version, a.data_ptr(), a._version)
-        if stamp != self._rest_stamp:
-            self._rest_stamp = stamp
-            return False
-        return True
+    # (_rest_buffer / _rest_alpha / _at_rest: _mirror.WeightsAtRestMixin)
 
     @torch.no_grad()
     def _forward(self, data, display=False):

@@ -1034,6 +1034,61 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
     del junk
 
 
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_weights_at_rest_under_inference_mode_and_on_temporaries(antq_lib, dev, tree, capsys):
+    """(1) a bf16 model run under torch.inference_mode() with weights at rest -- tensors created inside the
+    forward have no version counter; the mode must neither raise nor cache such a tensor; (2) a weight quantiser called on
+    a TEMPORARY (a fresh tensor object per call whose address the caching allocator recycles) never launches unordered;
+    (3) a codebook change without touching weight or alpha makes the next launch ordered."""
+    import importlib
+    import torch
+    import torch.nn as nn
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qutil.set_quantizer(_args(mode="ant-int-flint", wbit=4, abit=4, w_up=150, a_up=150))
+    torch.manual_seed(5)
+    x = torch.randn(16, 1024, device=dev)
+    for dt in (torch.float32, torch.bfloat16):
+        net = nn.Sequential(nn.Linear(1024, 2048), nn.GELU(), nn.Linear(2048, 64))
+        model = qmod.quantize_model(net).to(dev).eval()
+        qutil.enable_quantization(model)
+        with torch.no_grad():
+            model(x)                                    # calibration (fp32)
+            model = model.to(dt)
+            xd = x.to(dt)
+            ref = model(xd)
+        qutil.set_weights_at_rest(model, True)
+        with torch.inference_mode():
+            for _ in range(4):
+                assert torch.equal(model(xd), ref)
+        with torch.no_grad():                           # ... and back outside: still the same bits
+            assert torch.equal(model(xd), ref)
+        qw = [m.quant_weight for m in model.modules() if hasattr(m, "quant_weight")]
+        assert all(not torch.is_inference(q._rest_out) for q in qw)
+        if dt != torch.float32:
+            assert all(q._alpha32 is None or not torch.is_inference(q._alpha32) for q in qw)
+    # (2) temporaries: same address, same version 0, a new object each time -> never at rest
+    q = qw[0]
+    w = next(m for m in model.modules() if hasattr(m, "quant_weight")).weight
+    with torch.no_grad():
+        seen = set()
+        for _ in range(6):
+            tmp = (w * 1.0)                             # a kernel in flight writes tmp right before the quantiser reads it
+            seen.add(tmp.data_ptr())
+            assert q._at_rest(tmp) is False
+            del tmp
+        assert len(seen) < 6                            # (the allocator did recycle an address: the case the advice describes)
+        assert q._at_rest(w) is False and q._at_rest(w) is True
+        # (3) a new plan object / gmax with weight and alpha untouched
+        q._gmax = q._gmax * 2.0
+        assert q._at_rest(w) is False and q._at_rest(w) is True
+        q._gmax = q._gmax / 2.0
+    import pickle
+    st = pickle.loads(pickle.dumps(q.__getstate__()["_rest_src"]))
+    assert st is None
+    capsys.readouterr()
+
+
 def test_far_clipped_elements_keep_the_tables_decision(antq_lib, oracle, dev):
     """Elements clipped beyond twice the outermost grid value (|x / s| >= xlim): the straight-through arithmetic
     ((q - d) + d) * s is no longer q * s out there, but the table's decision still is right -- the row-table kernels redo
