@@ -23,7 +23,7 @@ FLAG_UNORDERED = 4     # antq_fakequant: the launch may start while earlier laun
 IDX_NONE = -1
 IDX_VICTIM = -2
 MAX_GRID = 1024
-PLAN_MAX_BYTES = 96 + 4 * MAX_GRID + 16 * 3072 + 20 * 1024
+PLAN_MAX_BYTES = 128 + 4 * MAX_GRID + 16 * 3072 + 20 * 1024 + 16 * 64
 
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.float64: F64}
 

@@ -90,7 +90,8 @@ class WeightsAtRestMixin:
         if st is None:                             # an inference tensor: no version counter, nothing to key a cache on
             return a
         if self._alpha32_stamp != st:
-            self._alpha32 = a.detach().to(torch.float32).reshape(-1).contiguous()
+            with torch.inference_mode(False):      # an ordinary tensor even when the forward runs under inference_mode
+                self._alpha32 = a.detach().to(torch.float32).reshape(-1).contiguous()
             self._alpha32_stamp = st
         return self._alpha32
 

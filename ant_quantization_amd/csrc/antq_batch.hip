@@ -42,7 +42,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     double batch_bytes = 0.0;
     for (int i = 0; i < n; i++) batch_bytes += 2.0 * (double)jobs[i].rows * (double)jobs[i].row_len * (dtype == ANTQ_F32 ? 4.0 : 2.0);
     const bool big_footprint = batch_bytes >= 8.0 * 1073741824.0;
-    size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0, 0}, lds = 0;
+    size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0, 0, 0}, lds = 0;
     bool any_da = false;
     for (int i = 0; i < n; i++) {
         const antq_job &J = jobs[i];
@@ -75,6 +75,23 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                 if ((d.vpr & (d.vpr - 1u)) == 0u) { d.vshift = 0; while ((1u << d.vshift) < d.vpr) d.vshift++; }
                 blocks = (size_t)((d.n_vec + 256u * kBatchU - 1u) / (256u * kBatchU));
             }
+            HArgs hx;
+            if (d.kind == 0 && g_knob_h != 0 && hargs_from_plan(J.plan_host, dtype, J.gmax, hx)) {
+                // 16-bit rows in their own domain (antq_k_hrow.h): 4 KiB of the row per wavefront unless 3 or 2 leave fewer
+                // idle lanes; 24 workgroups per CU (kHRowLdsPad)
+                d.kind = 13;
+                d.u = row_task_u(d.vpr);
+                if (g_knob_u >= 2 && g_knob_u <= 4) d.u = (uint32_t)g_knob_u;     // knob 0 (A/B): vectors per lane and task
+                d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
+                const size_t total = (J.alpha_per_row ? J.rows : (size_t)1) * (size_t)d.tpr;   // per tensor: ONE row
+                if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
+                d.total_tasks = (uint32_t)total;
+                blocks = (total + 3) / 4;
+                d.rot = (d.vpr % (64u * d.u) != 0u && (d.tpr % 2u) == 0u) ? 1u : 0u;
+                d.tlist = plan_tlist_dev(J.plan_host, J.plan_dev);
+                d.h_n = hx.n_thr | (hx.n_neg << 16);
+                d.hshift = hx.hshift;
+            }
             if (d.kind == 0 && xdom) {
                 // x-domain rows: the task size that leaves the fewest idle lanes for this row length
                 d.kind = 2;
@@ -91,7 +108,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             // (groups of 16 / 32 / 64 vectors: a per-group x-domain table was round 1's answer for bf16 group-128 ... 512; the
             //  lane kernel with the exact per-element decision matches it for 16-bit data -- 75.2-76.7 vs 76.5-77.5 % -- and
             //  beats it for fp32 with 2-vector tasks -- 79.7-80.4 vs 77-79 %: profiles/r02_lane_task_ab.log -- so it is gone)
-            f = d.kind == 2 ? 0 : (d.kind == 3 ? -1 : (d.pa.adom ? 1 : 2));
+            f = d.kind == 13 ? 5 : d.kind == 2 ? 0 : (d.kind == 3 ? -1 : (d.pa.adom ? 1 : 2));
         } else {
             // alpha computed in the kernel: the group / row has to live in the registers of a few lanes, one wavefront
             // or one workgroup
@@ -165,11 +182,31 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     }
     if (!dyn) {
         // jobs of more than one static family: ONE launch of the all-in-one kernel instead of a launch per family
-        bool seen[kBatchFamilies] = {false, false, false, false, false};
+        bool seen[kBatchFamilies] = {false, false, false, false, false, false};
         int nf = 0;
         for (int i = 0; i < n; i++)
             if (!seen[fam[(size_t)i]]) { seen[fam[(size_t)i]] = true; nf++; }
         if (nf > 1) {
+            // (the all-in-one kernel knows the fp32-domain row table, not the 16-bit one: such jobs go back to kind 2 --
+            //  every plan with hdom that came here as kind 0 has xdom or stays kind 0)
+            for (int i = 0; i < n; i++) {
+                BatchDesc &d = descs[i];
+                if (d.kind != 13) continue;
+                const PlanHeader *ph = static_cast<const PlanHeader *>(jobs[i].plan_host);
+                if (g_knob_x && d.pa.kind == kPlanLut && ph->xdom) {
+                    d.kind = 2;
+                    d.u = row_task_u_small(d.vpr);
+                    d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
+                    d.total_tasks = (uint32_t)((jobs[i].alpha_per_row ? jobs[i].rows : (size_t)1) * (size_t)d.tpr);
+                    d.rot = (d.vpr % (64u * d.u) != 0u && (d.tpr % 2u) == 0u) ? 1u : 0u;
+                } else {
+                    const size_t tpr = (d.vpr + 64 * kBatchU - 1) / (64 * kBatchU);
+                    d.kind = 0; d.u = (uint32_t)kBatchU; d.tpr = (uint32_t)tpr; d.rot = 0;
+                    d.total_tasks = (uint32_t)((jobs[i].alpha_per_row ? jobs[i].rows : (size_t)1) * tpr);
+                    lds = std::max(lds, lds_table(d.pa, false));
+                }
+                nblk[(size_t)i] = ((size_t)d.total_tasks + 3) / 4;
+            }
             h.pad = 1u;
             for (int i = 0; i < n; i++) fam[(size_t)i] = 0;
         }
@@ -203,6 +240,18 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     memcpy(p, &h, sizeof(h));
     return (int)h.bytes;
 }
+
+// family 5 (16-bit dtypes only)
+template <typename T>
+static void launch_hbatch(uint32_t map_entries, const BatchDesc *descs, const uint32_t *map, bool ovp, hipStream_t st)
+{
+    const dim3 g(map_entries * 4u), b(64u);
+    const unsigned pad = g_knob_hlds >= 0 ? (unsigned)g_knob_hlds : kHRowLdsPad;
+    if (ovp) hipLaunchKernelGGL((k_fq_hbatch<T, true>), g, b, pad, st, descs, map, (uint32_t)g_knob_rot);
+    else hipLaunchKernelGGL((k_fq_hbatch<T, false>), g, b, pad, st, descs, map, (uint32_t)g_knob_rot);
+}
+template <>
+void launch_hbatch<float>(uint32_t, const BatchDesc *, const uint32_t *, bool, hipStream_t) {}
 
 extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_dev, void *stream)
 {
@@ -247,6 +296,7 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
             else { if (ovp) hipLaunchKernelGGL((k_fq_batch<TT, true, 4>), g_, b_, 0, st, descs, fmap[0], rot_);                \
                    else hipLaunchKernelGGL((k_fq_batch<TT, false, 4>), g_, b_, 0, st, descs, fmap[0], rot_); }                 \
         }                                                                                                         \
+        if (h->fam_blocks[5]) launch_hbatch<TT>(h->fam_blocks[5], descs, fmap[5], ovp, st);                       \
         if (h->fam_blocks[1]) { if (ovp) ANTQ_LAUNCH_D(TT, true, true); else ANTQ_LAUNCH_D(TT, false, true); }    \
         if (h->fam_blocks[2]) { if (ovp) ANTQ_LAUNCH_D(TT, true, false); else ANTQ_LAUNCH_D(TT, false, false); }  \
         if (h->fam_blocks[3]) {                                                                                   \

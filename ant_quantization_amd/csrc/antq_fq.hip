@@ -21,9 +21,11 @@
 // This translation unit: antq_fakequant / antq_fakequant_dynamic (one tensor per launch).
 #include "antq_host.h"
 #include "antq_k_fakequant.h"
+#include "antq_k_hrow.h"
 #include "antq_k_aux.h"
 
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 namespace antq {
 
@@ -166,6 +168,41 @@ static int launch_uniform(const void *x, void *out, int16_t *idx, size_t rows, s
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+// 16-bit rows of >= 128 vectors in their own 16-bit domain (antq_k_hrow.h): one wavefront per workgroup, up to 4 KiB of
+// one row per wavefront.  Returns ANTQ_ERR_UNSUPPORTED when the plan / dtype / shape has no such path.
+template <typename T, bool OVP>
+static int launch_hrow(const void *x, void *out, size_t rows, size_t vpr, const float *alpha, int per_row, float gmax,
+                       const void *plan_host, const void *plan_dev, hipStream_t st)
+{
+    if constexpr (std::is_same<T, float>::value) {
+        return ANTQ_ERR_UNSUPPORTED;
+    } else {
+        HArgs ha;
+        if (g_knob_h == 0 || vpr < kRowKernelMinVpr || vpr > 0xffffffffull || !hargs_from_plan(plan_host, IO<T>::DTYPE, gmax, ha))
+            return ANTQ_ERR_UNSUPPORTED;
+        int U = (int)row_task_u((uint32_t)vpr);
+        if (g_knob_u >= 2 && g_knob_u <= 4) U = g_knob_u;
+        const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
+        const size_t total = rows * tpr;
+        if (total > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
+        // The occupancy cap (kHRowLdsPad: 24 workgroups per CU) pays once a launch is many rounds of workgroups; one
+        // 33.5 MB tensor is a single round and wants every slot (tools/probe_per_tensor.py)
+        const bool big = total >= (size_t)4 * 8192;
+        const unsigned pad = g_knob_hlds >= 0 ? (unsigned)g_knob_hlds : (big ? kHRowLdsPad : 0u);
+        const int W = (g_knob_waves == 4 || g_knob_waves == 1) ? g_knob_waves : 1;
+        const dim3 g((unsigned)((total + W - 1) / W)), b(64 * W);
+        const uint4 *tl = plan_tlist_dev(plan_host, plan_dev);
+        const float *grid = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev));
+#define ANTQ_LAUNCH_H(UU, WW)                                                                                      \
+    launch_k(k_fq_hrow<T, OVP, UU, WW>, g, b, (WW) == 1 ? pad : 0u, st, static_cast<const uint4 *>(x), static_cast<uint4 *>(out), (uint32_t)total,  \
+             (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ha, tl, grid)
+        if (W == 4) { if (U == 4) ANTQ_LAUNCH_H(4, 4); else if (U == 3) ANTQ_LAUNCH_H(3, 4); else ANTQ_LAUNCH_H(2, 4); }
+        else { if (U == 4) ANTQ_LAUNCH_H(4, 1); else if (U == 3) ANTQ_LAUNCH_H(3, 1); else ANTQ_LAUNCH_H(2, 1); }
+#undef ANTQ_LAUNCH_H
+        return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+    }
+}
+
 template <typename T, bool OVP, bool IDX>
 static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t row_len,
                      const float *alpha, int per_row, float gmax, const PlanArgs &pa,
@@ -191,6 +228,10 @@ static int launch_fq(const void *x, void *out, int16_t *idx, size_t rows, size_t
         // Unordered launches overlap their neighbours, i.e. run in something like the batched kernels' steady state, where
         // the per-row table kernel's leaner element loop wins (tools/exp_lane.hip: 74.7 % against 71.1 %): they take it
         // whenever the plan has the x-domain form (knob 5 = 2 keeps the lane kernel)
+        if constexpr (!IDX) {
+            const int rc = launch_hrow<T, OVP>(x, out, rows, vpr, alpha, per_row, gmax, plan_host, plan_dev, st);
+            if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
+        }
         const PlanHeader *ph_ = static_cast<const PlanHeader *>(plan_host);
         const bool rows_unordered = t_unordered && !IDX && g_knob_lane_rows == 1 && g_knob_x != 0 && pa.kind == kPlanLut &&
                                     ph_->xdom && vpr >= kRowKernelMinVpr;

@@ -5,7 +5,7 @@
 namespace antq {
 
 constexpr uint32_t kPlanMagic = 0x51544E41u;  // "ANTQ"
-constexpr uint32_t kPlanVersion = 8;
+constexpr uint32_t kPlanVersion = 9;
 
 constexpr uint32_t kPlanScan = 0;  // kernels run the literal scan for every element
 constexpr uint32_t kPlanLut = 1;   // table plan: one LDS lookup + one compare per element
@@ -58,8 +58,30 @@ struct PlanHeader {      // 80 bytes
     // of their bucket's threshold are redone with the true division.
     uint32_t adom;
     uint32_t atab_slots;  // adom plans: number of a-table slots stored behind the entries (see blob layout below)
+    // 16-bit-domain row path (antq_k_hrow.h): rows of bf16 / f16 elements quantised on their bit patterns.  hdom bit 0 / 1:
+    // usable for bf16 / f16.  Needs what `xdom` needs except the table-size and bucket-edge conditions (the slot comes from
+    // the element's own bits, exactly), plus: at most kHMaxThr thresholds, a key of hmb mantissa bits that puts every
+    // threshold (and the row's limit) into a slot of its own for ANY scale, at most kHSlots slots per sign, and -- OliVe --
+    // outputs of normal values and of outliers that stay apart after the rounding to 16 bits.
+    uint32_t hdom;
+    uint32_t h_nthr;      // decision thresholds in `tlist` (ascending; the first h_nneg are negative)
+    uint32_t h_nneg;
+    uint32_t hshift;      // byte 0: bf16 (7 - hmb), byte 1: f16 (10 - hmb): key = magnitude pattern >> hshift
+    uint32_t tlist_off;   // byte offset of HThr tlist[h_nthr] in the blob
+    uint32_t pad_[3];
 };
-static_assert(sizeof(PlanHeader) == 96, "PlanHeader must be 96 bytes");
+static_assert(sizeof(PlanHeader) == 128, "PlanHeader must be 128 bytes");
+
+// one decision threshold of the grid's step function (16-bit-domain row path)
+struct HThr {
+    float T;          // RN(x / s) >= T  ->  v_hi, else v_lo
+    float v_lo;
+    float v_hi;
+    uint32_t flags;   // bit 0: |v_lo| > 32, bit 1: |v_hi| > 32 (OliVe outlier test, OQ:314)
+};
+static_assert(sizeof(HThr) == 16, "HThr must be 16 bytes");
+constexpr uint32_t kHSlots = 128;         // slots per sign of the wave-private table (2 KiB per wavefront)
+constexpr uint32_t kHMaxThr = 64;         // decision thresholds (one lane each)
 
 // bits 15 / 31 of LutEntry::idx flag |v_lo| > 32 / |v_hi| > 32 (OliVe outlier test, OQ:314)
 constexpr uint32_t kIdxMask = 0x7fffu;
@@ -89,6 +111,7 @@ constexpr uint32_t kATabMaxSlots = 1024;   // 16 KiB of LDS; bigger tables keep 
 
 // blob layout:  PlanHeader | float grid[m_pad] | LutEntry entries[n_entries]
 //               | ATabEntry atab[atab_slots] | uint32 aidx[atab_slots rounded up to 4]      (adom plans only)
+//               | HThr tlist[h_nthr]                                                        (hdom plans only)
 inline const float *plan_grid(const void *blob)
 {
     return reinterpret_cast<const float *>(static_cast<const char *>(blob) + sizeof(PlanHeader));
@@ -98,6 +121,12 @@ inline const LutEntry *plan_entries(const void *blob)
     const PlanHeader *h = static_cast<const PlanHeader *>(blob);
     return reinterpret_cast<const LutEntry *>(static_cast<const char *>(blob) + sizeof(PlanHeader) +
                                               sizeof(float) * h->m_pad);
+}
+
+inline const HThr *plan_tlist(const void *blob)
+{
+    const PlanHeader *h = static_cast<const PlanHeader *>(blob);
+    return reinterpret_cast<const HThr *>(static_cast<const char *>(blob) + h->tlist_off);
 }
 
 }  // namespace antq

@@ -4,13 +4,14 @@
 #define ANTQ_K_BATCH_H
 
 #include "antq_k_fakequant.h"
+#include "antq_k_hrow.h"
 
 namespace antq {
 
-constexpr uint32_t kBatchMagic = 0x32544E41u;  // "ANT2"
+constexpr uint32_t kBatchMagic = 0x33544E41u;  // "ANT3"
 constexpr int kBatchU = 4;                      // vectors per lane per task (4 KiB per wavefront: best measured)
 
-struct BatchDesc {   // 176 bytes, device-visible
+struct BatchDesc {   // 192 bytes, device-visible
     const uint4 *x;
     uint4 *out;
     const float *alpha;    // ANTQ_FLAG_DYNAMIC: an OUTPUT
@@ -27,6 +28,7 @@ struct BatchDesc {   // 176 bytes, device-visible
                            // 4..7 = kind 2 with the alpha computed in the kernel (ANTQ_FLAG_DYNAMIC, k_fq_batch_dyn): the row in
                            //         one wavefront, 4 / 8 vectors per lane (<= 256 / <= 512 vectors: kinds 4 / 6), or spread
                            //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7; <= 512 with 2 vectors per lane: kind 12)
+                           // 13 = 16-bit rows through the table in their own 16-bit domain (antq_k_hrow.h): tasks of u vectors per lane
     int32_t per_row;
     float gmax;
     PlanArgs pa;
@@ -42,8 +44,11 @@ struct BatchDesc {   // 176 bytes, device-visible
     float vmin, vmax;      // the grid's extreme values (XArgs::vmin / vmax: what far-clipped elements quantise to)
     uint32_t pad_;
     double inv_gmax;       // 1.0 / (double)gmax (XArgs::inv_gmax: the row's scale without a division)
+    const uint4 *tlist;    // kind 13: the plan's threshold list (HThr[h_nthr]) on the device
+    uint32_t h_n;          // kind 13: thresholds | negative ones << 16
+    uint32_t hshift;       // kind 13: key = magnitude pattern >> hshift
 };
-static_assert(sizeof(BatchDesc) == 176, "BatchDesc must be 176 bytes");
+static_assert(sizeof(BatchDesc) == 192, "BatchDesc must be 192 bytes");
 
 // A batch is up to four launches, one per kernel FAMILY, so that no kernel carries the registers of code paths its
 // jobs never take (the headline x-domain row kernel keeps its 80 VGPRs whatever else a batch may contain):
@@ -52,15 +57,17 @@ static_assert(sizeof(BatchDesc) == 176, "BatchDesc must be 176 bytes");
 //   family 2  k_fq_batch_d      d-domain table, exact division (scan plans, arbitrary value lists): kinds 0, 1, 3
 //   family 3  k_fq_batch_dyn    ANTQ_FLAG_DYNAMIC rows of >= 128 vectors with an x-domain plan: kinds 4..7
 //   family 4  k_fq_batch_dyn16  the same for rows of 2049..8192 vectors, one row per 1024-thread workgroup: kinds 9, 10
+//   family 5  k_fq_hbatch       16-bit rows in their own 16-bit domain (bf16 / f16, 4- / 5-bit codebooks): kind 13
 // (with ANTQ_FLAG_DYNAMIC families 1 / 2 run their DYN instantiation: groups of <= 64 vectors, rows of <= 256 vectors)
-constexpr int kBatchFamilies = 5;
+constexpr int kBatchFamilies = 6;
 
-struct BatchHeader {   // 56 bytes
+struct BatchHeader {   // 64 bytes
     uint32_t magic, n, dtype, flags, lds_bytes, map_offset, bytes, total_blocks;
     uint32_t fam_blocks[kBatchFamilies];
-    uint32_t pad;
+    uint32_t pad;          // bit 0: mixed static batch (one launch of the all-in-one kernel); bits 8..: wavefronts per workgroup of family 0
+    uint32_t pad2;
 };
-static_assert(sizeof(BatchHeader) == 56, "BatchHeader must be 56 bytes");
+static_assert(sizeof(BatchHeader) == 64, "BatchHeader must be 64 bytes");
 
 __device__ __forceinline__ XArgs xargs_of(const BatchDesc &D)
 {
@@ -124,6 +131,31 @@ k_fq_batch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ blo
                                            wtab_all[wv], lane, wv)
     if (D.u == 4u) ANTQ_XROW(4); else if (D.u == 3u) ANTQ_XROW(3); else if (D.u == 1u) ANTQ_XROW(1); else ANTQ_XROW(2);
 #undef ANTQ_XROW
+}
+
+// Family 5: 16-bit rows in their own domain.  One wavefront per workgroup; the block -> job map is in units of 4 tasks
+// like family 0's (4 workgroups per map entry); the same per-group rotation for jobs with a partial last task.
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(64)
+k_fq_hbatch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map, uint32_t rotate)
+{
+    __shared__ __attribute__((aligned(16))) uint2 tab[kHSlots * 2];
+    uint32_t blk = blockIdx.x;
+    const uint32_t g8 = blk >> 3;
+    if ((g8 << 3) + 8u <= gridDim.x && (rotate == 1u || (rotate == 0u && descs[block_map[(g8 << 3) >> 2]].rot)))
+        blk = (g8 << 3) + ((blk + g8) & 7u);
+    const uint32_t b4 = blk >> 2, sub = blk & 3u;
+    const BatchDesc &D = descs[block_map[b4]];
+    const uint32_t task = (b4 - D.first_block) * 4u + sub;
+    if (task >= D.total_tasks) return;
+    HArgs ha;
+    ha.n_thr = D.h_n & 0xffffu; ha.n_neg = D.h_n >> 16; ha.hshift = D.hshift; ha.m = D.pa.m;
+    ha.flim = D.pa.fastlim * 0.99999f; ha.lim = fminf(ha.flim, D.pa.xlim);
+    ha.vmin = D.vmin; ha.vmax = D.vmax; ha.vout = D.vout; ha.inv_gmax = D.inv_gmax;
+    const float *grid = reinterpret_cast<const float *>(D.plan_tab);
+#define ANTQ_HROW(UU) hrow_wave_task<T, OVP, UU>(D.x, D.out, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, ha, D.tlist, grid, tab, threadIdx.x)
+    if (D.u == 4u) ANTQ_HROW(4); else if (D.u == 3u) ANTQ_HROW(3); else ANTQ_HROW(2);
+#undef ANTQ_HROW
 }
 
 // Families 1 / 2: the plan's own (d-domain) table staged per workgroup.

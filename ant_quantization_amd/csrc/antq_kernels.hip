@@ -37,6 +37,8 @@ thread_local int g_knob_a = 1;
 thread_local int g_knob_waves = 0;
 thread_local int g_knob_lane_u = 0;
 thread_local int g_knob_rot = 0;
+thread_local int g_knob_h = 1;
+thread_local int g_knob_hlds = -1;
 
 }  // namespace antq
 
@@ -210,6 +212,8 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 6) g_knob_waves = value;
     else if (key == 7) g_knob_lane_u = value;
     else if (key == 8) g_knob_rot = value;
+    else if (key == 9) g_knob_h = value;
+    else if (key == 10) g_knob_hlds = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }

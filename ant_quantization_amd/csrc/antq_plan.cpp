@@ -328,6 +328,8 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         // q == 0 is always exact.  Every region of the step function has to satisfy this for all of its d:
         // true of every ANT / OliVe codebook (adjacent magnitudes within a factor of two, zero included), not of
         // arbitrary value lists -- those keep the d-domain kernels, which do the arithmetic literally.
+        const bool ok_edges = ok;                        // condition (1): only the approximate-quotient paths need it
+        ok = true;
         auto limit_of = [](float v_edge) -> double {      // how far the outermost region may extend
             if (v_edge == 0.0f) return INFINITY;
             return 2.0 * fabs((double)v_edge);
@@ -354,8 +356,11 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
             if (a > 32.0f) vout = std::min(vout, a);
             else vnorm = std::max(vnorm, a);
         }
+        const bool ok_ste = ok;                         // condition (2)
+        ok = ok_edges && ok_ste;
         h.adom = ok ? 1u : 0u;                          // (the d-domain path reads the outlier flags of the entries)
-        if (vout < INFINITY && !((double)vout >= (double)vnorm * (1.0 + 0x1p-20))) ok = false;
+        bool ok_out = true;                             // the outlier tests on pre-multiplied outputs
+        if (vout < INFINITY && !((double)vout >= (double)vnorm * (1.0 + 0x1p-20))) ok_out = false;
         // ... and an element clipped beyond xlim keeps the table's decision (the extreme value of its sign) but redoes the
         // straight-through step, t = (q - d) + d = q -+ ulp(d) / 2: if that extreme value is an outlier, t has to stay
         // recognisable as one, |t| >= vout.  True of every reference codebook (384 against 48); a value list whose only
@@ -363,10 +368,50 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         // d-domain kernels, whose entries carry the flag.
         for (const float ve : {dv[0].v, dv[k - 1].v}) {
             const double a = fabs((double)ve);
-            if (a > 32.0 && !(a - (double)vout >= 0x1p-22 * (double)h.fastlim)) ok = false;
+            if (a > 32.0 && !(a - (double)vout >= 0x1p-22 * (double)h.fastlim)) ok_out = false;
         }
         h.vout = vout;
-        h.xdom = (ok && h.n_entries <= 128) ? 1u : 0u;
+        h.xdom = (ok && ok_out && h.n_entries <= 128) ? 1u : 0u;
+
+        // 16-bit-domain row path (antq_k_hrow.h, PlanHeader::hdom).  The slot of an element comes from its own bit pattern,
+        // so condition (1) is not needed; what is: every threshold -- and the row's limit, the sentinel -- in a slot of its
+        // own whatever the scale.  A slot spans a factor of at most 1 + 2^-hmb; the 16-bit threshold patterns are within a
+        // factor 1 + 2^-MANT above the thresholds themselves: consecutive same-sign thresholds a factor
+        // (1 + 2^-hmb)(1 + 2^-MANT) apart can never share one.
+        if (ok_ste && ok_out && k - 1 <= (int)kHMaxThr) {
+            const double lim = std::min((double)h.fastlim * 0.99999, (double)h.xlim) * 0.999;     // (the kernel's margins)
+            double rmin = INFINITY, tmin = INFINITY;
+            int n_neg = 0;
+            for (int i = 0; i + 1 < k; i++) {
+                if (T[i] < 0.0f) n_neg++;
+                tmin = std::min(tmin, fabs((double)T[i]));
+                if (i + 2 < k && ((T[i] < 0.0f) == (T[i + 1] < 0.0f))) {
+                    const double a = fabs((double)T[i]), b = fabs((double)T[i + 1]);
+                    rmin = std::min(rmin, std::max(a, b) / std::min(a, b));
+                }
+            }
+            if (n_neg > 0) rmin = std::min(rmin, lim / fabs((double)T[0]));              // the outermost thresholds against the limit
+            if (n_neg < k - 1) rmin = std::min(rmin, lim / fabs((double)T[k - 2]));
+            // 16-bit outputs of the largest normal magnitude and of the smallest outlier must stay apart
+            auto outputs_apart = [&](int mant) { return !(vout < INFINITY) || (double)vout >= (double)vnorm * (1.0 + ldexp(1.0, -(mant - 1))); };
+            uint32_t hshift = 0;
+            int mant_of[2] = {7, 10};
+            for (int t = 0; t < 2; t++) {
+                const int mant = mant_of[t];
+                int mb = 1;                                                       // (a whole octave per slot is never enough)
+                while (mb <= mant && (1.0 + ldexp(1.0, -mb)) * (1.0 + ldexp(1.0, -mant)) > rmin * (1.0 - 1e-6)) mb++;
+                if (mb > mant || !outputs_apart(mant)) continue;
+                const double slots = ldexp(1.0, mb) * (log2(lim / tmin) + 1.0) + 2.0;       // keys between the innermost threshold and the limit
+                if (!(slots <= (double)kHSlots)) continue;
+                h.hdom |= 1u << t;
+                hshift |= (uint32_t)(mant - mb) << (8 * t);
+            }
+            if (h.hdom) {
+                h.h_nthr = (uint32_t)(k - 1);
+                h.h_nneg = (uint32_t)n_neg;
+                h.hshift = hshift;
+            }
+        }
     }
 
     // self-check against the literal scan
@@ -433,8 +478,23 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
         }
     }
 
+    std::vector<HThr> tlist;
+    if (h.hdom) {
+        for (int i = 0; i + 1 < k; i++) {
+            HThr t;
+            t.T = T[i];
+            t.v_lo = grid[dv[i].win];
+            t.v_hi = grid[dv[i + 1].win];
+            t.flags = (fabsf(t.v_lo) > 32.0f ? 1u : 0u) | (fabsf(t.v_hi) > 32.0f ? 2u : 0u);
+            tlist.push_back(t);
+        }
+        h.tlist_off = h.bytes;
+        h.bytes += (uint32_t)(sizeof(HThr) * tlist.size());
+        if (cap < h.bytes) return ANTQ_ERR_PLAN;
+    }
     char *p = static_cast<char *>(blob);
     memcpy(p, &h, sizeof(h));
+    if (!tlist.empty()) memcpy(p + h.tlist_off, tlist.data(), sizeof(HThr) * tlist.size());
     float *g = reinterpret_cast<float *>(p + sizeof(PlanHeader));
     for (size_t i = 0; i < m_pad; i++) g[i] = (i < (size_t)m) ? grid[i] : 0.0f;
     char *q = p + sizeof(PlanHeader) + 4 * m_pad;
@@ -533,6 +593,228 @@ extern "C" int antq_plan_eval_host_a(const void *blob, const float *x, size_t n,
         }
         if (idx) idx[i] = (int16_t)j;
         if (slow) slow[i] = fast ? 0 : 1;
+    }
+    return ANTQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Host model of the 16-bit-domain row path (antq_k_hrow.h): one row of n 16-bit patterns x16 at scale alpha / gmax ->
+// the output patterns, formed exactly the way the kernel forms them -- the per-row table of 8-byte slots keyed by the
+// pattern's top bits, the sentinel slot, the far-clipped arithmetic, the literal sequence for what is left -- so that the
+// CPU test-suite can hold the whole construction against the oracle without a GPU.  path[i] (nullable): 0 = table,
+// 1 = far-clipped arithmetic, 2 = literal sequence.  ANTQ_ERR_UNSUPPORTED when the plan has no hdom for `dtype`.
+// ------------------------------------------------------------------------------------------------------------------
+namespace antq {
+namespace {
+
+inline uint32_t f32_to_f16(float f)          // round to nearest even, as v_cvt_f16_f32 / tensor.to(float16)
+{
+    const uint32_t u = f2u(f), sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return sign | 0x7e00u;                 // NaN
+    if (a >= 0x47800000u) return sign | 0x7c00u;                // >= 65536 (or Inf): Inf; [65520, 65536) rounds up to Inf below
+    if (a < 0x33000000u) return sign;                           // < 2^-25: zero
+    const int e = (int)(a >> 23) - 127;
+    uint32_t mant = (a & 0x7fffffu) | 0x800000u;
+    int shift = e >= -14 ? 13 : (13 + (-14 - e));               // bits to drop
+    const uint32_t half = 1u << (shift - 1), mask = (1u << shift) - 1u;
+    uint32_t r = mant >> shift;
+    const uint32_t rem = mant & mask;
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    uint32_t h;
+    if (e >= -14) h = (uint32_t)((e + 15) << 10) + (r - 0x400u);     // (r may carry into the exponent: still right)
+    else h = r;                                                      // subnormal (r may become 0x400 = the smallest normal)
+    return sign | h;
+}
+inline float f16_to_f32(uint32_t h)
+{
+    const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0x1fu) return u2f(sign | 0x7f800000u | (m << 13));
+    if (e == 0) return u2f(sign) + (sign ? -1.0f : 1.0f) * ldexpf((float)m, -24);
+    return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+inline uint32_t bf16_rne(float f)
+{
+    uint32_t u = f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+struct H16Host {
+    int dtype;
+    uint32_t up(float U) const     // smallest magnitude pattern with value >= U (U > 0)
+    {
+        if (dtype == ANTQ_BF16) return (f2u(U) + 0xffffu) >> 16;
+        uint32_t h = f32_to_f16(U);
+        if (f16_to_f32(h) < U) h++;
+        return h;
+    }
+    uint32_t down(float A) const   // largest magnitude pattern with value <= A (A > 0)
+    {
+        if (dtype == ANTQ_BF16) return f2u(A) >> 16;
+        uint32_t h = f32_to_f16(A);
+        if (f16_to_f32(h) > A) h--;
+        return h;
+    }
+    uint32_t out(float o) const { return dtype == ANTQ_BF16 ? (bf16_rne(o) & 0xffffu) : f32_to_f16(o); }
+    float val(uint32_t p) const { return dtype == ANTQ_BF16 ? u2f(p << 16) : f16_to_f32(p); }
+};
+
+// antq_k_fakequant.h: row_scale / x_threshold, restated on the host
+inline float host_row_scale(float alpha, float gmax, bool &ok)
+{
+    const double inv = 1.0 / (double)gmax;
+    float s = (float)((double)alpha * inv);
+    ok = (inv != 0.0) && (s >= kScaleLo) && (s <= kScaleHi);
+    if (!ok) {
+        s = alpha / gmax;
+        const float as = fabsf(s);
+        ok = (as >= kScaleLo) && (as <= kScaleHi);
+    }
+    return s;
+}
+inline float host_x_threshold(float T, float s)
+{
+    const double M = 0.5 * ((double)next_dn(T) + (double)T);
+    const double prod = M * (double)s;
+    const float xf = (float)prod;
+    const double back = (double)xf;
+    const bool t_even = (f2u(T) & 1u) == 0u;
+    return ((back > prod) || (back == prod && t_even)) ? xf : next_up(xf);
+}
+
+}  // namespace
+}  // namespace antq
+
+extern "C" int antq_plan_eval_host_h(const void *blob, const uint16_t *x16, size_t n, float alpha, float gmax, int dtype,
+                                     unsigned flags, uint16_t *out16, uint8_t *path)
+{
+    if (!blob || !x16 || !out16) return ANTQ_ERR_ARG;
+    const PlanHeader *h = static_cast<const PlanHeader *>(blob);
+    if (h->magic != kPlanMagic || h->version != kPlanVersion) return ANTQ_ERR_PLAN;
+    const int t = dtype == ANTQ_BF16 ? 0 : dtype == ANTQ_F16 ? 1 : -1;
+    if (t < 0 || h->kind != kPlanLut || !(h->hdom & (1u << t))) return ANTQ_ERR_UNSUPPORTED;
+    const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
+    const H16Host H{dtype};
+    const float *grid = plan_grid(blob);
+    const HThr *tl = plan_tlist(blob);
+    const uint32_t n_thr = h->h_nthr, n_neg = h->h_nneg, hshift = (h->hshift >> (8 * t)) & 0xffu;
+    const float flim = h->fastlim * 0.99999f, lim = fminf(flim, h->xlim);
+    float vmin = grid[0], vmax = grid[0];
+    for (uint32_t i = 1; i < h->m; i++) { vmin = std::min(vmin, grid[i]); vmax = std::max(vmax, grid[i]); }
+    bool ok;
+    const float s = host_row_scale(alpha, gmax, ok);
+    ok = ok && (s > 0.0f);
+    const float rs = 1.0f / s;                      // (the device takes v_rcp_f32: only used for the |x * rs| < flim test)
+    std::vector<uint32_t> tab0(2 * kHSlots, 0u), tab1(2 * kHSlots, 0u);      // word 0 / word 1 of every slot
+    uint32_t kmin = 0, klim = 0;
+    if (ok) {
+        const float limx = lim * s * 0.999f;
+        const uint32_t lim16 = H.down(fminf(limx, 3.0e38f));
+        klim = lim16 >> hshift;
+        std::vector<uint32_t> t16(n_thr), key(n_thr), first(n_thr), second(n_thr);
+        for (uint32_t i = 0; i < n_thr; i++) {
+            const bool neg = i < n_neg;
+            const float U = host_x_threshold(tl[i].T, s);
+            t16[i] = neg ? H.down(-U) + 1u : H.up(U);
+            key[i] = t16[i] >> hshift;
+            const uint32_t o_lo = H.out((tl[i].v_lo + 0.0f) * s), o_hi = H.out((tl[i].v_hi + 0.0f) * s);
+            first[i] = neg ? o_hi : o_lo;
+            second[i] = neg ? o_lo : o_hi;
+        }
+        const uint32_t kpos = n_neg < n_thr ? key[n_neg] : 0xffffffffu, kneg = n_neg > 0 ? key[n_neg - 1] : 0xffffffffu;
+        kmin = std::min(kpos, kneg);
+        ok = (klim >= kmin) && (klim - kmin < kHSlots);
+        for (uint32_t i = 0; i < n_thr && ok; i++) {
+            const bool neg = i < n_neg;
+            const bool last = neg ? (i == 0) : (i + 1 == n_thr);
+            const uint32_t nxt = last ? klim : (neg ? key[i - 1] : key[i + 1]);
+            if (!(key[i] < nxt)) ok = false;
+        }
+        if (ok && ovp) {
+            const uint32_t othr = H.out(h->vout * s) & 0x7fffu;
+            if (othr >= (dtype == ANTQ_BF16 ? 0x7f80u : 0x7c00u) && h->vout < INFINITY) ok = false;   // outputs of outliers overflow
+        }
+        if (ok) {
+            auto put = [&](uint32_t k, bool ng, uint32_t w0, uint32_t w1) { const uint32_t j = ((k - kmin) << 1) + (ng ? 1u : 0u); tab0[j] = w0; tab1[j] = w1; };
+            for (uint32_t i = 0; i < n_thr; i++) {
+                const bool neg = i < n_neg;
+                const bool last = neg ? (i == 0) : (i + 1 == n_thr), firsts = neg ? (i + 1 == n_neg) : (i == n_neg);
+                const uint32_t nxt = last ? klim : (neg ? key[i - 1] : key[i + 1]);
+                const uint32_t sbit = neg ? 0x80000000u : 0u;
+                put(key[i], neg, sbit | (t16[i] << 16), first[i] | (second[i] << 16));
+                for (uint32_t k = key[i] + 1u; k < nxt; k++) put(k, neg, 0xffffffffu, second[i] | (second[i] << 16));
+                if (firsts) for (uint32_t k = kmin; k < key[i]; k++) put(k, neg, 0xffffffffu, first[i] | (first[i] << 16));
+                if (last) put(klim, neg, sbit | (lim16 << 16), second[i] | (0xffffu << 16));
+            }
+            if (n_neg == 0 || n_neg == n_thr) {
+                const bool ng = n_neg == 0;
+                const uint32_t o = ng ? first[0] : first[n_thr - 1];
+                for (uint32_t k = kmin; k < klim; k++) put(k, ng, 0xffffffffu, o | (o << 16));
+                put(klim, ng, (ng ? 0x80000000u : 0u) | (lim16 << 16), o | (0xffffu << 16));
+            }
+        }
+    }
+    const uint32_t othr = (ok && ovp) ? (H.out(h->vout * s) & 0x7fffu) : 0u;
+    auto lookup = [&](uint32_t pat) -> uint32_t {              // hrow_pair for one element (pattern in the high half)
+        const uint32_t w = pat << 16;
+        const uint32_t key = (w >> (16 + hshift)) & ((1u << (15 - hshift)) - 1u);
+        const uint32_t ck = std::min(std::max(key, kmin), klim);
+        const uint32_t sl = ((ck - kmin) << 1) | (w >> 31);
+        return (w >= tab0[sl]) ? (tab1[sl] >> 16) : (tab1[sl] & 0xffffu);
+    };
+    auto exact_pair = [&](uint32_t p0, uint32_t p1, bool has1, uint16_t &o0, uint16_t &o1) {
+        float x[2] = {H.val(p0), H.val(p1)}, d[2], q[2];
+        for (int e = 0; e < 2; e++) { int j; d[e] = x[e] / s; q[e] = scan_one(d[e], grid, (int)h->m, &j); }
+        if (ovp && has1) {
+            const bool me = fabsf(q[0]) > 32.0f, mo = fabsf(q[1]) > 32.0f;
+            q[0] = q[0] * ((mo && !me) ? 0.0f : 1.0f);
+            q[1] = q[1] * (me ? 0.0f : 1.0f);
+        }
+        o0 = (uint16_t)H.out(((q[0] - d[0]) + d[0]) * s);
+        o1 = (uint16_t)H.out(((q[1] - d[1]) + d[1]) * s);
+    };
+    // vectors of 8 elements, as the kernel takes them (a vector with an element in the sentinel slot is formed again as a
+    // whole; n need not be a multiple of 8 here: the tail is a short vector)
+    for (size_t b = 0; b < n; b += 8) {
+        const size_t e1 = std::min(n, b + 8);
+        bool sentinel = false, decided = true;
+        uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint8_t pth[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) {
+            for (size_t i = b; i < e1; i++) {
+                o[i - b] = lookup(x16[i]);
+                if (o[i - b] == 0xffffu) sentinel = true;
+            }
+            if (sentinel) {
+                for (size_t i = b; i < e1; i++) {
+                    if (o[i - b] != 0xffffu) continue;
+                    const float xe = H.val(x16[i]);
+                    decided = decided && (fabsf(xe * rs) < flim);
+                    const float d = xe / s;
+                    const float q = (d > 0.0f ? vmax : vmin) + 0.0f;
+                    o[i - b] = H.out(((q - d) + d) * s);
+                    pth[i - b] = 1;
+                }
+            }
+            if (ovp && decided) {
+                for (size_t i = b; i + 1 < e1; i += 2) {
+                    const bool me = (o[i - b] & 0x7fffu) >= othr, mo = (o[i + 1 - b] & 0x7fffu) >= othr;
+                    if (mo && !me) o[i - b] = 0;
+                    if (me) o[i + 1 - b] = 0;
+                }
+            }
+        }
+        if (!ok || !decided) {
+            for (size_t i = b; i < e1; i += 2) {
+                uint16_t o0, o1;
+                const bool has1 = i + 1 < e1;
+                exact_pair(x16[i], has1 ? x16[i + 1] : 0, has1, o0, o1);
+                o[i - b] = o0; pth[i - b] = 2;
+                if (has1) { o[i + 1 - b] = o1; pth[i + 1 - b] = 2; }
+            }
+        }
+        for (size_t i = b; i < e1; i++) { out16[i] = (uint16_t)o[i - b]; if (path) path[i] = pth[i - b]; }
     }
     return ANTQ_OK;
 }

@@ -71,7 +71,7 @@ extern "C" {
 #define ANTQ_IDX_VICTIM  (-2)      /* OliVe victim: value forced to zero             */
 
 #define ANTQ_MAX_GRID     1024     /* entries; the reference's LDS array holds 256   */
-#define ANTQ_PLAN_MAX_BYTES (96 + 4 * ANTQ_MAX_GRID + 16 * 3072 + 20 * 1024)
+#define ANTQ_PLAN_MAX_BYTES (128 + 4 * ANTQ_MAX_GRID + 16 * 3072 + 20 * 1024 + 16 * 64)
 
 int         antq_abi_version(void);
 const char *antq_strerror(int code);
@@ -131,6 +131,14 @@ int antq_plan_eval_host(const void *plan_host, const float *d, float *q, int16_t
  * without that path. */
 int antq_plan_eval_host_a(const void *plan_host, const float *x, size_t n, float alpha, float gmax, int rs_ulps,
                           float *out, int16_t *idx, uint8_t *slow);
+
+/* Host model of the 16-bit-domain row path (bf16 / f16 rows of at least 128 vectors with a 4- / 5-bit codebook: the
+ * headline kernels; pure CPU): one row of n 16-bit patterns x16 at scale alpha / gmax -> the output patterns out16,
+ * through the same per-row slot table, sentinel slot, far-clipped arithmetic and literal sequence the kernel uses.
+ * path[i] (nullable): 0 = table, 1 = far-clipped arithmetic, 2 = literal sequence.  flags: ANTQ_FLAG_OVP (pairs inside
+ * the row: n even).  ANTQ_ERR_UNSUPPORTED when the plan does not allow that path for `dtype` (ANTQ_BF16 / ANTQ_F16). */
+int antq_plan_eval_host_h(const void *plan_host, const uint16_t *x16, size_t n, float alpha, float gmax, int dtype,
+                          unsigned flags, uint16_t *out16, uint8_t *path);
 
 /* ---------------------------------------------------------------------------
  * Fused Quantizer._forward with a calibrated (static) alpha:
@@ -356,7 +364,9 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
  *          default: lane kernel for one-launch-per-tensor calls and fp32 batches)
  *   key 6: wavefronts per workgroup (1 / 2 / 4) of the batched row-table launch and of the one-launch lane kernel (0 = heuristic)
  *   key 7: vectors per lane of the one-launch lane kernel (0 = heuristic)
- *   key 8: workgroup -> task map rotation of the batched row-table launch: 0 per job (default), 1 always, 2 never */
+ *   key 8: workgroup -> task map rotation of the batched row-table launch: 0 per job (default), 1 always, 2 never
+ *   key 9: 0 disables the 16-bit-domain row kernels (bf16 / f16 rows of >= 128 vectors go back to the fp32-domain row table)
+ *   key 10: dynamic LDS bytes per workgroup of those kernels (occupancy A/B; -1 = default: 24 workgroups per CU) */
 int antq_debug_set(int key, int value);
 
 #ifdef __cplusplus

@@ -459,6 +459,72 @@ def test_approximate_quotient_path_host_model_equals_oracle(antq_lib, oracle):
     assert n_plans > 120, n_plans
 
 
+def _half_bits_equal(got16, ref_f32, dtype, orc):
+    """got16: uint16 patterns; ref_f32: the oracle's fp32 outputs -> the same rounding to 16 bits; equal bits or both NaN."""
+    if dtype == 1:
+        ref16 = orc.f32_to_bf16(ref_f32)
+        gf, rf = orc.bf16_to_f32(got16), orc.bf16_to_f32(ref16)
+    else:
+        with np.errstate(all="ignore"):
+            ref16 = np.asarray(ref_f32, dtype=np.float32).astype(np.float16).view(np.uint16)
+        gf, rf = got16.view(np.float16).astype(np.float32), ref16.view(np.float16).astype(np.float32)
+    bad = ~((got16 == ref16) | (np.isnan(gf) & np.isnan(rf)))
+    return bad
+
+
+def test_16bit_domain_row_path_host_model_equals_oracle_on_every_pattern(antq_lib, oracle):
+    """K1h (csrc/antq_k_hrow.h): bf16 / f16 rows quantised on their bit patterns through a per-row slot table.  Its host
+    model (antq_plan_eval_host_h: the same table construction, sentinel slot, far-clipped arithmetic and literal sequence
+    as the kernel) against the oracle -- division, scan, pair rule, (q - d) + d, * s in fp32, then the rounding to 16 bits --
+    on EVERY one of the 65 536 input patterns (in order and shuffled: other pairs), for every codebook that allows the path,
+    both dtypes, with and without the pair rule, at scales from 1e-9 to 1e9 plus zero / negative / NaN / Inf alphas."""
+    L = antq_lib.lib()
+    L.antq_plan_eval_host_h.restype = ctypes.c_int
+    rng = np.random.default_rng(23)
+    allpat = np.arange(65536, dtype=np.uint16)
+    shuf = rng.permutation(allpat)
+    n_plans = n_table = n_far = n_rows = 0
+    for k, g in _all_grids().items():
+        if g.size > antq_lib.MAX_GRID:
+            continue
+        plan = antq_lib.Plan(g)
+        hdr = plan.host[:128].view(np.uint32)
+        hdom = int(hdr[24]) if plan.is_table else 0                    # PlanHeader::hdom (word 24)
+        if k in ("flint_b4_s", "int_b4_s", "olive_flint_b4_s", "olive_int_b4_s", "flint_b4_u", "olive_flint_b4_u"):
+            assert hdom == 3, (k, hdom)                                # the codebooks the headline configs use
+        if not hdom:
+            continue
+        n_plans += 1
+        olive = k.startswith("olive_") and not k.startswith("olive_noout_")
+        gmax = float(np.max(g[np.abs(g) <= 32])) if olive else float(np.max(g))
+        alphas = np.concatenate([np.float32([1.0, 0.06, 0.0, -0.05, np.nan, np.inf, 1e-30, 1e30]),
+                                 np.exp(rng.uniform(-20, 20, 4)).astype(np.float32)])
+        for dtype in (1, 2):
+            if not (hdom >> (dtype - 1)) & 1:
+                continue
+            for pats in (allpat, shuf):
+                xf = oracle.bf16_to_f32(pats) if dtype == 1 else pats.view(np.float16).astype(np.float32)
+                for alpha in alphas:
+                    for ovp in ((False, True) if olive else (False,)):
+                        with np.errstate(all="ignore"):
+                            ref, _ = oracle.forward(xf.reshape(1, -1), np.float32([alpha]), g, gmax, ovp)
+                        out = np.empty(65536, np.uint16)
+                        path = np.empty(65536, np.uint8)
+                        rc = L.antq_plan_eval_host_h(plan.host_ptr(), pats.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(65536),
+                                                     ctypes.c_float(alpha), ctypes.c_float(gmax), ctypes.c_int(dtype),
+                                                     ctypes.c_uint(1 if ovp else 0), out.ctypes.data_as(ctypes.c_void_p),
+                                                     path.ctypes.data_as(ctypes.c_void_p))
+                        assert rc == 0
+                        bad = _half_bits_equal(out, ref.reshape(-1), dtype, oracle)
+                        assert not bad.any(), (k, dtype, float(alpha), ovp, int(bad.sum()), pats[bad][:4], out[bad][:4], path[bad][:4])
+                        n_table += int((path == 0).sum())
+                        n_far += int((path == 1).sum())
+                        n_rows += 1
+    assert n_plans >= 12 and n_rows > 500
+    # (most of the 65 536 patterns lie beyond any one row's limit, and whole 8-element vectors are redone around them)
+    assert n_table > 0.1 * 65536 * n_rows and n_far > 0.01 * 65536 * n_rows    # table path and far-clipped arithmetic both exercised
+
+
 def test_batch_descriptor_builder_host_logic(antq_lib):
     """antq_batch_build is pure host code: every job of a batch gets its blocks exactly once, inside its family's map
     region, row jobs have tasks that cover their rows (per-tensor jobs are ONE row), mixed static batches collapse to the
@@ -481,14 +547,14 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
         if n <= 0:
             return n, None
         assert n <= cap
-        h = host[:56].view(np.uint32)
-        total, fam, mixed, waves = int(h[7]), [int(v) for v in h[8:13]], int(h[13]) & 1, (int(h[13]) >> 8) & 7
+        h = host[:64].view(np.uint32)
+        total, fam, mixed, waves = int(h[7]), [int(v) for v in h[8:14]], int(h[14]) & 1, (int(h[14]) >> 8) & 7
         assert waves in (1, 4)          # wavefronts per workgroup the row-table launch will use (bits 8.. of the last word)
         assert sum(fam) == total and int(h[6]) == n == int(h[5]) + 4 * total
         bmap = host[int(h[5]):n].view(np.uint32)
         descs = []
         for k in range(len(jobs)):
-            d = host[56 + 176 * k:56 + 176 * (k + 1)]
+            d = host[64 + 192 * k:64 + 192 * (k + 1)]
             w = d[40:72].view(np.uint32)          # total_tasks vpr tpr vshift first_block kind per_row gmax
             descs.append(dict(n_vec=int(d[32:40].view(np.uint64)[0]), total_tasks=int(w[0]), vpr=int(w[1]), tpr=int(w[2]),
                               first_block=int(w[4]), kind=int(w[5]), u=int(d[148:152].view(np.uint32)[0])))
@@ -502,18 +568,26 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
             d["blocks"], d["family"] = int(pos.size), f
         return n, dict(descs=descs, fam=fam, mixed=mixed, lds=int(h[4]))
 
-    # static rows that are NOT a power of two of vectors (3x3 conv rows): the per-row table family alone, on its lean kernel;
-    # rows of 576 / 144 / 192 vectors are cut into tasks of 3 vectors per lane
+    # 16-bit static rows of >= 128 vectors with a 4-bit codebook: the 16-bit-domain row family (5, kind 13) alone; rows of
+    # 576 / 144 / 192 vectors are cut into tasks of 3 vectors per lane, powers of two into tasks of 4 (2 for 128-vector rows)
+    for dt in (1, 2):
+        n, b = build([(4096, 4608, True, flint)] * 3 + [(512, 1152, True, flint), (64, 1536, True, flint)], dtype=dt)
+        assert b["mixed"] == 0 and b["fam"][5] > 0 and sum(b["fam"][:5]) == 0
+        assert [d["u"] for d in b["descs"]] == [3, 3, 3, 3, 3] and all(d["kind"] == 13 for d in b["descs"])
+        for d, rows in zip(b["descs"], (4096, 4096, 4096, 512, 64)):
+            assert d["total_tasks"] == rows * d["tpr"] and d["tpr"] * 64 * d["u"] >= d["vpr"] and d["blocks"] == -(-d["total_tasks"] // 4)
+        n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint), (8, 1 << 16, False, pol)], dtype=dt)
+        assert b["mixed"] == 0 and b["fam"][5] > 0 and sum(b["fam"][:5]) == 0 and all(d["kind"] == 13 for d in b["descs"])
+        assert [d["u"] for d in b["descs"]] == [4, 4, 4, 2, 4] and b["descs"][4]["tpr"] == b["descs"][4]["total_tasks"] == 256
+    # ... with knob 9 = 0 the fp32-domain row table (family 0, kind 2) as in round 3
+    L.antq_debug_set(9, 0)
     n, b = build([(4096, 4608, True, flint)] * 3 + [(512, 1152, True, flint), (64, 1536, True, flint)], dtype=1)
     assert b["mixed"] == 0 and b["fam"][0] > 0 and sum(b["fam"][1:]) == 0
     assert [d["u"] for d in b["descs"]] == [3, 3, 3, 3, 3] and all(d["kind"] == 2 for d in b["descs"])
-    for d, rows in zip(b["descs"], (4096, 4096, 4096, 512, 64)):
-        assert d["total_tasks"] == rows * d["tpr"] and d["tpr"] * 64 * d["u"] >= d["vpr"] and d["blocks"] == -(-d["total_tasks"] // 4)
-    # rows of a power of two of vectors: 16-bit data (the headline shape: 4096 bf16 elements = 512 vectors) stays on the
-    # per-row table kernel, fp32 becomes lane jobs (family 1 alone)
     n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint)], dtype=1)
     assert b["mixed"] == 0 and b["fam"][0] > 0 and sum(b["fam"][1:]) == 0 and all(d["kind"] == 2 for d in b["descs"])
     assert [d["u"] for d in b["descs"]] == [2, 2, 2, 2]      # (round 3: one-wavefront workgroups stream best with 2 KiB each)
+    L.antq_debug_set(9, 1)
     n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint)], dtype=0)
     assert b["mixed"] == 0 and b["fam"][1] > 0 and b["fam"][0] == 0 and all(d["kind"] == 1 for d in b["descs"])
     assert [d["n_vec"] for d in b["descs"]] == [4096 * 1024] * 3 + [512 * 256]
