@@ -3186,3 +3186,94 @@ def test_fp16_io_fuzz_every_launch_form(antq_lib, oracle, dev, seed):
         for j in js:
             got = j[1].cpu().numpy()
             assert bool(np.all((got.view(np.uint16) == j[8].view(np.uint16)) | (np.isnan(got) & np.isnan(j[8])))), ("batched", j[9])
+
+
+@pytest.mark.gpu
+def test_16bit_domain_row_kernels_on_every_pattern(antq_lib, oracle, dev):
+    """K1h on the device (csrc/antq_k_hrow.h: k_fq_hrow one tensor per launch, k_fq_hbatch many): rows that hold EVERY one of
+    the 65 536 bf16 / f16 patterns (in order and shuffled: other pairs, other lane / vector positions), one row per scale --
+    ordinary ones from 1e-9 to 1e9, zero, negative, NaN, Inf, denormal-range and overflowing ones -- against the oracle's
+    fp32 sequence rounded to 16 bits, bit for bit, for the headline codebooks and a few 3- / 5-bit ones, with and without
+    the pair rule; the same rows through the batched launch, through 3- and 2-vector tasks (rows of 576 / 128 vectors) and
+    with the round-3 fp32-domain kernels (knob 9 = 0), which must agree as well."""
+    import torch
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    rng = np.random.default_rng(41)
+    allpat = np.arange(65536, dtype=np.uint16)
+    books = [("flint_b4_s", G["flint_b4_s"], None, False), ("int_b4_s", G["int_b4_s"], None, False),
+             ("flint_b4_u", G["flint_b4_u"], None, False), ("pot_b4_s", G["pot_b4_s"], None, False),
+             ("float_b5_s", G["float_b5_s"], None, False), ("int_b3_u", G["int_b3_u"], None, False),
+             ("olive_flint_b4_s", np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]]), float(O["flint_b4_s"].max()), True),
+             ("olive_int_b4_s", np.concatenate([O["int_b4_s"], O["outlier_b4_s"]]), float(O["int_b4_s"].max()), True),
+             ("olive_flint_b4_u", np.concatenate([O["flint_b4_u"], O["outlier_b4_u"]]), float(O["flint_b4_u"].max()), True)]
+    knob = antq_lib.lib().antq_debug_set
+    for name, g, gmax, olive in books:
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        gmax = float(g.max()) if gmax is None else gmax
+        plan = antq_lib.plan_for(g)
+        assert plan.is_table and int(plan.host[:128].view(np.uint32)[24]) == 3, name      # hdom for both dtypes
+        alphas = np.concatenate([np.float32([1.0, 0.06, 0.0, -0.05, np.nan, np.inf, 1e-30, 1e30, 65504.0, 6e-8]),
+                                 np.exp(rng.uniform(-20, 20, 6)).astype(np.float32)])
+        rows = len(alphas)
+        for tdt, npdt in ((torch.bfloat16, None), (torch.float16, np.float16)):
+            for pats in (allpat, rng.permutation(allpat)):
+                x16 = np.ascontiguousarray(np.broadcast_to(pats, (rows, 65536)))
+                xf = oracle.bf16_to_f32(x16) if npdt is None else x16.view(np.float16).astype(np.float32)
+                xt = torch.from_numpy(x16.view(np.int16)).to(dev).view(tdt)
+                at = torch.from_numpy(alphas).to(dev)
+                for ovp in ((False, True) if olive else (False,)):
+                    with np.errstate(all="ignore"):
+                        ref, _ = oracle.forward(xf, alphas, g, gmax, ovp)
+                        ref16 = oracle.f32_to_bf16(ref) if npdt is None else ref.astype(np.float16).view(np.uint16)
+
+                    def same(t, what):
+                        got = t.view(torch.int16).cpu().numpy().view(np.uint16).reshape(ref16.shape)
+                        gf = oracle.bf16_to_f32(got) if npdt is None else got.view(np.float16).astype(np.float32)
+                        rf = oracle.bf16_to_f32(ref16) if npdt is None else ref16.view(np.float16).astype(np.float32)
+                        bad = ~((got == ref16) | (np.isnan(gf) & np.isnan(rf)))
+                        assert not bad.any(), (name, str(tdt), ovp, what, int(bad.sum()), np.argwhere(bad)[:3].tolist(),
+                                               x16[bad][:3], got[bad][:3], ref16[bad][:3])
+
+                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "one launch")
+                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp, out=torch.empty_like(xt), unordered=True), "unordered")
+                    knob(9, 0)
+                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "round-3 kernels")
+                    knob(9, 1)
+                    out = torch.empty_like(xt)
+                    antq_lib.Batch([(xt, out, at, plan, gmax, rows, 65536, True)], ovp=ovp).run()
+                    same(out, "batched")
+                    # the same elements as rows of 576 vectors (tasks of 3 vectors per lane) and of 128 vectors (2): per-row
+                    # scales repeated so that every short row keeps the scale of the long row it came from
+                    for rl in (4608, 1024):
+                        if 65536 % rl:
+                            n_keep = (65536 // rl) * rl
+                            xs = xt[:, :n_keep].contiguous().view(-1, rl)
+                            a2 = at.repeat_interleave(n_keep // rl)
+                            keep = ref16[:, :n_keep]
+                        else:
+                            n_keep = 65536
+                            xs, a2, keep = xt.view(-1, rl), at.repeat_interleave(65536 // rl), ref16
+                        if ovp and rl % 2:
+                            continue
+                        o2 = torch.empty_like(xs)
+                        antq_lib.Batch([(xs, o2, a2, plan, gmax, xs.shape[0], rl, True)], ovp=ovp).run()
+                        got = o2.view(torch.int16).cpu().numpy().view(np.uint16).reshape(keep.shape)
+                        gf = oracle.bf16_to_f32(got) if npdt is None else got.view(np.float16).astype(np.float32)
+                        rf = oracle.bf16_to_f32(keep) if npdt is None else keep.view(np.float16).astype(np.float32)
+                        assert np.all((got == keep) | (np.isnan(gf) & np.isnan(rf))), (name, str(tdt), ovp, rl)
+                        o3 = antq_lib.fakequant(xs, a2, plan, gmax, xs.shape[0], rl, True, ovp=ovp)
+                        assert torch.equal(o3.view(torch.int16), o2.view(torch.int16)), (name, rl)
+    # a per-tensor scale (one row however the tensor is shaped) and an in-place launch
+    g = np.ascontiguousarray(G["flint_b4_s"], dtype=np.float32)
+    plan = antq_lib.plan_for(g)
+    x16 = rng.permutation(allpat)
+    xt = torch.from_numpy(np.tile(x16, 4).view(np.int16)).to(dev).view(torch.bfloat16).view(64, 4096)
+    a1 = torch.tensor([0.37], device=dev)
+    with np.errstate(all="ignore"):
+        ref, _ = oracle.forward(oracle.bf16_to_f32(np.tile(x16, 4)).reshape(1, -1), np.float32([0.37]), g, 10.0, False)
+    ref16 = oracle.f32_to_bf16(ref).reshape(-1)
+    got = antq_lib.fakequant(xt, a1, plan, 10.0, 64, 4096, False)
+    assert bf16_same(bf16_bits(got).reshape(-1), ref16, oracle)
+    xi = xt.clone()
+    antq_lib.fakequant(xi, a1, plan, 10.0, 64, 4096, False, out=xi)
+    assert bf16_same(bf16_bits(xi).reshape(-1), ref16, oracle)
