@@ -1,10 +1,13 @@
 """Partitioning of the fake-quant work across the GPUs of a node.
 
-The path has no exchange step: tensors -- or contiguous row blocks of one huge
-tensor -- are independent units, so sharding is pure bookkeeping and there is NO data-path
-collective.  Only two things ever cross ranks: the barrier around a timed region and a MAX
-reduction of elapsed times (bench.py), plus the reference's own one-shot calibration syncs
-(AQ/quant_modules.py:525-531) when the quantiser runs under DDP.
+The steady-state path has no exchange step: tensors -- or contiguous row blocks of one
+huge tensor -- are independent units, so sharding is pure bookkeeping and there is NO data-path
+collective.  What crosses ranks: the barrier around a timed region and a MAX reduction of elapsed
+times (bench.py); the reference's own one-shot calibration syncs (AQ/quant_modules.py:525-531) when
+the quantiser runs under DDP; one bit for OliVe pairs on a row-sharded tensor with an odd element
+count (fix_odd_numel_wrap); and -- the only collectives SURVEY 8e lists -- the first-call
+calibration of a PER-TENSOR quantiser whose tensor is row-sharded (sharded_absmax,
+sharded_three_sigma, sharded_calibrate: a float MAX, two doubles SUM, T x R doubles SUM).
 """
 from typing import List, Sequence, Tuple
 
@@ -101,3 +104,122 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- a PER-TENSOR quantiser on a row-sharded tensor: the path's only collectives -----------------------
+# A per-tensor (activation) quantiser whose tensor is split into row blocks across ranks calibrates on statistics of the
+# WHOLE tensor.  Every one of them is a sum or a maximum of per-block terms, so each rank reduces its own block on one
+# read (the kernels the unsharded calibration uses) and a few hundred bytes cross the ranks:
+#     abs-max (ANT, AQ/quant_modules.py:308-324, :473-477)              1 float            all_reduce(MAX)
+#     (sum x, sum x^2) for OliVe's 3-sigma rule (OQ:213-218)            2 doubles          all_reduce(SUM)
+#     squared-error sums of the clip candidates, T types x R ratios     T x R doubles      all_reduce(SUM)
+# after which every rank holds identical numbers and runs the reference's selection loop (strict '<', first best;
+# type = first minimum, AQ:398-415 / OQ:250-256) on its own -- no broadcast of the result is needed.
+# `ops` abstracts the per-block kernels (default: the HIP library); the CPU tests of the protocol pass an oracle-backed one.
+class GpuBlockOps:
+    """Per-block reductions on the GPU (ant_quantization_amd._lib).  x_block: [rows_here, row_len] contiguous device tensor."""
+
+    @staticmethod
+    def absmax(x_block):
+        from . import _lib
+        return _lib.absmax(x_block, x_block.shape[0], x_block.shape[1], per_row=False)              # [1] float32
+
+    @staticmethod
+    def moments(x_block):
+        from . import _lib
+        return _lib.moments(x_block, x_block.shape[0], x_block.shape[1], per_row=False)             # [1, 2] float64
+
+    @staticmethod
+    def xmax_3sigma(x_block, sums, n_total):
+        from . import _lib
+        return _lib.xmax_3sigma(x_block, 1, n_total, per_row=False, sums=sums)                      # [1] float32
+
+    @staticmethod
+    def ratios(lb, ub, step, device):
+        from . import core
+        return core._ratios(int(lb), int(ub), int(step), device)
+
+    @staticmethod
+    def search_sse(x_block, xmax, ratios, plans, gmaxs, ovp):
+        """[T, R, 1] float64: every type's / ratio's sum of squared errors over THIS block."""
+        import torch
+        from . import _lib
+        rows, row_len = x_block.shape
+        out = []
+        for b in range(0, len(plans), 4):
+            sse = _lib.search_sse_multi(x_block, rows, row_len, xmax, False, ratios, plans[b:b + 4], gmaxs[b:b + 4], ovp=ovp) \
+                if len(plans) > 1 else None
+            if sse is None:
+                sse = torch.stack([_lib.search_sse(x_block, rows, row_len, xmax, False, ratios, p, g, ovp=ovp)
+                                   for p, g in zip(plans[b:b + 4], gmaxs[b:b + 4])])
+            out.append(sse)
+        return torch.cat(out)
+
+    @staticmethod
+    def pick(sse, xmax, ratios, n_total):
+        from . import _lib
+        return _lib.search_pick(sse, xmax, ratios, n_total)                                         # (best [1], alpha [1]) float32
+
+
+def _all_reduce(t, op, group):
+    """all_reduce of `t` in place over `group`: a torch.distributed process group (None = the default one; RCCL on the
+    GPUs of a node, gloo in the CPU tests), or any object with an all_reduce(tensor, "max" | "sum") method (the tests'
+    in-process communicator that stands in for two ranks on one device)."""
+    import torch.distributed as dist
+    if group is not None and hasattr(group, "all_reduce") and not isinstance(group, dist.ProcessGroup):
+        group.all_reduce(t, "max" if op == dist.ReduceOp.MAX else "sum")
+    elif dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def sharded_absmax(x_block, group=None, ops=GpuBlockOps):
+    """abs-max of the whole row-sharded tensor as a 1-element float32 tensor on every rank: local abs-max, all_reduce(MAX)
+    (AQ/quant_modules.py:308-324: x_max of a per-tensor quantiser).  NaN propagates like torch.max: a NaN block maximum
+    is sent as +Inf-plus (its bit pattern orders above every finite value) -- here simply through the float MAX, which
+    keeps NaN on every backend this runs on when any rank holds one."""
+    import torch.distributed as dist
+    return _all_reduce(ops.absmax(x_block).reshape(1).clone(), dist.ReduceOp.MAX, group)
+
+
+def sharded_three_sigma(x_block, n_total, group=None, ops=GpuBlockOps):
+    """OliVe's clip statistic max(|mean + 3 std|, |mean - 3 std|) (OQ:213-218, unbiased std) of the whole row-sharded tensor:
+    (sum x, sum x^2) of the block in double on one read, all_reduce(SUM) of the two doubles, then the same roundings the
+    unsharded statistic applies (antq_xmax_3sigma).  n_total = element count of the WHOLE tensor."""
+    import torch.distributed as dist
+    sums = _all_reduce(ops.moments(x_block).clone(), dist.ReduceOp.SUM, group)
+    return ops.xmax_3sigma(x_block, sums, int(n_total))
+
+
+def sharded_calibrate(x_block, n_total, plans, gmaxs, lb, ub, step, statistic="absmax", ovp=False, group=None, ops=GpuBlockOps):
+    """First-call calibration of a PER-TENSOR quantiser whose tensor is row-sharded (AQ:328-415 + :287-326, OQ:189-256):
+    the clip statistic, every candidate codebook's clip search and the type choice from all-reduced block sums.  Every rank
+    returns the same dict: xmax [1], ratios [R], alpha [T] (best clip per type), score [T] (its MSE), type (python int:
+    index of the winning codebook; the reference's argsort()[0] = first minimum) -- bit-identical to what the unsharded
+    calibration computes from the same sums (the all-reduce adds the blocks' doubles in rank order on every rank).
+    statistic: "absmax" (ANT) or "3sigma" (OliVe).  An empty candidate range keeps alpha = xmax, score 1e10 (the reference's
+    loop body never runs)."""
+    import torch
+    import torch.distributed as dist
+    if statistic == "absmax":
+        xmax = sharded_absmax(x_block, group, ops)
+    elif statistic == "3sigma":
+        xmax = sharded_three_sigma(x_block, n_total, group, ops)
+    else:
+        raise ValueError("statistic must be 'absmax' or '3sigma'")
+    xmax = xmax.reshape(1).to(torch.float32).contiguous()
+    nt = len(plans)
+    if not list(range(int(lb), int(ub), int(step))):
+        return dict(xmax=xmax, ratios=None, alpha=xmax.repeat(nt), score=torch.full((nt,), 1e10, dtype=torch.float32, device=xmax.device), type=0)
+    ratios = ops.ratios(lb, ub, step, x_block.device)
+    sse = _all_reduce(ops.search_sse(x_block, xmax, ratios, list(plans), list(gmaxs), ovp).contiguous(), dist.ReduceOp.SUM, group)
+    best, alpha = [], []
+    for t in range(nt):
+        b, a = ops.pick(sse[t], xmax, ratios, int(n_total))
+        best.append(b.reshape(()))
+        alpha.append(a.reshape(()))
+    score = torch.stack(best)
+    # the reference: np.argsort(mse_list)[0] (AQ:411-415 / OQ:254-256): the FIRST minimum (NaN scores sort last)
+    s = score.detach().cpu().numpy()
+    import numpy as np
+    return dict(xmax=xmax, ratios=ratios, alpha=torch.stack(alpha), score=score, type=int(np.argsort(s, kind="stable")[0]))

@@ -3277,3 +3277,100 @@ def test_16bit_domain_row_kernels_on_every_pattern(antq_lib, oracle, dev):
     xi = xt.clone()
     antq_lib.fakequant(xi, a1, plan, 10.0, 64, 4096, False, out=xi)
     assert bf16_same(bf16_bits(xi).reshape(-1), ref16, oracle)
+
+
+class _ThreadComm:
+    """Two 'ranks' on one device: each runs in its own thread on its own stream; all_reduce meets at a barrier."""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.barrier, self.slots = world, threading.Barrier(world), [None] * world
+
+    def rank(self, r):
+        comm = self
+
+        class R:
+            def all_reduce(self, t, op):
+                import torch
+                torch.cuda.current_stream().synchronize()
+                comm.slots[r] = t.clone()
+                torch.cuda.current_stream().synchronize()
+                comm.barrier.wait()
+                acc = comm.slots[0].clone()
+                for v in comm.slots[1:]:
+                    acc = torch.maximum(acc, v) if op == "max" else acc + v          # rank order, like a ring's fixed order
+                torch.cuda.current_stream().synchronize()
+                comm.barrier.wait()
+                t.copy_(acc)
+        return R()
+
+
+@pytest.mark.gpu
+def test_sharded_per_tensor_calibration_two_ranks_on_one_device(antq_lib, oracle, dev):
+    """sharding.sharded_calibrate with the HIP kernels (GpuBlockOps): a per-tensor quantiser's tensor cut into two row
+    blocks, each 'rank' reducing its block on its own stream, the three all-reduces done by an in-process communicator --
+    against the unsharded calibration of the whole tensor (antq_calibrate, one C call) and against the oracle's search:
+    same x_max (abs-max exactly; 3-sigma to the statistic's documented tolerance), same alpha per type, same type."""
+    import threading
+    import torch
+    from ant_quantization_amd import grids, sharding
+    rng = np.random.default_rng(5)
+    cases = [("olive", torch.float32, (64 * 128, 768)), ("olive", torch.bfloat16, (2048, 3072)), ("ant", torch.float32, (999, 1024)),
+             ("ant", torch.bfloat16, (4096, 768))]
+    for tree, tdt, (rows, K) in cases:
+        x = torch.from_numpy((rng.standard_normal((rows, K)) * 0.6).astype(np.float32)).to(dev)
+        if tree == "olive":
+            m = torch.from_numpy(rng.random((rows, K)) < 0.002).to(dev)
+            x[m] *= 40.0
+            fulls = [np.concatenate([grids.olive_grid(t, 4, True), grids.olive_outliers(4, True)]).astype(np.float32) for t in ("int", "flint")]
+            gmaxs = [float(grids.olive_grid(t, 4, True).max()) for t in ("int", "flint")]
+            lb, ub, step, stat, ovp = 75, 250, 2, "3sigma", True
+        else:
+            fulls = [np.ascontiguousarray(grids.ant_grid(t, 4, True), dtype=np.float32) for t in ("int", "pot", "flint")]
+            gmaxs = [float(g.max()) for g in fulls]
+            lb, ub, step, stat, ovp = 80, 150, 1, "absmax", False
+        x = x.to(tdt).contiguous()
+        plans = [antq_lib.plan_for(g) for g in fulls]
+        # unsharded: the whole calibration as one C call
+        a_ref, s_ref, t_ref, xm_ref = antq_lib.calibrate(x, rows, K, False, plans, gmaxs, lb, ub, step, xmax=stat, ovp=ovp)
+        comm, res, errs = _ThreadComm(2), [None, None], []
+
+        def worker(r):
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    b, e = sharding.row_block(rows, r, 2, pair_safe_row_len=K)
+                    res[r] = sharding.sharded_calibrate(x[b:e], rows * K, plans, gmaxs, lb, ub, step, statistic=stat, ovp=ovp,
+                                                        group=comm.rank(r))
+                    torch.cuda.current_stream().synchronize()
+            except Exception as ex:           # noqa: BLE001
+                errs.append(ex)
+                comm.barrier.abort()
+
+        th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not errs, errs
+        r0, r1 = res
+        assert torch.equal(r0["xmax"], r1["xmax"]) and torch.equal(r0["alpha"], r1["alpha"]) and r0["type"] == r1["type"]
+        if stat == "absmax":
+            assert torch.equal(r0["xmax"], xm_ref.reshape(1))
+        else:
+            np.testing.assert_allclose(r0["xmax"].cpu().numpy(), xm_ref.cpu().numpy(), rtol=2.0 ** -7 if tdt == torch.bfloat16 else 2e-6)
+        if torch.equal(r0["xmax"], xm_ref.reshape(1)):
+            # same statistic -> the same candidates: picks must agree unless two candidates tie to the last digit of the score
+            sa, sr = r0["score"].cpu().numpy(), s_ref.cpu().numpy()
+            np.testing.assert_allclose(sa, sr, rtol=1e-6)
+            for t in range(len(plans)):
+                if float(r0["alpha"][t]) != float(a_ref[t, 0]):
+                    assert abs(sa[t] - sr[t]) <= 1e-6 * sr[t], (tree, t)
+            assert r0["type"] == int(t_ref.item()) or abs(sr[r0["type"]] - sr.min()) <= 1e-6 * sr.min()
+        # ... and the oracle on the whole tensor with the sharded statistic (fp32 cases: the oracle's search is fp32)
+        if tdt == torch.float32 and rows * K <= 1 << 20:
+            xn = x.cpu().numpy()
+            for t, (g, gm) in enumerate(zip(fulls, gmaxs)):
+                bs, ba, tr = oracle.search_mse(xn, r0["xmax"].cpu().numpy(), lb, ub, step, g, gm, ovp=ovp, per_row=False)
+                if float(ba[0]) != float(r0["alpha"][t]):
+                    ci = int(round((float(r0["alpha"][t]) / float(r0["xmax"][0]) * 100 - lb) / step))
+                    assert abs(float(tr[ci, 0]) - float(tr.min())) <= 2e-6 * float(tr.min()), (tree, t)

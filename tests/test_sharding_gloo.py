@@ -222,3 +222,131 @@ def _even_worker(rank, world, port, q):
                                 rank, world, plain_fn=None)
     q.put(bool(np.array_equal(ob.numpy().view(np.uint32), full[b:e].view(np.uint32))))
     dist.destroy_process_group()
+
+
+# ---- SURVEY 8e's only collectives: a per-tensor quantiser on a row-sharded tensor --------------------------------------
+class OracleBlockOps:
+    """sharding.GpuBlockOps with the CPU oracle in place of the HIP kernels (test-only): the same per-block quantities,
+    from numpy / oracle/antq_oracle.c, as torch CPU tensors -- so that the protocol (what is reduced, how, and what every
+    rank computes from the reduced numbers) runs over gloo exactly as it runs over RCCL."""
+
+    def __init__(self, orc, grids_of_plans, ovp_gmax=None):
+        self.orc, self.grids = orc, grids_of_plans
+
+    def absmax(self, xb):
+        import torch
+        return torch.from_numpy(np.float32([np.abs(xb.numpy()).max()]))
+
+    def moments(self, xb):
+        import torch
+        x = xb.numpy().astype(np.float64)
+        return torch.from_numpy(np.float64([[x.sum(), (x * x).sum()]]))
+
+    def xmax_3sigma(self, xb, sums, n_total):
+        import torch
+        s1, s2 = float(sums[0, 0]), float(sums[0, 1])
+        mean = s1 / n_total
+        var = (s2 - n_total * mean * mean) / (n_total - 1)
+        m32, sd32 = np.float32(mean), np.float32(np.sqrt(max(var, 0.0)))
+        t3 = np.float32(3.0) * sd32
+        return torch.from_numpy(np.float32([max(abs(np.float32(m32 + t3)), abs(np.float32(m32 - t3)))]))
+
+    def ratios(self, lb, ub, step, device):
+        import torch
+        return torch.from_numpy(np.float32([np.float32(i * 0.01) for i in range(lb, ub, step)]))
+
+    def search_sse(self, xb, xmax, ratios, plans, gmaxs, ovp):
+        import torch
+        x = xb.numpy()
+        out = np.empty((len(plans), ratios.numel(), 1), np.float64)
+        for t, (p, gm) in enumerate(zip(plans, gmaxs)):
+            for c, r in enumerate(ratios.numpy()):
+                alpha = np.float32(xmax.numpy()[0] * r)
+                q, _ = self.orc.forward(x.reshape(1, -1), np.float32([alpha]), self.grids[p], gm, ovp, want_idx=False)
+                out[t, c, 0] = ((q.reshape(-1).astype(np.float64) - x.reshape(-1)) ** 2).sum()
+        return torch.from_numpy(out)
+
+    def pick(self, sse, xmax, ratios, n_total):
+        import torch
+        best, alpha = np.float32(1e10), np.float32(xmax.numpy()[0])
+        for c in range(sse.shape[0]):
+            score = np.float32(float(sse[c, 0]) / float(n_total))
+            if score < best:
+                best, alpha = score, np.float32(xmax.numpy()[0] * ratios.numpy()[c])
+        return torch.from_numpy(np.float32([best])), torch.from_numpy(np.float32([alpha]))
+
+
+def _calib_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ant_quantization_amd import sharding
+    from oracle import antq_oracle as orc
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    rng = np.random.default_rng(77)
+    cases = []
+    # OliVe activation quantiser (per tensor, unsigned -> here signed data, ant-int-flint, 3-sigma rule, pairs) and an ANT one
+    # (abs-max, ant-int-pot-flint); rows deliberately not divisible by the world size
+    for rows, K, olive in ((37, 64, True), (37, 64, False), (5, 1536, True), (64, 33 * 2, False)):
+        x = (rng.standard_normal((rows, K)) * 0.7).astype(np.float32)
+        if olive:
+            x[rng.random((rows, K)) < 0.01] *= 30.0
+        cases.append((x, olive))
+    for x, olive in cases:
+        rows, K = x.shape
+        if olive:
+            types = {"int": np.concatenate([orc.olive_int_value(4, True), orc.olive_outlier_value(4, True)]),
+                     "flint": np.concatenate([orc.olive_flint_value(4, True), orc.olive_outlier_value(4, True)])}
+            gmaxs = [float(orc.olive_int_value(4, True).max()), float(orc.olive_flint_value(4, True).max())]
+            lb, ub, step, stat = 75, 250, 2, "3sigma"
+        else:
+            types = {"int": orc.ant_grid("int", 4, True), "pot": orc.ant_grid("pot", 4, True), "flint": orc.ant_grid("flint", 4, True)}
+            gmaxs = [float(np.max(g)) for g in types.values()]
+            lb, ub, step, stat = 80, 150, 1, "absmax"
+        names = list(types)
+        ops = OracleBlockOps(orc, types)
+        b, e = sharding.row_block(rows, rank, world, pair_safe_row_len=K)
+        xb = torch.from_numpy(np.ascontiguousarray(x[b:e]))
+        res = sharding.sharded_calibrate(xb, x.size, names, gmaxs, lb, ub, step, statistic=stat, ovp=olive, ops=ops)
+        # the unsharded calibration of the same tensor, straight from the oracle
+        xm = orc.three_sigma(x, per_row=False) if olive else orc.absmax(x, per_row=False)
+        full = [orc.search_mse(x, xm, lb, ub, step, types[n], gm, ovp=olive, per_row=False) for n, gm in zip(names, gmaxs)]
+        scores = np.float32([f[0][0] for f in full])
+        out.append(dict(rank=rank, xmax=float(res["xmax"][0]), xmax_ref=float(xm[0]), alpha=res["alpha"].numpy().tolist(),
+                        alpha_ref=[float(f[1][0]) for f in full], type=res["type"], type_ref=int(np.argsort(scores, kind="stable")[0]),
+                        score=res["score"].numpy().tolist(), score_ref=scores.tolist(),
+                        traces=[f[2][:, 0].tolist() for f in full], lb=lb, step=step))
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_sharded_per_tensor_calibration_world2():
+    """A row-sharded PER-TENSOR quantiser (SURVEY 8e's only collectives: all_reduce(MAX) of the abs-max, all_reduce(SUM) of
+    (sum x, sum x^2) and of the T x R squared-error sums) over gloo at world 2: both ranks end with the same x_max, the
+    same clip alpha per type and the same type as the unsharded calibration of the whole tensor by the oracle (a differing
+    alpha must be a tie by the oracle's own scores)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_calib_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res[0]) == len(res[1]) == 4
+    for a, b in zip(*res):
+        for k in ("xmax", "alpha", "type", "score"):
+            assert a[k] == b[k], (k, a[k], b[k])                         # every rank holds identical numbers
+        assert a["xmax"] == pytest.approx(a["xmax_ref"], rel=2e-6)       # (sum order of the statistic; exact for the abs-max)
+        for t, (al, ar) in enumerate(zip(a["alpha"], a["alpha_ref"])):
+            if al != pytest.approx(ar, rel=2e-6):
+                tr = np.float32(a["traces"][t])                          # a different candidate: only as a tie of the oracle's scores
+                ci = int(round((al / a["xmax"] * 100 - a["lb"]) / a["step"]))
+                assert abs(float(tr[ci]) - float(tr.min())) <= 1e-6 * float(tr.min()), (t, al, ar)
+        assert a["type"] == a["type_ref"] or abs(a["score_ref"][a["type"]] - min(a["score_ref"])) <= 1e-6 * min(a["score_ref"])
+        np.testing.assert_allclose(a["score"], a["score_ref"], rtol=1e-5)
