@@ -150,7 +150,22 @@ def report(h, args, elems_per_step_per_gpu, elapsed, extra):
 # ------------------------------------------------------------------------------------------------
 # CPU baselines (rank 0, N = 1 only; a bounded sample of the same workload)
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline(seconds_budget=12.0):
+def _physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo (None when it cannot be read)."""
+    try:
+        seen, phys = set(), None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    seen.add((phys, line.split(":", 1)[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(seconds_budget=12.0, threads=None):
     """Oracle (port of the reference op sequence, oracle/antq_oracle.c) with OpenMP on every host core: 64 rows of 4096
     bf16 elements per hardware thread, swept `reps` times inside ONE parallel region (thread start-up is paid once,
     outside the sweeps that matter); about `seconds_budget` CPU-seconds per core.  Plus the same on one thread."""
@@ -158,7 +173,7 @@ def cpu_baseline(seconds_budget=12.0):
     from oracle import antq_oracle as orc
     from ant_quantization_amd import grids
     orc.build()
-    cores = os.cpu_count() or 1
+    cores = threads or os.cpu_count() or 1
     rng = np.random.default_rng(6)
     rows = 64 * cores
     x = orc.f32_to_bf16((rng.standard_normal((rows, COLS)) * 0.02).astype(np.float32))
@@ -227,6 +242,52 @@ def cpu_baseline_torch(seconds_budget=6.0):
 
 
 # ------------------------------------------------------------------------------------------------
+# HBM traffic of the dominant kernel, measured (rank 0, N = 1): two rocprofv3 --pmc child runs of this very file
+# ------------------------------------------------------------------------------------------------
+def measure_traffic(nbuf, kernel_substr="k_fq_hbatch", timeout_s=240):
+    """FETCH_SIZE and WRITE_SIZE of the batched kernel, one counter per pass as MI355X_MICROARCH.md's HBM section
+    prescribes (`rocprofv3 --pmc <C> --kernel-trace`, nothing else), each pass a child `bench.py --traffic-child` that
+    builds the same workload and issues 3 launches.  Units and the gfx950 correction as in that guide: both counters are
+    KiB; FETCH_SIZE tallies the 128-byte requests of 16 B / lane streaming reads at 64 B and is doubled.
+    Returns (bytes per launch, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "bench.py is itself running under rocprofv3: no nested counter passes"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="antq_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--traffic-child", "--nbuf", str(nbuf)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            got = []
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, "rocprofv3 --pmc %s gave no row for %s (rc %d)" % (counter, kernel_substr, r.returncode)
+            vals[counter] = sum(got) / len(got)
+        except Exception as ex:           # noqa: BLE001  (a missing profiler must not cost the bench its line)
+            return None, "rocprofv3 --pmc %s failed: %r" % (counter, ex)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0))
+    return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child passes of `bench.py "
+                   "--traffic-child`, 3 launches each; FETCH_SIZE %.1f KiB x 2 per the guide's gfx950 correction + WRITE_SIZE "
+                   "%.1f KiB)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+
+
+# ------------------------------------------------------------------------------------------------
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves -- one fresh process per GPU, the same
     command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, exactly what
@@ -272,6 +333,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nbuf", type=int, default=32, help="distinct 4096x4096 bf16 tensors per GPU (one step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic falls back "
+                                                               "to the committed profiles/hbm_traffic.json value)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))             # no launcher around us: one process per GPU, started here
@@ -303,6 +367,12 @@ def main():
 
     def step():
         batch.run()
+
+    if args.traffic_child:              # a counter pass of measure_traffic(): the batched launch and nothing else
+        for _ in range(3):
+            step()
+        h.sync()
+        return
 
     def step_per_tensor():          # the reference's granularity: one launch per tensor (reported beside it)
         for i in range(args.nbuf):
@@ -354,14 +424,16 @@ def main():
     ceiling = max(algo_bytes / copy_s, algo_bytes / d2d_s) / 1e9
 
     traffic, traffic_note = None, None
+    if h.world == 1 and not args.no_traffic:
+        traffic, traffic_note = measure_traffic(args.nbuf)       # (the children build their own copy of the workload)
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # rocprofv3 --pmc result, see profiles/README.md
-    if os.path.exists(tpath):
+    if traffic is None and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             per_tensor = tj.get("headline_bytes_per_tensor", tj.get("k_fq_batch_bf16_bytes_per_tensor"))
             traffic = int(per_tensor * args.nbuf) if per_tensor else None
             traffic_note = ("from profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                            "command (FETCH_SIZE x2 per the guide's gfx950 correction), NOT measured in this run")
+                            "command (FETCH_SIZE x2 per the guide's gfx950 correction), NOT measured in this run (%s)" % traffic_note)
         except Exception:
             traffic = None
 
@@ -377,17 +449,17 @@ def main():
                                                    "each launch marked ANTQ_FLAG_UNORDERED (inputs at rest: its dispatch "
                                                    "packet carries no barrier bit, so it may start while its predecessor "
                                                    "drains); `ordered` = the same launches without the flag" % args.nbuf,
-                                           "kernel": "antq::k_fq_xrow<bf16,...,U=4,WPB=1> (per-row table, one wavefront per workgroup)",
+                                           "kernel": "antq::k_fq_hrow<bf16,false,4> (16-bit-domain row table, one wavefront per workgroup)",
                                            "launch_us": round(ptu_launch_s * 1e6, 2),
                                            "gelem_per_s": round(ROWS * COLS / ptu_launch_s / 1e9, 1),
                                            "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9, 1),
                                            "frac": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9 / HBM_PEAK_GBPS, 4),
-                                           "ordered": {"kernel": "antq::k_fq_lane<bf16,...,U=2,AD>",
+                                           "ordered": {"kernel": "antq::k_fq_hrow<bf16,false,4>",
                                                        "launch_us": round(pt_launch_s * 1e6, 2),
                                                        "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": "antq::k_fq_batch<bf16,false,1>", "launch_us": round(launch_s * 1e6, 2),
+                     "kernel": "antq::k_fq_hbatch<bf16,false>", "launch_us": round(launch_s * 1e6, 2),
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "copy_ceiling": {"antq_copy_GBps": round(algo_bytes / copy_s / 1e9, 1),
                                       "hipMemcpyDtoD_GBps": round(algo_bytes / d2d_s / 1e9, 1),
@@ -397,6 +469,9 @@ def main():
     })
     if h.world == 1 and not args.no_cpu_baseline:      # reported baselines, N=1 only
         res["cpu_baseline"] = cpu_baseline()
+        phys = _physical_cores()
+        if phys and phys < (os.cpu_count() or 1):      # SMT box: the same port with one thread per physical core beside it
+            res["cpu_baseline_physical_cores"] = cpu_baseline(seconds_budget=6.0, threads=phys)
         res["cpu_baseline_torch"] = cpu_baseline_torch()
     print(json.dumps(res), flush=True)
     h.finish()
