@@ -57,7 +57,7 @@ def lib():
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
                              "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
                              "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma",
-                             "antq_calibrate"):
+                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 L.antq_search_workspace_bytes.restype = ctypes.c_size_t
@@ -71,6 +71,57 @@ def lib():
                 L.antq_copy.argtypes = [vp, vp, sz, vp]
                 _lib = L
     return _lib
+
+
+_prefetched = set()
+
+
+def prefetch_kernels(device=None):
+    """Load the library's GPU code objects for `device` (default: the current one) now instead of inside the first
+    calibrating forward (antq_prefetch_kernels; ~50 ms, once per process and device).  A no-op without a GPU."""
+    if not torch.cuda.is_available():
+        return
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx in _prefetched:
+        return
+    with torch.cuda.device(idx):
+        lib().antq_prefetch_kernels()
+    _prefetched.add(idx)
+
+
+_prewarmed = set()
+
+
+def prewarm(device, dtype=torch.float32):
+    """Run the calibration and steady-state entry points once on a toy tensor (256 x 1024 of `dtype`, per row and per
+    tensor, with and without the pair rule): HIP resolves every kernel at its FIRST launch (1-3 ms each, ~50 ms for the
+    dozen a calibrating forward uses) and torch does the same for the few elementwise kernels around them -- paid here, at
+    enable_quantization time, instead of inside the first forward.  Once per (device, dtype); a no-op without a GPU."""
+    if not torch.cuda.is_available() or dtype not in _DTYPES or _DTYPES[dtype] == F64:
+        return
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), dtype)
+    if key in _prewarmed:
+        return
+    _prewarmed.add(key)
+    from . import grids
+    prefetch_kernels(device)
+    with torch.no_grad():
+        x = (torch.randn(256, 1024, device=device) * 0.1).to(dtype)
+        plans_a = [plan_for(grids.ant_grid(t, 4, True)) for t in ("int", "flint")]
+        on = grids.olive_grid("flint", 4, True)
+        plan_o = plan_for(np.concatenate([on, grids.olive_outliers(4, True)]))
+        for per_row in (True, False):
+            a, _, _, xm = calibrate(x, 256, 1024, per_row, plans_a, [10.0, 10.0], 95, 100, 1, xmax="absmax")
+            calibrate(x, 256, 1024, per_row, plans_a[:1], [10.0], 95, 100, 1, xmax="absmax")
+            calibrate(x, 256, 1024, per_row, [plan_o], [float(on.max())], 95, 100, 2, xmax="3sigma", ovp=True)
+            fakequant(x, a[0].contiguous(), plans_a[0], 10.0, 256, 1024, per_row)
+            fakequant(x, a[0].contiguous(), plan_o, float(on.max()), 256, 1024, per_row, ovp=True)
+            al = absmax(x, 256, 1024, per_row)
+            (al / xm).mean()
+        (x.min() < 0).item()
 
 
 _ext_mod = False          # False: not tried yet; None: unavailable

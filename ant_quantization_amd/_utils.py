@@ -56,6 +56,11 @@ def make_walkers(Q):
     """The three model walkers of quant_utils.py:62-78 for quantiser class Q."""
     def walker(method, with_name):
         def walk(model):
+            if method == "enable_quantization":        # (the calibrating forward usually follows: first-launch costs paid now, _lib.prewarm)
+                from . import _lib
+                p0 = next(model.parameters(), None)
+                if p0 is not None and p0.is_cuda:
+                    _lib.prewarm(p0.device, p0.dtype)
             for name, module in model.named_modules():
                 if isinstance(module, Q):
                     getattr(module, method)(*((name,) if with_name else ()))

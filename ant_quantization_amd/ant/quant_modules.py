@@ -359,6 +359,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
             self._hm_known('has_inited_quant_para', 1.0)
             self._steady = True
             self._type_search = None
+            core.forget_absmax()
 
     # ---------------------------------------------------------------- steady state
     # (_rest_buffer / _rest_alpha / _at_rest: _mirror.WeightsAtRestMixin)

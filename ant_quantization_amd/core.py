@@ -185,7 +185,28 @@ def device_grid(values, device):
     return t.clone()
 
 
+_absmax_memo = [None]          # (tensor, version, per_channel, result) of the last call: one calibration asks twice
+
+
+def forget_absmax():
+    """End of a calibration: drop the memo (a later `.data` edit of the same tensor object would not move its version)."""
+    _absmax_memo[0] = None
+
+
 def row_absmax(x, per_channel):
+    """max |x| per row / per tensor as float32 (AQ:473-477, :289 / :308).  The first-call calibration asks for it twice on
+    the same tensor (the initial alpha, then search_mse's x_max): the second call is answered from a one-entry memo keyed by
+    the tensor object and its version counter (a weak reference: nothing is kept alive)."""
+    import weakref
+    m = _absmax_memo[0]
+    ver = None if torch.is_inference(x) else x._version
+    if m is not None and m[0]() is x and m[1] == ver and ver is not None and m[2] == bool(per_channel):
+        return m[3]
     xc = _calib_view(x).detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)
-    return _lib.absmax(xc, rows, row_len, per_row=per_channel)
+    out = _lib.absmax(xc, rows, row_len, per_row=per_channel)
+    try:
+        _absmax_memo[0] = (weakref.ref(x), ver, bool(per_channel), out)
+    except TypeError:
+        _absmax_memo[0] = None
+    return out

@@ -318,3 +318,11 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
 #undef ANTQ_LAUNCH_D
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
+
+namespace antq {
+int prefetch_unit_batch()        // antq_prefetch_kernels (antq_kernels.hip): load this unit's code object now
+{
+    hipFuncAttributes at;
+    return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_fq_hbatch<bf16_tag, false>)) == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+}  // namespace antq

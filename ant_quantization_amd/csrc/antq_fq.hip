@@ -411,3 +411,11 @@ extern "C" int antq_fakequant_dynamic(const void *x, void *out, int16_t *idx, fl
     default: return ANTQ_ERR_UNSUPPORTED;
     }
 }
+
+namespace antq {
+int prefetch_unit_fq()        // antq_prefetch_kernels (antq_kernels.hip): load this unit's code object now
+{
+    hipFuncAttributes at;
+    return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_fq_hrow<bf16_tag, false, 4, 1>)) == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+}  // namespace antq

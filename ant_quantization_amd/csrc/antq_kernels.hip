@@ -201,6 +201,25 @@ extern "C" int antq_copy(const void *src, void *dst, size_t bytes, void *stream)
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+// HIP loads a translation unit's code object when one of its kernels is first launched (or asked about): ~50 ms for the
+// four units of this library, which would otherwise land inside the first calibrating forward.  hipFuncGetAttributes on
+// one kernel per unit does the loading now, on the calling thread's current device; nothing is launched.
+namespace antq {
+int prefetch_unit_fq();        // antq_fq.hip
+int prefetch_unit_batch();     // antq_batch.hip
+int prefetch_unit_search();    // antq_search.hip
+}
+extern "C" int antq_prefetch_kernels(void)
+{
+    hipFuncAttributes at;
+    int rc = hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_copy)) == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+    if (antq::prefetch_unit_fq() != ANTQ_OK) rc = ANTQ_ERR_LAUNCH;
+    if (antq::prefetch_unit_batch() != ANTQ_OK) rc = ANTQ_ERR_LAUNCH;
+    if (antq::prefetch_unit_search() != ANTQ_OK) rc = ANTQ_ERR_LAUNCH;
+    (void)hipGetLastError();
+    return rc;
+}
+
 extern "C" int antq_debug_set(int key, int value)
 {
     if (key == 0) g_knob_u = value;

@@ -300,3 +300,11 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
     hipLaunchKernelGGL(k_calib_type_pick, dim3(1), dim3(1), 0, st, score, ntypes, type);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
+
+namespace antq {
+int prefetch_unit_search()        // antq_prefetch_kernels (antq_kernels.hip): load this unit's code object now
+{
+    hipFuncAttributes at;
+    return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_search_pick)) == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+}  // namespace antq

@@ -15,6 +15,8 @@ reproduces its arithmetic exactly:
 The host keeps the grid (numpy float32): it is needed to build the kernel's decision-table
 plan without any device->host copy.
 """
+import functools
+
 import numpy as np
 
 _F32 = np.float32
@@ -133,6 +135,18 @@ def ant_apot(bit, signed):
     return _ant_normalise(v, bit)
 
 
+def _frozen(fn):
+    """The generators below are pure functions of tiny arguments and a calibration asks for the same codebook once per
+    quantiser (146 times in BERT-base): memoised, the array handed out read-only so that no caller can edit the cache."""
+    @functools.lru_cache(maxsize=None)
+    def cached(*a):
+        v = np.ascontiguousarray(fn(*a))
+        v.setflags(write=False)
+        return v
+    return functools.wraps(fn)(lambda *a: cached(*a))
+
+
+@_frozen
 def ant_grid(mode, bit, signed):
     """Grid the reference installs for a resolved mode string (AQ:488-511)."""
     if mode == "int":
@@ -168,6 +182,7 @@ def olive_flint(bit, signed):
     return (v * _F32(32 / (2 ** exp_max))).astype(_F32)
 
 
+@_frozen
 def olive_outliers(bit, signed, exp_bit=2, exp_base=5):
     """abfloat outlier codebook 2^i (1 + j 2^-m), i = 5..8, without 32 itself (OQ:155-179)."""
     B = _value_bits(bit, signed)
@@ -184,6 +199,7 @@ def olive_outliers(bit, signed, exp_bit=2, exp_base=5):
     return np.sort(np.asarray(mags)).astype(_F32)
 
 
+@_frozen
 def olive_grid(mode, bit, signed):
     if mode == "int":
         return olive_int(bit, signed)

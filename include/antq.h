@@ -369,6 +369,10 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
  *   key 10: dynamic LDS bytes per workgroup of those kernels (occupancy A/B; -1 = default: 24 workgroups per CU) */
 int antq_debug_set(int key, int value);
 
+/* Load the library's GPU code objects for the current device now (HIP would load each of them at the first launch of one
+ * of its kernels, ~50 ms in total, i.e. inside the first calibrating forward).  Launches nothing; idempotent. */
+int antq_prefetch_kernels(void);
+
 #ifdef __cplusplus
 }
 #endif
