@@ -42,7 +42,7 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     double batch_bytes = 0.0;
     for (int i = 0; i < n; i++) batch_bytes += 2.0 * (double)jobs[i].rows * (double)jobs[i].row_len * (dtype == ANTQ_F32 ? 4.0 : 2.0);
     const bool big_footprint = batch_bytes >= 8.0 * 1073741824.0;
-    size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0, 0, 0}, lds = 0;
+    size_t fam_blocks[kBatchFamilies] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, lds = 0;
     bool any_da = false;
     for (int i = 0; i < n; i++) {
         const antq_job &J = jobs[i];
@@ -76,11 +76,13 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                 blocks = (size_t)((d.n_vec + 256u * kBatchU - 1u) / (256u * kBatchU));
             }
             HArgs hx;
-            if (d.kind == 0 && g_knob_h != 0 && hargs_from_plan(J.plan_host, dtype, J.gmax, hx)) {
+            const uint32_t hu = (d.kind == 0 && g_knob_h != 0 && hargs_from_plan(J.plan_host, dtype, J.gmax, hx))
+                                    ? (g_knob_h == 2 ? row_task_u(d.vpr) : hrow_static_u(d.vpr, xdom)) : 0u;      // (knob 9 = 2: every row, A/B)
+            if (hu != 0u) {
                 // 16-bit rows in their own domain (antq_k_hrow.h): 4 KiB of the row per wavefront unless 3 or 2 leave fewer
                 // idle lanes; 24 workgroups per CU (kHRowLdsPad)
                 d.kind = 13;
-                d.u = row_task_u(d.vpr);
+                d.u = hu;
                 if (g_knob_u >= 2 && g_knob_u <= 4) d.u = (uint32_t)g_knob_u;     // knob 0 (A/B): vectors per lane and task
                 d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
                 const size_t total = (J.alpha_per_row ? J.rows : (size_t)1) * (size_t)d.tpr;   // per tensor: ONE row
@@ -113,13 +115,30 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
             // alpha computed in the kernel: the group / row has to live in the registers of a few lanes, one wavefront
             // or one workgroup
             if (!J.alpha_per_row || d.kind == 3 || J.rows > 0x3ffffff0ull) return ANTQ_ERR_UNSUPPORTED;
-            if (d.kind == 0 && d.pa.adom && dtype != ANTQ_F32 && d.vpr == 128u && g_knob_u != 1) {
+            HArgs hprobe;
+            const bool h_dyn = d.kind == 0 && g_knob_h != 0 && d.vpr <= 8192u && hargs_from_plan(J.plan_host, dtype, J.gmax, hprobe);
+            if (!h_dyn && d.kind == 0 && d.pa.adom && dtype != ANTQ_F32 && d.vpr == 128u && g_knob_u != 1) {
                 // 16-bit rows of 128 vectors as lane jobs whose groups span 2 wavefronts of a workgroup (LDS exchange of
                 // the wavefront maxima): 4 vectors in flight per lane instead of a wavefront per row: 71 -> 75 %; at 256
                 // vectors the wavefront-per-row kernel stays ahead (79 vs 75 %)
                 d.kind = 1; d.total_tasks = 0; d.tpr = 1; d.vshift = 7;
                 blocks = (size_t)((d.n_vec + 256u * kBatchU - 1u) / (256u * kBatchU));
             }
+            const HArgs &hx = hprobe;
+            if (h_dyn) {
+                // 16-bit rows of 128 .. 8192 vectors in their own domain: the row in one wavefront (<= 512 vectors), one
+                // workgroup of 4 (<= 2048) or of 16 wavefronts
+                const HDynShape sh = hrow_dyn_shape(d.vpr);
+                d.kind = sh.wpr == 1 ? 14 : (sh.wpr == 4 ? 15 : 16);
+                d.u = (uint32_t)sh.vpt;
+                d.tpr = (uint32_t)sh.wpr;
+                d.total_tasks = (uint32_t)(J.rows * (size_t)sh.wpr);
+                blocks = sh.wpr == 1 ? (J.rows + 3) / 4 : J.rows;
+                d.tlist = plan_tlist_dev(J.plan_host, J.plan_dev);
+                d.h_n = hx.n_thr | (hx.n_neg << 16);
+                d.hshift = hx.hshift;
+                f = sh.wpr == 1 ? 6 : (sh.wpr == 4 ? 7 : 8);
+            } else
             if (d.kind == 1) {
                 if (d.vshift < 0 || d.vpr > 256u) return ANTQ_ERR_UNSUPPORTED;  // butterfly over a power-of-two group
                 f = d.pa.adom ? 1 : 2;       // (per-group tables with the abs-max in front measured slower: 66 vs 71 %)
@@ -182,16 +201,21 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
     }
     if (!dyn) {
         // jobs of more than one static family: ONE launch of the all-in-one kernel instead of a launch per family
-        bool seen[kBatchFamilies] = {false, false, false, false, false, false};
-        int nf = 0;
+        // The 16-bit-domain rows (family 5) keep a launch of their own next to the others when they are a launch's worth of
+        // work (>= 128 MiB moved: ~20 us at full speed, so that its ramp and tail are small change); a smaller share rides
+        // in the all-in-one kernel as fp32-domain rows like round 3.
+        double h_bytes = 0.0;
         for (int i = 0; i < n; i++)
-            if (!seen[fam[(size_t)i]]) { seen[fam[(size_t)i]] = true; nf++; }
-        if (nf > 1) {
-            // (the all-in-one kernel knows the fp32-domain row table, not the 16-bit one: such jobs go back to kind 2 --
-            //  every plan with hdom that came here as kind 0 has xdom or stays kind 0)
+            if (fam[(size_t)i] == 5) h_bytes += 2.0 * (double)jobs[i].rows * (double)jobs[i].row_len * (dtype == ANTQ_F32 ? 4.0 : 2.0);
+        const bool h_apart = h_bytes >= 128.0 * 1048576.0;
+        if (!h_apart) {
+            // (every plan with hdom that came here as kind 0 has xdom or keeps the d-domain row kernel)
             for (int i = 0; i < n; i++) {
                 BatchDesc &d = descs[i];
                 if (d.kind != 13) continue;
+                bool other = false;
+                for (int k = 0; k < n && !other; k++) other = fam[(size_t)k] != 5;
+                if (!other) break;                                  // the whole (small) batch is family 5: its own launch
                 const PlanHeader *ph = static_cast<const PlanHeader *>(jobs[i].plan_host);
                 if (g_knob_x && d.pa.kind == kPlanLut && ph->xdom) {
                     d.kind = 2;
@@ -199,16 +223,26 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
                     d.tpr = (d.vpr + 64u * d.u - 1u) / (64u * d.u);
                     d.total_tasks = (uint32_t)((jobs[i].alpha_per_row ? jobs[i].rows : (size_t)1) * (size_t)d.tpr);
                     d.rot = (d.vpr % (64u * d.u) != 0u && (d.tpr % 2u) == 0u) ? 1u : 0u;
+                    fam[(size_t)i] = 0;
                 } else {
                     const size_t tpr = (d.vpr + 64 * kBatchU - 1) / (64 * kBatchU);
                     d.kind = 0; d.u = (uint32_t)kBatchU; d.tpr = (uint32_t)tpr; d.rot = 0;
                     d.total_tasks = (uint32_t)((jobs[i].alpha_per_row ? jobs[i].rows : (size_t)1) * tpr);
                     lds = std::max(lds, lds_table(d.pa, false));
+                    fam[(size_t)i] = (uint8_t)(d.pa.adom ? 1 : 2);
                 }
                 nblk[(size_t)i] = ((size_t)d.total_tasks + 3) / 4;
             }
+        }
+        bool seen[kBatchFamilies] = {false, false, false, false, false, false, false, false, false};
+        int nf_rest = 0;
+        for (int i = 0; i < n; i++)
+            if (fam[(size_t)i] != 5 && !seen[fam[(size_t)i]]) { seen[fam[(size_t)i]] = true; nf_rest++; }
+        if (nf_rest > 1) {
+            // several families besides (a big) family 5: they share the all-in-one launch
             h.pad = 1u;
-            for (int i = 0; i < n; i++) fam[(size_t)i] = 0;
+            for (int i = 0; i < n; i++)
+                if (fam[(size_t)i] != 5) fam[(size_t)i] = 0;
         }
     }
     {
@@ -219,6 +253,12 @@ extern "C" int antq_batch_build(const antq_job *jobs, int n, int dtype, unsigned
         for (int i = 0; i < n; i++)
             if (descs[i].kind == 2) (descs[i].vpr >= 256u ? long_b : short_b) += (double)descs[i].total_tasks * descs[i].u;
         h.pad |= ((long_b >= short_b && !big_footprint) ? 1u : 4u) << 8;          // (big footprints: see batch_bytes above)
+    }
+    {
+        uint32_t umax = 0;
+        for (int i = 0; i < n; i++)
+            if (descs[i].kind == 14) umax = std::max(umax, descs[i].u);
+        h.pad2[0] = hrow_dyn_lds_pad(HDynShape{1, (int)umax});
     }
     size_t total_blocks = 0;
     for (int i = 0; i < n; i++) {
@@ -253,6 +293,30 @@ static void launch_hbatch(uint32_t map_entries, const BatchDesc *descs, const ui
 template <>
 void launch_hbatch<float>(uint32_t, const BatchDesc *, const uint32_t *, bool, hipStream_t) {}
 
+// families 6 / 7 / 8 (16-bit dtypes only).  The occupancy cap of family 6 follows the widest job of the batch.
+template <typename T>
+static void launch_hbatch_dyn(const BatchHeader *h, const BatchDesc *descs, const uint32_t *const *fmap, bool ovp, hipStream_t st)
+{
+    if (h->fam_blocks[6]) {
+        const dim3 g(h->fam_blocks[6] * 4u), b(64u);
+        const unsigned pad = g_knob_hlds >= 0 ? (unsigned)g_knob_hlds : h->pad2[0];
+        if (ovp) hipLaunchKernelGGL((k_fq_hbatch_dyn<T, true, 1>), g, b, pad, st, descs, fmap[6]);
+        else hipLaunchKernelGGL((k_fq_hbatch_dyn<T, false, 1>), g, b, pad, st, descs, fmap[6]);
+    }
+    if (h->fam_blocks[7]) {
+        const dim3 g(h->fam_blocks[7]), b(256u);
+        if (ovp) hipLaunchKernelGGL((k_fq_hbatch_dyn<T, true, 4>), g, b, 0, st, descs, fmap[7]);
+        else hipLaunchKernelGGL((k_fq_hbatch_dyn<T, false, 4>), g, b, 0, st, descs, fmap[7]);
+    }
+    if (h->fam_blocks[8]) {
+        const dim3 g(h->fam_blocks[8]), b(1024u);
+        if (ovp) hipLaunchKernelGGL((k_fq_hbatch_dyn<T, true, 16>), g, b, 0, st, descs, fmap[8]);
+        else hipLaunchKernelGGL((k_fq_hbatch_dyn<T, false, 16>), g, b, 0, st, descs, fmap[8]);
+    }
+}
+template <>
+void launch_hbatch_dyn<float>(const BatchHeader *, const BatchDesc *, const uint32_t *const *, bool, hipStream_t) {}
+
 extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_dev, void *stream)
 {
     if (!batch_host || !batch_dev) return ANTQ_ERR_ARG;
@@ -282,6 +346,7 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
         if (h->pad & 1u) {      /* mixed static batch: the all-in-one kernel */                                       \
             if (ovp) hipLaunchKernelGGL((k_fq_batch_all<TT, true>), dim3(h->fam_blocks[0]), block, h->lds_bytes, st, descs, fmap[0]);  \
             else hipLaunchKernelGGL((k_fq_batch_all<TT, false>), dim3(h->fam_blocks[0]), block, h->lds_bytes, st, descs, fmap[0]);     \
+            if (h->fam_blocks[5]) launch_hbatch<TT>(h->fam_blocks[5], descs, fmap[5], ovp, st);   /* (a big 16-bit-domain share keeps its own launch) */ \
             break;                                                                                                \
         }                                                                                                         \
         if (h->fam_blocks[0]) {                                                                                   \
@@ -297,6 +362,7 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
                    else hipLaunchKernelGGL((k_fq_batch<TT, false, 4>), g_, b_, 0, st, descs, fmap[0], rot_); }                 \
         }                                                                                                         \
         if (h->fam_blocks[5]) launch_hbatch<TT>(h->fam_blocks[5], descs, fmap[5], ovp, st);                       \
+        if (h->fam_blocks[6] || h->fam_blocks[7] || h->fam_blocks[8]) launch_hbatch_dyn<TT>(h, descs, fmap, ovp, st);      \
         if (h->fam_blocks[1]) { if (ovp) ANTQ_LAUNCH_D(TT, true, true); else ANTQ_LAUNCH_D(TT, false, true); }    \
         if (h->fam_blocks[2]) { if (ovp) ANTQ_LAUNCH_D(TT, true, false); else ANTQ_LAUNCH_D(TT, false, false); }  \
         if (h->fam_blocks[3]) {                                                                                   \

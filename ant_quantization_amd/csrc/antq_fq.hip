@@ -180,7 +180,9 @@ static int launch_hrow(const void *x, void *out, size_t rows, size_t vpr, const 
         HArgs ha;
         if (g_knob_h == 0 || vpr < kRowKernelMinVpr || vpr > 0xffffffffull || !hargs_from_plan(plan_host, IO<T>::DTYPE, gmax, ha))
             return ANTQ_ERR_UNSUPPORTED;
-        int U = (int)row_task_u((uint32_t)vpr);
+        const PlanHeader *php = static_cast<const PlanHeader *>(plan_host);
+        int U = g_knob_h == 2 ? (int)row_task_u((uint32_t)vpr) : (int)hrow_static_u((uint32_t)vpr, g_knob_x != 0 && php->xdom != 0u);
+        if (U == 0) return ANTQ_ERR_UNSUPPORTED;          // (short / awkward rows: the fp32-domain row table, see hrow_static_u)
         if (g_knob_u >= 2 && g_knob_u <= 4) U = g_knob_u;
         const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
         const size_t total = rows * tpr;
@@ -330,6 +332,23 @@ static int launch_dynamic(const void *x, void *out, int16_t *idx, float *alpha_o
                                    static_cast<const uint4 *>(x), static_cast<uint4 *>(out), idx, n_vec, (uint32_t)vpr,
                                    vshift, (const float *)nullptr, 1, gmax, ratio, alpha_out, pa, tab);
             return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+        }
+        if constexpr (!IDX && !std::is_same<T, float>::value) {
+            // 16-bit rows of 128 .. 8192 vectors in their own domain (antq_k_hrow.h): the row in 1 / 4 / 16 wavefronts
+            HArgs ha;
+            if (g_knob_h != 0 && vpr >= kRowKernelMinVpr && vpr <= 8192 && rows <= 0x7fffffffull &&
+                hargs_from_plan(plan_host, IO<T>::DTYPE, gmax, ha)) {
+                const HDynShape sh = hrow_dyn_shape((uint32_t)vpr);
+                const unsigned pad = g_knob_hlds >= 0 ? (unsigned)g_knob_hlds : (rows >= 4 * 8192 ? hrow_dyn_lds_pad(sh) : 0u);
+                const uint4 *tl = plan_tlist_dev(plan_host, plan_dev);
+                const float *grid = reinterpret_cast<const float *>(tab);
+                const dim3 g((unsigned)rows), b(64u * sh.wpr);
+#define ANTQ_HD(WW) hipLaunchKernelGGL((k_fq_hrow_dyn<T, OVP, WW>), g, b, (WW) == 1 ? pad : 0u, st, static_cast<const uint4 *>(x), \
+                                       static_cast<uint4 *>(out), (uint32_t)rows, (uint32_t)vpr, (uint32_t)sh.vpt, ratio, alpha_out, gmax, ha, tl, grid)
+                if (sh.wpr == 1) ANTQ_HD(1); else if (sh.wpr == 4) ANTQ_HD(4); else ANTQ_HD(16);
+#undef ANTQ_HD
+                return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+            }
         }
         if (vpr <= 8192) {
             // one quant group (row) per wavefront (<= 512 vectors) or per workgroup (<= 2048: 4 wavefronts, <= 8192:

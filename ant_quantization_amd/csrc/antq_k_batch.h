@@ -29,6 +29,7 @@ struct BatchDesc {   // 192 bytes, device-visible
                            //         one wavefront, 4 / 8 vectors per lane (<= 256 / <= 512 vectors: kinds 4 / 6), or spread
                            //         over the 4 wavefronts of the workgroup (<= 1024 / <= 2048: kinds 5 / 7; <= 512 with 2 vectors per lane: kind 12)
                            // 13 = 16-bit rows through the table in their own 16-bit domain (antq_k_hrow.h): tasks of u vectors per lane
+                           // 14 / 15 / 16 = the same with the alpha computed in the kernel: the row in 1 / 4 / 16 wavefronts, u vectors per lane
     int32_t per_row;
     float gmax;
     PlanArgs pa;
@@ -58,16 +59,19 @@ static_assert(sizeof(BatchDesc) == 192, "BatchDesc must be 192 bytes");
 //   family 3  k_fq_batch_dyn    ANTQ_FLAG_DYNAMIC rows of >= 128 vectors with an x-domain plan: kinds 4..7
 //   family 4  k_fq_batch_dyn16  the same for rows of 2049..8192 vectors, one row per 1024-thread workgroup: kinds 9, 10
 //   family 5  k_fq_hbatch       16-bit rows in their own 16-bit domain (bf16 / f16, 4- / 5-bit codebooks): kind 13
+//   family 6 / 7 / 8  k_fq_hbatch_dyn<.., 1 / 4 / 16>  the same with ANTQ_FLAG_DYNAMIC: a row of 128..512 vectors per
+//             wavefront (one-wavefront workgroups; map entries of 4 rows), of <= 2048 / <= 8192 vectors per workgroup of
+//             4 / 16 wavefronts (one map entry per row): kinds 14 / 15 / 16
 // (with ANTQ_FLAG_DYNAMIC families 1 / 2 run their DYN instantiation: groups of <= 64 vectors, rows of <= 256 vectors)
-constexpr int kBatchFamilies = 6;
+constexpr int kBatchFamilies = 9;
 
-struct BatchHeader {   // 64 bytes
+struct BatchHeader {   // 80 bytes
     uint32_t magic, n, dtype, flags, lds_bytes, map_offset, bytes, total_blocks;
     uint32_t fam_blocks[kBatchFamilies];
     uint32_t pad;          // bit 0: mixed static batch (one launch of the all-in-one kernel); bits 8..: wavefronts per workgroup of family 0
-    uint32_t pad2;
+    uint32_t pad2[2];
 };
-static_assert(sizeof(BatchHeader) == 64, "BatchHeader must be 64 bytes");
+static_assert(sizeof(BatchHeader) == 80, "BatchHeader must be 80 bytes");
 
 __device__ __forceinline__ XArgs xargs_of(const BatchDesc &D)
 {
@@ -156,6 +160,28 @@ k_fq_hbatch(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ bl
 #define ANTQ_HROW(UU) hrow_wave_task<T, OVP, UU>(D.x, D.out, task, D.vpr, D.tpr, D.alpha, D.per_row, D.gmax, ha, D.tlist, grid, tab, threadIdx.x)
     if (D.u == 4u) ANTQ_HROW(4); else if (D.u == 3u) ANTQ_HROW(3); else ANTQ_HROW(2);
 #undef ANTQ_HROW
+}
+
+// Families 6 / 7 / 8: 16-bit rows in their own domain, the scale computed from the row (ANTQ_FLAG_DYNAMIC).
+template <typename T, bool OVP, int WPR>
+__global__ void __launch_bounds__(64 * WPR)
+k_fq_hbatch_dyn(const BatchDesc *__restrict__ descs, const uint32_t *__restrict__ block_map)
+{
+    __shared__ __attribute__((aligned(16))) uint2 tab[WPR][kHSlots * 2];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // WPR = 1: one-wavefront workgroups, a map entry per 4 rows; else one workgroup (= one map entry) per row
+    const uint32_t ent = WPR == 1 ? (blockIdx.x >> 2) : blockIdx.x;
+    const BatchDesc &D = descs[block_map[ent]];
+    const uint32_t rowi = WPR == 1 ? (ent - D.first_block) * 4u + (blockIdx.x & 3u) : ent - D.first_block;
+    if (rowi * (uint32_t)WPR >= D.total_tasks) return;
+    const uint32_t task = __builtin_amdgcn_readfirstlane(rowi * WPR + wv);
+    HArgs ha;
+    ha.n_thr = D.h_n & 0xffffu; ha.n_neg = D.h_n >> 16; ha.hshift = D.hshift; ha.m = D.pa.m;
+    ha.flim = D.pa.fastlim * 0.99999f; ha.lim = fminf(ha.flim, D.pa.xlim);
+    ha.vmin = D.vmin; ha.vmax = D.vmax; ha.vout = D.vout; ha.inv_gmax = D.inv_gmax;
+    const float *grid = reinterpret_cast<const float *>(D.plan_tab);
+    float *alpha_out = const_cast<float *>(D.alpha);
+    hrow_wave_task_dyn<T, OVP, WPR>(D.x, D.out, task, D.vpr, D.u, D.ratio, alpha_out, D.gmax, ha, D.tlist, grid, tab[wv], lane, wv);
 }
 
 // Families 1 / 2: the plan's own (d-domain) table staged per workgroup.

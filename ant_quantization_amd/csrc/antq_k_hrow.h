@@ -257,8 +257,10 @@ __device__ __forceinline__ uint4 hrow_vec_far(const uint4 &v, uint32_t tbase, ui
 template <typename T, bool OVP, int VPT>
 __device__ __forceinline__ void hrow_task(const uint4 (&v)[VPT], uint4 *__restrict__ out, uint32_t v0, uint32_t vpr,
                                           const HRow &R, uint32_t tab_addr, uint32_t hshift, uint32_t othr, float s,
-                                          const HFar &far, const float *__restrict__ grid, uint32_t m)
+                                          const HFar &far, const float *__restrict__ grid, uint32_t m, uint32_t nv = VPT)
 {
+    // nv (wave-uniform, <= VPT): vectors per lane actually in use -- the dynamic kernels are compiled once for VPT = 8 and
+    // walk rows of any length with it (steps beyond nv are skipped by a scalar branch)
     const uint32_t kpos = 16u + hshift;
     uint32_t vkmin = R.kmin, vklim = R.klim, vkwid = 15u - hshift;
     asm volatile("" : "+v"(vkmin), "+v"(vklim), "+v"(vkwid));          // (VGPR copies: gfx9 takes one SGPR per VOP3)
@@ -267,7 +269,7 @@ __device__ __forceinline__ void hrow_task(const uint4 (&v)[VPT], uint4 *__restri
         u16x2_t acc = as_u16x2(0u);
 #pragma unroll
         for (int u = 0; u < VPT; u++) {
-            if (v0 + 64u * u < vpr) {
+            if ((uint32_t)u < nv && v0 + 64u * u < vpr) {
                 const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
                 uint32_t o[4];
 #pragma unroll
@@ -291,13 +293,34 @@ __device__ __forceinline__ void hrow_task(const uint4 (&v)[VPT], uint4 *__restri
     const uint32_t slot0 = R.klim << hshift;          // first pattern of the sentinel slot (a superset of "beyond the limit")
 #pragma unroll
     for (int u = 0; u < VPT; u++) {
-        if (v0 + 64u * u < vpr) {
+        if ((uint32_t)u < nv && v0 + 64u * u < vpr) {
             const uint32_t top = IO<T>::amax_acc(0u, v[u]);
             if (!R.fast) st_stream(out + 64u * u, hrow_exact<T, OVP>(v[u], s, grid, m));
             else if (max(top & 0xffffu, top >> 16) >= slot0)
                 st_stream(out + 64u * u, hrow_vec_far<T, OVP>(v[u], tbase, vkmin, vklim, kpos, vkwid, othr, s, far, grid, m));
         }
     }
+}
+
+// Dynamic LDS on top of the 2 KiB table so that 24 one-wavefront workgroups fit a CU (160 KiB): with 4 KiB of reads per
+// wavefront that is 96 KiB in flight per CU.  More in flight measured SLOWER (32 workgroups: 78.6 % against 81.4 % of
+// 8 TB/s on 32 x 4096^2 bf16), fewer starve the CU whenever the clocks dip (16: 82.8 % steady but 76 % right after an
+// idle period); tools/exp_hrow.hip, profiles/r04_exp_hrow_*.log.
+constexpr unsigned kHRowLdsPad = 6656u - kHSlots * 16u;
+
+// What follows the loads of a wavefront task: the row's scale, its table, the elements.
+template <typename T, bool OVP, int VPT>
+__device__ __forceinline__ void hrow_wave_finish(const uint4 (&v)[VPT], uint4 *__restrict__ out, uint32_t v0, uint32_t vpr,
+                                                 float a, float gmax, const HArgs &ha, const uint4 &thr,
+                                                 const float *__restrict__ grid, uint2 *tab, uint32_t lane, uint32_t nv = VPT)
+{
+    const Scale sc = row_scale(a, gmax, ha.inv_gmax);
+    HRow R = hrow_build<T>(ha, thr, sc, tab, lane);
+    const uint32_t othr = OVP ? H16<T>::out(ha.vout * sc.s) & 0x7fffu : 0u;
+    if (OVP && othr >= H16<T>::INF && ha.vout < __builtin_inff()) R.fast = false;     // the outliers' outputs overflow
+    const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)tab;
+    const HFar far = {sc.rs, ha.flim, ha.vmin, ha.vmax};
+    hrow_task<T, OVP, VPT>(v, out, v0, vpr, R, tab_addr, ha.hshift, othr, sc.s, far, grid, ha.m, nv);
 }
 
 // One wavefront task of the row kernels: up to 64 * VPT vectors of ONE row (quant group); shared by the batched launch
@@ -319,13 +342,96 @@ __device__ __forceinline__ void hrow_wave_task(const uint4 *__restrict__ x, uint
 #pragma unroll
     for (int u = 0; u < VPT; u++) v[u] = ld_stream(p + min(v0 + 64u * u, vpr - 1u));
     __builtin_amdgcn_sched_barrier(0);                 // nothing that consumes a load is scheduled above this line
-    const Scale sc = row_scale(a, gmax, ha.inv_gmax);
-    HRow R = hrow_build<T>(ha, thr, sc, tab, lane);
-    const uint32_t othr = OVP ? H16<T>::out(ha.vout * sc.s) & 0x7fffu : 0u;
-    if (OVP && othr >= H16<T>::INF && ha.vout < __builtin_inff()) R.fast = false;     // the outliers' outputs overflow
-    const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)tab;
-    const HFar far = {sc.rs, ha.flim, ha.vmin, ha.vmax};
-    hrow_task<T, OVP, VPT>(v, out + (size_t)row * vpr + v0, v0, vpr, R, tab_addr, ha.hshift, othr, sc.s, far, grid, ha.m);
+    hrow_wave_finish<T, OVP, VPT>(v, out + (size_t)row * vpr + v0, v0, vpr, a, gmax, ha, thr, grid, tab, lane);
+}
+
+// The same with the scale computed from the row (ANTQ_FLAG_DYNAMIC): alpha = fl32(max |row| * ratio) (AQ:473-477, :300) from
+// the 16-bit magnitude patterns of the registers that hold the row -- one HBM read.  The row lives in the WPR (1, 4 or 16)
+// wavefronts of the workgroup, nv <= 8 vectors per lane each (vpr <= 64 * nv * WPR; nv wave-uniform: ONE instantiation walks
+// every row length, the unused vector steps cost a scalar branch each); task = row * WPR + wavefront.
+constexpr int kHDynV = 8;
+template <typename T, bool OVP, int WPR>
+__device__ __forceinline__ void hrow_wave_task_dyn(const uint4 *__restrict__ x, uint4 *__restrict__ out, uint32_t task, uint32_t vpr,
+                                                   uint32_t nv, float ratio, float *__restrict__ alpha_out, float gmax,
+                                                   const HArgs &ha, const uint4 *__restrict__ tlist, const float *__restrict__ grid,
+                                                   uint2 *tab, uint32_t lane, uint32_t wv)
+{
+    const uint32_t row = WPR == 1 ? task : task / WPR, g = WPR == 1 ? 0u : task - row * WPR;
+    const uint4 thr = ld_global(tlist + min(lane, ha.n_thr - 1u));
+    const uint32_t v0 = g * (64u * nv) + lane;
+    const uint4 *p = x + (size_t)row * vpr;
+    uint4 v[kHDynV];
+#pragma unroll
+    for (int u = 0; u < kHDynV; u++) {
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)u < nv) v[u] = ld_stream(p + min(v0 + 64u * u, vpr - 1u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t m = 0;
+#pragma unroll
+    for (int u = 0; u < kHDynV; u++)
+        if ((uint32_t)u < nv && v0 + 64u * u < vpr) m = IO<T>::amax_acc(m, v[u]);       // (lanes past the row end hold a duplicate: masked)
+    m = wave_max_u32(IO<T>::amax_bits(m));
+    if (WPR > 1) {
+        __shared__ uint32_t wmax[WPR];
+        if (lane == 0) wmax[wv] = m;
+        __syncthreads();
+        m = wmax[0];
+#pragma unroll
+        for (int w = 1; w < WPR; w++) m = max(m, wmax[w]);
+    }
+    const float a = u2f(m) * ratio;
+    if (alpha_out && lane == 0 && (WPR == 1 || wv == 0)) st_global(alpha_out + row, a);
+    hrow_wave_finish<T, OVP, kHDynV>(v, out + (size_t)row * vpr + v0, v0, vpr, a, gmax, ha, thr, grid, tab, lane, nv);
+}
+
+// One tensor per launch, ANTQ_FLAG_DYNAMIC: a row per wavefront (WPR = 1, one wavefront per workgroup) or per workgroup.
+template <typename T, bool OVP, int WPR>
+__global__ void __launch_bounds__(64 * WPR)
+k_fq_hrow_dyn(const uint4 *__restrict__ x, uint4 *__restrict__ out, uint32_t rows, uint32_t vpr, uint32_t nv, float ratio,
+              float *__restrict__ alpha_out, float gmax, HArgs ha, const uint4 *__restrict__ tlist, const float *__restrict__ grid)
+{
+    __shared__ __attribute__((aligned(16))) uint2 tab[WPR][kHSlots * 2];
+    const uint32_t wv = threadIdx.x >> 6;
+    if (blockIdx.x >= rows) return;                     // (whole workgroups: the barrier inside is never split)
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * WPR + wv);
+    hrow_wave_task_dyn<T, OVP, WPR>(x, out, task, vpr, nv, ratio, alpha_out, gmax, ha, tlist, grid, tab[wv], threadIdx.x & 63u, wv);
+}
+
+// Vectors per lane and task (4, 3 or 2) of a STATIC row of vpr vectors, or 0 when the row is better left to the fp32-domain
+// row table (have_xdom): K1h pays ~150 instructions per task for its table -- short rows (<= 144 vectors: 75 against 82 % of
+// 8 TB/s) and rows that only split into tasks with many idle lanes (288 vectors: 75 against 77 %) lose that against the
+// 14-instruction closed form of the older kernel; everything else is level or ahead, and far ahead whenever the clocks are
+// not settled or the pair rule is on (tools/probe_hrow_rows.py, profiles/r04_hrow_rows*.log).
+static inline uint32_t hrow_static_u(uint32_t vpr, bool have_xdom)
+{
+    uint32_t best_u = 0;
+    double best = -1.0;
+    for (uint32_t u = 4; u >= 2; u--) {
+        const uint32_t span = 64u * u, tasks = (vpr + span - 1u) / span;
+        const double util = (double)vpr / (double)(tasks * span);
+        if (util > best + 0.02) { best = util; best_u = u; }          // (near ties: the larger task)
+    }
+    // (2-vector tasks: the table build is half the task -- 11008-wide rows, 1376 vectors, 74 against 81 %)
+    if (have_xdom && (vpr < 192u || best < 0.93 || best_u < 3u)) return 0u;
+    return best_u;
+}
+
+// Shape of a dynamic row job: wavefronts per row and vectors per lane for a row of vpr vectors (128 .. 8192)
+struct HDynShape { int wpr, vpt; };      // vpt: vectors per lane in use (the `nv` of the kernels)
+static inline HDynShape hrow_dyn_shape(uint32_t vpr)
+{
+    const int wpr = vpr <= 512u ? 1 : (vpr <= 2048u ? 4 : 16);
+    return {wpr, (int)((vpr + 64u * wpr - 1u) / (64u * wpr))};
+}
+// dynamic LDS per workgroup (occupancy): about 96 KiB of reads in flight per CU (see kHRowLdsPad) -- wavefronts that hold
+// 4 KiB are capped at 24 per CU, 6 KiB at 16, 8 KiB at 12; shorter ones are not capped
+static inline unsigned hrow_dyn_lds_pad(const HDynShape &sh)
+{
+    if (sh.wpr != 1 || sh.vpt < 4) return 0u;
+    const unsigned per_cu = 96u / (unsigned)sh.vpt;                    // workgroups per CU
+    const unsigned lds = (160u * 1024u / per_cu) & ~511u;
+    return lds > kHSlots * 16u ? lds - kHSlots * 16u : 0u;
 }
 
 // One tensor per launch: WAVES wavefronts per workgroup (wave-private tables, no barrier), one task each.
@@ -365,11 +471,6 @@ static inline const uint4 *plan_tlist_dev(const void *plan_host, const void *pla
     return reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev) + static_cast<const PlanHeader *>(plan_host)->tlist_off);
 }
 
-// Dynamic LDS on top of the 2 KiB table so that 24 one-wavefront workgroups fit a CU (160 KiB): with 4 KiB of reads per
-// wavefront that is 96 KiB in flight per CU.  More in flight measured SLOWER (32 workgroups: 78.6 % against 81.4 % of
-// 8 TB/s on 32 x 4096^2 bf16), fewer starve the CU whenever the clocks dip (16: 82.8 % steady but 76 % right after an
-// idle period); tools/exp_hrow.hip, profiles/r04_exp_hrow_*.log.
-constexpr unsigned kHRowLdsPad = 6656u - kHSlots * 16u;
 
 }  // namespace antq
 

@@ -547,14 +547,14 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
         if n <= 0:
             return n, None
         assert n <= cap
-        h = host[:64].view(np.uint32)
-        total, fam, mixed, waves = int(h[7]), [int(v) for v in h[8:14]], int(h[14]) & 1, (int(h[14]) >> 8) & 7
+        h = host[:80].view(np.uint32)
+        total, fam, mixed, waves = int(h[7]), [int(v) for v in h[8:17]], int(h[17]) & 1, (int(h[17]) >> 8) & 7
         assert waves in (1, 4)          # wavefronts per workgroup the row-table launch will use (bits 8.. of the last word)
         assert sum(fam) == total and int(h[6]) == n == int(h[5]) + 4 * total
         bmap = host[int(h[5]):n].view(np.uint32)
         descs = []
         for k in range(len(jobs)):
-            d = host[64 + 192 * k:64 + 192 * (k + 1)]
+            d = host[80 + 192 * k:80 + 192 * (k + 1)]
             w = d[40:72].view(np.uint32)          # total_tasks vpr tpr vshift first_block kind per_row gmax
             descs.append(dict(n_vec=int(d[32:40].view(np.uint64)[0]), total_tasks=int(w[0]), vpr=int(w[1]), tpr=int(w[2]),
                               first_block=int(w[4]), kind=int(w[5]), u=int(d[148:152].view(np.uint32)[0])))
@@ -568,17 +568,24 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
             d["blocks"], d["family"] = int(pos.size), f
         return n, dict(descs=descs, fam=fam, mixed=mixed, lds=int(h[4]))
 
-    # 16-bit static rows of >= 128 vectors with a 4-bit codebook: the 16-bit-domain row family (5, kind 13) alone; rows of
-    # 576 / 144 / 192 vectors are cut into tasks of 3 vectors per lane, powers of two into tasks of 4 (2 for 128-vector rows)
+    # 16-bit static rows of >= 192 vectors with a 4-bit codebook that split into full tasks: the 16-bit-domain row family (5,
+    # kind 13) -- rows of 576 / 192 vectors in tasks of 3 vectors per lane, powers of two in tasks of 4; rows of 144 / 128 / 288
+    # vectors (short, or many idle lanes) stay with the fp32-domain row table (family 0).  A family-5 share of >= 128 MiB keeps
+    # its own launch next to the other family; a small one joins the all-in-one launch as fp32-domain rows.
     for dt in (1, 2):
         n, b = build([(4096, 4608, True, flint)] * 3 + [(512, 1152, True, flint), (64, 1536, True, flint)], dtype=dt)
-        assert b["mixed"] == 0 and b["fam"][5] > 0 and sum(b["fam"][:5]) == 0
-        assert [d["u"] for d in b["descs"]] == [3, 3, 3, 3, 3] and all(d["kind"] == 13 for d in b["descs"])
+        assert b["mixed"] == 0 and b["fam"][5] > 0 and b["fam"][0] > 0 and sum(b["fam"]) == b["fam"][5] + b["fam"][0]
+        assert [d["u"] for d in b["descs"]] == [3, 3, 3, 3, 3] and [d["kind"] for d in b["descs"]] == [13, 13, 13, 2, 13]
         for d, rows in zip(b["descs"], (4096, 4096, 4096, 512, 64)):
             assert d["total_tasks"] == rows * d["tpr"] and d["tpr"] * 64 * d["u"] >= d["vpr"] and d["blocks"] == -(-d["total_tasks"] // 4)
-        n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 1024, True, flint), (8, 1 << 16, False, pol)], dtype=dt)
-        assert b["mixed"] == 0 and b["fam"][5] > 0 and sum(b["fam"][:5]) == 0 and all(d["kind"] == 13 for d in b["descs"])
-        assert [d["u"] for d in b["descs"]] == [4, 4, 4, 2, 4] and b["descs"][4]["tpr"] == b["descs"][4]["total_tasks"] == 256
+        n, b = build([(4096, 4096, True, flint)] * 3 + [(512, 2048, True, flint), (8, 1 << 16, False, pol)], dtype=dt)
+        assert b["mixed"] == 0 and b["fam"][5] > 0 and sum(b["fam"]) == b["fam"][5] and all(d["kind"] == 13 for d in b["descs"])
+        assert [d["u"] for d in b["descs"]] == [4, 4, 4, 4, 4] and b["descs"][4]["tpr"] == b["descs"][4]["total_tasks"] == 256
+        n, b = build([(64, 4096, True, flint), (512, 1024, True, flint), (64, 2304, True, flint)], dtype=dt)     # small: one family-0 launch
+        assert b["mixed"] == 0 and b["fam"][0] == sum(b["fam"]) and all(d["kind"] == 2 for d in b["descs"])
+        n, b = build([(4096, 4096, True, flint)] * 4 + [(512, 1024, True, flint), (64, 147, True, flint), (64, 64, True, flint)], dtype=dt)
+        assert b["mixed"] == 1 and b["fam"][5] > 0 and b["fam"][0] > 0 and sum(b["fam"]) == b["fam"][5] + b["fam"][0]
+        assert [d["kind"] for d in b["descs"]] == [13, 13, 13, 13, 2, 3, 1]      # big family 5 apart, the rest all-in-one
     # ... with knob 9 = 0 the fp32-domain row table (family 0, kind 2) as in round 3
     L.antq_debug_set(9, 0)
     n, b = build([(4096, 4608, True, flint)] * 3 + [(512, 1152, True, flint), (64, 1536, True, flint)], dtype=1)
@@ -621,14 +628,28 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
     # dynamic: groups (power of two, <= 64 vectors), rows in a wavefront / a workgroup / a 1024-thread workgroup
     n, b = build([(1 << 14, 16, True, flint), (4096, 512, True, flint), (512, 4096, True, flint), (64, 28672, True, flint),
                   (16, 65536, True, flint), (300, 2048, True, flint)], dtype=1, flags=2)
+    # (16-bit rows of 128 .. 8192 vectors: the 16-bit-domain kernels -- the row in 1 / 4 / 16 wavefronts, families 6 / 7 / 8)
+    assert [d["kind"] for d in b["descs"]] == [1, 1, 14, 16, 16, 14] and [d["family"] for d in b["descs"]] == [1, 1, 6, 8, 8, 6]
+    assert [d["u"] for d in b["descs"]][2:] == [8, 4, 8, 4]
+    assert b["descs"][3]["blocks"] == 64 and b["descs"][2]["blocks"] == 128 and b["descs"][5]["blocks"] == 75
+    n, b = build([(100, 8192, True, flint), (100, 16384, True, flint)], dtype=2, flags=2)
+    assert [d["kind"] for d in b["descs"]] == [15, 15] and [d["u"] for d in b["descs"]] == [4, 8] and b["fam"][7] == 200
+    L.antq_debug_set(9, 0)             # ... and the round-3 kernels without them
+    n, b = build([(1 << 14, 16, True, flint), (4096, 512, True, flint), (512, 4096, True, flint), (64, 28672, True, flint),
+                  (16, 65536, True, flint), (300, 2048, True, flint)], dtype=1, flags=2)
     assert [d["kind"] for d in b["descs"]] == [1, 1, 6, 9, 10, 0] and [d["family"] for d in b["descs"]] == [1, 1, 3, 4, 4, 1]
-    assert b["descs"][3]["blocks"] == 64 and b["descs"][2]["blocks"] == 128
+    L.antq_debug_set(9, 1)
     for bad in ([(8, 576, True, flint)], [(8, 65544, True, flint)], [(8, 147, True, flint)], [(64, 64, False, flint)]):
         n, _ = build(bad, dtype=1, flags=2)
         assert n == -2, bad                              # ANTQ_ERR_UNSUPPORTED
-    # 16-bit dynamic rows of 128 vectors: lane jobs whose groups span 2 wavefronts (4 vectors per lane, never 2)
+    # 16-bit dynamic rows of 128 vectors: a row per wavefront in the 16-bit domain; without those kernels lane jobs whose
+    # groups span 2 wavefronts (4 vectors per lane, never 2)
+    n, b = build([(4096, 1024, True, flint)], dtype=1, flags=2)
+    assert b["descs"][0]["kind"] == 14 and b["descs"][0]["vpr"] == 128 and b["descs"][0]["u"] == 2 and b["descs"][0]["family"] == 6
+    L.antq_debug_set(9, 0)
     n, b = build([(4096, 1024, True, flint)], dtype=1, flags=2)
     assert b["descs"][0]["kind"] == 1 and b["descs"][0]["vpr"] == 128 and b["descs"][0]["u"] == 4 and b["descs"][0]["family"] == 1
+    L.antq_debug_set(9, 1)
     # alpha_dev: required for a static job, optional (the scales are simply not stored) for a dynamic one
     arr = (antq_lib._Job * 1)()
     for flags, want in ((0, -1), (2, None)):
