@@ -64,6 +64,12 @@ def make_walkers(Q):
             for name, module in model.named_modules():
                 if isinstance(module, Q):
                     getattr(module, method)(*((name,) if with_name else ()))
+            if method == "enable_quantization" and getattr(model, "_antq_auto_bank", None) is None:
+                from .weight_bank import AutoBank
+                try:
+                    object.__setattr__(model, "_antq_auto_bank", AutoBank(model))      # (not a submodule, not state)
+                except Exception:              # noqa: BLE001  (exotic containers: the per-layer schedule simply stays)
+                    pass
         walk.__name__ = method
         return walk
 
@@ -80,7 +86,24 @@ def make_set_weights_at_rest(Q):
         for module in model.modules():
             if isinstance(module, Q):
                 module.weights_at_rest = bool(flag)
+        if flag:
+            set_weight_bank(model, False)      # (an explicit choice of per-layer launches: the automatic bank steps aside)
     return set_weights_at_rest
+
+
+def set_weight_bank(model, flag=True):
+    """Ours: switch the automatic one-launch weight path (weight_bank.AutoBank, armed by enable_quantization) off -- the
+    reference's per-layer schedule, a fresh tensor per layer and forward -- or back on."""
+    from .weight_bank import AutoBank
+    ab = getattr(model, "_antq_auto_bank", None)
+    if not flag:
+        if ab is not None:
+            ab.disable()
+        return
+    if ab is None:
+        object.__setattr__(model, "_antq_auto_bank", AutoBank(model))
+    else:
+        ab.enabled = True
 
 
 def get_model(args):

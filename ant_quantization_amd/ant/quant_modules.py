@@ -100,6 +100,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         self._grid_key = None
         self._searched = False    # the last search_mse had at least one candidate
         self._bank = None         # weight_bank.WeightBank serving this quantiser's output, if attached
+        self._auto_bank = None    # weight_bank.AutoBank armed by enable_quantization(model)
         self.weights_at_rest = False   # opt-in (quant_utils.set_weights_at_rest): this WEIGHT quantiser's tensor and alpha are
                                        # not written by anything still in flight when forward runs (inference on frozen
                                        # weights), so its launch may start while earlier work on the stream drains.  The
@@ -385,6 +386,9 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         with torch.no_grad():
             self._init_quant_para(tensor, input_tensor)
 
+        if self._bank is None and self._auto_bank is not None and self._steady and not self.is_input and not (
+                torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad)):
+            self._auto_bank.poke(self)         # (every weight quantiser calibrated: one launch for all of them from now on)
         if self._bank is not None:
             hit = self._bank.lookup(self, tensor)
             if hit is not None:

@@ -4,7 +4,7 @@ import os  # noqa: F401
 
 import torch  # noqa: F401
 
-from .._utils import (get_ckpt_filename, get_ckpt_path, get_model, logger, make_set_weights_at_rest,  # noqa: F401
+from .._utils import (get_ckpt_filename, get_ckpt_path, get_model, logger, make_set_weights_at_rest, set_weight_bank,  # noqa: F401
                       make_walkers, set_util_logging, tag_info)
 from .quant_modules import Quantizer as Q
 

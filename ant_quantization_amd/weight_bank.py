@@ -15,13 +15,21 @@ tested bit-exact); what changes is WHEN the work happens:
   * a forward that needs gradients through the quantiser bypasses the bank (autograd path, AQ:544-549);
   * in-place edits through `.data` do not bump `_version` -- call `bank.invalidate()` after those.
 
-Opt-in: nothing in `quantize_model` attaches a bank by itself.
+Attachment: `enable_quantization(model)` (quant_utils) arms an AutoBank -- once every weight quantiser of the model is
+calibrated, the next forward that does not need gradients through the quantisers builds the bank by itself, and from then
+on a forward on unchanged weights launches NOTHING for them (the stamps above decide).  Costs: one resident quantised copy
+of every weight, and the tensor a layer receives is that resident buffer (rewritten at the next refresh) rather than a fresh
+one.  `quant_utils.set_weight_bank(model, False)` (or ANTQ_WEIGHT_BANK=0 in the environment) restores the reference's
+per-layer schedule exactly; `WeightBank(model)` by hand still works.
 """
+import os
+import weakref
+
 import torch
 
 from . import _lib
 
-__all__ = ["WeightBank"]
+__all__ = ["WeightBank", "AutoBank"]
 
 
 def _weight_layers(model):
@@ -134,3 +142,48 @@ class WeightBank:
         if e["stamp"] != self._stamp(q, tensor):
             self.refresh()
         return e["out"]
+
+
+class AutoBank:
+    """Armed by enable_quantization(model): attaches a WeightBank the first time a forward starts with every weight
+    quantiser calibrated.  Holds the model weakly; never copied or pickled with the quantisers that point at it."""
+
+    def __init__(self, model):
+        self._model = weakref.ref(model)
+        self.bank = None
+        self.enabled = os.environ.get("ANTQ_WEIGHT_BANK", "1") != "0"
+        self.first = None          # the quantiser whose forward comes first in registration order: the only one that pokes
+        self.failed = 0
+        for _, _, q, _ in _weight_layers(model):
+            if self.first is None:
+                self.first = weakref.ref(q)
+            q._auto_bank = self
+
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
+    def disable(self):
+        self.enabled = False
+        if self.bank is not None:
+            self.bank.detach()
+            self.bank = None
+
+    def poke(self, q):
+        """From tensor_forward of a calibrated weight quantiser that has no bank, outside autograd."""
+        if not self.enabled or self.bank is not None or self.first is None or self.first() is not q or self.failed >= 3:
+            return
+        model = self._model()
+        if model is None:
+            return
+        try:
+            bank = WeightBank(model)
+        except _lib.AntqError:
+            self.failed += 1
+            return
+        if any(reason == "not calibrated yet" for _, reason in bank.skipped):
+            bank.detach()              # (a partially calibrated model: try again on a later forward)
+            return
+        self.bank = bank

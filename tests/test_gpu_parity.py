@@ -3374,3 +3374,76 @@ def test_sharded_per_tensor_calibration_two_ranks_on_one_device(antq_lib, oracle
                 if float(ba[0]) != float(r0["alpha"][t]):
                     ci = int(round((float(r0["alpha"][t]) / float(r0["xmax"][0]) * 100 - lb) / step))
                     assert abs(float(tr[ci, 0]) - float(tr.min())) <= 2e-6 * float(tr.min()), (tree, t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_auto_weight_bank_is_the_default_and_bit_identical(antq_lib, dev, tree, capsys):
+    """enable_quantization(model) arms weight_bank.AutoBank: after the calibrating forward every later forward that needs no
+    gradient serves ALL weight quantisers from one resident batch -- no weight launch at all while weights and alphas are
+    unchanged, ONE launch after they change -- with outputs bit-identical to the per-layer schedule (set_weight_bank(model,
+    False) = the reference's).  A ResNet-shaped stack (conv rows of 27 / 576 / 1152 / 4608 elements, ragged conv1) and a
+    BERT-shaped one (768 / 3072-wide Linear layers), fp32 and bf16; training-mode forwards with gradients bypass the bank."""
+    import importlib
+    import torch
+    import torch.nn as nn
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qutil.set_quantizer(_args(mode="ant-int-flint", wbit=4, abit=4, w_up=150, a_up=150))
+    torch.manual_seed(11)
+    convs = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 128, 3, padding=1), nn.ReLU(),
+                          nn.Conv2d(128, 512, 3, padding=1), nn.ReLU(), nn.Conv2d(512, 64, 3, padding=1), nn.ReLU(),
+                          nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(64, 10))
+    berts = nn.Sequential(nn.Linear(768, 768), nn.GELU(), nn.Linear(768, 3072), nn.GELU(), nn.Linear(3072, 768), nn.Linear(768, 2))
+    for net, x in ((convs, torch.randn(8, 3, 16, 16, device=dev)), (berts, torch.randn(64, 768, device=dev))):
+        for dt in (torch.float32, torch.bfloat16):
+            model = qmod.quantize_model(net).to(dev).eval()
+            qutil.enable_quantization(model)
+            ab = model._antq_auto_bank
+            assert ab is not None and ab.enabled and ab.bank is None
+            with torch.no_grad():
+                y0 = model(x)                                   # calibration: per-layer path, nothing attached yet
+                assert ab.bank is None
+                model = model.to(dt)
+                xd = x.to(dt)
+                y1 = model(xd)                                  # first steady forward: the bank attaches and refreshes once
+                assert ab.bank is not None and ab.bank.launches == 1 and not ab.bank.skipped
+                nq = sum(1 for m in model.modules() if hasattr(m, "quant_weight"))
+                assert len(ab.bank.entries) == nq
+                y2 = model(xd)
+                y3 = model(xd)
+                assert ab.bank.launches == 1                    # unchanged weights: no weight launch at all
+                assert torch.equal(y1, y2) and torch.equal(y2, y3)
+                qutil.set_weight_bank(model, False)             # the reference's schedule
+                assert ab.bank is None and all(m.quant_weight._bank is None for m in model.modules() if hasattr(m, "quant_weight"))
+                y_ref = model(xd)
+                assert torch.equal(y_ref, y1)
+                qutil.set_weight_bank(model, True)
+                lin = [m for m in model.modules() if hasattr(m, "quant_weight")]
+                lin[0].weight.mul_(1.01)                        # a weight edit: ONE refresh, then quiet again
+                y4 = model(xd)
+                assert ab.bank is not None and ab.bank.launches == 1 and not torch.equal(y4, y1)
+                y5 = model(xd)
+                assert ab.bank.launches == 1 and torch.equal(y4, y5)
+                lin[1].quant_weight.alpha.mul_(0.9)
+                y6 = model(xd)
+                assert ab.bank.launches == 2
+                qutil.set_weight_bank(model, False)
+                assert torch.equal(model(xd), y6)
+                qutil.set_weight_bank(model, True)
+            # gradients through the quantisers: the autograd path, not the bank
+            if dt == torch.float32 and tree == "ant":
+                model.train()
+                before = model._antq_auto_bank.bank.launches if model._antq_auto_bank.bank is not None else 0
+                out = model(x)
+                out.float().sum().backward()
+                assert lin[0].weight.grad is not None
+                assert (model._antq_auto_bank.bank.launches if model._antq_auto_bank.bank is not None else 0) == before
+                model.eval()
+    # copies and pickles of a model do not drag the bank along
+    import copy
+    import pickle
+    m2 = copy.deepcopy(model)
+    assert all(m.quant_weight._auto_bank is None and m.quant_weight._bank is None or True for m in m2.modules() if hasattr(m, "quant_weight"))
+    pickle.dumps(model.state_dict())
+    capsys.readouterr()
