@@ -286,7 +286,9 @@ template <typename T>
 static void launch_hbatch(uint32_t map_entries, const BatchDesc *descs, const uint32_t *map, bool ovp, hipStream_t st)
 {
     const dim3 g(map_entries * 4u), b(64u);
-    const unsigned pad = g_knob_hlds >= 0 ? (unsigned)g_knob_hlds : kHRowLdsPad;
+    // (the occupancy cap pays once the launch is several rounds of workgroups; a small batch wants every slot -- as a single
+    //  tensor does, antq_fq.hip)
+    const unsigned pad = g_knob_hlds >= 0 ? (unsigned)g_knob_hlds : (map_entries >= 8192u ? kHRowLdsPad : 0u);
     if (ovp) hipLaunchKernelGGL((k_fq_hbatch<T, true>), g, b, pad, st, descs, map, (uint32_t)g_knob_rot);
     else hipLaunchKernelGGL((k_fq_hbatch<T, false>), g, b, pad, st, descs, map, (uint32_t)g_knob_rot);
 }

@@ -255,7 +255,7 @@ def measure_traffic(nbuf, kernel_substr="k_fq_hbatch", timeout_s=240):
     import shutil
     import subprocess
     import tempfile
-    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "bench.py is itself running under rocprofv3: no nested counter passes"
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:

@@ -3,14 +3,18 @@
 #   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r03'
 # Everything is written under gpurun_out/<tag>/ (small text files only); copy what should be judged into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 PY="python"
 
-$PY bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"
+# the driver's exact command line first (--steps 20 --warmup 5: three plain runs, one under rocprofv3 --kernel-trace with the
+# per-launch durations kept), then the long run
+bash tools/driver_cmd.sh "$TAG" > "$OUT/driver_cmd.log" 2>&1
+tail -32 "$OUT/driver_cmd.log" | head -30
+$PY bench.py --steps 200 --warmup 20 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"
 tail -1 "$OUT/${TAG}_bench.json" | cut -c1-400
 
 # the launch form the driver uses for N > 1 (one rank per GPU over RCCL), on the one GPU of this box
@@ -20,7 +24,7 @@ cut -c1-200 "$OUT/${TAG}_bench_torchrun_n1.json"
 
 # kernel trace of the same command (no PMC in this pass)
 ( cd /tmp && rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- \
-    $PY "$REPO/bench.py" --no-cpu-baseline > "$OUT/bench_profiled.json" 2> /tmp/prof_kt.err )
+    $PY "$REPO/bench.py" --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > "$OUT/bench_profiled.json" 2> /tmp/prof_kt.err )
 KS=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/${TAG}_bench_kernel_stats.csv"
 tail -1 "$OUT/bench_profiled.json" | cut -c1-200
@@ -56,6 +60,12 @@ $PY tools/probe_footprint.py 2 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP\|^ROCm\|^Host
 ( $PY tools/probe_call_overhead.py; ANTQ_NO_EXT=1 $PY tools/probe_call_overhead.py ) 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > "$OUT/${TAG}_call_overhead.log"
 $PY tools/probe_box.py 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > "$OUT/${TAG}_box.log"
 [ -x tools/exp_lane ] && ./tools/exp_lane > "$OUT/${TAG}_exp_lane.log" 2>&1
+# round 4: the 16-bit-domain kernels -- launch-shape experiment, row-length A/B against the round-3 kernels, one launch per tensor
+[ -x tools/exp_hrow ] && ( ./tools/exp_hrow > "$OUT/${TAG}_exp_hrow_ant.log" 2>&1; ./tools/exp_hrow olive > "$OUT/${TAG}_exp_hrow_olive.log" 2>&1 )
+( $PY tools/probe_hrow_rows.py; $PY tools/probe_hrow_rows.py olive ) 2>&1 | grep -v amdgpu > "$OUT/${TAG}_hrow_rows.log"
+$PY tools/probe_per_tensor.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_per_tensor_shapes.log"
+$PY tools/probe_transient.py 40 1.5 2>&1 | grep -v amdgpu > "$OUT/${TAG}_transient.log"
+$PY tools/probe_first_forward.py 2>&1 | grep "forward" > "$OUT/${TAG}_first_forward.log"
 [ -x tools/stream_shapes ] && ./tools/stream_shapes all > "$OUT/${TAG}_stream_shapes.log" 2>&1
 [ -x tools/launch_anatomy ] && ./tools/launch_anatomy 2>&1 | cut -c1-70 > "$OUT/${TAG}_launch_anatomy.log"
 [ -x tools/valu_rates ] && ./tools/valu_rates > "$OUT/${TAG}_valu_rates.log" 2>&1
