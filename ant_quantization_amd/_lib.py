@@ -15,7 +15,7 @@ import torch  # must be imported before libantq.so so that ONE libamdhip64 is sh
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ANTQ_LIB") or os.path.join(_HERE, "libantq.so")   # ANTQ_LIB: A/B builds (dev)
 
-ABI_VERSION = 3         # include/antq.h ANTQ_ABI_VERSION this binding was written against
+ABI_VERSION = 4         # include/antq.h ANTQ_ABI_VERSION this binding was written against
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_OVP = 1
 FLAG_DYNAMIC = 2

@@ -37,8 +37,10 @@ extern "C" {
 
 /* 2 (round 3): antq_search_sse / antq_alpha_grad take a caller workspace before `stream`, antq_absmax initialises its
  * output, the batch blob changed (plan version 8), ANTQ_FLAG_UNORDERED.  3: antq_calibrate / antq_calibrate_workspace_bytes
- * added (nothing else changed).  A caller built against another version must not call in: the argument lists differ. */
-#define ANTQ_ABI_VERSION 3
+ * added (nothing else changed).  4 (round 4): the plan blob grew (version 9: 128-byte header + the threshold list of the
+ * 16-bit-domain kernels; ANTQ_PLAN_MAX_BYTES with it), the batch blob changed, antq_plan_eval_host_h and
+ * antq_prefetch_kernels added.  A caller built against another version must not call in: the blobs / argument lists differ. */
+#define ANTQ_ABI_VERSION 4
 
 /* element types of x / out */
 #define ANTQ_F32  0

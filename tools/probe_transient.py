@@ -34,11 +34,13 @@ torch.cuda.synchronize()
 BYTES = nb * 4096 * 4096 * 4
 
 
-def make_batch(waves, u, rot):
+def make_batch(waves, u, h):
     knob(6, waves)
     knob(0, u)
+    knob(9, h)
     b = _lib.Batch([(x, o, a, plan, 10.0, 4096, 4096, True) for x, a, o in zip(xs, al, outs)])
     knob(0, 0)
+    knob(9, 1)
     return b
 
 
@@ -73,10 +75,12 @@ def show(tag, s):
         flush=True)
 
 
-shapes = [("W=1 u=2 (shipped)", 1, 2), ("W=4 u=2", 4, 2), ("W=1 u=4", 1, 4), ("W=4 u=4", 4, 4), ("W=2 u=2", 2, 2)]
+# (round 4: bf16 rows take the 16-bit-domain kernel -- one wavefront per workgroup always, knob 6 is moot for it; knob 0 forces
+#  the vectors per lane and task; knob 9 = 0 brings back the round-3 kernel, for which knob 6 = wavefronts per workgroup)
+shapes = [("K1h u=4 (shipped)", 0, 0, 1), ("K1h u=2 (forced)", 0, 2, 1), ("K1h u=3 (forced)", 0, 3, 1), ("round-3 kernel W=1 u=2", 1, 2, 0), ("round-3 kernel W=4 u=2", 4, 2, 0)]
 for rnd in range(2):
-    for name, w, u in shapes:
-        bt = make_batch(w, u, 0)
+    for name, w, u, h in shapes:
+        bt = make_batch(w, u, h)
         knob(6, w)
         # (a) the bench's prelude: per-tensor launches 0.3 s ordered + 0.15 s unordered, then the batched launches
         time.sleep(IDLE)
