@@ -119,9 +119,14 @@ __device__ __forceinline__ HRow hrow_build(const HArgs &ha, const uint4 &thr, co
     const uint32_t sbit = neg ? 0x80000000u : 0u;
     if (mine) {
         slot(key, neg) = make_uint2(sbit | (t16 << 16), first | (second << 16));
+        // (plain rolled loops, a handful of iterations: the loop vectoriser turned them into a kilobyte of unrolled
+        //  ds_write_b32 bodies with scalar epilogues)
+#pragma clang loop vectorize(disable) unroll(disable)
         for (uint32_t k = key + 1u; k < nxt; k++) slot(k, neg) = make_uint2(kHNoThr, second | (second << 16));
-        if (first_of_side)
+        if (first_of_side) {
+#pragma clang loop vectorize(disable) unroll(disable)
             for (uint32_t k = kmin; k < key; k++) slot(k, neg) = make_uint2(kHNoThr, first | (first << 16));
+        }
         if (last_of_side) slot(klim, neg) = make_uint2(sbit | (lim16 << 16), second | (kHSentinel << 16));
     }
     // a side without thresholds (unsigned grid: every negative x is in the lowest region; all-negative grid: the mirror
@@ -129,6 +134,7 @@ __device__ __forceinline__ HRow hrow_build(const HArgs &ha, const uint4 &thr, co
     if (ha.n_neg == 0u || ha.n_neg == ha.n_thr) {
         const bool ng = ha.n_neg == 0u;
         const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)first, ng ? 0 : (int)(ha.n_thr - 1u));
+#pragma clang loop vectorize(disable) unroll(disable)
         for (uint32_t k = kmin + lane; k < klim; k += 64u) slot(k, ng) = make_uint2(kHNoThr, o | (o << 16));
         if (lane == 0u) slot(klim, ng) = make_uint2((ng ? 0x80000000u : 0u) | (lim16 << 16), o | (kHSentinel << 16));
     }
@@ -291,13 +297,19 @@ __device__ __forceinline__ void hrow_task(const uint4 (&v)[VPT], uint4 *__restri
     // outliers at a 3-sigma alpha, activations far above a calibrated clip); anything else (Inf, NaN, beyond flim) sends
     // the vector through the literal sequence.
     const uint32_t slot0 = R.klim << hshift;          // first pattern of the sentinel slot (a superset of "beyond the limit")
+    // (a rolled loop with the vector picked by wave-uniform selects: ONE copy of the far-clipped and the literal code in the
+    //  kernel instead of VPT of each)
+#pragma unroll 1
+    for (uint32_t u = 0; u < nv; u++) {
+        uint4 cur = v[0];
 #pragma unroll
-    for (int u = 0; u < VPT; u++) {
-        if ((uint32_t)u < nv && v0 + 64u * u < vpr) {
-            const uint32_t top = IO<T>::amax_acc(0u, v[u]);
-            if (!R.fast) st_stream(out + 64u * u, hrow_exact<T, OVP>(v[u], s, grid, m));
+        for (int k = 1; k < VPT; k++)
+            if (u == (uint32_t)k) cur = v[k];
+        if (v0 + 64u * u < vpr) {
+            const uint32_t top = IO<T>::amax_acc(0u, cur);
+            if (!R.fast) st_stream(out + 64u * u, hrow_exact<T, OVP>(cur, s, grid, m));
             else if (max(top & 0xffffu, top >> 16) >= slot0)
-                st_stream(out + 64u * u, hrow_vec_far<T, OVP>(v[u], tbase, vkmin, vklim, kpos, vkwid, othr, s, far, grid, m));
+                st_stream(out + 64u * u, hrow_vec_far<T, OVP>(cur, tbase, vkmin, vklim, kpos, vkwid, othr, s, far, grid, m));
         }
     }
 }
@@ -332,17 +344,25 @@ __device__ __forceinline__ void hrow_wave_task(const uint4 *__restrict__ x, uint
                                                const HArgs &ha, const uint4 *__restrict__ tlist, const float *__restrict__ grid,
                                                uint2 *tab, uint32_t lane)
 {
+    // (VPT is a template parameter on purpose: with a run-time vector count the loads sit under scalar branches, the
+    //  compiler no longer knows how many of them follow the threshold-list load, and waits for ALL of them -- vmcnt(0) --
+    //  before the table build instead of building the table while the data is in flight)
+    constexpr uint32_t nv = VPT;
     uint32_t row = task, g = 0;
     if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
-    const uint4 thr = ld_global(tlist + min(lane, ha.n_thr - 1u));
+    uint4 thr = ld_global(tlist + min(lane, ha.n_thr - 1u));
     const float a = ld_global(alpha + (per_row ? row : 0));
-    const uint32_t v0 = g * (64u * VPT) + lane;
+    const uint32_t v0 = g * (64u * nv) + lane;
     const uint4 *p = x + (size_t)row * vpr;
     uint4 v[VPT];
 #pragma unroll
     for (int u = 0; u < VPT; u++) v[u] = ld_stream(p + min(v0 + 64u * u, vpr - 1u));
     __builtin_amdgcn_sched_barrier(0);                 // nothing that consumes a load is scheduled above this line
-    hrow_wave_finish<T, OVP, VPT>(v, out + (size_t)row * vpr + v0, v0, vpr, a, gmax, ha, thr, grid, tab, lane);
+    // (all four registers of `thr` stay claimed until here: with the unused fourth one free the allocator handed it to an
+    //  address computation BETWEEN the data loads, which then had to wait -- vmcnt(0) -- for the first vector to land before
+    //  the second was even requested)
+    asm volatile("" : "+v"(thr.x), "+v"(thr.y), "+v"(thr.z), "+v"(thr.w));
+    hrow_wave_finish<T, OVP, VPT>(v, out + (size_t)row * vpr + v0, v0, vpr, a, gmax, ha, thr, grid, tab, lane, nv);
 }
 
 // The same with the scale computed from the row (ANTQ_FLAG_DYNAMIC): alpha = fl32(max |row| * ratio) (AQ:473-477, :300) from
@@ -357,7 +377,7 @@ __device__ __forceinline__ void hrow_wave_task_dyn(const uint4 *__restrict__ x, 
                                                    uint2 *tab, uint32_t lane, uint32_t wv)
 {
     const uint32_t row = WPR == 1 ? task : task / WPR, g = WPR == 1 ? 0u : task - row * WPR;
-    const uint4 thr = ld_global(tlist + min(lane, ha.n_thr - 1u));
+    uint4 thr = ld_global(tlist + min(lane, ha.n_thr - 1u));
     const uint32_t v0 = g * (64u * nv) + lane;
     const uint4 *p = x + (size_t)row * vpr;
     uint4 v[kHDynV];
@@ -367,6 +387,7 @@ __device__ __forceinline__ void hrow_wave_task_dyn(const uint4 *__restrict__ x, 
         if ((uint32_t)u < nv) v[u] = ld_stream(p + min(v0 + 64u * u, vpr - 1u));
     }
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(thr.x), "+v"(thr.y), "+v"(thr.z), "+v"(thr.w));      // (see hrow_wave_task)
     uint32_t m = 0;
 #pragma unroll
     for (int u = 0; u < kHDynV; u++)
