@@ -340,8 +340,9 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
 #define ANTQ_LAUNCH_D(TT, OO, AA)                                                                                   \
     do {                                                                                                            \
         const int f_ = (AA) ? 1 : 2;                                                                                \
-        if (dyn) hipLaunchKernelGGL((k_fq_batch_d<TT, OO, AA, true>), dim3(h->fam_blocks[f_]), block, h->lds_bytes, st, descs, fmap[f_]);  \
-        else hipLaunchKernelGGL((k_fq_batch_d<TT, OO, AA, false>), dim3(h->fam_blocks[f_]), block, h->lds_bytes, st, descs, fmap[f_]);     \
+        const unsigned lds_ = h->lds_bytes + (g_knob_dlds > 0 ? (unsigned)g_knob_dlds : 0u);                        \
+        if (dyn) hipLaunchKernelGGL((k_fq_batch_d<TT, OO, AA, true>), dim3(h->fam_blocks[f_]), block, lds_, st, descs, fmap[f_]);  \
+        else hipLaunchKernelGGL((k_fq_batch_d<TT, OO, AA, false>), dim3(h->fam_blocks[f_]), block, lds_, st, descs, fmap[f_]);     \
     } while (0)
 #define ANTQ_LAUNCH_B(TT)                                                                                         \
     do {                                                                                                          \
