@@ -122,6 +122,14 @@ def prewarm(device, dtype=torch.float32):
             al = absmax(x, 256, 1024, per_row)
             (al / xm).mean()
         (x.min() < 0).item()
+        # rows of >= 512 vectors take the 8-vector search tasks; the sign probe's pinned slots and its async copy
+        xl = x.view(64, 4096)
+        calibrate(xl, 64, 4096, True, plans_a[:1], [10.0], 95, 100, 1, xmax="absmax")
+        calibrate(xl, 64, 4096, True, [plan_o], [float(on.max())], 95, 100, 2, xmax="3sigma", ovp=True)
+        from . import _mirror
+        _mirror._slots.take().copy_(x.min().float().reshape(1), non_blocking=True)
+        torch.ones_like(al), al.clone()
+        torch.cuda.synchronize(device)
 
 
 _ext_mod = False          # False: not tried yet; None: unavailable

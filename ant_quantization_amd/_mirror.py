@@ -51,6 +51,79 @@ class HostMirrorMixin:
         return out
 
 
+class _PinnedSlots:
+    """A small ring of pinned host floats for device->host copies nobody wants to wait for at issue time."""
+
+    def __init__(self, n=256):
+        self.n, self.buf, self.i = n, None, 0
+
+    def take(self):
+        if self.buf is None:
+            self.buf = torch.zeros(self.n, dtype=torch.float32).pin_memory()
+        self.i = (self.i + 1) % self.n
+        return self.buf[self.i:self.i + 1]
+
+
+_slots = _PinnedSlots()
+
+
+class CalibrationMixin:
+    """First-call calibration without stalling the stream (shared by the ANT and the OliVe Quantizer).
+
+    * The sign probe.  An input quantiser starts unsigned and learns from its first tensor whether it needs a signed codebook
+      (`if tensor.min() < 0`, AQ:61-63 / OQ:62-64): a device->host read in front of everything else its calibration does.
+      Read on the spot it drains the stream once per layer -- and the GPU then idles while the host issues the calibration
+      launches.  The wrapper layers therefore call `prefetch_sign(input)` BEFORE they calibrate their weight: the minimum goes
+      to pinned memory asynchronously, the weight's calibration is issued behind it, and when the input quantiser asks, the
+      answer has long arrived while the stream is still busy.  Without a matching probe `update_signed` reads on the spot.
+    * `mse`, the log value of the reference (AQ:519-520), is formed when somebody reads it.
+    """
+    _sign_probe = None
+
+    def prefetch_sign(self, tensor):
+        if self.is_signed or self._steady or not isinstance(tensor, torch.Tensor) or not tensor.is_cuda or tensor.numel() == 0:
+            return
+        if not self.is_enable or self.mode == "base" or not (self.is_enable_activation if self.is_input else self.is_enable_weight):
+            return
+        if self._hm_get('has_inited_quant_para') != 0:
+            return
+        with torch.no_grad():
+            slot = _slots.take()
+            slot.copy_(tensor.detach().min().float().reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(tensor.device))
+        self._sign_probe = (tensor, _tensor_stamp(tensor), slot, ev)
+
+    def update_signed(self, tensor):
+        if self.is_signed:                               # already signed (weights): nothing to learn, no sync
+            return
+        probe, self._sign_probe = self._sign_probe, None
+        if probe is not None and probe[0] is tensor and probe[1] is not None and probe[1] == _tensor_stamp(tensor):
+            probe[3].synchronize()                       # (recorded before the weight's calibration was issued)
+            negative = float(probe[2][0]) < 0
+        else:
+            negative = bool(tensor.min() < 0)
+        if negative:
+            self.is_signed = True
+
+    @property
+    def mse(self):
+        lazy = self.__dict__.get('_mse_lazy')
+        if lazy is not None:
+            best, n = lazy
+            self.__dict__['_mse_val'] = best.sum() / n
+            self.__dict__['_mse_lazy'] = None
+        return self.__dict__.get('_mse_val')
+
+    @mse.setter
+    def mse(self, value):
+        self.__dict__['_mse_val'] = value
+        self.__dict__['_mse_lazy'] = None
+
+    def _mse_later(self, best_score, n):
+        self.__dict__['_mse_lazy'] = (best_score, n)
+
+
 class WeightsAtRestMixin:
     """The weights-at-rest launch mode of a WEIGHT quantiser (quant_utils.set_weights_at_rest), shared by the ANT and the
     OliVe Quantizer: the steady-state launch may start while earlier work on the stream drains (ANTQ_FLAG_UNORDERED) when
@@ -63,7 +136,7 @@ class WeightsAtRestMixin:
     def __getstate__(self):
         """torch.save(model) pickles the module: the launch-mode caches (a weak reference among them) are not state."""
         st = self.__dict__.copy()
-        for k in ("_rest_src", "_rest_stamp", "_rest_out", "_alpha32", "_alpha32_stamp"):
+        for k in ("_rest_src", "_rest_stamp", "_rest_out", "_alpha32", "_alpha32_stamp", "_sign_probe"):
             if k in st:
                 st[k] = None
         return st

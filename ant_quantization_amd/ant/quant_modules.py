@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, core, grids
-from .._mirror import HostMirrorMixin, WeightsAtRestMixin
+from .._mirror import CalibrationMixin, HostMirrorMixin, WeightsAtRestMixin
 from .quant_affine import *  # noqa: F401,F403  (the reference star-imports it, AQ:9)
 
 _TYPE_ORDER = ("int", "flint", "pot", "float", "float1", "float2", "float3", "float4", "apot")
@@ -58,7 +58,7 @@ class QuantBase():
             return QuantBase._quantization(real_val, quant_grid, plan)
 
 
-class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
+class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module):
     def __init__(self, mode="base", bit=8, is_signed=True, is_enable=False, is_input=False, args=None, operator=None):
         super(Quantizer, self).__init__()
         self.mode = mode
@@ -126,9 +126,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         self.name = name
         self.is_enable = False
 
-    def update_signed(self, tensor):
-        if not self.is_signed and tensor.min() < 0:      # already signed (weights): nothing to learn, no sync
-            self.is_signed = True
+    # (update_signed / prefetch_sign / the lazily formed `mse`: _mirror.CalibrationMixin)
 
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
         super()._load_from_state_dict(state_dict, prefix, *a, **k)
@@ -205,10 +203,10 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
             lb = int(95)
         return lb, ub
 
-    def search_mse(self, tensor):
-        """AQ:287-326: clip search over i in [lb, ub), alpha_i = x_max * (i*0.01)."""
+    def _clip_search(self, tensor, need_xmax=True):
+        """search_mse's device work: (best_score [rows or 1], alpha [rows or 1], x_max), nothing reduced or reshaped yet."""
         per_channel = self.is_perchannel and (not self.is_input)
-        x_max = core.row_absmax(tensor, per_channel)
+        x_max = None
         lb, ub = self._search_window(per_channel)
         plan = self._ensure_plan()
         # (keyed on the window as well: a pass over another [lb, ub) can never stand in for this search)
@@ -216,8 +214,24 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         if hit is not None:
             best_score, alpha, ratios = hit       # this very search was part of the type selection's single pass
         else:
-            best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 1, plan, self._gmax)
+            # (a parallel branch's input quantiser may have searched this very tensor a moment ago: core.SearchMemo)
+            key = ("ant", lb, ub, 1, plan.grid.tobytes(), self._gmax) if not per_channel else None
+            seen = core.search_memo.get(tensor, key) if key else None
+            if seen is not None:
+                best_score, alpha, ratios = seen[0], seen[1].clone(), seen[2]
+            else:
+                x_max = core.row_absmax(tensor, per_channel)
+                best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 1, plan, self._gmax)
+                if key:
+                    core.search_memo.put(tensor, key, (best_score, alpha.clone(), ratios))
         self._searched = ratios is not None
+        if x_max is None and need_xmax:
+            x_max = core.row_absmax(tensor, per_channel)
+        return best_score, alpha, x_max, per_channel
+
+    def search_mse(self, tensor):
+        """AQ:287-326: clip search over i in [lb, ub), alpha_i = x_max * (i*0.01)."""
+        best_score, alpha, x_max, per_channel = self._clip_search(tensor)
         ratio = (alpha / x_max).mean()        # 0-dim tensor: the reference's float, without the sync
         if per_channel:
             return best_score.sum(), alpha.unsqueeze(1), ratio
@@ -247,7 +261,14 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         with np.errstate(all="ignore"):
             gmaxs = [float(np.max(g)) for g in uniq]
         x_max = core.row_absmax(data, per_channel)
-        res = core.clip_search_types(data, x_max, per_channel, lb, ub, 1, plans, gmaxs) if len(uniq) > 1 else None
+        key = ("ant-types", lb, ub, 1, tuple(g.tobytes() for g in uniq), tuple(gmaxs)) if not per_channel and len(uniq) > 1 else None
+        res = core.search_memo.get(data, key) if key else None
+        if res is not None:
+            res = [(b, a.clone(), r) for b, a, r in res]
+        else:
+            res = core.clip_search_types(data, x_max, per_channel, lb, ub, 1, plans, gmaxs) if len(uniq) > 1 else None
+            if key and res is not None:
+                core.search_memo.put(data, key, [(b, a.clone(), r) for b, a, r in res])
         if res is not None:
             self._type_search = {(g.tobytes(), lb, ub): r for g, r in zip(uniq, res)}
             mse_list = [self._type_search[(g.tobytes(), lb, ub)][0].sum().reshape(()) for g in type_grids]
@@ -336,12 +357,15 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
                 raise RuntimeError("Unsupported mode: " + self.mode)
             self._install_grid(grids.ant_grid(self.mode, self._bits(), self.is_signed))
 
-            best_sum, self.alpha.data, alpha_ratio = self.search_mse(data)
+            # (search_mse without its two log values -- the summed score and the mean clip ratio, AQ:326 -- which nothing
+            #  here reads: four small launches per quantiser less on the calibration pass)
+            best_score, alpha, _, per_channel = self._clip_search(data, need_xmax=False)
+            self.alpha.data = alpha.unsqueeze(1) if per_channel else alpha.reshape(())
 
             # AQ:519-520 runs _forward + mse_loss once more for the log value `mse`; that MSE is the winning
-            # candidate's score, which the search already holds (mean over rows of the per-row best).
+            # candidate's score, which the search already holds (mean over rows of the per-row best): formed when read.
             if self._searched:
-                self.mse = best_sum / (self.alpha.numel() if self.is_perchannel else 1)
+                self._mse_later(best_score, self.alpha.numel() if self.is_perchannel else 1)
             else:
                 self.mse = self.mse_loss(self._forward(data), data, 2, is_perchannel=self.is_perchannel).mean()
             if _dist_on():
@@ -443,6 +467,8 @@ class Conv2dQuantizer(nn.Module):
         return F.conv2d(input, weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
     def forward(self, input):
+        if not self.quant_input._steady:
+            self.quant_input.prefetch_sign(input)          # (first call: its sign is on its way while the weight calibrates)
         weight = self.quant_weight(self.weight, input)     # re-quantised on every forward, like the reference
         input = self.quant_input(input, self.weight)
         return self._conv_forward(input, weight)
@@ -460,6 +486,8 @@ class LinearQuantizer(nn.Module):
         _adopt_parameters(self, linear, linear.out_features)
 
     def forward(self, input):
+        if not self.quant_input._steady:
+            self.quant_input.prefetch_sign(input)
         weight = self.quant_weight(self.weight, input)
         input = self.quant_input(input, self.weight)
         return F.linear(input, weight, self.bias)

@@ -340,7 +340,9 @@ extern "C" int antq_fakequant_batch(const void *batch_host, const void *batch_de
 #define ANTQ_LAUNCH_D(TT, OO, AA)                                                                                   \
     do {                                                                                                            \
         const int f_ = (AA) ? 1 : 2;                                                                                \
-        const unsigned lds_ = h->lds_bytes + (g_knob_dlds > 0 ? (unsigned)g_knob_dlds : 0u);                        \
+        /* (fp32 static lane jobs, launches of many rounds: 6 workgroups = 24 wavefronts per CU, +1.5..2 points; r04_fp32_occupancy.log) */ \
+        const unsigned cap_ = (sizeof(TT) == 4 && !dyn && h->fam_blocks[f_] >= 32768u && h->lds_bytes < 24576u) ? 24576u - h->lds_bytes : 0u;  \
+        const unsigned lds_ = h->lds_bytes + (g_knob_dlds >= 0 ? (unsigned)g_knob_dlds : cap_);                    \
         if (dyn) hipLaunchKernelGGL((k_fq_batch_d<TT, OO, AA, true>), dim3(h->fam_blocks[f_]), block, lds_, st, descs, fmap[f_]);  \
         else hipLaunchKernelGGL((k_fq_batch_d<TT, OO, AA, false>), dim3(h->fam_blocks[f_]), block, lds_, st, descs, fmap[f_]);     \
     } while (0)

@@ -39,7 +39,8 @@ thread_local int g_knob_lane_u = 0;
 thread_local int g_knob_rot = 0;
 thread_local int g_knob_h = 1;
 thread_local int g_knob_hlds = -1;
-thread_local int g_knob_dlds = 0;
+thread_local int g_knob_dlds = -1;
+thread_local int g_knob_schunks = 0;
 
 }  // namespace antq
 
@@ -235,6 +236,7 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 9) g_knob_h = value;
     else if (key == 10) g_knob_hlds = value;
     else if (key == 11) g_knob_dlds = value;
+    else if (key == 12) g_knob_schunks = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }

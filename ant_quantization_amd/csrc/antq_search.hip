@@ -1,10 +1,81 @@
 // antq_search.hip -- calibration entry points of libantq: antq_search_sse, antq_search_sse_multi, antq_search_pick, antq_calibrate
 // (reference: search_mse AQ/quant_modules.py:287-326, search_adaptive_numeric_type :328-415; OQ:189-256).  gfx950 only.
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
 #include "antq_host.h"
 #include "antq_k_fakequant.h"
 #include "antq_k_search.h"
 
 namespace antq {
+
+// ---- grid of a clip-search launch -------------------------------------------------------------------------------------
+// A search workgroup (4 wavefronts) walks its share of the tensor once per candidate of its chunk of the candidate list
+// (blockIdx.y splits the list); the kernels hold 3-6 workgroups per CU (84-160 registers).  Measured (tools/
+// probe_search_split.py, profiles/r04_search_split.log):
+//   * launches of many rounds of workgroups run best with ~10 candidates per chunk whatever the tensor size (4096^2 fp32:
+//     504 us with the whole list in one chunk, 462 us with 8 chunks, 501 us with 19): short workgroups balance the CUs and
+//     XCDs dynamically, shorter ones pay the per-task load / unpack / table-build overhead too often;
+//   * launches of one to three rounds are ruled by the round count: a grid of 1.1 or 1.5 rounds costs two (768 x 3072 per
+//     row: 77.6 us with 960 workgroups on 1024 slots, 98.7 us with 1152), so there the split is the one with the smallest
+//     rounds x work per workgroup, with the kernel's real occupancy on this device.
+struct SearchGrid {
+    size_t blocks;
+    int chunks, chunk;
+};
+template <typename K>
+static int resident_workgroups(K kernel, size_t dyn_lds)
+{
+    // (cached per kernel and dynamic-LDS size: the search launches of a calibration pass repeat a handful of pairs)
+    struct Ent { const void *k; size_t lds; int n; };
+    static std::mutex mu;
+    static std::vector<Ent> seen;
+    const void *key = reinterpret_cast<const void *>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Ent &e : seen)
+        if (e.k == key && e.lds == dyn_lds) return e.n;
+    int dev = 0, ncu = 256, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    (void)hipGetLastError();
+    const int n = std::max(1, ncu) * per_cu;
+    seen.push_back(Ent{key, dyn_lds, n});
+    return n;
+}
+// units: wavefront-sized pieces (per tensor: tasks; per row: rows, each `unit_work` tasks long); n: entries of the candidate
+// list; resident: workgroups the device holds at once
+static SearchGrid search_grid(size_t units, size_t unit_work, bool pt, int n, int resident)
+{
+    const size_t cap = pt ? 256 * 4 : 256 * 8;
+    const int cmin = (n + kPtCand - 1) / kPtCand;
+    const int c_many = std::max(cmin, (n + 9) / 10);                 // ~10 candidates per chunk
+    const bool many_rounds = std::min((units + 3) / 4, cap) * (size_t)c_many >= 3 * (size_t)resident;
+    SearchGrid best{0, 0, 0};
+    double best_cost = 0.0;
+    for (int c = cmin; c <= std::min(n, 64); c++) {
+        const int want = g_knob_schunks > 0 ? std::max(cmin, std::min(g_knob_schunks, n)) : (many_rounds ? c_many : 0);   // knob 12 (A/B)
+        if (want > 0 && c != want) continue;
+        const int chunk = (n + c - 1) / c;
+        const int ce = (n + chunk - 1) / chunk;
+        if (ce != c && c != cmin && want == 0) continue;             // (the same split as a smaller c)
+        size_t blocks = std::min((units + 3) / 4, cap);
+        if (pt) {
+            if (ce > kWsSlots) break;
+            blocks = std::min(blocks, (size_t)(kWsSlots / ce));
+        }
+        const size_t upw = (units + blocks * 4 - 1) / (blocks * 4);               // units a wavefront walks
+        const size_t rounds = (blocks * (size_t)ce + (size_t)resident - 1) / (size_t)resident;
+        // per unit and candidate ~1, plus the load / unpack / magnitude pass of the unit (~3 candidates' worth)
+        const double cost = (double)rounds * (double)upw * (double)unit_work * ((double)chunk + 3.0);
+        if (best.chunks == 0 || cost < best_cost * 0.98) { best = SearchGrid{blocks, ce, chunk}; best_cost = cost; }
+    }
+    if (getenv("ANTQ_DEBUG_GRID"))
+        fprintf(stderr, "search_grid: units %zu x %zu pt %d n %d resident %d -> blocks %zu chunks %d chunk %d\n", units, unit_work,
+                (int)pt, n, resident, best.blocks, best.chunks, best.chunk);
+    return best;
+}
 
 template <typename T, bool OVP>
 static int launch_search(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
@@ -40,33 +111,26 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
     const bool pt = rows == 1;
     // per tensor: tasks over all wavefronts; per row: one wavefront per row (it walks the row's tasks in order)
-    size_t blocks = ((pt ? total : rows) + 3) / 4;
-    const size_t cap = pt ? 256 * 4 : 256 * 8;
-    if (blocks > cap) blocks = cap;
-    // enough wavefronts to fill 256 CUs x 8 waves/SIMD: split the candidates when there are few rows
-    int chunks = (int)std::min<size_t>((size_t)ncand, std::max<size_t>(1, (size_t)2048 / blocks));
-    chunks = std::max(chunks, (ncand + kPtCand - 1) / kPtCand);
-    const int cand_chunk = (ncand + chunks - 1) / chunks;
-    chunks = (ncand + cand_chunk - 1) / cand_chunk;
-    if (pt) {
-        if (chunks > kWsSlots) return ANTQ_ERR_UNSUPPORTED;
-        blocks = std::min(blocks, (size_t)(kWsSlots / chunks));
-    }
     const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
     const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr;
     const XArgs xa = xargs_from_plan(plan_host, pa);
-    const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
     const uint4 *xv = static_cast<const uint4 *>(x);
+    SearchGrid sg{0, 0, 0};
 #define ANTQ_LAUNCH_S(PT_, XD_, U_)                                                                                \
-    hipLaunchKernelGGL((k_search_sse<T, OVP, U_, PT_, XD_>), gdim, bdim, (XD_) ? 0 : lds, st, xv, (uint32_t)total,   \
-                       (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, gmax, sse, ws, pa,          \
-                       plan_tab_ptr(plan_dev), cand_chunk, xa)
+    do {                                                                                                           \
+        const int resident_ = resident_workgroups(k_search_sse<T, OVP, U_, PT_, XD_>, (XD_) ? 0 : lds);            \
+        sg = search_grid(PT_ ? total : rows, PT_ ? 1 : tpr, PT_, ncand, resident_);                                \
+        if (sg.chunks == 0) return ANTQ_ERR_UNSUPPORTED;                                                           \
+        hipLaunchKernelGGL((k_search_sse<T, OVP, U_, PT_, XD_>), dim3((unsigned)sg.blocks, (unsigned)sg.chunks), dim3(256), \
+                           (XD_) ? 0 : lds, st, xv, (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row,  \
+                           ratios, ncand, gmax, sse, ws, pa, plan_tab_ptr(plan_dev), sg.chunk, xa);                 \
+    } while (0)
 #define ANTQ_LAUNCH_SU(PT_, XD_) do { if (U == 8) ANTQ_LAUNCH_S(PT_, XD_, 8); else ANTQ_LAUNCH_S(PT_, XD_, 4); } while (0)
     if (pt) { if (xd) ANTQ_LAUNCH_SU(true, true); else ANTQ_LAUNCH_SU(true, false); }
     else    { if (xd) ANTQ_LAUNCH_SU(false, true); else ANTQ_LAUNCH_SU(false, false); }
 #undef ANTQ_LAUNCH_SU
 #undef ANTQ_LAUNCH_S
-    if (pt) hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)blocks, cand_chunk, sse);
+    if (pt) hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)sg.blocks, sg.chunk, sse);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
@@ -101,27 +165,20 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
     const bool pt = rows == 1;
-    size_t blocks = ((pt ? total : rows) + 3) / 4;
-    const size_t cap = pt ? 256 * 4 : 256 * 8;
-    if (blocks > cap) blocks = cap;
-    // enough wavefronts to fill 256 CUs x 8 waves/SIMD: split the flattened (type, ratio) list when there are few rows
     const int nflat = ntypes * ncand;
-    int chunks = (int)std::min<size_t>((size_t)nflat, std::max<size_t>(1, (size_t)2048 / blocks));
-    chunks = std::max(chunks, (nflat + kPtCand - 1) / kPtCand);
-    const int flat_chunk = (nflat + chunks - 1) / chunks;
-    chunks = (nflat + flat_chunk - 1) / flat_chunk;
-    if (pt) {
-        if (chunks > kWsSlots) return ANTQ_ERR_UNSUPPORTED;
-        blocks = std::min(blocks, (size_t)(kWsSlots / chunks));
-    }
-    const dim3 gdim((unsigned)blocks, (unsigned)chunks), bdim(256);
     const uint4 *xv = static_cast<const uint4 *>(x);
+    SearchGrid sg{0, 0, 0};
 #define ANTQ_LAUNCH_M(PT_, U_)                                                                                            \
-    hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U_, PT_>), gdim, bdim, 0, st, xv, (uint32_t)total, (uint32_t)vpr,      \
-                       (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, flat_chunk)
+    do {                                                                                                                  \
+        const int resident_ = resident_workgroups(k_search_sse_multi<T, OVP, U_, PT_>, 0);                                \
+        sg = search_grid(PT_ ? total : rows, PT_ ? 1 : tpr, PT_, nflat, resident_);                                       \
+        if (sg.chunks == 0) return ANTQ_ERR_UNSUPPORTED;                                                                  \
+        hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U_, PT_>), dim3((unsigned)sg.blocks, (unsigned)sg.chunks), dim3(256), 0, st, \
+                           xv, (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, sg.chunk); \
+    } while (0)
     if (pt) {
         if (U == 8) ANTQ_LAUNCH_M(true, 8); else ANTQ_LAUNCH_M(true, 4);
-        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nflat), dim3(256), 0, st, ws, (uint32_t)blocks, flat_chunk, sse);
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nflat), dim3(256), 0, st, ws, (uint32_t)sg.blocks, sg.chunk, sse);
     } else {
         if (U == 8) ANTQ_LAUNCH_M(false, 8); else ANTQ_LAUNCH_M(false, 4);
     }
@@ -195,7 +252,7 @@ extern "C" int antq_search_pick(const double *sse, const float *xmax, const floa
 {
     if (na == 0) return ANTQ_OK;
     if (!sse || !xmax || !ratios || !best_score || !best_alpha || ncand < 0 || row_len == 0) return ANTQ_ERR_ARG;
-    const size_t blocks = (na + 255) / 256;
+    const size_t blocks = (na + 3) / 4;              // one wavefront per row
     if (blocks > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(antq::k_search_pick, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), sse, xmax,
                        ratios, ncand, na, (double)row_len, best_score, best_alpha);

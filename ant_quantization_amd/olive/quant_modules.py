@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, core, grids
-from .._mirror import HostMirrorMixin, WeightsAtRestMixin
+from .._mirror import CalibrationMixin, HostMirrorMixin, WeightsAtRestMixin
 
 
 class QuantBase():
@@ -42,7 +42,7 @@ class QuantBase():
             return QuantBase._quantization(real_val, quant_grid, plan)
 
 
-class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
+class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module):
     def __init__(self, mode="base", bit=8, is_signed=True, is_enable=False, is_input=False, args=None, operator=None):
         super(Quantizer, self).__init__()
         self.mode = mode
@@ -106,9 +106,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         self.name = name
         self.is_enable = False
 
-    def update_signed(self, tensor):
-        if not self.is_signed and tensor.min() < 0:      # already signed (weights): nothing to learn, no sync
-            self.is_signed = True
+    # (update_signed / prefetch_sign / the lazily formed `mse`: _mirror.CalibrationMixin)
 
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
         super()._load_from_state_dict(state_dict, prefix, *a, **k)
@@ -197,9 +195,10 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         return _lib.xmax_3sigma(t, rows, t.numel() // rows, per_row=per_channel)
 
     @torch.no_grad()
-    def search_mse(self, tensor):
+    def _clip_search(self, tensor, need_xmax=True):
+        """search_mse's device work: (best_score [rows or 1], alpha [rows or 1], x_max), nothing reduced or reshaped yet."""
         per_channel = self.is_perchannel and (not self.is_input)
-        x_max = self._three_sigma(tensor, per_channel)
+        x_max = None
         lb = int(self.w_low) if per_channel else int(self.a_low)
         ub = int(self.w_up) if per_channel else int(self.a_up)
         plan = self._ensure_plan()
@@ -207,9 +206,25 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         if hit is not None:
             best_score, alpha, ratios = hit       # this very search was part of the type selection's single pass
         else:
-            best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 2, plan, self._gmax,
-                                                         ovp=not self._no_outlier)
+            # (a parallel branch's input quantiser may have searched this very tensor a moment ago: core.SearchMemo)
+            ovp = not self._no_outlier
+            key = ("olive", lb, ub, 2, plan.grid.tobytes(), self._gmax, ovp) if not per_channel else None
+            seen = core.search_memo.get(tensor, key) if key else None
+            if seen is not None:
+                best_score, alpha, ratios = seen[0], seen[1].clone(), seen[2]
+            else:
+                x_max = self._three_sigma(tensor, per_channel)
+                best_score, alpha, ratios = core.clip_search(tensor, x_max, per_channel, lb, ub, 2, plan, self._gmax, ovp=ovp)
+                if key:
+                    core.search_memo.put(tensor, key, (best_score, alpha.clone(), ratios))
         self._searched = ratios is not None
+        if x_max is None and need_xmax:
+            x_max = self._three_sigma(tensor, per_channel)
+        return best_score, alpha, x_max, per_channel
+
+    @torch.no_grad()
+    def search_mse(self, tensor):
+        best_score, alpha, x_max, per_channel = self._clip_search(tensor)
         ratio = (alpha / x_max).mean()        # 0-dim tensor: the reference's float, without the sync
         if per_channel:
             return best_score.sum(), alpha.unsqueeze(1), ratio
@@ -228,9 +243,17 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
         per_channel = self.is_perchannel and (not self.is_input)
         lb = int(self.w_low) if per_channel else int(self.a_low)
         ub = int(self.w_up) if per_channel else int(self.a_up)
-        res = core.clip_search_types(data, self._three_sigma(data, per_channel), per_channel, lb, ub, 2,
-                                     [_lib.plan_for(f) for f in fulls], [float(np.max(n)) for n in normals],
-                                     ovp=not self._no_outlier)
+        gm = [float(np.max(n)) for n in normals]
+        key = (("olive-types", lb, ub, 2, tuple(f.tobytes() for f in fulls), tuple(gm), not self._no_outlier)
+               if not per_channel and len(fulls) > 1 else None)
+        res = core.search_memo.get(data, key) if key else None
+        if res is not None:
+            res = [(b, a.clone(), r) for b, a, r in res]
+        else:
+            res = core.clip_search_types(data, self._three_sigma(data, per_channel), per_channel, lb, ub, 2,
+                                         [_lib.plan_for(f) for f in fulls], gm, ovp=not self._no_outlier)
+            if key and res is not None:
+                core.search_memo.put(data, key, [(b, a.clone(), r) for b, a, r in res])
         mse_list = []
         if res is not None:
             self._type_search = {(f.tobytes(), lb, ub): r for f, r in zip(fulls, res)}
@@ -271,11 +294,14 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, nn.Module):
             raise RuntimeError("Unsupported mode: " + self.mode)
         self._install(grids.olive_grid(self.mode, self._bits(), self.is_signed), outl)
 
-        best_sum, self.alpha.data, alpha_ratio = self.search_mse(data)
+        # (search_mse without its two log values, the summed score and the mean clip ratio, which nothing here reads)
+        best_score, alpha, _, per_channel = self._clip_search(data, need_xmax=False)
+        self.alpha.data = alpha.unsqueeze(1) if per_channel else alpha.reshape(())
 
-        # OQ:283-284 runs _forward + mse_loss once more for the log value `mse`: it is the winning candidate's score
+        # OQ:283-284 runs _forward + mse_loss once more for the log value `mse`: it is the winning candidate's score,
+        # formed when somebody reads it
         if self._searched:
-            self.mse = best_sum / (self.alpha.numel() if self.is_perchannel else 1)
+            self._mse_later(best_score, self.alpha.numel() if self.is_perchannel else 1)
         else:
             self.mse = self.mse_loss(self._forward(data), data, 2, is_perchannel=self.is_perchannel).mean()
         print(self.mode, end="\t")
@@ -361,6 +387,8 @@ class Conv1dQuantizer(nn.Module):
         return x.view(size_out)
 
     def forward(self, input):
+        if not self.quant_input._steady:
+            self.quant_input.prefetch_sign(input)          # (first call: its sign is on its way while the weight calibrates)
         weight = self.quant_weight(self.weight, input)
         input = self.quant_input(input, self.weight)
         return self._conv_forward(input, weight)
@@ -389,6 +417,8 @@ class Conv2dQuantizer(nn.Module):
         return F.conv2d(input, weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
     def forward(self, input):
+        if not self.quant_input._steady:
+            self.quant_input.prefetch_sign(input)          # (first call: its sign is on its way while the weight calibrates)
         weight = self.quant_weight(self.weight, input)
         input = self.quant_input(input, self.weight)
         return self._conv_forward(input, weight)
@@ -409,6 +439,8 @@ class LinearQuantizer(nn.Module):
         _clone_wb(self, linear)
 
     def forward(self, input):
+        if not self.quant_input._steady:
+            self.quant_input.prefetch_sign(input)          # (first call: its sign is on its way while the weight calibrates)
         weight = self.quant_weight(self.weight, input)
         input = self.quant_input(input, self.weight)
         return F.linear(input, weight, self.bias)

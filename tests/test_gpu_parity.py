@@ -1749,8 +1749,9 @@ def test_quantizer_end_to_end_long_rows_single_read_type_selection(antq_lib, dev
             expect_single = 1 if any(t in mode for t in ("float1", "float2", "float3", "float4")) and "float" in q.mode and q.mode != "float" else 0
             if tree == "olive" and bit >= 5 and om == "ovp":
                 # 5-bit codebook + outliers: more than 128 buckets, no per-row table -> the single-read entry declines and the
-                # quantiser searches type by type (2 types + the installed grid)
-                assert calls == {"multi": 1, "single": 3}, (k, calls)
+                # quantiser searches type by type (2 types + the installed grid; for a per-tensor input the installed grid's
+                # search is the one a moment ago on this very tensor: core.SearchMemo)
+                assert calls == {"multi": 1, "single": 2 if is_input else 3}, (k, calls)
             else:
                 assert calls["multi"] >= 1 and calls["single"] == expect_single, (k, calls, q.mode)
             same = _check_calibration(antq_lib, dev, q, x, out, k, sel, tr, lo, up, 1 if tree == "ant" else 2,
@@ -3446,4 +3447,199 @@ def test_auto_weight_bank_is_the_default_and_bit_identical(antq_lib, dev, tree, 
     m2 = copy.deepcopy(model)
     assert all(m.quant_weight._auto_bank is None and m.quant_weight._bank is None or True for m in m2.modules() if hasattr(m, "quant_weight"))
     pickle.dumps(model.state_dict())
+    capsys.readouterr()
+
+
+def test_search_pick_selection_rule(antq_lib, dev):
+    """antq_search_pick (one wavefront per row, candidates over the lanes) against the reference's sequential loop
+    (AQ:299-306: best = 1e10, ascending candidates, strict '<'): ties keep the earliest candidate, NaN scores and scores of
+    1e10 or more are never taken (alpha stays x_max), candidate lists shorter and longer than a wavefront."""
+    import torch
+    rng = np.random.default_rng(11)
+    for ncand, na in ((1, 1), (7, 5), (64, 3), (65, 9), (76, 1), (76, 300), (200, 17)):
+        row_len = 768
+        sse = rng.random((ncand, na)) * 50.0
+        # ties (exact duplicates, some of them the minimum), NaNs, huge scores, whole rows without any eligible candidate
+        for r in range(na):
+            k = rng.integers(0, 6)
+            if k == 0 and ncand > 2:
+                i, j = sorted(rng.choice(ncand, 2, replace=False))
+                sse[i, r] = sse[j, r] = 0.001
+            elif k == 1:
+                sse[rng.integers(0, ncand), r] = np.nan
+            elif k == 2:
+                sse[:, r] = 1e10 * row_len * (1.0 + rng.random(ncand))
+            elif k == 3:
+                sse[:, r] = np.nan
+            elif k == 4 and ncand > 70:
+                sse[:, r] = 5.0
+                sse[[3, 67], r] = 1.0                     # the same minimum in two different lanes' strides and in one lane's
+                sse[67 - 64, r] = 1.0
+        xm = (rng.random(na) + 0.5).astype(np.float32)
+        ratios = np.float32([np.float32((75 + c) * 0.01) for c in range(ncand)])
+        best_ref = np.full(na, 1e10, np.float32)
+        alpha_ref = xm.copy()
+        for r in range(na):
+            for c in range(ncand):
+                with np.errstate(all="ignore"):
+                    score = np.float32(sse[c, r] / float(row_len))
+                if score < best_ref[r]:
+                    best_ref[r] = score
+                    alpha_ref[r] = np.float32(xm[r] * ratios[c])
+        best, alpha = antq_lib.search_pick(torch.from_numpy(sse).to(dev), torch.from_numpy(xm).to(dev),
+                                           torch.from_numpy(ratios).to(dev), row_len)
+        assert f32_same(best.cpu().numpy(), best_ref), (ncand, na)
+        assert f32_same(alpha.cpu().numpy(), alpha_ref), (ncand, na)
+
+
+def test_search_sums_do_not_depend_on_the_grid_split(antq_lib, dev, oracle):
+    """The clip-search launches split the candidate list over blockIdx.y by a cost model (rounds of resident workgroups x work
+    per workgroup, antq_search.hip: search_grid); the sums of squared errors must not depend on that split: every candidate's
+    sum is formed in one fixed order whatever chunk it rides in.  Checked by evaluating the same candidates as ONE list and
+    as several shorter lists (each its own launch, hence its own split), per row and per tensor, fp32 and bf16, several sizes
+    (few / many workgroups per round), one codebook and the multi-codebook kernel."""
+    import torch
+    from ant_quantization_amd import grids
+    rng = np.random.default_rng(5)
+    plans = [antq_lib.plan_for(grids.ant_flint(4, True)), antq_lib.plan_for(grids.ant_int(4, True))]
+    ratios_np = np.float32([np.float32(i * 0.01) for i in range(75, 151)])
+    for (rows, K), per_row, bf16 in (((768, 768), True, False), ((96, 3072), True, True), ((2048, 768), False, False),
+                                     ((8192, 768), False, False), ((1024, 3072), False, True), ((3, 512), True, False)):
+        x = (rng.standard_normal((rows, K)) * 0.05).astype(np.float32)
+        xh = oracle.f32_to_bf16(x) if bf16 else x
+        xt = to_dev(xh, dev, bf16)
+        r_, k_ = (rows, K) if per_row else (1, rows * K)
+        xm = antq_lib.absmax(xt, r_, k_, per_row=per_row).reshape(-1)
+        ratios = torch.from_numpy(ratios_np).to(dev)
+        whole = antq_lib.search_sse(xt, r_, k_, xm, per_row, ratios, plans[0], 10.0)
+        for cut in (1, 5, 19, 40):
+            parts = [antq_lib.search_sse(xt, r_, k_, xm, per_row, ratios[a:a + cut].contiguous(), plans[0], 10.0)
+                     for a in range(0, 76, cut)]
+            assert torch.equal(torch.cat(parts, 0), whole), (rows, K, per_row, bf16, cut)
+        multi = antq_lib.search_sse_multi(xt, r_, k_, xm, per_row, ratios, plans, [10.0, 7.0])
+        if multi is not None:
+            assert torch.equal(multi[0], whole), (rows, K, per_row, bf16)
+            second = antq_lib.search_sse(xt, r_, k_, xm, per_row, ratios, plans[1], 7.0)
+            assert torch.equal(multi[1], second), (rows, K, per_row, bf16)
+
+
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_sign_probe_and_lazy_log_values_on_the_calibration_pass(tree, dev, capsys):
+    """The wrapper layers ask for the input's sign BEFORE they calibrate their weight (prefetch_sign: the minimum travels to
+    pinned memory while the weight's calibration is issued) and `mse` is formed when read: same signedness, alphas, grids,
+    outputs and `mse` as quantisers calibrated without the probe (update_signed reading on the spot), for inputs with and
+    without negative values; a probe taken on ANOTHER tensor object, or on one edited in place since, is not trusted."""
+    import importlib
+    import torch
+    import torch.nn as nn
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qutil.set_quantizer(_args(mode="flint", wbit=4, abit=4))
+
+    def make():
+        torch.manual_seed(9)
+        net = nn.Sequential(nn.Linear(256, 512), nn.ReLU(), nn.Linear(512, 128))
+        m = qmod.quantize_model(net).to(dev).eval()
+        qutil.enable_quantization(m)
+        return m
+
+    torch.manual_seed(1)
+    x = torch.randn(64, 256, device=dev)
+    with torch.no_grad():
+        a = make()
+        ya = a(x)                                            # probes on
+        b = make()
+        for m in b.modules():
+            if hasattr(m, "quant_input"):
+                m.quant_input.prefetch_sign = lambda t: None     # reference behaviour: the read happens on the spot
+        yb = b(x)
+        assert torch.equal(ya, yb)
+        la = [m for m in a.modules() if hasattr(m, "quant_input")]
+        lb = [m for m in b.modules() if hasattr(m, "quant_input")]
+        assert [m.quant_input.is_signed for m in la] == [m.quant_input.is_signed for m in lb] == [True, False]
+        for ma, mb in zip(la, lb):
+            for qa, qb in ((ma.quant_input, mb.quant_input), (ma.quant_weight, mb.quant_weight)):
+                assert torch.equal(qa.alpha, qb.alpha) and torch.equal(qa.quant_grid, qb.quant_grid)
+                assert qa._sign_probe is None
+                assert torch.equal(qa.mse, qb.mse) and qa.mse.numel() == 1 and float(qa.mse) > 0
+                assert qa.mse is qa.mse                      # formed once
+        # a stale probe: taken on a tensor that is edited in place afterwards / on another object
+        c = make()
+        lin = [m for m in c.modules() if hasattr(m, "quant_input")][0]
+        pos = torch.rand(64, 256, device=dev)
+        lin.quant_input.prefetch_sign(pos)
+        pos.sub_(0.5)                                        # now it has negative values; the probe saw none
+        lin.quant_input.update_signed(pos)
+        assert lin.quant_input.is_signed
+        d = make()
+        lin = [m for m in d.modules() if hasattr(m, "quant_input")][0]
+        lin.quant_input.prefetch_sign(torch.rand(64, 256, device=dev))
+        lin.quant_input.update_signed(-torch.rand(64, 256, device=dev))
+        assert lin.quant_input.is_signed and lin.quant_input._sign_probe is None
+    capsys.readouterr()
+
+
+@pytest.mark.parametrize("tree,mode", [("ant", "flint"), ("ant", "ant-int-flint"), ("olive", "flint"), ("olive", "ant-int-flint")])
+def test_parallel_branches_search_their_shared_input_once(tree, mode, dev, capsys):
+    """Query / key / value projections calibrate their input quantisers on ONE tensor object: the per-tensor clip search
+    (and the type selection's pass) runs once and is looked up twice (core.SearchMemo) -- same alphas, grids and outputs as
+    with the memo switched off; an in-place edit of the tensor (version counter) or another tensor object is searched anew;
+    every quantiser owns its alpha storage."""
+    import importlib
+    import torch
+    import torch.nn as nn
+    from ant_quantization_amd import core
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qutil.set_quantizer(_args(mode=mode, wbit=4, abit=4))
+
+    class QKV(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.k, self.v, self.o = nn.Linear(256, 256), nn.Linear(256, 256), nn.Linear(256, 256), nn.Linear(256, 64)
+
+        def forward(self, x):
+            return self.o(self.q(x) * torch.sigmoid(self.k(x)) + self.v(x))
+
+    def make():
+        torch.manual_seed(4)
+        m = qmod.quantize_model(QKV()).to(dev).eval()
+        qutil.enable_quantization(m)
+        return m
+
+    torch.manual_seed(2)
+    x = torch.randn(128, 256, device=dev)
+    with torch.no_grad():
+        core.search_memo.clear()
+        core.search_memo.hits = 0
+        a = make()
+        ya = a(x)
+        assert core.search_memo.hits >= 2                        # k and v found q's search (type pass and / or clip search)
+        hits = core.search_memo.hits
+        core.search_memo.enabled = False
+        try:
+            b = make()
+            yb = b(x)
+        finally:
+            core.search_memo.enabled = True
+        assert core.search_memo.hits == hits and torch.equal(ya, yb)
+        for (na, qa), (nb, qb) in zip(a.named_modules(), b.named_modules()):
+            if hasattr(qa, "quant_input"):
+                for u, v in ((qa.quant_input, qb.quant_input), (qa.quant_weight, qb.quant_weight)):
+                    assert u.mode == v.mode and torch.equal(u.alpha, v.alpha) and torch.equal(u.quant_grid, v.quant_grid), na
+        ptrs = [m.quant_input.alpha.data_ptr() for m in a.modules() if hasattr(m, "quant_input")]
+        assert len(set(ptrs)) == len(ptrs)                       # nobody shares the memo's tensors
+        # the same object edited in place, and a different object with the same values: searched anew
+        core.search_memo.clear()
+        core.search_memo.hits = 0
+        c = make()
+        lin = [m for m in c.modules() if hasattr(m, "quant_input")]
+        x2 = x.clone()
+        lin[0].quant_input(x2)
+        x2.mul_(2.0)
+        lin[1].quant_input(x2)
+        lin[2].quant_input(x2.clone())
+        assert core.search_memo.hits == 0
+        assert torch.equal(lin[1].quant_input.alpha, lin[2].quant_input.alpha)
+        assert not torch.equal(lin[0].quant_input.alpha, lin[1].quant_input.alpha)
     capsys.readouterr()
