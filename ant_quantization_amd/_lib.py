@@ -15,7 +15,7 @@ import torch  # must be imported before libantq.so so that ONE libamdhip64 is sh
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ANTQ_LIB") or os.path.join(_HERE, "libantq.so")   # ANTQ_LIB: A/B builds (dev)
 
-ABI_VERSION = 4         # include/antq.h ANTQ_ABI_VERSION this binding was written against
+ABI_VERSION = 5         # include/antq.h ANTQ_ABI_VERSION this binding was written against
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_OVP = 1
 FLAG_DYNAMIC = 2
@@ -57,11 +57,12 @@ def lib():
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
                              "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
                              "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma",
-                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h"):
+                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h", "antq_calibrate_batch"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 L.antq_search_workspace_bytes.restype = ctypes.c_size_t
                 L.antq_calibrate_workspace_bytes.restype = ctypes.c_size_t
+                L.antq_calibrate_batch_workspace_bytes.restype = ctypes.c_size_t
                 # declared signatures: plain python ints go straight through (no per-call wrapper objects)
                 vp, sz, ci, cf, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_uint
                 L.antq_fakequant.argtypes = [vp, vp, vp, sz, sz, vp, ci, cf, vp, vp, cu, ci, vp]
@@ -615,6 +616,67 @@ def calibrate(x, rows, row_len, per_row, plans, gmaxs, lb, ub, step, xmax="absma
                                   _vp(alpha), _vp(score), _vp(typ), _vp(ws), ctypes.c_size_t(nbytes), _stream(x.device))
     _check(rc, "antq_calibrate")
     return alpha, score, typ, xm
+
+
+class _CalibJob(ctypes.Structure):           # include/antq.h: antq_calib_job
+    _fields_ = [("x_dev", ctypes.c_void_p), ("rows", ctypes.c_size_t), ("row_len", ctypes.c_size_t),
+                ("alpha_per_row", ctypes.c_int), ("xmax_mode", ctypes.c_int), ("xmax_dev", ctypes.c_void_p),
+                ("lb", ctypes.c_int), ("ub", ctypes.c_int), ("step", ctypes.c_int), ("ntypes", ctypes.c_int),
+                ("gmax_host", ctypes.POINTER(ctypes.c_float)), ("plan_host", ctypes.POINTER(ctypes.c_void_p)),
+                ("plan_dev", ctypes.POINTER(ctypes.c_void_p)), ("alpha_dev", ctypes.c_void_p),
+                ("score_dev", ctypes.c_void_p), ("type_dev", ctypes.c_void_p)]
+
+
+def calibrate_batch(jobs, xmax="absmax", ovp=False):
+    """antq_calibrate_batch: the calibrations of many quantisers (one model's weights) in one C call, stream-ordered, no
+    device->host sync.  jobs: sequence of (x, rows, row_len, per_row, plans, gmaxs, lb, ub, step); one dtype and one device
+    for the batch.  Returns (results, types): results[i] = (alpha [ntypes_i, na_i], score [ntypes_i], xmax [na_i]) -- views
+    of two flat float32 buffers -- and types: ONE int32 tensor with the n type picks (a single read-back for the model)."""
+    jobs = list(jobs)
+    if not jobs:
+        return [], None
+    x0 = jobs[0][0]
+    _require_gpu(x0, "x")
+    dt = _DTYPES.get(x0.dtype)
+    if dt is None or dt == F64:
+        raise AntqError("unsupported dtype %s" % x0.dtype)
+    mode = {"absmax": XMAX_ABSMAX, "3sigma": XMAX_3SIGMA}.get(xmax)
+    if mode is None:
+        raise AntqError("xmax must be 'absmax' or '3sigma'")
+    dev = x0.device
+    n = len(jobs)
+    arr = (_CalibJob * n)()
+    keep, sizes = [], []
+    total = 0
+    for x, rows, row_len, per_row, plans, gmaxs, lb, ub, step in jobs:
+        if x.device != dev or x.dtype != x0.dtype or not x.is_contiguous():
+            raise AntqError("calibrate_batch: one device, one dtype, contiguous tensors")
+        if rows * row_len != x.numel() or len(plans) < 1 or len(plans) != len(gmaxs):
+            raise AntqError("calibrate_batch: rows*row_len != numel, or plans / gmaxs mismatch")
+        na, nt = (rows if per_row else 1), len(plans)
+        sizes.append((na, nt, total))
+        total += nt * na + nt + na
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    types = torch.empty(n, dtype=torch.int32, device=dev)
+    results = []
+    for i, ((x, rows, row_len, per_row, plans, gmaxs, lb, ub, step), (na, nt, off)) in enumerate(zip(jobs, sizes)):
+        alpha, score, xm = flat[off:off + nt * na].view(nt, na), flat[off + nt * na:off + nt * na + nt], flat[off + nt * na + nt:off + nt * na + nt + na]
+        ph = (ctypes.c_void_p * nt)(*[p.host_addr for p in plans])
+        pd = (ctypes.c_void_p * nt)(*[p.dev(dev).data_ptr() for p in plans])
+        gm = (ctypes.c_float * nt)(*[float(g) for g in gmaxs])
+        keep.append((ph, pd, gm))
+        arr[i] = _CalibJob(x.data_ptr(), rows, row_len, 1 if per_row else 0, mode, xm.data_ptr(), int(lb), int(ub), int(step), nt,
+                           gm, ph, pd, alpha.data_ptr(), score.data_ptr(), types.data_ptr() + 4 * i)
+        results.append((alpha, score, xm))
+    nbytes = lib().antq_calibrate_batch_workspace_bytes(arr, ctypes.c_int(n))
+    if nbytes == 0:
+        raise AntqError("antq_calibrate_batch: bad candidate range / type count")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with _on_device(dev):
+        rc = lib().antq_calibrate_batch(arr, ctypes.c_int(n), ctypes.c_int(dt), ctypes.c_uint(FLAG_OVP if ovp else 0), _vp(ws),
+                                        ctypes.c_size_t(nbytes), _stream(dev))
+    _check(rc, "antq_calibrate_batch")
+    return results, types
 
 
 def search_pick(sse, xmax, ratios, row_len):

@@ -51,6 +51,13 @@ class HostMirrorMixin:
         return out
 
 
+def _lib_tensor_key(t):
+    """What has to be unchanged for a search run ahead of the forward to stand for the tensor now at hand."""
+    if not isinstance(t, torch.Tensor) or torch.is_inference(t):
+        return None
+    return (t.data_ptr(), t._version, t.dtype, tuple(t.shape), t.is_contiguous())
+
+
 class _PinnedSlots:
     """A small ring of pinned host floats for device->host copies nobody wants to wait for at issue time."""
 
@@ -79,6 +86,20 @@ class CalibrationMixin:
     * `mse`, the log value of the reference (AQ:519-520), is formed when somebody reads it.
     """
     _sign_probe = None
+    _calib_ready = None           # (weight key, spec, type, alpha, score, rows) from weight_bank.AutoBank.precalibrate
+
+    def _before_calibration(self, tensor):
+        """First thing in tensor_forward of an enabled quantiser.  A weight quantiser that is not calibrated yet lets the model
+        search all its weights at once (weight_bank.AutoBank.precalibrate); one whose search is done installs the result --
+        provided the tensor in its hands is still the one that was searched (address, version, shape)."""
+        if self._steady or self.is_input:
+            return
+        if self._calib_ready is None and self._auto_bank is not None:
+            self._auto_bank.precalibrate()
+        ready, self._calib_ready = self._calib_ready, None
+        if ready is not None and ready[0] == _lib_tensor_key(tensor) and self._hm_get('has_inited_quant_para') == 0:
+            with torch.no_grad():
+                self._calib_apply(*ready[1:])
 
     def prefetch_sign(self, tensor):
         if self.is_signed or self._steady or not isinstance(tensor, torch.Tensor) or not tensor.is_cuda or tensor.numel() == 0:

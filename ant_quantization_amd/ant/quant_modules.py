@@ -386,6 +386,51 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
             self._type_search = None
             core.forget_absmax()
 
+    # ---------------------------------------------------------------- calibrated ahead of the forward (weight_bank.precalibrate)
+    def _calib_spec(self, weight):
+        """What _init_quant_para would search for this WEIGHT quantiser (AQ:468-533): the candidate types in the order of
+        search_adaptive_numeric_type, their codebooks (duplicates searched once, the first of equals wins as np.argsort's
+        does), the window -- or None when the quantiser keeps the per-layer path."""
+        if self.is_input or not self.is_signed or not self.is_perchannel or self.mode in ("base", "outlier"):
+            return None
+        if not (self.is_enable and self.is_enable_weight) or self._steady or self._hm_get('has_inited_quant_para') != 0:
+            return None
+        bit = self._bits()
+        if bit > 6:
+            modes = ["int"]
+        elif "ant-" in self.mode:
+            modes = [t for t in _TYPE_ORDER if ("-" + t) in self.mode]
+            if not modes or any(t in ("float1", "float2", "float3", "float4") for t in modes):
+                return None                # (those search float_value(1) and install another grid, AQ:370-397)
+        elif self.mode in _TYPE_ORDER:
+            modes = [self.mode]
+        else:
+            return None                    # (the per-layer path raises the reference's error)
+        lb, ub = self._search_window(True)
+        if not range(lb, ub, 1):
+            return None
+        uniq = {}
+        for t in modes:
+            g = np.ascontiguousarray(grids.ant_grid(t, bit, True), dtype=np.float32)
+            uniq.setdefault(g.tobytes(), (t, g))
+        with np.errstate(all="ignore"):
+            return dict(modes=[t for t, _ in uniq.values()], grids=[g for _, g in uniq.values()],
+                        gmaxs=[float(np.max(g)) for _, g in uniq.values()], lb=lb, ub=ub, step=1, stat="absmax", ovp=False)
+
+    def _calib_apply(self, spec, t, alpha, score, rows):
+        """The state _init_quant_para leaves behind, from the batch's results for type t."""
+        self.mode = spec["modes"][t]
+        self._install_grid(spec["grids"][t])
+        self.alpha.data = alpha.clone().unsqueeze(1)
+        self._searched = True
+        self._mse_later(score, rows)
+        if _rank() == 0:
+            print(self.mode, end="\t")
+            print("%d-bit \t %s," % (self._bits(), self.name))
+        self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
+        self._hm_known('has_inited_quant_para', 1.0)
+        self._steady = True
+
     # ---------------------------------------------------------------- steady state
     # (_rest_buffer / _rest_alpha / _at_rest: _mirror.WeightsAtRestMixin)
 
@@ -407,6 +452,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
             if not self.is_enable_weight:
                 return tensor
 
+        self._before_calibration(tensor)
         with torch.no_grad():
             self._init_quant_para(tensor, input_tensor)
 

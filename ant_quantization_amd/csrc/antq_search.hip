@@ -358,6 +358,34 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+extern "C" size_t antq_calibrate_batch_workspace_bytes(const antq_calib_job *jobs, int n)
+{
+    if (!jobs || n < 0) return 0;
+    size_t need = 256;
+    for (int i = 0; i < n; i++) {
+        const antq_calib_job &J = jobs[i];
+        const size_t b = antq_calibrate_workspace_bytes(J.rows, J.alpha_per_row, J.lb, J.ub, J.step, J.ntypes);
+        if (b == 0) return 0;
+        need = std::max(need, b);
+    }
+    return need;
+}
+
+extern "C" int antq_calibrate_batch(const antq_calib_job *jobs, int n, int dtype, unsigned flags, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    if (n == 0) return ANTQ_OK;
+    if (!jobs || n < 0) return ANTQ_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        const antq_calib_job &J = jobs[i];
+        const int rc = antq_calibrate(J.x_dev, J.rows, J.row_len, J.alpha_per_row, dtype, J.xmax_mode, J.xmax_dev, J.lb, J.ub,
+                                      J.step, J.ntypes, J.gmax_host, J.plan_host, J.plan_dev, flags, J.alpha_dev, J.score_dev,
+                                      J.type_dev, workspace, workspace_bytes, stream);
+        if (rc != ANTQ_OK) return rc;
+    }
+    return ANTQ_OK;
+}
+
 namespace antq {
 int prefetch_unit_search()        // antq_prefetch_kernels (antq_kernels.hip): load this unit's code object now
 {

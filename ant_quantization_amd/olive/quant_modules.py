@@ -313,6 +313,48 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         self._type_search = None
         core.forget_absmax()
 
+    # ---------------------------------------------------------------- calibrated ahead of the forward (weight_bank.precalibrate)
+    def _calib_spec(self, weight):
+        """What _init_quant_para would search for this WEIGHT quantiser (OQ:258-292): candidate types in the order of
+        search_adaptive_numeric_type, normal codebooks (+ outliers unless no_outlier), the 3-sigma statistic, step 2 -- or
+        None when the quantiser keeps the per-layer path."""
+        if self.is_input or not self.is_signed or not self.is_perchannel or self.mode == "base":
+            return None
+        if not (self.is_enable and self.is_enable_weight) or self._steady or self._hm_get('has_inited_quant_para') != 0:
+            return None
+        bit = self._bits()
+        if bit > 6:
+            modes = ["int"]
+        elif "ant-" in self.mode:
+            modes = [t for t in ("int", "flint") if ("-" + t) in self.mode]
+            if not modes:
+                return None
+        elif self.mode in ("flint", "int"):
+            modes = [self.mode]
+        else:
+            return None                    # (the per-layer path raises the reference's error)
+        lb, ub = int(self.w_low), int(self.w_up)
+        if not range(lb, ub, 2):
+            return None
+        outl = np.ascontiguousarray(grids.olive_outliers(bit, True), dtype=np.float32)
+        normals = [np.ascontiguousarray(grids.olive_grid(t, bit, True), dtype=np.float32) for t in modes]
+        fulls = [n if self._no_outlier else np.concatenate([n, outl]) for n in normals]
+        return dict(modes=modes, grids=fulls, normals=normals, outl=outl, gmaxs=[float(np.max(n)) for n in normals], lb=lb, ub=ub,
+                    step=2, stat="absmax" if self._no_outlier else "3sigma", ovp=not self._no_outlier)
+
+    def _calib_apply(self, spec, t, alpha, score, rows):
+        """The state _init_quant_para leaves behind, from the batch's results for type t."""
+        self.mode = spec["modes"][t]
+        self._install(spec["normals"][t], spec["outl"])
+        self.alpha.data = alpha.clone().unsqueeze(1)
+        self._searched = True
+        self._mse_later(score, rows)
+        print(self.mode, end="\t")
+        print("%d-bit \t %s," % (self._bits(), self.name))
+        self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
+        self._hm_known('has_inited_quant_para', 1.0)
+        self._steady = True
+
     # ---------------------------------------------------------------- steady state
     # (_rest_buffer / _rest_alpha / _at_rest: _mirror.WeightsAtRestMixin)
 
@@ -335,6 +377,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         else:
             if not self.is_enable_weight:
                 return tensor
+        self._before_calibration(tensor)
         self._init_quant_para(tensor, input_tensor)
         if self._bank is None and self._auto_bank is not None and self._steady and not self.is_input and not (
                 torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad)):

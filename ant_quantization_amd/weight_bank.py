@@ -28,6 +28,7 @@ import weakref
 import torch
 
 from . import _lib
+from ._mirror import _lib_tensor_key as _tensor_key
 
 __all__ = ["WeightBank", "AutoBank"]
 
@@ -154,6 +155,9 @@ class AutoBank:
         self.enabled = os.environ.get("ANTQ_WEIGHT_BANK", "1") != "0"
         self.first = None          # the quantiser whose forward comes first in registration order: the only one that pokes
         self.failed = 0
+        self.batch_calibration = {"0": 0, "2": 2}.get(os.environ.get("ANTQ_BATCH_CALIB", "1"), 1)
+        self.precal_done = False
+        self.precalibrated = 0     # weight quantisers calibrated by precalibrate() (tests / logging)
         for _, _, q, _ in _weight_layers(model):
             if self.first is None:
                 self.first = weakref.ref(q)
@@ -161,6 +165,52 @@ class AutoBank:
 
     def __deepcopy__(self, memo):
         return None
+
+    # ------------------------------------------------------------------ the weights' calibration, all at once
+    def precalibrate(self):
+        """From the first not-yet-calibrated weight quantiser whose forward runs: search EVERY weight quantiser of the model
+        now, in one call (antq_calibrate_batch), and read all type picks back in one copy.  A weight's calibration depends on
+        nothing but the weight (AQ:468-533 with data = self.weight), so each quantiser gets the state its own first forward
+        would have given it -- same kernels, same bits; it installs that state (and prints the reference's line) when its
+        forward comes, while the stream is busy with the activations' searches.  What this saves is the read-back per type
+        selection (np.argsort(...cpu()), AQ:413): 73 stream drains for BERT-base's weights become one.  Models whose weight
+        quantisers select no type (a fixed mode: their per-layer calibration is sync-free already and overlaps the stream),
+        quantisers the batch cannot take (outlier / base modes, float1-4 types, an empty candidate range, a float64 or host
+        weight) and runs under torch.distributed (the reference's per-quantiser collectives keep their order) take the
+        per-layer path as before.  ANTQ_BATCH_CALIB=0 switches this off, =2 batches fixed modes too."""
+        if self.precal_done or not self.batch_calibration:
+            return
+        self.precal_done = True
+        model = self._model()
+        if model is None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return
+        groups = {}
+        with torch.no_grad():
+            for name, mod, q, w in _weight_layers(model):
+                spec = q._calib_spec(w) if hasattr(q, "_calib_spec") else None
+                if spec is None or not w.is_cuda or w.dtype not in _lib._DTYPES or w.dtype == torch.float64 or w.numel() == 0:
+                    continue
+                wc = w.detach().contiguous()
+                groups.setdefault((w.device, w.dtype, spec["stat"], spec["ovp"]), []).append((q, spec, wc, _tensor_key(w)))
+            for (_, _, stat, ovp), items in groups.items():
+                if len(items) < 2 or not (self.batch_calibration == 2 or any(len(spec["grids"]) > 1 for _, spec, _, _ in items)):
+                    continue
+                # (issued in a few calls, a small one first: the stream starts on it while the host prepares the rest)
+                results, types = [], []
+                for b0, b1 in [(0, 4)] + [(b, b + 24) for b in range(4, len(items), 24)]:
+                    jobs = []
+                    for q, spec, wc, _ in items[b0:b1]:
+                        rows = wc.shape[0]
+                        plans = [_lib.plan_for(g) for g in spec["grids"]]
+                        jobs.append((wc, rows, wc.numel() // rows, True, plans, spec["gmaxs"], spec["lb"], spec["ub"], spec["step"]))
+                    if jobs:
+                        r, t = _lib.calibrate_batch(jobs, xmax=stat, ovp=ovp)
+                        results += r
+                        types.append(t)
+                picks = torch.cat(types).cpu().tolist()           # ONE read-back for the group
+                for (q, spec, wc, key), (alpha, score, _), t in zip(items, results, picks):
+                    q._calib_ready = (key, spec, int(t), alpha[int(t)], score[int(t):int(t) + 1], wc.shape[0])
+                self.precalibrated += len(items)
 
     def __reduce__(self):
         return (type(None), ())

@@ -39,8 +39,9 @@ extern "C" {
  * output, the batch blob changed (plan version 8), ANTQ_FLAG_UNORDERED.  3: antq_calibrate / antq_calibrate_workspace_bytes
  * added (nothing else changed).  4 (round 4): the plan blob grew (version 9: 128-byte header + the threshold list of the
  * 16-bit-domain kernels; ANTQ_PLAN_MAX_BYTES with it), the batch blob changed, antq_plan_eval_host_h and
- * antq_prefetch_kernels added.  A caller built against another version must not call in: the blobs / argument lists differ. */
-#define ANTQ_ABI_VERSION 4
+ * antq_prefetch_kernels added.  5: antq_calibrate_batch / antq_calibrate_batch_workspace_bytes added (nothing else changed).
+ * A caller built against another version must not call in: the blobs / argument lists differ. */
+#define ANTQ_ABI_VERSION 5
 
 /* element types of x / out */
 #define ANTQ_F32  0
@@ -264,6 +265,33 @@ int antq_calibrate(const void *x_dev, size_t rows, size_t row_len, int alpha_per
                    int ntypes, const float *gmax_host, const void *const *plan_host, const void *const *plan_dev,
                    unsigned flags, float *alpha_dev, float *score_dev, int32_t *type_dev,
                    void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* The calibration of MANY quantisers in one call: job i is exactly antq_calibrate(jobs[i]...) -- same kernels, same order,
+ * same bits -- all enqueued on `stream` one after the other through ONE workspace (antq_calibrate_batch_workspace_bytes: the
+ * largest job's need; the jobs are stream-ordered, so they can share it).  The weight quantisers of a model do not depend
+ * on any activation: a model calibrates all of them with this call before its first layer runs, reads the n type picks
+ * back in ONE copy, and the per-layer host work and read-backs of the reference's first forward (one `if cuda_tensor:` per
+ * quantiser, AQ:470, and np.argsort(...cpu()) per type selection, AQ:413) are gone for them.  dtype / flags are common to
+ * the batch (a model's weights share a dtype; ANT or OliVe decides the pair rule).  Stops at the first job that fails and
+ * returns its error; jobs before it are enqueued. */
+typedef struct antq_calib_job {
+    const void *x_dev;            /* rows x row_len elements */
+    size_t rows, row_len;
+    int alpha_per_row;
+    int xmax_mode;                /* ANTQ_XMAX_* */
+    float *xmax_dev;              /* na floats: output (ABSMAX / 3SIGMA) or input (GIVEN) */
+    int lb, ub, step;
+    int ntypes;
+    const float *gmax_host;       /* ntypes */
+    const void *const *plan_host; /* ntypes */
+    const void *const *plan_dev;  /* ntypes */
+    float *alpha_dev;             /* ntypes x na */
+    float *score_dev;             /* ntypes */
+    int32_t *type_dev;            /* 1 */
+} antq_calib_job;
+size_t antq_calibrate_batch_workspace_bytes(const antq_calib_job *jobs, int n);     /* 0: a job has a bad range / type count */
+int antq_calibrate_batch(const antq_calib_job *jobs, int n, int dtype, unsigned flags, void *workspace_dev,
+                         size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * AsymmetricQuantFunction.forward (ant_quantization/antquant/quant_affine.py:95-115)

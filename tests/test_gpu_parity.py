@@ -3643,3 +3643,118 @@ def test_parallel_branches_search_their_shared_input_once(tree, mode, dev, capsy
         assert torch.equal(lin[1].quant_input.alpha, lin[2].quant_input.alpha)
         assert not torch.equal(lin[0].quant_input.alpha, lin[1].quant_input.alpha)
     capsys.readouterr()
+
+
+@pytest.mark.parametrize("tree,mode", [("ant", "flint"), ("ant", "ant-int-pot-flint"), ("ant", "ant-int-float2-flint"),
+                                       ("olive", "flint"), ("olive", "ant-int-flint")])
+def test_weights_calibrated_in_one_batch_before_the_first_layer(tree, mode, dev, capsys):
+    """antq_calibrate_batch through the model path (weight_bank.AutoBank.precalibrate): every weight quantiser is calibrated
+    by ONE call when the first layer's forward starts, the type picks come back in one copy -- and every quantiser ends up in
+    exactly the state its own first forward would have produced (mode, codebook, alpha bits, mse), the model prints the same
+    lines in the same order and returns the same output.  Conv rows that are not whole vectors (K = 27), Linear rows, an
+    8-bit layer (window 95..), fp32 and bf16; quantisers the batch cannot take (float1-4 types) keep the per-layer path."""
+    import importlib
+    import torch
+    import torch.nn as nn
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qutil.set_quantizer(_args(mode=mode, wbit=4, abit=4))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.c2 = nn.Conv2d(3, 16, 3, padding=1), nn.Conv2d(16, 32, 3, padding=1)
+            self.f1, self.f2 = nn.Linear(32 * 8 * 8, 256), nn.Linear(256, 10)
+
+        def forward(self, x):
+            x = torch.relu(self.c2(torch.relu(self.c1(x))))
+            return self.f2(torch.relu(self.f1(x.flatten(1))))
+
+    for dt in (torch.float32, torch.bfloat16):
+        outs, states, logs, counts = [], [], [], []
+        for batch in (True, False):
+            torch.manual_seed(12)
+            model = qmod.quantize_model(Net()).to(dev).to(dt).eval()
+            qs = [m for m in model.modules() if hasattr(m, "quant_weight")]
+            qs[1].quant_weight.bit.data = torch.tensor(8, device=dev)          # an 8-bit layer: 'int', window from 95
+            qs[1].quant_weight.rearm()
+            capsys.readouterr()
+            qutil.enable_quantization(model)
+            model._antq_auto_bank.batch_calibration = 2 if batch else 0        # (2: fixed modes too; the default batches only type selections)
+            torch.manual_seed(13)
+            x = torch.randn(8, 3, 8, 8, device=dev).to(dt)
+            from ant_quantization_amd import core
+            per_layer = []
+            real = (core.clip_search, core.clip_search_types)
+            core.clip_search = lambda t, xm, pc, *a, **k: (per_layer.append(pc), real[0](t, xm, pc, *a, **k))[1]
+            core.clip_search_types = lambda t, xm, pc, *a, **k: (per_layer.append(pc), real[1](t, xm, pc, *a, **k))[1]
+            try:
+                with torch.no_grad():
+                    outs.append(model(x))
+            finally:
+                core.clip_search, core.clip_search_types = real
+            # (per-channel searches issued by layers: none for the weights the batch took)
+            assert sum(per_layer) == 0 if (batch and "float2" not in mode) else sum(per_layer) >= 4, (per_layer, batch, mode)
+            logs.append(capsys.readouterr().out)
+            counts.append(model._antq_auto_bank.precalibrated)
+            states.append([(q.quant_weight.mode, q.quant_weight.quant_grid.clone(), q.quant_weight.alpha.detach().clone(),
+                            q.quant_weight.mse.clone(), q.quant_input.alpha.detach().clone(), q.quant_input.mode) for q in qs])
+        takes = 0 if "float2" in mode else 4
+        assert counts == [takes, 0], (counts, mode)
+        assert logs[0] == logs[1] and logs[0].count("-bit") == 8, (tree, mode, dt)
+        assert torch.equal(outs[0], outs[1]), (tree, mode, dt)
+        for (m0, g0, a0, e0, ia0, im0), (m1, g1, a1, e1, ia1, im1) in zip(*states):
+            assert m0 == m1 and im0 == im1 and torch.equal(g0, g1) and torch.equal(a0, a1) and torch.equal(ia0, ia1), (tree, mode, dt)
+            np.testing.assert_allclose(e0.float().cpu().numpy(), e1.float().cpu().numpy(), rtol=1e-5)
+        assert states[0][1][0] == "int"
+    # default setting: a fixed mode keeps the (sync-free) per-layer path, a type selection is batched; a weight edited between
+    # the batch's search and its layer's forward is searched again by the layer
+    torch.manual_seed(12)
+    model = qmod.quantize_model(Net()).to(dev).eval()
+    qutil.enable_quantization(model)
+    ab = model._antq_auto_bank
+    assert ab.batch_calibration == 1
+    qs = [m for m in model.modules() if hasattr(m, "quant_weight")]
+    with torch.no_grad():
+        ab.precalibrate()
+        batched = mode.startswith("ant-") and "float2" not in mode
+        assert ab.precalibrated == (4 if batched else 0)
+        qs[2].weight.mul_(3.0)
+        torch.manual_seed(13)
+        x = torch.randn(8, 3, 8, 8, device=dev)
+        y = model(x)
+        torch.manual_seed(12)
+        ref = qmod.quantize_model(Net()).to(dev).eval()
+        qutil.enable_quantization(ref)
+        ref._antq_auto_bank.batch_calibration = 0
+        [m for m in ref.modules() if hasattr(m, "quant_weight")][2].weight.mul_(3.0)
+        assert torch.equal(ref(x), y)
+        for a, b in zip(qs, [m for m in ref.modules() if hasattr(m, "quant_weight")]):
+            assert torch.equal(a.quant_weight.alpha, b.quant_weight.alpha) and a.quant_weight.mode == b.quant_weight.mode
+    capsys.readouterr()
+
+
+def test_calibrate_batch_equals_calibrate_per_job(antq_lib, dev):
+    """antq_calibrate_batch(jobs) = antq_calibrate(job) for every job, bit for bit: mixed shapes (ragged rows, short rows,
+    long rows), one and several candidate codebooks, per row and per tensor, ANT (abs-max) and OliVe (3 sigma, pair rule)."""
+    import torch
+    from ant_quantization_amd import grids
+    rng = np.random.default_rng(21)
+    plans_a = [antq_lib.plan_for(grids.ant_grid(t, 4, True)) for t in ("int", "pot", "flint")]
+    on = grids.olive_grid("flint", 4, True)
+    plan_o = antq_lib.plan_for(np.concatenate([on, grids.olive_outliers(4, True)]))
+    shapes = [(16, 27, True), (64, 576, True), (8, 4096, True), (32, 768, False), (3, 100, True), (12, 2048, True)]
+    for dt in (torch.float32, torch.bfloat16):
+        xs = [torch.from_numpy((rng.standard_normal((r, k)) * 0.05).astype(np.float32)).to(dev).to(dt) for r, k, _ in shapes]
+        for stat, ovp, plans, gm, lb, ub, step in (("absmax", False, plans_a, [7.0, 64.0, 10.0], 75, 150, 1),
+                                                   ("absmax", False, plans_a[2:], [10.0], 95, 150, 1),
+                                                   ("3sigma", True, [plan_o], [float(on.max())], 75, 250, 2)):
+            jobs = [(x, r, k, pr, plans, gm, lb, ub, step) for x, (r, k, pr) in zip(xs, shapes)]
+            res, types = antq_lib.calibrate_batch(jobs, xmax=stat, ovp=ovp)
+            assert types.shape == (len(jobs),)
+            for i, (x, (r, k, pr)) in enumerate(zip(xs, shapes)):
+                a1, s1, t1, xm1 = antq_lib.calibrate(x, r, k, pr, plans, gm, lb, ub, step, xmax=stat, ovp=ovp)
+                assert torch.equal(res[i][0], a1) and torch.equal(res[i][1], s1) and torch.equal(res[i][2], xm1.reshape(-1)), (dt, stat, i)
+                assert int(types[i]) == int(t1[0])
+    res, types = antq_lib.calibrate_batch([])
+    assert res == [] and types is None
