@@ -130,6 +130,8 @@ def main():
     af = _lib.absmax(flat, flat.numel() // 16, 16)
     report("   (same bytes as ONE group-16 launch over a flat buffer)", elems, 8,
            timed(lambda: _lib.fakequant(flat, af, plan, 10.0, flat.numel() // 16, 16, True, out=fo), 50), 1)
+    # ... and what a plain copy of the same bytes reaches in a launch this short (the ceiling of a 33 us pass)
+    report("   (the copy kernel over the same flat buffer, antq_copy)", elems, 8, timed(lambda: _lib.copy(flat, fo), 50), 1)
     del ws, outs, flat, fo
 
     # ---------------- C2: BERT-base Linear weights: steady state + calibration (ant-int-pot-flint)

@@ -65,7 +65,10 @@ $PY tools/probe_box.py 2>&1 | grep -v "amdgpu\|^RCCL\|^HIP\|^ROCm\|^Host\|^Librc
 ( $PY tools/probe_hrow_rows.py; $PY tools/probe_hrow_rows.py olive ) 2>&1 | grep -v amdgpu > "$OUT/${TAG}_hrow_rows.log"
 $PY tools/probe_per_tensor.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_per_tensor_shapes.log"
 $PY tools/probe_transient.py 40 1.5 2>&1 | grep -v amdgpu > "$OUT/${TAG}_transient.log"
-$PY tools/probe_first_forward.py 2>&1 | grep "forward" > "$OUT/${TAG}_first_forward.log"
+( $PY tools/probe_first_forward.py; $PY tools/probe_first_forward.py ant-int-pot-flint ) 2>&1 | grep "forward" > "$OUT/${TAG}_first_forward.log"
+( $PY tools/probe_precalibrate.py; $PY tools/probe_precalibrate.py flint ) 2>&1 | grep "forward\|precalibrate" > "$OUT/${TAG}_precalibrate.log"
+$PY tools/probe_search_split.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_search_split.log"
+$PY tools/probe_fp32_occupancy.py 2>&1 | grep -v amdgpu > "$OUT/${TAG}_fp32_occupancy.log"
 [ -x tools/stream_shapes ] && ./tools/stream_shapes all > "$OUT/${TAG}_stream_shapes.log" 2>&1
 [ -x tools/launch_anatomy ] && ./tools/launch_anatomy 2>&1 | cut -c1-70 > "$OUT/${TAG}_launch_anatomy.log"
 [ -x tools/valu_rates ] && ./tools/valu_rates > "$OUT/${TAG}_valu_rates.log" 2>&1
