@@ -382,6 +382,69 @@ def test_host_mirror_of_bit_and_inited_buffers(tree, monkeypatch):
     assert q._bits() == 7 and len(reads) == n0 + 1                                                      # ... until re-armed
 
 
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_calibration_pass_host_logic(tree):
+    """The host side of the calibration pass, no kernel involved: the search memo (same tensor object, address, version and
+    key only; never a Parameter; a handful of entries, dead tensors dropped), `mse` formed when read, and what a weight
+    quantiser offers the batched pre-calibration (candidate types in the reference's order, duplicates once, float1-4 and
+    empty windows declined, 8-bit layers = 'int' from 95)."""
+    import importlib
+    import torch
+    from ant_quantization_amd import core
+    qm = importlib.import_module("ant_quantization_amd.%s.quant_modules" % tree)
+    memo = core.SearchMemo(keep=3)
+    a, b = torch.randn(4, 8), torch.randn(4, 8)
+    assert memo.get(a, ("k",)) is None
+    memo.put(a, ("k",), "A")
+    assert memo.get(a, ("k",)) == "A" and memo.hits == 1
+    assert memo.get(a, ("other",)) is None and memo.get(b, ("k",)) is None and memo.get(a.clone(), ("k",)) is None
+    a.add_(1.0)                                                   # version counter moved
+    assert memo.get(a, ("k",)) is None
+    memo.put(torch.nn.Parameter(b), ("k",), "P")                  # Parameters are never kept
+    assert len(memo.entries) == 1
+    for i in range(5):
+        memo.put(torch.randn(2), ("t", i), i)                     # temporaries die: their entries go with the next put
+    assert len(memo.entries) <= 3
+    memo.enabled = False
+    memo.put(b, ("k",), "B")
+    assert memo.get(b, ("k",)) is None
+    memo.enabled = True
+    with torch.inference_mode():
+        c = torch.randn(3)
+    memo.put(c, ("k",), "C")                                      # no version counter: not kept
+    assert memo.get(c, ("k",)) is None
+
+    q = qm.TensorQuantizer(mode="flint", bit=4, is_signed=True, is_enable=True, args=_args())
+    assert float(q.mse) == 0.0
+    best = torch.tensor([1.0, 3.0])
+    q._mse_later(best, 2)
+    m = q.mse
+    assert float(m) == 2.0 and q.mse is m                         # formed once, on the first read
+    q.mse = torch.tensor(5.0)
+    assert float(q.mse) == 5.0
+
+    w = torch.randn(8, 16)
+    spec = q._calib_spec(w)
+    assert spec["modes"] == ["flint"] and len(spec["grids"]) == 1 and spec["step"] == (1 if tree == "ant" else 2)
+    assert (spec["lb"], spec["ub"]) == (75, 150)
+    qa = qm.TensorQuantizer(mode="ant-int-flint", bit=4, is_signed=True, is_enable=True, args=_args())
+    sa = qa._calib_spec(w)
+    assert sa["modes"] == ["int", "flint"] and len(sa["grids"]) == 2 and sa["ovp"] == (tree == "olive")
+    assert sa["stat"] == ("absmax" if tree == "ant" else "3sigma")
+    q8 = qm.TensorQuantizer(mode="ant-int-flint", bit=8, is_signed=True, is_enable=True, args=_args())
+    s8 = q8._calib_spec(w)
+    assert s8["modes"] == ["int"] and (s8["lb"] == 95 if tree == "ant" else True)
+    assert qm.TensorQuantizer(mode="flint", bit=4, is_signed=False, is_enable=True, is_input=True, args=_args())._calib_spec(w) is None
+    assert qm.TensorQuantizer(mode="flint", bit=4, is_signed=True, is_enable=True, args=_args(w_low=150, w_up=150))._calib_spec(w) is None
+    assert qm.TensorQuantizer(mode="flint", bit=4, is_signed=True, is_enable=False, args=_args())._calib_spec(w) is None
+    if tree == "ant":
+        assert qm.TensorQuantizer(mode="ant-int-float2", bit=4, is_signed=True, is_enable=True, args=_args())._calib_spec(w) is None
+        qd = qm.TensorQuantizer(mode="ant-int-pot-float-flint", bit=4, is_signed=True, is_enable=True, args=_args())
+        # _TYPE_ORDER, as search_adaptive_numeric_type walks it; the 4-bit float codebook IS the pot codebook: searched once,
+        # and the first of equals (pot) is what np.argsort(mse)[0] would name
+        assert qd._calib_spec(w)["modes"] == ["int", "flint", "pot"] and len(qd._calib_spec(w)["grids"]) == 3
+
+
 def test_dropin_directories_import_the_reference_way(tmp_path):
     """`import quant_cuda` (AQ/quant_modules.py:7) and the harnesses' `sys.path.append("../antquant"); from quant_model
     import *; from quant_utils import *` (ImageNet/main.py:14-16, llm/run_clm.py:56-59) from a clean interpreter whose
