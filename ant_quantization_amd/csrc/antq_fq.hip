@@ -391,6 +391,7 @@ extern "C" int antq_fakequant(const void *x, void *out, int16_t *idx, size_t row
 {
     if (rows == 0 || row_len == 0) return ANTQ_OK;
     if (!x || !out || !alpha || !plan_host || !plan_dev) return ANTQ_ERR_ARG;
+    if ((flags & ANTQ_FLAG_UNORDERED) && idx) return ANTQ_ERR_ARG;      // (the bindings refuse the pair as well)
     PlanArgs pa;
     if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -85,9 +85,12 @@ constexpr int kStaleSlots = 4096;
 // start to end (nothing here releases it), so a Hint returned by hint_for is not modified by another thread while quant()
 // uses it; the mutex keeps the cache itself consistent should a caller ever release the GIL around these calls.
 std::mutex g_mu;
-std::list<std::pair<Key, std::shared_ptr<Hint>>> g_lru;      // front = most recent
-std::unordered_map<Key, decltype(g_lru)::iterator, KeyHash> g_map;
-at::Tensor g_stale_pool;                                     // pinned int32[kStaleSlots]: never returned to the allocator, so a
+// The cache and the pinned pool hold device / pinned tensors: they are heap objects that are never destroyed (static
+// destruction at process exit can run after the HIP runtime and the caching host allocator are gone).
+using Lru = std::list<std::pair<Key, std::shared_ptr<Hint>>>;
+Lru &g_lru = *new Lru;                                       // front = most recent
+std::unordered_map<Key, Lru::iterator, KeyHash> &g_map = *new std::unordered_map<Key, Lru::iterator, KeyHash>;
+at::Tensor &g_stale_pool = *new at::Tensor;                  // pinned int32[kStaleSlots]: never returned to the allocator, so a
 int g_stale_next = 0;                                        // late write of a long-gone launch can only cost a re-plan
 
 // (after kStaleSlots beliefs a slot is handed out again: two live beliefs may then share a flag, and one going stale

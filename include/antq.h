@@ -67,7 +67,10 @@ extern "C" {
                                     * 2-3 us per 33.5 MB tensor when many weight tensors are quantised one launch each.
                                     * The OUTPUT buffer must be at rest too: not one a stream-ordered allocator has just
                                     * recycled from a kernel that may still be running (torch's caching allocator does that:
-                                    * the Python binding refuses the flag without a caller-owned `out`). */
+                                    * the Python binding refuses the flag without a caller-owned `out`).
+                                    * A HINT: honoured by the table / lane kernels that serve 4-bit codebooks (the cases it was
+                                    * measured on); the uniform-grid, scalar and literal-scan paths launch ordered whatever
+                                    * the flag says.  Not with an index output: ANTQ_ERR_ARG. */
 
 /* values written to the optional int16 index output */
 #define ANTQ_IDX_NONE    (-1)      /* no grid entry within 102400 (NaN/Inf/huge)     */

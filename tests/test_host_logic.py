@@ -95,6 +95,21 @@ def test_cabi_argument_errors_without_gpu(antq_lib):
     base = L.antq_search_workspace_bytes()
     assert wsb(8, 1, 100, 100, 1, 2) > base                       # an empty candidate range still needs the fixed parts
     assert wsb(4096, 1, 75, 150, 1, 3) - wsb(4096, 0, 75, 150, 1, 3) >= 3 * 75 * 4095 * 8      # sse: [types][cands][rows] doubles
+    # ANTQ_FLAG_UNORDERED (4) with an index output: refused before anything is launched (made-up non-null addresses)
+    vp = ctypes.c_void_p
+    plan = antq_lib.Plan(np.float32([-1, 0, 1, 2]))
+    assert L.antq_fakequant(vp(0x1000), vp(0x2000), vp(0x3000), sz(4), sz(4), vp(0x4000), 1, ctypes.c_float(2), vp(plan.host_addr),
+                            vp(0x5000), ctypes.c_uint(4), 0, None) == -1
+    # antq_calibrate_batch: empty batch, null job list, the workspace is the largest job's
+    assert L.antq_calibrate_batch(None, ci(0), ci(0), ctypes.c_uint(0), None, sz(0), None) == 0
+    assert L.antq_calibrate_batch(None, ci(3), ci(0), ctypes.c_uint(0), None, sz(0), None) == -1
+    jobs = (antq_lib._CalibJob * 2)()
+    for i, rows in enumerate((8, 4096)):
+        jobs[i].rows, jobs[i].row_len, jobs[i].alpha_per_row = rows, 64, 1
+        jobs[i].lb, jobs[i].ub, jobs[i].step, jobs[i].ntypes = 75, 150, 1, 3
+    assert L.antq_calibrate_batch_workspace_bytes(jobs, ci(2)) == wsb(4096, 1, 75, 150, 1, 3)
+    jobs[0].ntypes = 0
+    assert L.antq_calibrate_batch_workspace_bytes(jobs, ci(2)) == 0
 
 
 # ---------------------------------------------------------------- plans
