@@ -130,6 +130,13 @@ def prewarm(device, dtype=torch.float32):
         from . import _mirror
         _mirror._slots.take().copy_(x.min().float().reshape(1), non_blocking=True)
         torch.ones_like(al), al.clone()
+        # the device-side type pick of input quantisers (_mirror.CalibrationMixin._calibrate_deferred): its gathers and casts
+        a3, _, typ, _ = calibrate(x, 1, x.numel(), False, plans_a, [10.0, 10.0], 95, 100, 1, xmax="absmax")
+        idx = typ.long()
+        a3.index_select(0, idx).reshape(())
+        torch.stack([x, x]).index_select(0, idx)
+        torch.zeros(2, 16, device=device).index_select(0, idx)[0]
+        _mirror._slots.take().copy_(typ.float(), non_blocking=True)
         torch.cuda.synchronize(device)
 
 

@@ -87,11 +87,20 @@ class CalibrationMixin:
     """
     _sign_probe = None
     _calib_ready = None           # (weight key, spec, type, alpha, score, rows) from weight_bank.AutoBank.precalibrate
+    _calib_ctx = None             # the model's weight_bank.AutoBank (weight AND input quantisers): log order, deferred picks
+    _pending = None               # (event, pinned slot, spec): a type pick made on the device, not yet known to the host
+    _spec_out = None              # the calibrating forward's output of a quantiser whose pick is pending
+    _defer_allowed = False        # set by tensor_forward: no gradient is wanted through this call
 
     def _before_calibration(self, tensor):
         """First thing in tensor_forward of an enabled quantiser.  A weight quantiser that is not calibrated yet lets the model
         search all its weights at once (weight_bank.AutoBank.precalibrate); one whose search is done installs the result --
         provided the tensor in its hands is still the one that was searched (address, version, shape)."""
+        if self._pending is not None:                 # (a second forward before the model-level flush: learn the pick now)
+            if self._calib_ctx is not None:
+                self._calib_ctx.flush()
+            if self._pending is not None:
+                self._emit(self._resolve_pending())
         if self._steady or self.is_input:
             return
         if self._calib_ready is None and self._auto_bank is not None:
@@ -100,6 +109,71 @@ class CalibrationMixin:
         if ready is not None and ready[0] == _lib_tensor_key(tensor) and self._hm_get('has_inited_quant_para') == 0:
             with torch.no_grad():
                 self._calib_apply(*ready[1:])
+
+    def _emit(self, line):
+        """The reference's calibration log line (`print(mode, end="\\t"); print("%d-bit \\t %s," ...)`), kept in the order the
+        quantisers calibrate even when an earlier quantiser's line still waits for its type pick."""
+        if self._calib_ctx is not None:
+            self._calib_ctx.emit(line)
+        elif line:
+            print(line)
+
+    # ---- type selection without a stream drain (input quantisers of `ant-...` modes) -------------------------------------
+    # The host needs the picked type only to NAME it (mode string, host plan); the data path does not: the clip search of
+    # every candidate codebook and the pick run in one stream-ordered call (antq_calibrate), alpha and the codebook buffers
+    # are gathered by the device-side index, and this forward's output is the fake-quantised tensor of EVERY candidate with
+    # the picked one gathered the same way (T short launches and one gather instead of a drain: 73 drains per BERT-base
+    # forward).  The pick travels to pinned memory behind all that; the model's forward hook (or the quantiser's next
+    # forward) reads it, names the mode, builds the host plan and prints the line.
+    def _defer_ok(self, data):
+        ctx = self._calib_ctx
+        if ctx is None or not ctx.defer_types or not self.is_input or self.is_perchannel or not self._defer_allowed:
+            return False
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return False
+        return data.is_cuda and data.dtype in (torch.float32, torch.bfloat16, torch.float16) and data.numel() > 0
+
+    def _calibrate_deferred(self, data, spec):
+        from . import _lib, core
+        x = data.detach().contiguous()
+        plans = [_lib.plan_for(g) for g in spec["grids"]]
+        key = ("calibrate", spec["stat"], spec["ovp"], spec["lb"], spec["ub"], spec["step"],
+               tuple(g.tobytes() for g in spec["grids"]), tuple(spec["gmaxs"]))
+        seen = core.search_memo.get(data, key)
+        if seen is None:
+            alpha, score, typ, _ = _lib.calibrate(x, 1, x.numel(), False, plans, spec["gmaxs"], spec["lb"], spec["ub"],
+                                                  spec["step"], xmax=spec["stat"], ovp=spec["ovp"])
+            core.search_memo.put(data, key, (alpha, score, typ))
+        else:
+            alpha, score, typ = seen
+        idx = typ.long()
+        self.alpha.data = alpha.index_select(0, idx).reshape(())
+        self._install_selected(spec, idx)
+        self._searched = True
+        self._mse_later(score.index_select(0, idx), 1)
+        outs = torch.empty((len(plans),) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        for t, (p, gm) in enumerate(zip(plans, spec["gmaxs"])):
+            core.fake_quant(x, alpha[t], p, gm, False, ovp=spec["ovp"], out=outs[t])
+        self._spec_out = outs.index_select(0, idx)[0].view(data.shape)
+        slot = _slots.take()
+        slot.copy_(typ.float(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(data.device))
+        self._pending = (ev, slot, spec)
+        self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
+        self._hm_known('has_inited_quant_para', 1.0)
+        self._calib_ctx.defer(self)
+
+    def _resolve_pending(self):
+        """The pick has arrived (or is waited for): name the mode, adopt the host plan; returns the log line."""
+        ev, slot, spec = self._pending
+        self._pending = None
+        ev.synchronize()
+        t = int(slot[0])
+        self.mode = spec["modes"][t]
+        self._adopt_plan(spec, t)
+        self._steady = True
+        return self._calib_line()
 
     def prefetch_sign(self, tensor):
         if self.is_signed or self._steady or not isinstance(tensor, torch.Tensor) or not tensor.is_cuda or tensor.numel() == 0:
@@ -157,7 +231,8 @@ class WeightsAtRestMixin:
     def __getstate__(self):
         """torch.save(model) pickles the module: the launch-mode caches (a weak reference among them) are not state."""
         st = self.__dict__.copy()
-        for k in ("_rest_src", "_rest_stamp", "_rest_out", "_alpha32", "_alpha32_stamp", "_sign_probe"):
+        for k in ("_rest_src", "_rest_stamp", "_rest_out", "_alpha32", "_alpha32_stamp", "_sign_probe", "_pending", "_spec_out",
+                  "_calib_ctx", "_calib_ready"):
             if k in st:
                 st[k] = None
         return st

@@ -67,7 +67,10 @@ def make_walkers(Q):
             if method == "enable_quantization" and getattr(model, "_antq_auto_bank", None) is None:
                 from .weight_bank import AutoBank
                 try:
-                    object.__setattr__(model, "_antq_auto_bank", AutoBank(model))      # (not a submodule, not state)
+                    from .weight_bank import FlushHook
+                    auto = AutoBank(model)
+                    object.__setattr__(model, "_antq_auto_bank", auto)                 # (not a submodule, not state)
+                    model.register_forward_hook(FlushHook(auto))                       # (type picks made on the device: named here)
                 except Exception:              # noqa: BLE001  (exotic containers: the per-layer schedule simply stays)
                     pass
         walk.__name__ = method
@@ -101,7 +104,10 @@ def set_weight_bank(model, flag=True):
             ab.disable()
         return
     if ab is None:
-        object.__setattr__(model, "_antq_auto_bank", AutoBank(model))
+        from .weight_bank import FlushHook
+        ab = AutoBank(model)
+        object.__setattr__(model, "_antq_auto_bank", ab)
+        model.register_forward_hook(FlushHook(ab))
     else:
         ab.enabled = True
 

@@ -331,6 +331,11 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
                 return
             self.update_signed(data)
 
+            if "ant-" in self.mode and self._bits() <= 6 and self._defer_ok(data):
+                spec = self._calib_spec(data)
+                if spec is not None and len(spec["grids"]) > 1:
+                    return self._calibrate_deferred(data, spec)    # (the type pick stays on the device)
+
             if self.is_perchannel:
                 x_max = core.row_absmax(data, True)
                 self.alpha.data = x_max.unsqueeze(1)
@@ -370,9 +375,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
                 self.mse = self.mse_loss(self._forward(data), data, 2, is_perchannel=self.is_perchannel).mean()
             if _dist_on():
                 dist.broadcast(self.mse, 0)
-            if _rank() == 0:
-                print(self.mode, end="\t")
-                print("%d-bit \t %s," % (self._bits(), self.name))
+            self._emit(self._calib_line())
             if _dist_on():
                 rt = self.alpha.data.clone()
                 dist.all_reduce(rt, op=dist.ReduceOp.SUM)
@@ -387,15 +390,22 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
             core.forget_absmax()
 
     # ---------------------------------------------------------------- calibrated ahead of the forward (weight_bank.precalibrate)
-    def _calib_spec(self, weight):
-        """What _init_quant_para would search for this WEIGHT quantiser (AQ:468-533): the candidate types in the order of
+    def _calib_spec(self, tensor):
+        """What _init_quant_para would search for this quantiser (AQ:468-533): the candidate types in the order of
         search_adaptive_numeric_type, their codebooks (duplicates searched once, the first of equals wins as np.argsort's
-        does), the window -- or None when the quantiser keeps the per-layer path."""
-        if self.is_input or not self.is_signed or not self.is_perchannel or self.mode in ("base", "outlier"):
+        does), the window -- or None when the quantiser keeps the step-by-step path.  Weight quantisers (signed, per
+        channel): weight_bank.AutoBank.precalibrate; input quantisers (per tensor, sign already learnt): the type pick on
+        the device, _mirror.CalibrationMixin._calibrate_deferred."""
+        per_channel = self.is_perchannel and (not self.is_input)
+        if self.mode in ("base", "outlier") or (not self.is_input and not (per_channel and self.is_signed)):
             return None
-        if not (self.is_enable and self.is_enable_weight) or self._steady or self._hm_get('has_inited_quant_para') != 0:
+        if self.is_input and (self.is_perchannel or not self.is_enable_activation):
             return None
-        bit = self._bits()
+        if not self.is_enable or (not self.is_input and not self.is_enable_weight):
+            return None
+        if self._steady or self._hm_get('has_inited_quant_para') != 0:
+            return None
+        bit, signed = self._bits(), self.is_signed
         if bit > 6:
             modes = ["int"]
         elif "ant-" in self.mode:
@@ -405,17 +415,29 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         elif self.mode in _TYPE_ORDER:
             modes = [self.mode]
         else:
-            return None                    # (the per-layer path raises the reference's error)
-        lb, ub = self._search_window(True)
+            return None                    # (the step-by-step path raises the reference's error)
+        lb, ub = self._search_window(per_channel)
         if not range(lb, ub, 1):
             return None
         uniq = {}
         for t in modes:
-            g = np.ascontiguousarray(grids.ant_grid(t, bit, True), dtype=np.float32)
+            g = np.ascontiguousarray(grids.ant_grid(t, bit, signed), dtype=np.float32)
             uniq.setdefault(g.tobytes(), (t, g))
         with np.errstate(all="ignore"):
             return dict(modes=[t for t, _ in uniq.values()], grids=[g for _, g in uniq.values()],
                         gmaxs=[float(np.max(g)) for _, g in uniq.values()], lb=lb, ub=ub, step=1, stat="absmax", ovp=False)
+
+    def _calib_line(self):
+        return ("%s\t%d-bit \t %s," % (self.mode, self._bits(), self.name)) if _rank() == 0 else ""
+
+    def _install_selected(self, spec, idx):
+        """quant_grid <- the codebook of the device-side pick (a row of the stacked candidates)."""
+        self.quant_grid.data = self._to_grid(np.stack(spec["grids"])).index_select(0, idx)[0]
+
+    def _adopt_plan(self, spec, t):
+        self._plan = _lib.plan_for(spec["grids"][t])
+        self._gmax = spec["gmaxs"][t]
+        self._grid_key = self._grid_now()
 
     def _calib_apply(self, spec, t, alpha, score, rows):
         """The state _init_quant_para leaves behind, from the batch's results for type t."""
@@ -424,9 +446,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         self.alpha.data = alpha.clone().unsqueeze(1)
         self._searched = True
         self._mse_later(score, rows)
-        if _rank() == 0:
-            print(self.mode, end="\t")
-            print("%d-bit \t %s," % (self._bits(), self.name))
+        self._emit(self._calib_line())
         self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
         self._hm_known('has_inited_quant_para', 1.0)
         self._steady = True
@@ -453,8 +473,12 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
                 return tensor
 
         self._before_calibration(tensor)
+        self._defer_allowed = not (torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad))
         with torch.no_grad():
             self._init_quant_para(tensor, input_tensor)
+        if self._spec_out is not None:                  # calibrated a moment ago with the pick still on the device
+            out, self._spec_out = self._spec_out, None
+            return out
 
         if self._bank is None and self._auto_bank is not None and self._steady and not self.is_input and not (
                 torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad)):

@@ -277,6 +277,10 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
             self._steady = True
             return
         self.update_signed(data)
+        if "ant-" in self.mode and self._bits() <= 6 and self._defer_ok(data):
+            spec = self._calib_spec(data)
+            if spec is not None and len(spec["grids"]) > 1:
+                return self._calibrate_deferred(data, spec)        # (the type pick stays on the device)
         outl = grids.olive_outliers(self._bits(), self.is_signed)
         self.outliers.data = self._to_grid(outl)
 
@@ -304,8 +308,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
             self._mse_later(best_score, self.alpha.numel() if self.is_perchannel else 1)
         else:
             self.mse = self.mse_loss(self._forward(data), data, 2, is_perchannel=self.is_perchannel).mean()
-        print(self.mode, end="\t")
-        print("%d-bit \t %s," % (self._bits(), self.name))
+        self._emit(self._calib_line())
 
         self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
         self._hm_known('has_inited_quant_para', 1.0)
@@ -314,15 +317,22 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         core.forget_absmax()
 
     # ---------------------------------------------------------------- calibrated ahead of the forward (weight_bank.precalibrate)
-    def _calib_spec(self, weight):
-        """What _init_quant_para would search for this WEIGHT quantiser (OQ:258-292): candidate types in the order of
+    def _calib_spec(self, tensor):
+        """What _init_quant_para would search for this quantiser (OQ:258-292): candidate types in the order of
         search_adaptive_numeric_type, normal codebooks (+ outliers unless no_outlier), the 3-sigma statistic, step 2 -- or
-        None when the quantiser keeps the per-layer path."""
-        if self.is_input or not self.is_signed or not self.is_perchannel or self.mode == "base":
+        None when the quantiser keeps the step-by-step path.  Weight quantisers (signed, per channel):
+        weight_bank.AutoBank.precalibrate; input quantisers (per tensor, sign already learnt): the type pick on the device,
+        _mirror.CalibrationMixin._calibrate_deferred."""
+        per_channel = self.is_perchannel and (not self.is_input)
+        if self.mode == "base" or (not self.is_input and not (per_channel and self.is_signed)):
             return None
-        if not (self.is_enable and self.is_enable_weight) or self._steady or self._hm_get('has_inited_quant_para') != 0:
+        if self.is_input and (self.is_perchannel or not self.is_enable_activation):
             return None
-        bit = self._bits()
+        if not self.is_enable or (not self.is_input and not self.is_enable_weight):
+            return None
+        if self._steady or self._hm_get('has_inited_quant_para') != 0:
+            return None
+        bit, signed = self._bits(), self.is_signed
         if bit > 6:
             modes = ["int"]
         elif "ant-" in self.mode:
@@ -332,15 +342,28 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         elif self.mode in ("flint", "int"):
             modes = [self.mode]
         else:
-            return None                    # (the per-layer path raises the reference's error)
-        lb, ub = int(self.w_low), int(self.w_up)
+            return None                    # (the step-by-step path raises the reference's error)
+        lb, ub = (int(self.w_low), int(self.w_up)) if per_channel else (int(self.a_low), int(self.a_up))
         if not range(lb, ub, 2):
             return None
-        outl = np.ascontiguousarray(grids.olive_outliers(bit, True), dtype=np.float32)
-        normals = [np.ascontiguousarray(grids.olive_grid(t, bit, True), dtype=np.float32) for t in modes]
+        outl = np.ascontiguousarray(grids.olive_outliers(bit, signed), dtype=np.float32)
+        normals = [np.ascontiguousarray(grids.olive_grid(t, bit, signed), dtype=np.float32) for t in modes]
         fulls = [n if self._no_outlier else np.concatenate([n, outl]) for n in normals]
         return dict(modes=modes, grids=fulls, normals=normals, outl=outl, gmaxs=[float(np.max(n)) for n in normals], lb=lb, ub=ub,
                     step=2, stat="absmax" if self._no_outlier else "3sigma", ovp=not self._no_outlier)
+
+    def _calib_line(self):
+        return "%s\t%d-bit \t %s," % (self.mode, self._bits(), self.name)
+
+    def _install_selected(self, spec, idx):
+        """quant_grid <- the normal codebook of the device-side pick (a row of the stacked candidates); the outliers are the
+        same for every candidate."""
+        self.quant_grid.data = self._to_grid(np.stack(spec["normals"])).index_select(0, idx)[0]
+        self.outliers.data = self._to_grid(spec["outl"])
+
+    def _adopt_plan(self, spec, t):
+        self._set_plan(spec["normals"][t], spec["outl"])
+        self._grid_key = self._grid_now()
 
     def _calib_apply(self, spec, t, alpha, score, rows):
         """The state _init_quant_para leaves behind, from the batch's results for type t."""
@@ -349,8 +372,7 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         self.alpha.data = alpha.clone().unsqueeze(1)
         self._searched = True
         self._mse_later(score, rows)
-        print(self.mode, end="\t")
-        print("%d-bit \t %s," % (self._bits(), self.name))
+        self._emit(self._calib_line())
         self.has_inited_quant_para.data = torch.ones_like(self.has_inited_quant_para)
         self._hm_known('has_inited_quant_para', 1.0)
         self._steady = True
@@ -378,7 +400,11 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
             if not self.is_enable_weight:
                 return tensor
         self._before_calibration(tensor)
+        self._defer_allowed = True                      # (tensor_forward runs under no_grad in this tree: OQ:332)
         self._init_quant_para(tensor, input_tensor)
+        if self._spec_out is not None:                  # calibrated a moment ago with the pick still on the device
+            out, self._spec_out = self._spec_out, None
+            return out
         if self._bank is None and self._auto_bank is not None and self._steady and not self.is_input and not (
                 torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad)):
             self._auto_bank.poke(self)         # (every weight quantiser calibrated: one launch for all of them from now on)

@@ -30,7 +30,7 @@ import torch
 from . import _lib
 from ._mirror import _lib_tensor_key as _tensor_key
 
-__all__ = ["WeightBank", "AutoBank"]
+__all__ = ["WeightBank", "AutoBank", "FlushHook"]
 
 
 def _weight_layers(model):
@@ -156,6 +156,13 @@ class AutoBank:
         self.first = None          # the quantiser whose forward comes first in registration order: the only one that pokes
         self.failed = 0
         self.batch_calibration = {"0": 0, "2": 2}.get(os.environ.get("ANTQ_BATCH_CALIB", "1"), 1)
+        self.defer_types = os.environ.get("ANTQ_DEFER_TYPES", "1") != "0"      # _mirror.CalibrationMixin._calibrate_deferred
+        self.queue = []            # calibration log: lines in order, quantisers whose line waits for its type pick
+        self.deferred = 0          # picks made on the device so far (tests / logging)
+        for mod in model.modules():
+            for q in (getattr(mod, "quant_weight", None), getattr(mod, "quant_input", None)):
+                if q is not None and hasattr(q, "_calib_ctx"):
+                    q._calib_ctx = self
         self.precal_done = False
         self.precalibrated = 0     # weight quantisers calibrated by precalibrate() (tests / logging)
         for _, _, q, _ in _weight_layers(model):
@@ -165,6 +172,27 @@ class AutoBank:
 
     def __deepcopy__(self, memo):
         return None
+
+    # ------------------------------------------------------------------ the calibration log, in the reference's order
+    def emit(self, line):
+        if self.queue:
+            self.queue.append((None, line))
+        elif line:
+            print(line)
+
+    def defer(self, q):
+        self.queue.append((q, None))
+        self.deferred += 1
+
+    def flush(self):
+        """End of the model's forward (forward hook), or a pending quantiser's next forward: learn every pending pick -- they
+        arrived long ago -- and print the lines that queued up behind them."""
+        queue, self.queue = self.queue, []
+        for q, line in queue:
+            if q is not None:
+                line = q._resolve_pending() if q._pending is not None else None
+            if line:
+                print(line)
 
     # ------------------------------------------------------------------ the weights' calibration, all at once
     def precalibrate(self):
@@ -216,6 +244,7 @@ class AutoBank:
         return (type(None), ())
 
     def disable(self):
+        self.flush()
         self.enabled = False
         if self.bank is not None:
             self.bank.detach()
@@ -237,3 +266,19 @@ class AutoBank:
             bank.detach()              # (a partially calibrated model: try again on a later forward)
             return
         self.bank = bank
+
+
+class FlushHook:
+    """Forward hook of the model enable_quantization armed: AutoBank.flush() when its forward returns.  Holds the AutoBank
+    weakly; a deep copy of the model gets the very same (then harmless) hook object."""
+
+    def __init__(self, auto):
+        self._auto = weakref.ref(auto)
+
+    def __deepcopy__(self, memo):
+        return self
+
+    def __call__(self, module, inputs, output):
+        auto = self._auto()
+        if auto is not None and auto.queue:
+            auto.flush()

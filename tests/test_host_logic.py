@@ -449,7 +449,12 @@ def test_calibration_pass_host_logic(tree):
     q8 = qm.TensorQuantizer(mode="ant-int-flint", bit=8, is_signed=True, is_enable=True, args=_args())
     s8 = q8._calib_spec(w)
     assert s8["modes"] == ["int"] and (s8["lb"] == 95 if tree == "ant" else True)
-    assert qm.TensorQuantizer(mode="flint", bit=4, is_signed=False, is_enable=True, is_input=True, args=_args())._calib_spec(w) is None
+    # an input quantiser (per tensor, unsigned until a negative value was seen): what its device-side type pick searches
+    qi = qm.TensorQuantizer(mode="ant-int-flint", bit=4, is_signed=False, is_enable=True, is_input=True, args=_args(a_low=60, a_up=120))
+    si = qi._calib_spec(w)
+    assert si["modes"] == ["int", "flint"] and (si["lb"], si["ub"]) == (60, 120) and all(float(g.min()) >= 0 for g in si["normals" if tree == "olive" else "grids"])
+    qi.is_enable_activation = False
+    assert qi._calib_spec(w) is None
     assert qm.TensorQuantizer(mode="flint", bit=4, is_signed=True, is_enable=True, args=_args(w_low=150, w_up=150))._calib_spec(w) is None
     assert qm.TensorQuantizer(mode="flint", bit=4, is_signed=True, is_enable=False, args=_args())._calib_spec(w) is None
     if tree == "ant":
