@@ -183,7 +183,12 @@ static int launch_hrow(const void *x, void *out, size_t rows, size_t vpr, const 
         const PlanHeader *php = static_cast<const PlanHeader *>(plan_host);
         int U = g_knob_h == 2 ? (int)row_task_u((uint32_t)vpr) : (int)hrow_static_u((uint32_t)vpr, g_knob_x != 0 && php->xdom != 0u);
         if (U == 0) return ANTQ_ERR_UNSUPPORTED;          // (short / awkward rows: the fp32-domain row table, see hrow_static_u)
-        if (g_knob_u >= 2 && g_knob_u <= 4) U = g_knob_u;
+        // An ORDERED launch that fits one round of wavefronts (256 CUs x 32) when a wavefront takes 8 vectors per lane -- one
+        // 4096 x 4096 bf16 tensor: 8192 wavefronts, each a whole row, table built once per row -- starts and drains as one
+        // front: 13.3 -> 12.95 us (63.2 -> 64.8 %); an unordered launch overlaps its neighbours and keeps 4 (77 vs 74.4 %);
+        // longer launches keep 4 and the occupancy cap (tools/probe_per_tensor.py, profiles/r04_per_tensor_shapes.log)
+        if (U == 4 && !t_unordered && vpr % 512u == 0u && rows * (vpr / 512u) <= 8192u) U = 8;
+        if ((g_knob_u >= 2 && g_knob_u <= 4) || g_knob_u == 8) U = g_knob_u;      // knob 0 (A/B)
         const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
         const size_t total = rows * tpr;
         if (total > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
@@ -199,7 +204,7 @@ static int launch_hrow(const void *x, void *out, size_t rows, size_t vpr, const 
     launch_k(k_fq_hrow<T, OVP, UU, WW>, g, b, (WW) == 1 ? pad : 0u, st, static_cast<const uint4 *>(x), static_cast<uint4 *>(out), (uint32_t)total,  \
              (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, gmax, ha, tl, grid)
         if (W == 4) { if (U == 4) ANTQ_LAUNCH_H(4, 4); else if (U == 3) ANTQ_LAUNCH_H(3, 4); else ANTQ_LAUNCH_H(2, 4); }
-        else { if (U == 4) ANTQ_LAUNCH_H(4, 1); else if (U == 3) ANTQ_LAUNCH_H(3, 1); else ANTQ_LAUNCH_H(2, 1); }
+        else { if (U == 8) ANTQ_LAUNCH_H(8, 1); else if (U == 4) ANTQ_LAUNCH_H(4, 1); else if (U == 3) ANTQ_LAUNCH_H(3, 1); else ANTQ_LAUNCH_H(2, 1); }
 #undef ANTQ_LAUNCH_H
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }

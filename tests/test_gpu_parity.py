@@ -3235,7 +3235,10 @@ def test_16bit_domain_row_kernels_on_every_pattern(antq_lib, oracle, dev):
                         assert not bad.any(), (name, str(tdt), ovp, what, int(bad.sum()), np.argwhere(bad)[:3].tolist(),
                                                x16[bad][:3], got[bad][:3], ref16[bad][:3])
 
-                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "one launch")
+                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "one launch")     # (8-vector tasks)
+                    knob(0, 4)
+                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "one launch, 4-vector tasks")
+                    knob(0, 0)
                     same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp, out=torch.empty_like(xt), unordered=True), "unordered")
                     knob(9, 0)
                     same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "round-3 kernels")

@@ -34,7 +34,8 @@ for u in (2, 4):
     for pad in (0, 2048, 4608, 8192, 12 * 1024):
         variants.append(("hrow U=%d lds pad %5d (%d wg/CU)" % (u, pad, min(32, 160 * 1024 // (2048 + pad))), {0: u, 10: pad}))
 variants = [v for v in variants if "pad 12288" not in v[0] and "pad  8192" not in v[0]]
-variants += [("hrow U=4 W=4", {0: 4, 6: 4}), ("hrow U=2 W=4", {0: 2, 6: 4}), ("hrow default", {})]
+variants += [("hrow U=4 W=4", {0: 4, 6: 4}), ("hrow U=2 W=4", {0: 2, 6: 4}), ("hrow U=8 (one wavefront per 4096-element row)", {0: 8}),
+             ("hrow U=8 lds pad  4608 (24 wg/CU)", {0: 8, 10: 4608}), ("hrow default", {})]
 for rnd in range(2):
     for name, kn in variants:
         for k, v in kn.items(): knob(k, v)
