@@ -54,9 +54,9 @@ static SearchGrid search_grid(size_t units, size_t unit_work, bool pt, int n, in
     const bool many_rounds = std::min((units + 3) / 4, cap) * (size_t)c_many >= 3 * (size_t)resident;
     SearchGrid best{0, 0, 0};
     double best_cost = 0.0;
-    for (int c = cmin; c <= std::min(n, 64); c++) {
-        const int want = g_knob_schunks > 0 ? std::max(cmin, std::min(g_knob_schunks, n)) : (many_rounds ? c_many : 0);   // knob 12 (A/B)
-        if (want > 0 && c != want) continue;
+    const int want = g_knob_schunks > 0 ? std::max(cmin, std::min(g_knob_schunks, n)) : (many_rounds ? std::min(c_many, n) : 0);   // knob 12 (A/B)
+    const int c_lo = want > 0 ? want : cmin, c_hi = want > 0 ? want : std::max(cmin, std::min(n, 64));
+    for (int c = c_lo; c <= c_hi; c++) {
         const int chunk = (n + c - 1) / c;
         const int ce = (n + chunk - 1) / chunk;
         if (ce != c && c != cmin && want == 0) continue;             // (the same split as a smaller c)

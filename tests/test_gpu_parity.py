@@ -3524,6 +3524,20 @@ def test_search_sums_do_not_depend_on_the_grid_split(antq_lib, dev, oracle):
             assert torch.equal(multi[0], whole), (rows, K, per_row, bf16)
             second = antq_lib.search_sse(xt, r_, k_, xm, per_row, ratios, plans[1], 7.0)
             assert torch.equal(multi[1], second), (rows, K, per_row, bf16)
+    # long candidate lists: 300 ratios (3 chunks of <= 128 at least), and 4 codebooks x 175 ratios = 700 flat entries on one read
+    x = (rng.standard_normal((64, 1024)) * 0.05).astype(np.float32)
+    xt = to_dev(x, dev)
+    xm = antq_lib.absmax(xt, 64, 1024, per_row=True).reshape(-1)
+    long_r = torch.from_numpy(np.float32([np.float32(i * 0.005) for i in range(100, 400)])).to(dev)
+    whole = antq_lib.search_sse(xt, 64, 1024, xm, True, long_r, plans[0], 10.0)
+    parts = [antq_lib.search_sse(xt, 64, 1024, xm, True, long_r[a:a + 50].contiguous(), plans[0], 10.0) for a in range(0, 300, 50)]
+    assert torch.equal(torch.cat(parts, 0), whole)
+    r175 = torch.from_numpy(np.float32([np.float32(i * 0.01) for i in range(75, 250)])).to(dev)
+    four = [plans[0], plans[1], antq_lib.plan_for(grids.ant_pot(4, True)), antq_lib.plan_for(grids.ant_int(4, False))]
+    multi = antq_lib.search_sse_multi(xt, 64, 1024, xm, True, r175, four, [10.0, 7.0, 10.0, 15.0])
+    assert multi is not None and multi.shape[:2] == (4, 175)
+    for t, (p_, g_) in enumerate(zip(four, [10.0, 7.0, 10.0, 15.0])):
+        assert torch.equal(multi[t], antq_lib.search_sse(xt, 64, 1024, xm, True, r175, p_, g_)), t
 
 
 @pytest.mark.parametrize("tree", ["ant", "olive"])
