@@ -3853,3 +3853,83 @@ def test_type_pick_stays_on_the_device_for_input_quantisers(tree, mode, dev, cap
         out = lin[1](x.clone().requires_grad_(True))
         assert lin[1].quant_input._pending is None and lin[1].quant_input._steady and out.requires_grad
     capsys.readouterr()
+
+
+def _fuzz_seeds(default):
+    return int(os.environ.get("ANTQ_FUZZ_SEEDS", default))
+
+
+@pytest.mark.parametrize("seed", range(_fuzz_seeds(3)))
+def test_calibration_pass_fuzz_fast_schedule_equals_step_by_step(seed, dev, capsys):
+    """Random small models (shared inputs, conv + linear, ragged conv rows, random widths), random tree / mode / bit widths /
+    dtype / windows: the calibration pass with everything on (sign probes, search memo, weights searched in one batch, type
+    picks kept on the device, lazy log values) against the step-by-step schedule (all of it off) -- same modes, codebooks,
+    alphas, outputs of the calibrating and of the following forward, and the same printed lines in the same order."""
+    import importlib
+    import torch
+    import torch.nn as nn
+    from ant_quantization_amd import core
+    rng = np.random.default_rng(1000 + seed)
+    tree = ("ant", "olive")[int(rng.integers(0, 2))]
+    modes = {"ant": ["flint", "int", "ant-int-flint", "ant-int-pot-flint", "ant-int-pot-float-flint", "ant-int-float2-flint"],
+             "olive": ["flint", "int", "ant-int-flint"]}[tree]
+    mode = modes[int(rng.integers(0, len(modes)))]
+    dt = (torch.float32, torch.bfloat16, torch.float16)[int(rng.integers(0, 3))]
+    wbit, abit = int(rng.choice([3, 4, 4, 5])), int(rng.choice([4, 4, 5]))
+    lo, up = int(rng.integers(60, 96)), int(rng.integers(100, 180))
+    c_in, c_mid = int(rng.choice([3, 4, 8])), int(rng.choice([8, 16, 24]))
+    hw, feat = 6, int(rng.choice([64, 96, 128]))
+    qmod = importlib.import_module("ant_quantization_amd.%s.quant_model" % tree)
+    qutil = importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree)
+    qutil.set_quantizer(_args(mode=mode, wbit=wbit, abit=abit, w_low=lo, a_low=lo, w_up=up, a_up=up,
+                              no_outlier=bool(rng.integers(0, 4) == 0)))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = nn.Conv2d(c_in, c_mid, 3, padding=1)
+            self.q, self.k, self.v = nn.Linear(c_mid * hw * hw, feat), nn.Linear(c_mid * hw * hw, feat), nn.Linear(c_mid * hw * hw, feat)
+            self.o = nn.Linear(feat, 10)
+
+        def forward(self, x):
+            h = torch.relu(self.c1(x)).flatten(1)
+            return self.o(self.q(h) * torch.sigmoid(self.k(h)) + self.v(h))
+
+    torch.manual_seed(seed)
+    x = (torch.randn(16, c_in, hw, hw, device=dev) * float(rng.uniform(0.2, 3.0))).to(dt)
+    res = []
+    for fast in (True, False):
+        torch.manual_seed(seed + 77)
+        m = qmod.quantize_model(Net()).to(dev).to(dt).eval()
+        capsys.readouterr()
+        qutil.enable_quantization(m)
+        ab = m._antq_auto_bank
+        if not fast:
+            ab.batch_calibration, ab.defer_types = 0, False
+            for l in m.modules():
+                if hasattr(l, "quant_input"):
+                    l.quant_input.prefetch_sign = lambda t: None
+        core.search_memo.clear()
+        core.search_memo.enabled = fast
+        try:
+            with torch.no_grad():
+                y1 = m(x)
+                log = capsys.readouterr().out
+                y2 = m(x)
+        finally:
+            core.search_memo.enabled = True
+        st = []
+        for l in m.modules():
+            if hasattr(l, "quant_input"):
+                for q in (l.quant_weight, l.quant_input):
+                    assert q._steady and q._pending is None
+                    st.append((q.mode, q.is_signed, q.quant_grid.clone(), q.alpha.detach().clone(), q.mse.clone()))
+        res.append((y1, y2, log, st))
+    (a1, a2, la, sa), (b1, b2, lb, sb) = res
+    tag = (seed, tree, mode, str(dt), wbit, abit, lo, up)
+    assert la == lb and la.count("-bit") == 10, tag
+    for (m0, s0, g0, al0, e0), (m1, s1, g1, al1, e1) in zip(sa, sb):
+        assert m0 == m1 and s0 == s1 and torch.equal(g0, g1) and torch.equal(al0, al1), tag
+        np.testing.assert_allclose(e0.float().cpu().numpy(), e1.float().cpu().numpy(), rtol=1e-5, err_msg=str(tag))
+    assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(a1, a2), tag
+    capsys.readouterr()

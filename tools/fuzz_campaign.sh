@@ -2,7 +2,8 @@
 # Wide fuzz run on an MI355X (the -m gpu suite runs the same tests with a handful of seeds):
 #   gpurun -- 'bash tools/fuzz_campaign.sh 1500 120 300'
 # $1 seeds for test_fuzz_every_launch_form_long_rows (10 tensors each, every launch form against the oracle),
-# $2 seeds for the arbitrary-codebook / arbitrary-shape fuzz tests, $3 seeds (5 calibrations each) for the calibration fuzz.  Summary -> gpurun_out/fuzz_campaign.log
+# $2 seeds for the arbitrary-codebook / arbitrary-shape fuzz tests, $3 seeds (5 calibrations each) for the calibration fuzz,
+# $4 seeds (random models) for the calibration-pass fuzz.  Summary -> gpurun_out/fuzz_campaign.log
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -19,4 +20,7 @@ mkdir -p gpurun_out
   echo "== test_calibration_fuzz_random_shapes_vs_oracle, ${3:-300} seeds"
   ANTQ_FUZZ_SEEDS=${3:-300} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k calibration_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+  echo "== test_calibration_pass_fuzz_fast_schedule_equals_step_by_step, ${4:-150} seeds"
+  ANTQ_FUZZ_SEEDS=${4:-150} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k calibration_pass_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
 } | tee gpurun_out/fuzz_campaign.log
