@@ -183,11 +183,12 @@ static int launch_hrow(const void *x, void *out, size_t rows, size_t vpr, const 
         const PlanHeader *php = static_cast<const PlanHeader *>(plan_host);
         int U = g_knob_h == 2 ? (int)row_task_u((uint32_t)vpr) : (int)hrow_static_u((uint32_t)vpr, g_knob_x != 0 && php->xdom != 0u);
         if (U == 0) return ANTQ_ERR_UNSUPPORTED;          // (short / awkward rows: the fp32-domain row table, see hrow_static_u)
-        // An ORDERED launch that fits one round of wavefronts (256 CUs x 32) when a wavefront takes 8 vectors per lane -- one
-        // 4096 x 4096 bf16 tensor: 8192 wavefronts, each a whole row, table built once per row -- starts and drains as one
-        // front: 13.3 -> 12.95 us (63.2 -> 64.8 %); an unordered launch overlaps its neighbours and keeps 4 (77 vs 74.4 %);
-        // longer launches keep 4 and the occupancy cap (tools/probe_per_tensor.py, profiles/r04_per_tensor_shapes.log)
-        if (U == 4 && !t_unordered && vpr % 512u == 0u && rows * (vpr / 512u) <= 8192u) U = 8;
+        // An ORDERED launch of 1024 ... 4096 wavefronts when a wavefront takes 8 vectors per lane -- one 4096 x 4096 bf16 tensor:
+        // 4096 wavefronts, each a whole row, its table built once -- starts and drains as one front: 13.3 -> 12.9 us (63.3 ->
+        // 65.1 %), 1024 x 4096: 5.03 -> 4.84 us.  Fewer wavefronts than that leave CUs idle (256 rows: 3.6 -> 4.2 us), more
+        // (8192 x 4096: 23.3 -> 23.7 us) and every unordered launch (77 vs 74.4 %) do better with 4
+        // (tools/probe_per_tensor.py, profiles/r04_per_tensor_shapes.log)
+        if (U == 4 && !t_unordered && vpr % 512u == 0u && rows * (vpr / 512u) >= 1024u && rows * (vpr / 512u) <= 4096u) U = 8;
         if ((g_knob_u >= 2 && g_knob_u <= 4) || g_knob_u == 8) U = g_knob_u;      // knob 0 (A/B)
         const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
         const size_t total = rows * tpr;

@@ -454,7 +454,7 @@ def main():
                                            "gelem_per_s": round(ROWS * COLS / ptu_launch_s / 1e9, 1),
                                            "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9, 1),
                                            "frac": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9 / HBM_PEAK_GBPS, 4),
-                                           "ordered": {"kernel": "antq::k_fq_hrow<bf16,false,8> (one wavefront per row: the launch is one round of wavefronts)",
+                                           "ordered": {"kernel": "antq::k_fq_hrow<bf16,false,8> (one wavefront per row)",
                                                        "launch_us": round(pt_launch_s * 1e6, 2),
                                                        "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -3235,9 +3235,9 @@ def test_16bit_domain_row_kernels_on_every_pattern(antq_lib, oracle, dev):
                         assert not bad.any(), (name, str(tdt), ovp, what, int(bad.sum()), np.argwhere(bad)[:3].tolist(),
                                                x16[bad][:3], got[bad][:3], ref16[bad][:3])
 
-                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "one launch")     # (8-vector tasks)
-                    knob(0, 4)
-                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "one launch, 4-vector tasks")
+                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "one launch")
+                    knob(0, 8)      # (what an ordered launch of 1024 ... 4096 whole-row wavefronts takes by itself)
+                    same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp), "one launch, 8-vector tasks")
                     knob(0, 0)
                     same(antq_lib.fakequant(xt, at, plan, gmax, rows, 65536, True, ovp=ovp, out=torch.empty_like(xt), unordered=True), "unordered")
                     knob(9, 0)
@@ -3933,3 +3933,34 @@ def test_calibration_pass_fuzz_fast_schedule_equals_step_by_step(seed, dev, caps
         np.testing.assert_allclose(e0.float().cpu().numpy(), e1.float().cpu().numpy(), rtol=1e-5, err_msg=str(tag))
     assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(a1, a2), tag
     capsys.readouterr()
+
+
+def test_ordered_launch_with_whole_row_wavefronts(antq_lib, oracle, dev):
+    """An ordinary (ordered) launch of 1024 ... 4096 rows of 512 / 1024 vectors takes 8 vectors per lane (antq_fq.hip:
+    launch_hrow): 1024 x 4096 and 2048 x 8192 bf16 / f16, ANT and OliVe pairs, against the oracle; the unordered launch of the
+    same tensor (4-vector tasks) and the forced 4-vector ordered one agree bit for bit."""
+    import torch
+    from ant_quantization_amd import grids
+    rng = np.random.default_rng(77)
+    knob = antq_lib.lib().antq_debug_set
+    gn, go = grids.olive_flint(4, True), grids.olive_outliers(4, True)
+    for (rows, K) in ((1024, 4096), (2048, 8192)):
+        x = (rng.standard_normal((rows, K)) * 0.03).astype(np.float32)
+        x.reshape(-1)[::4099] *= 25.0
+        for f16 in (False, True):
+            xh = x.astype(np.float16).view(np.uint16) if f16 else oracle.f32_to_bf16(x)
+            xf = xh.view(np.float16).astype(np.float32) if f16 else oracle.bf16_to_f32(xh)
+            xt = torch.from_numpy(xh.view(np.int16)).to(dev).view(torch.float16 if f16 else torch.bfloat16)
+            for g, gmax, ovp, ratio in ((grids.ant_flint(4, True), 10.0, False, 0.9), (np.concatenate([gn, go]), float(gn.max()), True, 0.25)):
+                alpha = (np.abs(xf).max(1) * np.float32(ratio)).astype(np.float32)
+                ref, _ = oracle.forward(xf, alpha, np.ascontiguousarray(g, dtype=np.float32), gmax, ovp)
+                ref16 = ref.astype(np.float16).view(np.uint16) if f16 else oracle.f32_to_bf16(ref)
+                plan = antq_lib.plan_for(g)
+                at = torch.from_numpy(alpha).to(dev)
+                got = antq_lib.fakequant(xt, at, plan, gmax, rows, K, True, ovp=ovp)
+                assert np.array_equal(got.view(torch.int16).cpu().numpy().view(np.uint16), ref16), (rows, K, f16, ovp)
+                un = antq_lib.fakequant(xt, at, plan, gmax, rows, K, True, ovp=ovp, out=torch.empty_like(xt), unordered=True)
+                knob(0, 4)
+                four = antq_lib.fakequant(xt, at, plan, gmax, rows, K, True, ovp=ovp)
+                knob(0, 0)
+                assert torch.equal(un.view(torch.int16), got.view(torch.int16)) and torch.equal(four.view(torch.int16), got.view(torch.int16))
