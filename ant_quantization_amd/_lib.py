@@ -57,7 +57,7 @@ def lib():
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
                              "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
                              "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma",
-                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h", "antq_calibrate_batch"):
+                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h", "antq_calibrate_batch", "antq_absmax_into"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 L.antq_search_workspace_bytes.restype = ctypes.c_size_t
@@ -69,6 +69,7 @@ def lib():
                 L.antq_fakequant_dynamic.argtypes = [vp, vp, vp, vp, sz, sz, cf, cf, vp, vp, cu, ci, vp]
                 L.antq_nearest.argtypes = [vp, vp, vp, sz, vp, ci, ci, vp]
                 L.antq_absmax.argtypes = [vp, vp, sz, sz, ci, ci, vp]
+                L.antq_absmax_into.argtypes = [vp, vp, sz, ci, vp]
                 L.antq_copy.argtypes = [vp, vp, sz, vp]
                 _lib = L
     return _lib
@@ -441,11 +442,34 @@ def fakequant_dynamic(x, plan, gmax, rows, row_len, ratio=1.0, ovp=False, want_i
     return out, (alpha if want_alpha else None), idx
 
 
+_zero_pools = {}          # device index -> [float32 zeros, next free slot]
+
+
+def _zero_slot(device):
+    """A one-element float32 tensor holding 0 -- a slot of a pool zeroed once for 4096 calls, never handed out twice (the
+    whole-tensor abs-max then needs no launch of its own for that zero: antq_absmax_into)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _zero_pools.get(idx)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _zero_pools[idx] = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
+    pool[1] += 1
+    return pool[0][pool[1] - 1:pool[1]]
+
+
 def absmax(x, rows, row_len, per_row=True):
     _require_gpu(x, "x")
     dt = _DTYPES.get(x.dtype)
     if dt is None or dt == F64:
         raise AntqError("unsupported dtype %s" % x.dtype)
+    if not per_row and not torch.cuda.is_current_stream_capturing():
+        # one launch: the maximum is accumulated into a slot that already holds 0 (a captured graph would replay into the
+        # same slot, so captures keep the self-initialising entry below)
+        amax = _zero_slot(x.device)
+        with _on_device(x.device):
+            rc = lib().antq_absmax_into(x.data_ptr(), amax.data_ptr(), rows * row_len, dt, _stream_int(x.device))
+        if rc:
+            _check(rc, "antq_absmax_into")
+        return amax
     amax = torch.empty(rows if per_row else 1, dtype=torch.float32, device=x.device)     # (the entry point initialises it)
     with _on_device(x.device):
         rc = lib().antq_absmax(x.data_ptr(), amax.data_ptr(), rows, row_len, 1 if per_row else 0, dt, _stream_int(x.device))

@@ -189,7 +189,10 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
         __syncthreads();
         if (threadIdx.x == 0) {
             m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
-            if (m) atomicMax(reinterpret_cast<unsigned int *>(amax), m);
+            // (a look before the atomic: after the first few workgroups the running maximum already covers most of the
+            //  others, whose atomics -- serialised on ONE address -- then never happen: lets the launch use every CU slot)
+            unsigned int *dst = reinterpret_cast<unsigned int *>(amax);
+            if (m && m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
         }
     }
 }

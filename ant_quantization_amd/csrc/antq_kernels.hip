@@ -244,7 +244,7 @@ extern "C" int antq_debug_set(int key, int value)
 namespace antq {
 
 template <typename T>
-static int launch_absmax(const void *x, float *amax, size_t rows, size_t row_len, int per_row, hipStream_t st)
+static int launch_absmax(const void *x, float *amax, size_t rows, size_t row_len, int per_row, hipStream_t st, bool zero = true)
 {
     constexpr int EPL = IO<T>::EPL;
     const bool al = reinterpret_cast<uintptr_t>(x) % 16 == 0;
@@ -263,12 +263,14 @@ static int launch_absmax(const void *x, float *amax, size_t rows, size_t row_len
     }
     size_t waves = per_row ? rows : (rows * row_len + 64 * EPL * 4 - 1) / (64 * EPL * 4);
     size_t blocks = (waves + 3) / 4;
-    // (per tensor: one workgroup per CU -- every workgroup ends with an atomicMax on ONE address, and a thousand of them arriving
-    //  together cost more than the read: 23.6 -> 16.4 us for 67 MB with 256 instead of 1024 workgroups)
+    // (per tensor: one workgroup per CU.  More measured slower with and without the closing atomics -- 16384^2 bf16: 83.7 us
+    //  with 256 workgroups, 90 / 109 / 113 / 117 us with 512 / 1024 / 2048 / 4096 -- the block-strided walk wants few, long streams; a chunked walk with
+    //  1024 workgroups reads 33 MB in the per-row kernel's 7.5 us but then spends 15 us on its 1024 atomics to ONE address, which
+    //  all arrive together: 23 us against this shape's 9.3)
     if (blocks > (per_row ? 4096u : 256u)) blocks = per_row ? 4096 : 256;
     if (blocks < 1) blocks = 1;
     // the whole-tensor maximum is an atomicMax of workgroup maxima into a zero (stream-ordered, capturable)
-    if (!per_row) hipLaunchKernelGGL(k_zero_f32, dim3(1), dim3(64), 0, st, amax);
+    if (!per_row && zero) hipLaunchKernelGGL(k_zero_f32, dim3(1), dim3(64), 0, st, amax);
     hipLaunchKernelGGL((k_absmax<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, amax, rows, row_len, per_row, vec_ok);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
@@ -367,6 +369,19 @@ extern "C" int antq_absmax(const void *x, float *amax, size_t rows, size_t row_l
     case ANTQ_F32: return launch_absmax<float>(x, amax, rows, row_len, per_row ? 1 : 0, st);
     case ANTQ_BF16: return launch_absmax<bf16_tag>(x, amax, rows, row_len, per_row ? 1 : 0, st);
     case ANTQ_F16: return launch_absmax<f16_tag>(x, amax, rows, row_len, per_row ? 1 : 0, st);
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int antq_absmax_into(const void *x, float *amax, size_t n, int dtype, void *stream)
+{
+    if (n == 0) return ANTQ_OK;
+    if (!x || !amax) return ANTQ_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case ANTQ_F32: return launch_absmax<float>(x, amax, 1, n, 0, st, false);
+    case ANTQ_BF16: return launch_absmax<bf16_tag>(x, amax, 1, n, 0, st, false);
+    case ANTQ_F16: return launch_absmax<f16_tag>(x, amax, 1, n, 0, st, false);
     default: return ANTQ_ERR_UNSUPPORTED;
     }
 }

@@ -39,7 +39,7 @@ extern "C" {
  * output, the batch blob changed (plan version 8), ANTQ_FLAG_UNORDERED.  3: antq_calibrate / antq_calibrate_workspace_bytes
  * added (nothing else changed).  4 (round 4): the plan blob grew (version 9: 128-byte header + the threshold list of the
  * 16-bit-domain kernels; ANTQ_PLAN_MAX_BYTES with it), the batch blob changed, antq_plan_eval_host_h and
- * antq_prefetch_kernels added.  5: antq_calibrate_batch / antq_calibrate_batch_workspace_bytes added (nothing else changed).
+ * antq_prefetch_kernels added.  5: antq_calibrate_batch / antq_calibrate_batch_workspace_bytes and antq_absmax_into added (nothing else changed).
  * A caller built against another version must not call in: the blobs / argument lists differ. */
 #define ANTQ_ABI_VERSION 5
 
@@ -183,6 +183,13 @@ int antq_fakequant_dynamic(const void *x_dev, void *out_dev, int16_t *idx_dev,
  * ------------------------------------------------------------------------- */
 int antq_absmax(const void *x_dev, float *amax_dev, size_t rows, size_t row_len,
                 int per_row, int dtype, void *stream);
+
+/* The whole-tensor abs-max as ONE launch: *amax_dev = max(*amax_dev, max_i |x[i]|) over n elements.  The caller provides
+ * the initial value -- 0 for a fresh maximum (e.g. a slot of a buffer zeroed once for many calls: antq_absmax has to spend
+ * a launch on that zero, 10.8 -> 7.6 us for a 4096 x 4096 bf16 tensor), or the running maximum of the blocks seen so far
+ * (a tensor that arrives in pieces, a row-sharded quantiser's local blocks).  Same combination rule as antq_absmax
+ * (integer atomicMax on the float's bits: order-independent, NaN wins). */
+int antq_absmax_into(const void *x_dev, float *amax_dev, size_t n, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Backward of antq_fakequant with respect to alpha (QAT: alpha is a Parameter, AQ:39; the autograd graph of

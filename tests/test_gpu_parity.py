@@ -3964,3 +3964,35 @@ def test_ordered_launch_with_whole_row_wavefronts(antq_lib, oracle, dev):
                 four = antq_lib.fakequant(xt, at, plan, gmax, rows, K, True, ovp=ovp)
                 knob(0, 0)
                 assert torch.equal(un.view(torch.int16), got.view(torch.int16)) and torch.equal(four.view(torch.int16), got.view(torch.int16))
+
+
+def test_absmax_into_accumulates(antq_lib, oracle, dev):
+    """antq_absmax_into: max(initial, max|x|) in one launch -- a fresh maximum from a zeroed slot (what _lib.absmax does per
+    tensor), a tensor fed in pieces, an initial value above the data, NaN, ragged / unaligned pieces; fp32, bf16, f16."""
+    import ctypes
+    import torch
+    L = antq_lib.lib()
+    rng = np.random.default_rng(3)
+    for tdt, code in ((torch.float32, 0), (torch.bfloat16, 1), (torch.float16, 2)):
+        x = (torch.from_numpy((rng.standard_normal(1 << 20) * 3).astype(np.float32)).to(dev)).to(tdt)
+        want = x.float().abs().max()
+        got = antq_lib.absmax(x, 1024, 1024, per_row=False)
+        assert got.shape == (1,) and torch.equal(got[0], want)
+        acc = torch.zeros(1, device=dev)
+        for a, b in ((0, 1000), (1000, 300001), (300001, 1 << 20)):         # pieces that start at odd element offsets
+            piece = x[a:b]
+            assert L.antq_absmax_into(piece.data_ptr(), acc.data_ptr(), b - a, code, None) == 0
+        assert torch.equal(acc[0], want)
+        big = torch.full((1,), 1e6, device=dev)
+        assert L.antq_absmax_into(x.data_ptr(), big.data_ptr(), x.numel(), code, None) == 0 and float(big) == 1e6
+        xn = x.clone()
+        xn[12345] = float("nan")
+        acc = torch.zeros(1, device=dev)
+        assert L.antq_absmax_into(xn.data_ptr(), acc.data_ptr(), xn.numel(), code, None) == 0 and torch.isnan(acc).all()
+    assert L.antq_absmax_into(None, None, 0, 0, None) == 0 and L.antq_absmax_into(None, None, 8, 0, None) == -1
+    # many calls: slots are never handed out twice
+    seen = set()
+    for _ in range(5000):
+        t = antq_lib._zero_slot(dev)
+        assert t.data_ptr() not in seen
+        seen.add(t.data_ptr())
