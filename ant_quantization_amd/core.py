@@ -167,7 +167,8 @@ class SearchMemo:
     An entry is keyed by the tensor OBJECT (held weakly), its storage address and version counter, and by everything else the
     search depends on (the caller's key: statistic, window, step, codebook bytes, gmax, pair rule).  Only per-tensor searches
     of tensors that are not Parameters are kept (a weight has one quantiser; and Parameters are what `.data` edits, which
-    move no version counter, usually touch).  A handful of entries, newest first."""
+    move no version counter, usually touch).  A handful of entries, newest first; the forward hook enable_quantization
+    registers on the model clears them when the model's forward returns."""
 
     def __init__(self, keep=4):
         self.keep, self.entries, self.enabled, self.hits = keep, [], True, 0

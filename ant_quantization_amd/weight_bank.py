@@ -282,3 +282,6 @@ class FlushHook:
         auto = self._auto()
         if auto is not None and auto.queue:
             auto.flush()
+        from . import core
+        if core.search_memo.entries:
+            core.search_memo.clear()       # (shared activations are shared within ONE forward: nothing outlives it)
