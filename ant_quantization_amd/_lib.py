@@ -111,7 +111,8 @@ def prewarm(device, dtype=torch.float32):
     from . import grids
     prefetch_kernels(device)
     with torch.no_grad():
-        x = (torch.randn(256, 1024, device=device) * 0.1).to(dtype)
+        # (a deterministic toy tensor: the global RNG stream of a seeded run is not advanced by quantising the model)
+        x = (torch.sin(torch.arange(256 * 1024, device=device, dtype=torch.float32) * 0.37) * 0.1).view(256, 1024).to(dtype)
         plans_a = [plan_for(grids.ant_grid(t, 4, True)) for t in ("int", "flint")]
         on = grids.olive_grid("flint", 4, True)
         plan_o = plan_for(np.concatenate([on, grids.olive_outliers(4, True)]))
@@ -129,7 +130,8 @@ def prewarm(device, dtype=torch.float32):
         calibrate(xl, 64, 4096, True, plans_a[:1], [10.0], 95, 100, 1, xmax="absmax")
         calibrate(xl, 64, 4096, True, [plan_o], [float(on.max())], 95, 100, 2, xmax="3sigma", ovp=True)
         from . import _mirror
-        _mirror._slots.take().copy_(x.min().float().reshape(1), non_blocking=True)
+        s1 = _mirror._slots.take()
+        s1.copy_(x.min().float().reshape(1), non_blocking=True)
         torch.ones_like(al), al.clone()
         # the device-side type pick of input quantisers (_mirror.CalibrationMixin._calibrate_deferred): its gathers and casts
         a3, _, typ, _ = calibrate(x, 1, x.numel(), False, plans_a, [10.0, 10.0], 95, 100, 1, xmax="absmax")
@@ -137,8 +139,11 @@ def prewarm(device, dtype=torch.float32):
         a3.index_select(0, idx).reshape(())
         torch.stack([x, x]).index_select(0, idx)
         torch.zeros(2, 16, device=device).index_select(0, idx)[0]
-        _mirror._slots.take().copy_(typ.float(), non_blocking=True)
+        s2 = _mirror._slots.take()
+        s2.copy_(typ.float(), non_blocking=True)
         torch.cuda.synchronize(device)
+        _mirror._slots.give(s1)
+        _mirror._slots.give(s2)
 
 
 _ext_mod = False          # False: not tried yet; None: unavailable

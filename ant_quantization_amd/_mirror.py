@@ -59,16 +59,25 @@ def _lib_tensor_key(t):
 
 
 class _PinnedSlots:
-    """A small ring of pinned host floats for device->host copies nobody wants to wait for at issue time."""
+    """Pinned host floats for device->host copies nobody wants to wait for at issue time.  A slot belongs to whoever took it
+    until it is given back (`give`): a type pick parked until the end of the model's forward is never overwritten by a
+    later layer's probe, however many layers the model has (GPT-2 XL / OPT: 192 linears, two slots each).  The pool grows
+    by one pinned chunk whenever the free list runs dry; a slot nobody gives back costs four bytes."""
 
-    def __init__(self, n=256):
-        self.n, self.buf, self.i = n, None, 0
+    def __init__(self, chunk=256, alloc=None):
+        self.chunk, self.free, self.chunks = chunk, [], []
+        self._alloc = alloc or (lambda n: torch.zeros(n, dtype=torch.float32).pin_memory())
 
     def take(self):
-        if self.buf is None:
-            self.buf = torch.zeros(self.n, dtype=torch.float32).pin_memory()
-        self.i = (self.i + 1) % self.n
-        return self.buf[self.i:self.i + 1]
+        if not self.free:
+            buf = self._alloc(self.chunk)
+            self.chunks.append(buf)
+            self.free.extend(buf[i:i + 1] for i in range(self.chunk - 1, -1, -1))
+        return self.free.pop()
+
+    def give(self, slot):
+        if slot is not None:
+            self.free.append(slot)
 
 
 _slots = _PinnedSlots()
@@ -91,6 +100,7 @@ class CalibrationMixin:
     _pending = None               # (event, pinned slot, spec): a type pick made on the device, not yet known to the host
     _spec_out = None              # the calibrating forward's output of a quantiser whose pick is pending
     _defer_allowed = False        # set by tensor_forward: no gradient is wanted through this call
+    _grad_call = False            # set by tensor_forward: the caller's forward wants gradients for this tensor or alpha
 
     def _before_calibration(self, tensor):
         """First thing in tensor_forward of an enabled quantiser.  A weight quantiser that is not calibrated yet lets the model
@@ -170,6 +180,9 @@ class CalibrationMixin:
         self._pending = None
         ev.synchronize()
         t = int(slot[0])
+        _slots.give(slot)
+        if not 0 <= t < len(spec["modes"]):
+            raise RuntimeError("type pick %r out of range for %s" % (t, spec["modes"]))
         self.mode = spec["modes"][t]
         self._adopt_plan(spec, t)
         self._steady = True
@@ -182,6 +195,7 @@ class CalibrationMixin:
             return
         if self._hm_get('has_inited_quant_para') != 0:
             return
+        self._drop_probe()
         with torch.no_grad():
             slot = _slots.take()
             slot.copy_(tensor.detach().min().float().reshape(1), non_blocking=True)
@@ -189,13 +203,22 @@ class CalibrationMixin:
             ev.record(torch.cuda.current_stream(tensor.device))
         self._sign_probe = (tensor, _tensor_stamp(tensor), slot, ev)
 
+    def _drop_probe(self):
+        probe, self._sign_probe = self._sign_probe, None
+        if probe is not None:
+            probe[3].synchronize()                       # (the copy into the slot has landed: it may be reused)
+            _slots.give(probe[2])
+
     def update_signed(self, tensor):
         if self.is_signed:                               # already signed (weights): nothing to learn, no sync
             return
         probe, self._sign_probe = self._sign_probe, None
-        if probe is not None and probe[0] is tensor and probe[1] is not None and probe[1] == _tensor_stamp(tensor):
+        if probe is not None:
             probe[3].synchronize()                       # (recorded before the weight's calibration was issued)
-            negative = float(probe[2][0]) < 0
+            value = float(probe[2][0])
+            _slots.give(probe[2])
+        if probe is not None and probe[0] is tensor and probe[1] is not None and probe[1] == _tensor_stamp(tensor):
+            negative = value < 0
         else:
             negative = bool(tensor.min() < 0)
         if negative:
@@ -228,18 +251,33 @@ class WeightsAtRestMixin:
     def _rest_on(self):
         return self.weights_at_rest and not self.is_input
 
+    def _weights_may_change(self):
+        """A training forward of this quantiser, or a train() / eval() call on it: an optimiser step may follow (or have
+        happened), and optimisers that write through `.data` (the reference's BertAdam, BERT/optimization.py:161) move no
+        version counter.  Everything keyed on (address, version) is dropped: the attached WeightBank re-quantises on its next
+        lookup, the weights-at-rest mode launches ordered once and re-reads alpha."""
+        bank = self.__dict__.get("_bank")
+        if bank is not None:
+            bank.dirty = True
+        self._rest_stamp = self._rest_src = None
+        self._alpha32_stamp = None
+
+    def train(self, mode=True):
+        self._weights_may_change()
+        return super().train(mode)
+
     def __getstate__(self):
         """torch.save(model) pickles the module: the launch-mode caches (a weak reference among them) are not state."""
         st = self.__dict__.copy()
         for k in ("_rest_src", "_rest_stamp", "_rest_out", "_alpha32", "_alpha32_stamp", "_sign_probe", "_pending", "_spec_out",
-                  "_calib_ctx", "_calib_ready"):
+                  "_calib_ctx", "_calib_ready", "_bank", "_auto_bank"):
             if k in st:
                 st[k] = None
         return st
 
     def _rest_buffer(self, data):
         """The quantiser-owned output buffer of the weights-at-rest mode (None otherwise)."""
-        if not self._rest_on() or torch.is_grad_enabled() and data.requires_grad:
+        if not self._rest_on() or self._grad_call or torch.is_grad_enabled() and data.requires_grad:
             return None
         b = self._rest_out
         if b is None or b.shape != data.shape or b.dtype != data.dtype or b.device != data.device:
@@ -253,7 +291,7 @@ class WeightsAtRestMixin:
         it on every forward would put a kernel in flight right in front of the launch (which then has to stay ordered), so
         the weights-at-rest mode keeps a float32 copy, refreshed when the Parameter's storage or version changes."""
         a = self.alpha
-        if a.dtype == torch.float32 or not self._rest_on() or (torch.is_grad_enabled() and a.requires_grad):
+        if a.dtype == torch.float32 or not self._rest_on() or self._grad_call or (torch.is_grad_enabled() and a.requires_grad):
             return a
         st = _tensor_stamp(a)
         if st is None:                             # an inference tensor: no version counter, nothing to key a cache on
@@ -272,8 +310,13 @@ class WeightsAtRestMixin:
         writing or re-planning what this launch reads.  Whatever changed them (calibration a moment ago, load_state_dict, an
         optimiser step, a dtype / device move, a new grid) is then at least one ordinary, ordered launch of this quantiser in
         the past.  The first call after any such change launches ordered; so does every call on a tensor without a version
-        counter (created under torch.inference_mode).  (`.data` edits do not bump the counter: those stay the caller's promise.)"""
+        counter (created under torch.inference_mode), every training forward, and the first call after a training forward or
+        a train() / eval() call (`_weights_may_change`: optimisers that write through `.data`).  (A `.data` edit between two
+        no-grad forwards with none of those in between stays the caller's promise.)"""
         if not self._rest_on():
+            return False
+        if self._grad_call or (torch.is_grad_enabled() and (data.requires_grad or self.alpha.requires_grad)):
+            self._weights_may_change()             # (a training forward: the step that follows may write through `.data`)
             return False
         ds, as_ = _tensor_stamp(data), _tensor_stamp(self.alpha)
         if ds is None or as_ is None:

@@ -60,7 +60,10 @@ def make_walkers(Q):
                 from . import _lib
                 p0 = next(model.parameters(), None)
                 if p0 is not None and p0.is_cuda:
-                    _lib.prewarm(p0.device, p0.dtype)
+                    try:
+                        _lib.prewarm(p0.device, p0.dtype)
+                    except Exception as ex:        # noqa: BLE001  (a warm-up, never a reason to fail quantising the model)
+                        logger.warning("ant_quantization_amd: kernel prewarm skipped (%s)", ex)
             for name, module in model.named_modules():
                 if isinstance(module, Q):
                     getattr(module, method)(*((name,) if with_name else ()))

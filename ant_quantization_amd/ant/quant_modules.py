@@ -473,18 +473,22 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
                 return tensor
 
         self._before_calibration(tensor)
-        self._defer_allowed = not (torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad))
+        self._grad_call = torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad)
+        self._defer_allowed = not self._grad_call
         with torch.no_grad():
-            self._init_quant_para(tensor, input_tensor)
+            try:
+                self._init_quant_para(tensor, input_tensor)
+            except BaseException:
+                core.forget_absmax()
+                raise
         if self._spec_out is not None:                  # calibrated a moment ago with the pick still on the device
             out, self._spec_out = self._spec_out, None
             return out
 
-        if self._bank is None and self._auto_bank is not None and self._steady and not self.is_input and not (
-                torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad)):
+        if self._bank is None and self._auto_bank is not None and self._steady and not self.is_input and not self._grad_call:
             self._auto_bank.poke(self)         # (every weight quantiser calibrated: one launch for all of them from now on)
         if self._bank is not None:
-            hit = self._bank.lookup(self, tensor)
+            hit = self._bank.lookup(self, tensor, training=self._grad_call)
             if hit is not None:
                 return hit
 

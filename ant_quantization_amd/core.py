@@ -234,7 +234,7 @@ def device_grid(values, device):
     return t.clone()
 
 
-_absmax_memo = [None]          # (tensor, version, per_channel, result) of the last call: one calibration asks twice
+_absmax_memo = [None]          # (tensor, (version, address, dtype, shape, strides), per_channel, result) of the last call
 
 
 def forget_absmax():
@@ -248,14 +248,14 @@ def row_absmax(x, per_channel):
     the tensor object and its version counter (a weak reference: nothing is kept alive)."""
     import weakref
     m = _absmax_memo[0]
-    ver = None if torch.is_inference(x) else x._version
+    ver = None if torch.is_inference(x) else (x._version, x.data_ptr(), x.dtype, tuple(x.shape), tuple(x.stride()))
     if m is not None and m[0]() is x and m[1] == ver and ver is not None and m[2] == bool(per_channel):
-        return m[3]
+        return m[3].clone()            # (callers store the result into alpha.data: never hand the memo's own tensor out twice)
     xc = _calib_view(x).detach().contiguous()
     rows, row_len = view_rows(xc, per_channel)
     out = _lib.absmax(xc, rows, row_len, per_row=per_channel)
     try:
-        _absmax_memo[0] = (weakref.ref(x), ver, bool(per_channel), out)
+        _absmax_memo[0] = (weakref.ref(x), ver, bool(per_channel), out.clone())
     except TypeError:
         _absmax_memo[0] = None
     return out

@@ -387,8 +387,15 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         return core.fake_quant(data, self._rest_alpha(), plan, self._gmax, self.is_perchannel, ovp=not self._no_outlier,
                                unordered=self._at_rest(data), out=self._rest_buffer(data))
 
-    @torch.no_grad()
     def tensor_forward(self, tensor, input_tensor=None):
+        """OQ:332-359.  The reference runs it under @torch.no_grad(); whether the CALLER is in a training forward (gradients
+        enabled, the weight or alpha a leaf that wants one) is looked at before entering: such a call is followed by an
+        optimiser step, so nothing resident is served to it or trusted after it (weight_bank, weights-at-rest)."""
+        self._grad_call = torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad)
+        with torch.no_grad():
+            return self._tensor_forward(tensor, input_tensor)
+
+    def _tensor_forward(self, tensor, input_tensor=None):
         if self.mode == "base":
             return tensor
         if not self.is_enable:
@@ -401,15 +408,18 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
                 return tensor
         self._before_calibration(tensor)
         self._defer_allowed = True                      # (tensor_forward runs under no_grad in this tree: OQ:332)
-        self._init_quant_para(tensor, input_tensor)
+        try:
+            self._init_quant_para(tensor, input_tensor)
+        except BaseException:
+            core.forget_absmax()
+            raise
         if self._spec_out is not None:                  # calibrated a moment ago with the pick still on the device
             out, self._spec_out = self._spec_out, None
             return out
-        if self._bank is None and self._auto_bank is not None and self._steady and not self.is_input and not (
-                torch.is_grad_enabled() and (tensor.requires_grad or self.alpha.requires_grad)):
+        if self._bank is None and self._auto_bank is not None and self._steady and not self.is_input and not self._grad_call:
             self._auto_bank.poke(self)         # (every weight quantiser calibrated: one launch for all of them from now on)
         if self._bank is not None:
-            hit = self._bank.lookup(self, tensor)
+            hit = self._bank.lookup(self, tensor, training=self._grad_call)
             if hit is not None:
                 return hit
         return self._forward(tensor)

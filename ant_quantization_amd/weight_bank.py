@@ -12,8 +12,15 @@ tested bit-exact); what changes is WHEN the work happens:
 
   * weights and alphas are stamped by (`data_ptr`, `_version`); a layer whose stamp is stale triggers one
     refresh of the whole bank (so a QAT-style optimiser step costs one launch per step, not one per layer);
-  * a forward that needs gradients through the quantiser bypasses the bank (autograd path, AQ:544-549);
-  * in-place edits through `.data` do not bump `_version` -- call `bank.invalidate()` after those.
+  * a forward that needs gradients through the quantiser bypasses the bank (autograd path, AQ:544-549) AND marks the
+    whole bank dirty, and so does every `module.train()` / `.eval()` call on a wrapped layer: whoever trains between two
+    evaluations -- including optimisers that write through `.data` and never move a version counter, like the reference's
+    own BertAdam (`p.data.add_(-update_with_lr)`, BERT/optimization.py:161) -- gets freshly quantised weights on the
+    first no-grad forward afterwards (ONE launch), as the reference's cache-nothing schedule would (AQ:613-617, :642-646);
+  * THE ONE CASE LEFT TO THE CALLER: an in-place edit through `.data` (`w.data.mul_()`, `w.data.copy_()`) between two
+    no-grad forwards with no training forward and no train()/eval() call in between moves neither address nor version
+    counter and cannot be seen from here -- call `bank.invalidate()` (or `quant_utils.set_weight_bank(model, False)`,
+    which never caches) after such an edit.
 
 Attachment: `enable_quantization(model)` (quant_utils) arms an AutoBank -- once every weight quantiser of the model is
 calibrated, the next forward that does not need gradients through the quantisers builds the bank by itself, and from then
@@ -23,6 +30,7 @@ one.  `quant_utils.set_weight_bank(model, False)` (or ANTQ_WEIGHT_BANK=0 in the 
 per-layer schedule exactly; `WeightBank(model)` by hand still works.
 """
 import os
+import warnings
 import weakref
 
 import torch
@@ -47,19 +55,31 @@ class WeightBank:
         self.entries = {}          # id(quantiser) -> dict
         self._batches = []
         self._ptr_key = None
+        self.dirty = True          # set by whatever may have changed weights behind the stamps' back (mark_dirty)
         self.launches = 0          # refreshes run so far (for tests / logging)
         self.skipped = []          # (layer name, reason) of layers the bank leaves to the per-layer path
-        for name, mod, q, w in _weight_layers(model):
-            reason = self._unsuitable(q, w)
-            if reason:
-                self.skipped.append((name, reason))
-                continue
-            rows, row_len = (w.shape[0], w.numel() // w.shape[0]) if q.is_perchannel else (1, w.numel())
-            self.entries[id(q)] = dict(name=name, q=q, mod=mod, rows=rows, row_len=row_len,
-                                       out=torch.empty_like(w, memory_format=torch.contiguous_format), stamp=None)
-            q._bank = self
+        self.auto = None           # weakref to the AutoBank that built this bank (told when the bank gives up)
+        try:
+            for name, mod, q, w in _weight_layers(model):
+                reason = self._unsuitable(q, w)
+                if reason:
+                    self.skipped.append((name, reason))
+                    continue
+                rows, row_len = (w.shape[0], w.numel() // w.shape[0]) if q.is_perchannel else (1, w.numel())
+                self.entries[id(q)] = dict(name=name, q=q, mod=mod, rows=rows, row_len=row_len,
+                                           out=torch.empty_like(w, memory_format=torch.contiguous_format), stamp=None)
+                q._bank = self
+        except BaseException:      # (out of memory half way through: leave nothing attached)
+            self.detach()
+            raise
         if not self.entries:
             raise _lib.AntqError("WeightBank: no calibrated weight quantiser found (run one forward to calibrate first)")
+
+    def __deepcopy__(self, memo):       # (a copy of the model starts without a bank: its AutoBank -- if any -- builds its own)
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
 
     @staticmethod
     def _unsuitable(q, w):
@@ -82,8 +102,13 @@ class WeightBank:
         return (w.data_ptr(), w._version, a.data_ptr(), a._version, id(q._plan), q._gmax)
 
     def invalidate(self):
-        for e in self.entries.values():
-            e["stamp"] = None
+        """The next lookup re-quantises every weight (one launch).  For edits the stamps cannot see: `.data` writes."""
+        self.dirty = True
+
+    mark_dirty = invalidate
+
+    def nbytes(self):
+        return sum(e["out"].numel() * e["out"].element_size() for e in self.entries.values())
 
     def detach(self):
         for e in self.entries.values():
@@ -127,22 +152,43 @@ class WeightBank:
         for b in self._batches:
             b.run()
         self.launches += 1
+        self.dirty = False
         for e in self.entries.values():
             e["stamp"] = self._stamp(e["q"], e["mod"].weight)
 
-    def lookup(self, q, tensor):
+    def lookup(self, q, tensor, training=None):
         """Called from TensorQuantizer.tensor_forward in steady state.  Returns the resident fake-quantised
-        weight, or None when this forward has to take the per-layer path."""
+        weight, or None when this forward has to take the per-layer path.  `training`: the caller's forward wants gradients
+        for the weight or alpha (looked at before tensor_forward entered no_grad, OQ:332); None = decide here."""
         e = self.entries.get(id(q))
         if e is None or tensor is not e["mod"].weight:
             return None
-        if torch.is_grad_enabled() and (tensor.requires_grad or q.alpha.requires_grad):
+        if training is None:
+            training = torch.is_grad_enabled() and (tensor.requires_grad or q.alpha.requires_grad)
+        if training:
+            # a training forward: an optimiser step follows, and it may write through `.data` without moving any version
+            # counter (BERT/optimization.py:161) -- nothing resident is trusted after this
+            self.dirty = True
             return None
         if not q._steady or not (q.is_enable and q.is_enable_weight):
             return None
-        if e["stamp"] != self._stamp(q, tensor):
-            self.refresh()
+        if self.dirty or e["stamp"] != self._stamp(q, tensor):
+            try:
+                self.refresh()
+            except torch.cuda.OutOfMemoryError:
+                self._give_up("out of memory while refreshing the resident weights")
+                return None
         return e["out"]
+
+    def _give_up(self, why):
+        """The bank cannot serve this model (memory): detach for good, the per-layer schedule takes over."""
+        auto = self.auto() if self.auto is not None else None
+        self.detach()
+        if auto is not None:
+            auto.bank = None
+            auto.enabled = False
+            auto.reason = why
+        warnings.warn("ant_quantization_amd: weight bank switched off (%s); weights are quantised per layer" % why)
 
 
 class AutoBank:
@@ -155,6 +201,9 @@ class AutoBank:
         self.enabled = os.environ.get("ANTQ_WEIGHT_BANK", "1") != "0"
         self.first = None          # the quantiser whose forward comes first in registration order: the only one that pokes
         self.failed = 0
+        self.reason = None         # why the bank was switched off by itself, if it was (memory)
+        # the resident copies may take at most this fraction of the device memory that is free when the bank is built
+        self.mem_fraction = float(os.environ.get("ANTQ_BANK_MEM_FRACTION", "0.25"))
         self.batch_calibration = {"0": 0, "2": 2}.get(os.environ.get("ANTQ_BATCH_CALIB", "1"), 1)
         self.defer_types = os.environ.get("ANTQ_DEFER_TYPES", "1") != "0"      # _mirror.CalibrationMixin._calibrate_deferred
         self.queue = []            # calibration log: lines in order, quantisers whose line waits for its type pick
@@ -257,14 +306,33 @@ class AutoBank:
         model = self._model()
         if model is None:
             return
+        # One resident quantised copy of every weight: affordable for the models the reference evaluates, not for a model that
+        # fills the device.  Build only when the copies fit comfortably into what is free right now; otherwise (and after an
+        # allocation failure) the bank stays off for good and every layer keeps the reference's schedule.
+        need = {}
+        for _, _, q, w in _weight_layers(model):
+            if w.is_cuda and q._steady:
+                need[w.device] = need.get(w.device, 0) + w.numel() * w.element_size()
+        for dev, n in need.items():
+            free, _ = torch.cuda.mem_get_info(dev)
+            free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # (cached blocks torch can reuse)
+            if n > self.mem_fraction * free:
+                self.enabled = False
+                self.reason = "resident copies need %d MB, %d MB free on %s" % (n >> 20, free >> 20, dev)
+                return
         try:
             bank = WeightBank(model)
         except _lib.AntqError:
             self.failed += 1
             return
+        except (torch.cuda.OutOfMemoryError, RuntimeError) as ex:
+            self.enabled = False
+            self.reason = "building the bank failed: %s" % (str(ex).splitlines() or [""])[0]
+            return
         if any(reason == "not calibrated yet" for _, reason in bank.skipped):
             bank.detach()              # (a partially calibrated model: try again on a later forward)
             return
+        bank.auto = weakref.ref(self)
         self.bank = bank
 
 

@@ -5,7 +5,10 @@
 // upload it, call the fused entry points on its own stream and buffers.  Covers antq_nearest (the quant_cuda.quant
 // replacement, KQ/quant_kernel.cu:11-62), antq_fakequant (AQ:535-551), the OliVe victim rule (OQ:311-320),
 // antq_fakequant_dynamic + antq_absmax, antq_fakequant_batch, the packed 4-bit codec, antq_nearest_hinted, group-16 and the
-// calibration entry points (antq_search_sse with its workspace, antq_search_pick, and antq_calibrate: all of it in one call).
+// calibration entry points (antq_search_sse with its workspace, antq_search_pick, and antq_calibrate: all of it in one call),
+// and -- section 9 -- every ABI 4 / 5 entry: antq_nearest_plan, the host models antq_plan_eval_host[_a|_h], the 16-bit-domain row
+// kernels on bf16, antq_absmax_into, antq_search_sse_multi, antq_moments + antq_xmax_3sigma, antq_affine, antq_alpha_grad,
+// antq_calibrate_batch, antq_copy, antq_prefetch_kernels, antq_debug_set: every prototype of include/antq.h is called here.
 // Exit code 0 = every comparison bit-exact; prints one line per check.
 #include <hip/hip_runtime.h>
 
@@ -26,6 +29,11 @@ void antq_oracle_absmax_f32(const float *x, float *alpha, size_t rows, size_t ro
 int antq_oracle_search_mse_f32(const float *x, size_t rows, size_t row_len, int per_row, const float *x_max, int lb, int ub,
                                int step, const float *grid, int m, float gmax, int ovp, float *best_score, float *best_alpha,
                                float *trace);
+void antq_oracle_f32_to_bf16(const float *in, uint16_t *out, size_t n);
+void antq_oracle_forward_bf16(const uint16_t *x, uint16_t *out, int32_t *idx, size_t rows, size_t row_len, const float *alpha,
+                              int alpha_per_row, const float *grid, int m, float gmax, int ovp);
+void antq_oracle_affine_f32(const float *x, float *out, int32_t *qout, size_t rows, size_t row_len, int k, const float *x_min,
+                            const float *x_max, int per_row);
 }
 
 #define HIP_OK(e)                                                                                          \
@@ -334,6 +342,275 @@ int main()
                    bad ? "MISMATCH" : "ok", ty, osum[0], osum[1]);
             if (bad) failures++;
         }
+    }
+
+    // 9. ABI 4 / 5 entry points from the torch-free host ------------------------------------------------------------------
+    // 9a. antq_nearest_plan: the operator through a host-known plan == the literal scan (KQ/quant_kernel.cu:20-38)
+    {
+        ANTQ_OK_(antq_nearest_plan(dxf.p, dout.p, didx.p, n, plan.data(), dplan.p, ANTQ_F32, st));
+        antq_oracle_nearest_f32(xf.data(), ref.data(), ridx.data(), n, flint.data(), (int)flint.size());
+        same_bits("antq_nearest_plan values", dout.down(st), ref);
+        same_idx("antq_nearest_plan indices", didx.down(st), ridx);
+        if (antq_plan_bytes(plan.data()) != pb) { printf("antq_plan_bytes != antq_plan_build's size\n"); failures++; }
+    }
+
+    // 9b. host models of the device element paths (pure CPU): antq_plan_eval_host == the literal scan on grid-domain inputs;
+    //     antq_plan_eval_host_a == the oracle's forward for one scale, whatever the reciprocal's last bit
+    {
+        const size_t ne = 4096;
+        std::vector<float> d(ne), q(ne), qref(ne);
+        std::vector<int16_t> qi(ne);
+        std::vector<int32_t> qiref(ne);
+        for (size_t i = 0; i < ne; i++) d[i] = x[i] * 400.0f;
+        d[5] = NAN; d[7] = INFINITY;
+        ANTQ_OK_(antq_plan_eval_host(plan.data(), d.data(), q.data(), qi.data(), ne));
+        antq_oracle_nearest_f32(d.data(), qref.data(), qiref.data(), ne, flint.data(), (int)flint.size());
+        same_bits("antq_plan_eval_host == literal scan", q, qref);
+        same_idx("antq_plan_eval_host indices", qi, qiref);
+        const float a_one = 0.071f;
+        std::vector<float> xs(xf.begin(), xf.begin() + ne), oa(ne), oref(ne);
+        antq_oracle_forward_f32(xs.data(), oref.data(), qiref.data(), 1, ne, &a_one, 0, flint.data(), (int)flint.size(), 10.0f, 0);
+        for (int ulps = -1; ulps <= 1; ulps++) {
+            const int rc = antq_plan_eval_host_a(plan.data(), xs.data(), ne, a_one, 10.0f, ulps, oa.data(), qi.data(), nullptr);
+            if (rc == ANTQ_ERR_UNSUPPORTED) { printf("antq_plan_eval_host_a: plan without that path (skipped)\n"); break; }
+            ANTQ_OK_(rc);
+            same_bits(ulps == -1 ? "antq_plan_eval_host_a, reciprocal -1 ulp" : ulps == 0 ? "antq_plan_eval_host_a, exact reciprocal"
+                                                                                          : "antq_plan_eval_host_a, reciprocal +1 ulp", oa, oref);
+            same_idx("antq_plan_eval_host_a indices", qi, qiref);
+        }
+    }
+
+    // 9c. the 16-bit-domain row path: its host model (antq_plan_eval_host_h) and the kernel (antq_fakequant on bf16 rows of
+    //     4096) against the oracle's bf16 forward, ANT and OliVe pairs
+    {
+        std::vector<uint16_t> xb(n), refb(n), hostb(K);
+        antq_oracle_f32_to_bf16(xf.data(), xb.data(), n);
+        DevBuf<uint16_t> dxb(n), doutb(n);
+        dxb.up(xb, st);
+        for (int ovp = 0; ovp < 2; ovp++) {
+            const std::vector<float> &gr = ovp ? olive : flint;
+            const std::vector<float> &al = ovp ? alpha3 : alpha;
+            const float gm = ovp ? 32.0f : 10.0f;
+            antq_oracle_forward_bf16(xb.data(), refb.data(), ridx.data(), rows, K, al.data(), 1, gr.data(), (int)gr.size(), gm, ovp);
+            ANTQ_OK_(antq_fakequant(dxb.p, doutb.p, nullptr, rows, K, ovp ? dalpha3.p : dalpha.p, 1, gm, ovp ? plan2.data() : plan.data(),
+                                    ovp ? dplan2.p : dplan.p, ovp ? ANTQ_FLAG_OVP : 0u, ANTQ_BF16, st));
+            const std::vector<uint16_t> got = doutb.down(st);
+            size_t bad = 0, badh = 0;
+            for (size_t i = 0; i < n; i++) bad += got[i] != refb[i] && !((got[i] & 0x7fff) > 0x7f80 && (refb[i] & 0x7fff) > 0x7f80);
+            for (size_t r = 0; r < rows; r += 7) {
+                const int rc = antq_plan_eval_host_h(ovp ? plan2.data() : plan.data(), xb.data() + r * K, K, al[r], gm, ANTQ_BF16,
+                                                     ovp ? ANTQ_FLAG_OVP : 0u, hostb.data(), nullptr);
+                if (rc != ANTQ_OK) { badh += K; continue; }
+                for (size_t c = 0; c < K; c++) {
+                    const uint16_t a = hostb[c], b = refb[r * K + c];
+                    badh += a != b && !((a & 0x7fff) > 0x7f80 && (b & 0x7fff) > 0x7f80);
+                }
+            }
+            printf("%-58s %s (%zu kernel / %zu host-model elements differ)\n", ovp ? "bf16 rows of 4096, 16-bit domain, OliVe pairs"
+                                                                                   : "bf16 rows of 4096, 16-bit domain, ANT flint-4",
+                   (bad || badh) ? "FAIL" : "ok", bad, badh);
+            if (bad || badh) failures++;
+        }
+    }
+
+    // 9d. antq_absmax_into: a running maximum over a tensor that arrives in two pieces, from a zeroed slot
+    {
+        DevBuf<float> dslot(1);
+        HIP_OK(hipMemsetAsync(dslot.p, 0, 4, st));
+        const size_t half = (n / 2) & ~(size_t)7;
+        ANTQ_OK_(antq_absmax_into(dxf.p, dslot.p, half, ANTQ_F32, st));
+        ANTQ_OK_(antq_absmax_into(dxf.p + half, dslot.p, n - half, ANTQ_F32, st));
+        std::vector<float> want(1);
+        antq_oracle_absmax_f32(xf.data(), want.data(), 1, n, 0, 1.0f);
+        same_bits("antq_absmax_into, two pieces into one slot", dslot.down(st), want);
+    }
+
+    // 9e. antq_search_sse_multi: the sums of two codebooks on ONE read == one antq_search_sse per codebook, bit for bit
+    //     (same kernels' fixed summation order), per row and per tensor
+    {
+        std::vector<float> int4;
+        for (int k = -8; k <= 7; k++) int4.push_back((float)k * (10.0f / 7.0f));
+        std::vector<uint8_t> plan_i(ANTQ_PLAN_MAX_BYTES);
+        const int pbi = antq_plan_build(int4.data(), (int)int4.size(), plan_i.data(), plan_i.size());
+        DevBuf<uint8_t> dplan_i(ANTQ_PLAN_MAX_BYTES);
+        HIP_OK(hipMemcpyAsync(dplan_i.p, plan_i.data(), pbi, hipMemcpyHostToDevice, st));
+        const void *ph[2] = {plan_i.data(), plan.data()}, *pd[2] = {dplan_i.p, dplan.p};
+        const float gm[2] = {10.0f, 10.0f};
+        const int lb = 80, ub = 120, ncand = ub - lb;
+        std::vector<float> ratios((size_t)ncand);
+        for (int i = 0; i < ncand; i++) ratios[(size_t)i] = (float)((double)(lb + i) * 0.01);
+        DevBuf<float> dratios((size_t)ncand);
+        dratios.up(ratios, st);
+        DevBuf<uint8_t> dws(antq_search_workspace_bytes());
+        for (int per_row = 1; per_row >= 0; per_row--) {
+            const size_t na = per_row ? rows : 1;
+            DevBuf<float> dxm(na);
+            DevBuf<double> dm(2 * (size_t)ncand * na), ds((size_t)ncand * na);
+            ANTQ_OK_(antq_absmax(dxf.p, dxm.p, rows, K, per_row, ANTQ_F32, st));
+            const int rc = antq_search_sse_multi(dxf.p, rows, K, dxm.p, per_row, dratios.p, ncand, 2, gm, ph, pd, 0, ANTQ_F32, dm.p, dws.p, st);
+            ANTQ_OK_(rc);
+            const std::vector<double> multi = dm.down(st);
+            size_t bad = 0;
+            for (int t = 0; t < 2; t++) {
+                ANTQ_OK_(antq_search_sse(dxf.p, rows, K, dxm.p, per_row, dratios.p, ncand, 10.0f, ph[t], pd[t], 0, ANTQ_F32, ds.p, dws.p, st));
+                const std::vector<double> one = ds.down(st);
+                for (size_t i = 0; i < one.size(); i++) bad += std::memcmp(&one[i], &multi[(size_t)t * one.size() + i], 8) != 0;
+            }
+            printf("%-58s %s (%zu sums differ)\n", per_row ? "antq_search_sse_multi == per-type sums, per row" : "antq_search_sse_multi == per-type sums, per tensor",
+                   bad ? "FAIL" : "ok", bad);
+            if (bad) failures++;
+        }
+    }
+
+    // 9f. antq_moments + antq_xmax_3sigma (OliVe's clip statistic, OQ:193-197 / :213-218) against a double-precision host
+    //     computation of mean / unbiased std (the reference's torch reductions agree to their own summation noise)
+    {
+        DevBuf<double> dsums(2 * rows);
+        DevBuf<float> dx3(rows);
+        DevBuf<uint8_t> dws(antq_search_workspace_bytes());
+        for (int per_row = 1; per_row >= 0; per_row--) {
+            const size_t na = per_row ? rows : 1, per = per_row ? K : n;
+            ANTQ_OK_(antq_moments(dxf.p, rows, K, per_row, ANTQ_F32, dsums.p, dws.p, st));
+            ANTQ_OK_(antq_xmax_3sigma(dsums.p, na, per, ANTQ_F32, dx3.p, st));
+            const std::vector<double> sums = dsums.down(st);
+            const std::vector<float> x3 = dx3.down(st);
+            size_t bad = 0;
+            for (size_t r = 0; r < na; r++) {
+                double s1 = 0.0, s2 = 0.0;
+                for (size_t c = 0; c < per; c++) { const double v = xf[r * per + c]; s1 += v; s2 += v * v; }
+                if (std::fabs(sums[2 * r] - s1) > 1e-9 * (std::fabs(s1) + 1.0) || std::fabs(sums[2 * r + 1] - s2) > 1e-9 * s2) bad++;
+                const double mean = s1 / (double)per, var = (s2 - s1 * s1 / (double)per) / (double)(per - 1), sd = std::sqrt(var);
+                const double want = std::max(std::fabs(mean + 3.0 * sd), std::fabs(mean - 3.0 * sd));
+                if (std::fabs((double)x3[r] - want) > 2e-6 * want) bad++;
+            }
+            printf("%-58s %s (%zu of %zu off)\n", per_row ? "antq_moments + antq_xmax_3sigma, per row" : "antq_moments + antq_xmax_3sigma, per tensor",
+                   bad ? "FAIL" : "ok", bad, na);
+            if (bad) failures++;
+        }
+    }
+
+    // 9g. antq_affine (AsymmetricQuantFunction.forward, quant_affine.py:95-115) against the oracle, per row and per tensor
+    {
+        std::vector<float> mn(rows), mx(rows);
+        for (size_t r = 0; r < rows; r++) {
+            mn[r] = mx[r] = xf[r * K];
+            for (size_t c = 1; c < K; c++) { mn[r] = std::min(mn[r], xf[r * K + c]); mx[r] = std::max(mx[r], xf[r * K + c]); }
+        }
+        DevBuf<float> dmn(rows), dmx(rows);
+        DevBuf<int32_t> dq(n);
+        dmn.up(mn, st); dmx.up(mx, st);
+        std::vector<int32_t> qref(n);
+        for (int per_row = 1; per_row >= 0; per_row--) {
+            for (int k : {8, 4}) {
+                ANTQ_OK_(antq_affine(dxf.p, dout.p, dq.p, rows, K, k, dmn.p, dmx.p, per_row, st));
+                antq_oracle_affine_f32(xf.data(), ref.data(), qref.data(), rows, K, k, mn.data(), mx.data(), per_row);
+                same_bits(per_row ? (k == 8 ? "antq_affine 8-bit per row" : "antq_affine 4-bit per row")
+                                  : (k == 8 ? "antq_affine 8-bit per tensor" : "antq_affine 4-bit per tensor"), dout.down(st), ref);
+                const std::vector<int32_t> gq = dq.down(st);
+                size_t bad = 0;
+                for (size_t i = 0; i < n; i++) bad += gq[i] != qref[i];
+                if (bad) { printf("antq_affine integer codes: %zu differ\n", bad); failures++; }
+            }
+        }
+    }
+
+    // 9h. antq_alpha_grad: gsum[r] = sum_c fl32(g * fl32(out - x)) with fp32 terms and fp64 accumulation (the backward of
+    //     AQ:535-551 with respect to alpha, before the division by alpha) against the same sum formed on the host
+    {
+        std::vector<float> gout(n);
+        for (size_t i = 0; i < n; i++) gout[i] = nd(rng) * 50.0f;
+        DevBuf<float> dg(n);
+        dg.up(gout, st);
+        DevBuf<uint8_t> dws(antq_search_workspace_bytes());
+        ANTQ_OK_(antq_fakequant(dxf.p, dout.p, nullptr, rows, K, dalpha.p, 1, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
+        const std::vector<float> o = dout.down(st);
+        for (int per_row = 1; per_row >= 0; per_row--) {
+            const size_t na = per_row ? rows : 1, per = per_row ? K : n;
+            DevBuf<double> dgs(na);
+            ANTQ_OK_(antq_alpha_grad(dxf.p, dout.p, dg.p, rows, K, per_row, dgs.p, dws.p, ANTQ_F32, st));
+            const std::vector<double> gs = dgs.down(st);
+            size_t bad = 0;
+            for (size_t r = 0; r < na; r++) {
+                double want = 0.0, mag = 0.0;
+                for (size_t c = 0; c < per; c++) {
+                    const size_t i = r * per + c;
+                    const float diff = o[i] - xf[i];
+                    const float term = gout[i] * diff;
+                    want += (double)term;
+                    mag += std::fabs((double)term);
+                }
+                if (std::fabs(gs[r] - want) > 1e-6 * mag + 1e-30) bad++;      // (fp32 partial sums per lane: 1e-6 of the magnitude)
+            }
+            printf("%-58s %s (%zu of %zu off)\n", per_row ? "antq_alpha_grad per row" : "antq_alpha_grad per tensor", bad ? "FAIL" : "ok", bad, na);
+            if (bad) failures++;
+        }
+    }
+
+    // 9i. antq_calibrate_batch: three quantisers (per row, per tensor, per row on a sub-tensor) in ONE call == one
+    //     antq_calibrate each, bit for bit (same kernels, same order), through one shared workspace
+    {
+        std::vector<float> int4;
+        for (int k = -8; k <= 7; k++) int4.push_back((float)k * (10.0f / 7.0f));
+        std::vector<uint8_t> plan_i(ANTQ_PLAN_MAX_BYTES);
+        const int pbi = antq_plan_build(int4.data(), (int)int4.size(), plan_i.data(), plan_i.size());
+        DevBuf<uint8_t> dplan_i(ANTQ_PLAN_MAX_BYTES);
+        HIP_OK(hipMemcpyAsync(dplan_i.p, plan_i.data(), pbi, hipMemcpyHostToDevice, st));
+        const void *ph[2] = {plan_i.data(), plan.data()}, *pd[2] = {dplan_i.p, dplan.p};
+        const float gm[2] = {10.0f, 10.0f};
+        struct Shape { size_t off, rows, K; int per_row, lb, ub; } shapes[3] = {{0, rows, K, 1, 75, 150}, {0, rows, K, 0, 90, 130},
+                                                                               {16 * K, 32, 2 * K, 1, 95, 100}};
+        antq_calib_job jobs3[3];
+        std::vector<DevBuf<float> *> keep;
+        DevBuf<int32_t> dty(3), dty1(1);
+        size_t na_of[3];
+        DevBuf<float> *bx[3], *ba[3], *bs[3];
+        for (int j = 0; j < 3; j++) {
+            const Shape &s = shapes[j];
+            na_of[j] = s.per_row ? s.rows : 1;
+            bx[j] = new DevBuf<float>(na_of[j]); ba[j] = new DevBuf<float>(2 * na_of[j]); bs[j] = new DevBuf<float>(2);
+            jobs3[j] = {dxf.p + s.off, s.rows, s.K, s.per_row, ANTQ_XMAX_ABSMAX, bx[j]->p, s.lb, s.ub, 1, 2, gm, ph, pd, ba[j]->p, bs[j]->p,
+                        dty.p + j};
+        }
+        const size_t wsb = antq_calibrate_batch_workspace_bytes(jobs3, 3);
+        if (wsb == 0) { printf("antq_calibrate_batch_workspace_bytes returned 0\n"); failures++; }
+        DevBuf<uint8_t> dws(wsb ? wsb : 16);
+        ANTQ_OK_(antq_calibrate_batch(jobs3, 3, ANTQ_F32, 0, dws.p, wsb, st));
+        const std::vector<int32_t> types = dty.down(st);
+        size_t bad = 0;
+        for (int j = 0; j < 3; j++) {
+            const Shape &s = shapes[j];
+            const std::vector<float> b_al = ba[j]->down(st), b_sc = bs[j]->down(st), b_xm = bx[j]->down(st);
+            const size_t w1 = antq_calibrate_workspace_bytes(s.rows, s.per_row, s.lb, s.ub, 1, 2);
+            if (w1 > wsb) { printf("batch workspace smaller than job %d's own\n", j); bad++; }
+            DevBuf<uint8_t> dws1(w1);
+            DevBuf<float> dxm(na_of[j]), dal(2 * na_of[j]), dsc(2);
+            ANTQ_OK_(antq_calibrate(dxf.p + s.off, s.rows, s.K, s.per_row, ANTQ_F32, ANTQ_XMAX_ABSMAX, dxm.p, s.lb, s.ub, 1, 2, gm, ph, pd, 0,
+                                    dal.p, dsc.p, dty1.p, dws1.p, w1, st));
+            const std::vector<float> o_al = dal.down(st), o_sc = dsc.down(st), o_xm = dxm.down(st);
+            bad += std::memcmp(o_al.data(), b_al.data(), 4 * o_al.size()) != 0;
+            bad += std::memcmp(o_sc.data(), b_sc.data(), 8) != 0;
+            bad += std::memcmp(o_xm.data(), b_xm.data(), 4 * o_xm.size()) != 0;
+            bad += dty1.down(st)[0] != types[(size_t)j];
+            delete bx[j]; delete ba[j]; delete bs[j];
+        }
+        printf("%-58s %s (types %d %d %d)\n", "antq_calibrate_batch == antq_calibrate per job", bad ? "FAIL" : "ok", types[0], types[1], types[2]);
+        if (bad) failures++;
+        jobs3[1].ub = jobs3[1].lb - 5;                                        // an empty range is legal (AQ:299: the loop never runs) ...
+        jobs3[1].ntypes = 0;                                                  // ... no codebook is not
+        if (antq_calibrate_batch_workspace_bytes(jobs3, 3) != 0) { printf("bad job not rejected by the workspace query\n"); failures++; }
+    }
+
+    // 9j. the rest of the surface: antq_copy, antq_prefetch_kernels, antq_debug_set (thread-local knob, result unchanged)
+    {
+        ANTQ_OK_(antq_prefetch_kernels());
+        ANTQ_OK_(antq_copy(dxf.p, dout.p, n * sizeof(float), st));
+        same_bits("antq_copy", dout.down(st), xf);
+        ANTQ_OK_(antq_debug_set(9, 0));                                       // 16-bit-domain kernels off: fp32-domain row table
+        ANTQ_OK_(antq_fakequant(dxf.p, dout.p, nullptr, rows, K, dalpha.p, 1, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
+        ANTQ_OK_(antq_debug_set(9, 1));
+        antq_oracle_forward_f32(xf.data(), ref.data(), ridx.data(), rows, K, alpha.data(), 1, flint.data(), (int)flint.size(), 10.0f, 0);
+        same_bits("antq_fakequant under antq_debug_set(9, 0)", dout.down(st), ref);
+        if (antq_debug_set(-1, 0) == ANTQ_OK) { printf("unknown debug key accepted\n"); failures++; }
     }
 
     // 8. error behaviour: codes, not exceptions

@@ -1,0 +1,325 @@
+"""Module-level behaviour added in round 5 (GPU): the default weight bank under the reference's own train / eval loops, the
+pinned-slot pool behind deferred type picks on deep models, the bank's memory gate.
+
+Reference behaviour matched: nothing is cached between forwards (AQ:613-617, :642-646; OQ:413-416, :443-446), the BERT harness
+steps with `p.data.add_(-update_with_lr)` (BERT/optimization.py:161) and evaluates under torch.no_grad() after every epoch
+(BERT/run_glue.py:596-668)."""
+import copy
+import importlib
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _args(**kw):
+    d = dict(w_up=150, a_up=150, w_low=75, a_low=75, percent=100, search=False, no_outlier=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _trees(tree):
+    return (importlib.import_module("ant_quantization_amd.%s.quant_model" % tree),
+            importlib.import_module("ant_quantization_amd.%s.quant_utils" % tree))
+
+
+def _bert_adam_step(model, lr=0.05, wd=0.01):
+    """The update rule of the reference's BertAdam as far as version counters are concerned (BERT/optimization.py:150-161):
+    every write goes through `.data` -- no Parameter's `_version` moves.  Weight decay makes every parameter (weights AND
+    alphas) move even where no gradient arrives (the OliVe tree quantises under no_grad)."""
+    import torch
+    for p in model.parameters():
+        update = wd * p.data
+        if p.grad is not None:
+            update = update + p.grad.data
+            p.grad = None
+        v0 = p._version
+        p.data.add_(-lr * update)
+        assert p._version == v0
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_run_glue_epoch_loop_with_data_writing_optimiser(antq_lib, dev, tree, dtype_name, capsys):
+    """calibrate -> eval -> [train steps whose optimiser writes p.data.add_() on weights and alphas -> eval] x 3, the default
+    module path (AutoBank armed by enable_quantization) against the reference's schedule on the same parameters:
+    bit-identical outputs after every epoch, and ONE bank refresh per evaluation phase."""
+    import torch
+    import torch.nn as nn
+    qmod, qutil = _trees(tree)
+    dt = getattr(torch, dtype_name)
+    qutil.set_quantizer(_args(mode="flint", wbit=4, abit=4))
+    torch.manual_seed(5)
+    net = nn.Sequential(nn.Linear(256, 512), nn.GELU(), nn.Linear(512, 512), nn.GELU(), nn.Linear(512, 256), nn.Linear(256, 4))
+    model = qmod.quantize_model(net).to(dev).to(dt)
+    capsys.readouterr()
+    qutil.enable_quantization(model)
+    ab = model._antq_auto_bank
+    x = torch.randn(64, 256, device=dev).to(dt)
+    xt = torch.randn(32, 256, device=dev).to(dt)
+    model.eval()
+    with torch.no_grad():
+        model(x)                              # calibration
+        y_prev = model(x)                     # epoch-0 evaluation: the bank attaches
+        assert ab.bank is not None and ab.bank.launches == 1
+        model(x)
+        assert ab.bank.launches == 1          # unchanged weights under no_grad: nothing is launched for them
+    for epoch in range(3):
+        bank = ab.bank
+        before = bank.launches
+        model.train()
+        for _ in range(2):
+            out = model(xt)
+            out.float().pow(2).mean().backward()
+            _bert_adam_step(model)
+        assert ab.bank is bank and bank.launches == before        # training forwards never touch the resident copies
+        model.eval()
+        with torch.no_grad():
+            y_bank = model(x)
+            assert bank.launches == before + 1
+            y_again = model(x)
+            assert bank.launches == before + 1 and torch.equal(y_bank, y_again)
+            ref = copy.deepcopy(model)                            # no bank travels with a copy: per-layer schedule
+            assert all(m.quant_weight._bank is None for m in ref.modules() if hasattr(m, "quant_weight"))
+            y_ref = ref(x)
+            qutil.set_weight_bank(model, False)                   # ... and the reference's schedule on the model itself
+            y_ref2 = model(x)
+            qutil.set_weight_bank(model, True)
+            model(x)                                              # (the bank of this epoch's weights: stale after the next one)
+            assert ab.bank is not None
+        assert torch.equal(y_bank, y_ref) and torch.equal(y_bank, y_ref2), (tree, dtype_name, epoch)
+        assert not torch.equal(y_bank, y_prev), "the optimiser moved nothing: the test would prove nothing"
+        y_prev = y_bank
+    capsys.readouterr()
+
+
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_train_eval_transition_alone_refreshes_and_plain_data_edit_needs_invalidate(antq_lib, dev, tree, capsys):
+    """(1) model.train() / model.eval() with `.data` writes in between but NO forward at all (an EMA copy, a checkpoint
+    averaged into place): the first no-grad forward re-quantises.  (2) The documented remaining case: `w.data.mul_()`
+    between two no-grad forwards, nothing else -- invisible to (address, version) stamps; `bank.invalidate()` is the caller's."""
+    import torch
+    import torch.nn as nn
+    qmod, qutil = _trees(tree)
+    qutil.set_quantizer(_args(mode="int", wbit=4, abit=8))
+    torch.manual_seed(6)
+    model = qmod.quantize_model(nn.Sequential(nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 16))).to(dev).eval()
+    capsys.readouterr()
+    qutil.enable_quantization(model)
+    x = torch.randn(32, 128, device=dev)
+    lin = [m for m in model.modules() if hasattr(m, "quant_weight")]
+    with torch.no_grad():
+        model(x)
+        y0 = model(x)
+        bank = model._antq_auto_bank.bank
+        assert bank is not None and bank.launches == 1
+        model.train()
+        lin[0].weight.data.mul_(1.5)
+        model.eval()
+        y1 = model(x)
+        assert bank.launches == 2 and not torch.equal(y0, y1)
+        assert torch.equal(y1, copy.deepcopy(model)(x))
+        # (2)
+        lin[1].weight.data.mul_(0.5)
+        y_stale = model(x)
+        assert bank.launches == 2 and torch.equal(y_stale, y1)        # documented: this edit cannot be seen ...
+        bank.invalidate()
+        y2 = model(x)
+        assert bank.launches == 3 and not torch.equal(y2, y1)         # ... until the caller says so
+        assert torch.equal(y2, copy.deepcopy(model)(x))
+    capsys.readouterr()
+
+
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_weights_at_rest_mode_after_a_training_step(antq_lib, dev, tree, capsys):
+    """set_weights_at_rest (opt-in, bf16 model: alpha kept as a float32 copy keyed by (address, version)): a training step
+    that writes weight and alpha through `.data`, then evaluation -- the copy of alpha is re-read and the first launch is
+    ordered, outputs bit-identical to a fresh copy of the model without the mode."""
+    import torch
+    import torch.nn as nn
+    qmod, qutil = _trees(tree)
+    qutil.set_quantizer(_args(mode="flint", wbit=4, abit=4))
+    torch.manual_seed(8)
+    model = qmod.quantize_model(nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 8))).to(dev).to(torch.bfloat16)
+    capsys.readouterr()
+    qutil.enable_quantization(model)
+    qutil.set_weights_at_rest(model, True)
+    x = torch.randn(16, 256, device=dev).to(torch.bfloat16)
+    model.eval()
+    with torch.no_grad():
+        model(x)
+        model(x)
+        y0 = model(x)
+    for _ in range(2):
+        model.train()
+        model(x).float().pow(2).mean().backward()
+        _bert_adam_step(model, lr=0.2)
+        model.eval()
+        with torch.no_grad():
+            y1 = model(x)
+            y2 = model(x)
+            ref = copy.deepcopy(model)
+            qutil.set_weights_at_rest(ref, False)
+            assert torch.equal(y1, ref(x)) and torch.equal(y1, y2)
+        assert not torch.equal(y0, y1)
+        y0 = y1
+    capsys.readouterr()
+
+
+@pytest.mark.parametrize("tree,mode", [("ant", "ant-int-pot-flint"), ("olive", "ant-int-flint")])
+def test_deferred_type_picks_on_a_260_layer_model(antq_lib, dev, tree, mode, capsys):
+    """More quantised layers than any fixed ring of pinned slots would hold (two slots per layer: sign probe + parked type
+    pick; GPT-2 XL / OPT have 192 linears): every pick parked until the model-level flush is still its own when it is read.
+    Same modes, codebooks, alphas and outputs as with every pick read on the spot."""
+    import torch
+    import torch.nn as nn
+    qmod, qutil = _trees(tree)
+    qutil.set_quantizer(_args(mode=mode, wbit=4, abit=4))
+
+    class Deep(nn.Module):
+        def __init__(self, n=260, w=64):
+            super().__init__()
+            self.layers = nn.ModuleList([nn.Linear(w, w) for _ in range(n)])
+
+        def forward(self, h):
+            for i, l in enumerate(self.layers):
+                z = l(h)
+                # (different activation statistics per layer so that the picks differ along the depth)
+                h = (torch.tanh(z) if i % 3 == 0 else torch.relu(z) if i % 3 == 1 else z * z.abs()) + 0.5 * h
+                h = h / h.abs().amax().clamp_min(1e-6)
+            return h
+
+    res = []
+    for defer in (True, False):
+        torch.manual_seed(9)
+        m = qmod.quantize_model(Deep()).to(dev).eval()
+        capsys.readouterr()
+        qutil.enable_quantization(m)
+        m._antq_auto_bank.defer_types = defer
+        x = torch.randn(96, 64, device=dev)
+        with torch.no_grad():
+            y = m(x)
+            log = capsys.readouterr().out
+            y2 = m(x)
+        qs = [l.quant_input for l in m.modules() if hasattr(l, "quant_input")]
+        assert len(qs) == 260 and all(q._pending is None and q._steady for q in qs)
+        if defer:
+            assert m._antq_auto_bank.deferred == 260
+        res.append((y, y2, log, [(q.mode, q.quant_grid.clone(), q.alpha.detach().clone(), q._gmax) for q in qs]))
+    (ya, ya2, la, sa), (yb, yb2, lb, sb) = res
+    assert la == lb and la.count("-bit") == 520
+    assert len({s[0] for s in sa}) >= 2, "every layer picked the same type: the test would not see a mixed-up slot"
+    for i, (a, b) in enumerate(zip(sa, sb)):
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3], (tree, i, a[0], b[0])
+    assert torch.equal(ya, yb) and torch.equal(ya2, yb2) and torch.equal(ya, ya2)
+    from ant_quantization_amd import _mirror
+    pool = _mirror._slots
+    assert len(pool.free) == len(pool.chunks) * pool.chunk, "a pinned slot was not given back"
+
+
+def test_weight_bank_memory_gate_and_failure_are_permanent(antq_lib, dev, capsys, monkeypatch):
+    """The resident copies are only built when they fit comfortably (ANTQ_BANK_MEM_FRACTION of the free device memory);
+    a model that does not fit -- or an allocation failure while building -- leaves the per-layer schedule in place, for
+    good: no retry on every forward, nothing half-attached, the forward's result unchanged."""
+    import torch
+    import torch.nn as nn
+    from ant_quantization_amd import weight_bank
+    qmod, qutil = _trees("ant")
+    qutil.set_quantizer(_args(mode="flint", wbit=4, abit=4))
+    x = torch.randn(8, 128, device=dev)
+
+    def make():
+        torch.manual_seed(3)
+        m = qmod.quantize_model(nn.Sequential(nn.Linear(128, 256), nn.ReLU(), nn.Linear(256, 8))).to(dev).eval()
+        capsys.readouterr()
+        qutil.enable_quantization(m)
+        return m
+
+    m0 = make()
+    with torch.no_grad():
+        m0(x)
+        y_bank = m0(x)
+    assert m0._antq_auto_bank.bank is not None
+    # (a) the gate
+    m1 = make()
+    m1._antq_auto_bank.mem_fraction = 0.0
+    with torch.no_grad():
+        m1(x)
+        y1 = m1(x)
+    ab = m1._antq_auto_bank
+    assert ab.bank is None and not ab.enabled and "MB free" in ab.reason
+    assert all(l.quant_weight._bank is None for l in m1.modules() if hasattr(l, "quant_weight"))
+    assert torch.equal(y1, y_bank)
+    # (b) out of memory while the bank is being built
+    m2 = make()
+    with torch.no_grad():
+        m2(x)
+    built, state = [], {"n": 0, "armed": True}
+    real = torch.empty_like
+
+    class Counting(weight_bank.WeightBank):
+        def __init__(self, model):
+            built.append(1)
+            super().__init__(model)
+
+    def failing(t, *a, **k):
+        if state["armed"]:
+            state["n"] += 1
+            if state["n"] == 2:                                       # the second layer's resident copy
+                state["armed"] = False
+                raise torch.cuda.OutOfMemoryError("HIP out of memory (simulated)")
+        return real(t, *a, **k)
+
+    monkeypatch.setattr(weight_bank, "WeightBank", Counting)
+    monkeypatch.setattr(weight_bank.torch, "empty_like", failing)
+    with torch.no_grad():
+        y2 = m2(x)
+    monkeypatch.setattr(weight_bank.torch, "empty_like", real)
+    ab = m2._antq_auto_bank
+    assert ab.bank is None and not ab.enabled and "failed" in ab.reason and built == [1] and not state["armed"]
+    assert all(l.quant_weight._bank is None for l in m2.modules() if hasattr(l, "quant_weight"))
+    with torch.no_grad():
+        assert torch.equal(m2(x), y_bank) and torch.equal(y2, y_bank)
+    assert built == [1]                                               # no retry
+    monkeypatch.undo()
+    # (c) out of memory during a later refresh: the bank gives up, the forward still answers
+    m3 = make()
+    with torch.no_grad():
+        m3(x)
+        m3(x)
+        bank = m3._antq_auto_bank.bank
+        assert bank is not None
+        bank.invalidate()
+
+        def boom():
+            raise torch.cuda.OutOfMemoryError("HIP out of memory (simulated)")
+        bank.refresh = boom
+        with pytest.warns(UserWarning, match="weight bank switched off"):
+            y3 = m3(x)
+        assert torch.equal(y3, y_bank) and m3._antq_auto_bank.bank is None and not m3._antq_auto_bank.enabled
+        assert torch.equal(m3(x), y_bank)
+    capsys.readouterr()
+
+
+def test_prewarm_leaves_the_global_rng_alone(antq_lib, dev):
+    import torch
+    from ant_quantization_amd import _lib
+    torch.manual_seed(123)
+    torch.cuda.manual_seed(123)
+    a = torch.randn(4, device=dev)
+    torch.manual_seed(123)
+    torch.cuda.manual_seed(123)
+    _lib._prewarmed.discard((dev.index, torch.float16))
+    _lib.prewarm(dev, torch.float16)
+    b = torch.randn(4, device=dev)
+    assert torch.equal(a, b)

@@ -741,3 +741,24 @@ def test_batch_descriptor_builder_host_logic(antq_lib):
         host = np.zeros(cap, dtype=np.uint8)
         rc = L.antq_batch_build(arr, 1, 1, flags, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
         assert (rc == want) if want is not None else rc > 0, (flags, rc)
+
+
+def test_pinned_slot_pool_never_hands_out_a_slot_that_is_still_owned():
+    """_mirror._PinnedSlots: a slot belongs to its taker until given back; the pool grows instead of wrapping (a model with
+    more quantised layers than one chunk keeps every parked type pick intact)."""
+    import torch
+    from ant_quantization_amd._mirror import _PinnedSlots
+    pool = _PinnedSlots(chunk=8, alloc=lambda n: torch.zeros(n))
+    held = [pool.take() for _ in range(50)]
+    for i, s in enumerate(held):
+        s[0] = float(i)
+    assert len(pool.chunks) == 7 and len({s.data_ptr() for s in held}) == 50
+    assert [int(s[0]) for s in held] == list(range(50))
+    for s in held[::2]:
+        pool.give(s)
+    again = [pool.take() for _ in range(25)]
+    assert {s.data_ptr() for s in again} == {s.data_ptr() for s in held[::2]} and len(pool.chunks) == 7
+    for s in again:
+        s[0] = -1.0
+    assert [int(s[0]) for s in held[1::2]] == list(range(1, 50, 2))
+    pool.give(None)
