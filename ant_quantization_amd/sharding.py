@@ -44,6 +44,41 @@ def row_block(rows: int, rank: int, world: int, pair_safe_row_len: int = 0) -> T
     return b, e
 
 
+# ---- BASELINE configs[3] / [4]: which rank owns what ----------------------------------------------------------------
+def model_linear_shapes(name: str, layers: int = 0) -> List[Tuple[int, int]]:
+    """[rows, cols] of the Linear weights of the two sharded BASELINE workloads:
+    "opt6.7b"  -- OPT-6.7B, 32 decoder layers x {q, k, v, out: [4096, 4096]; fc1 [16384, 4096]; fc2 [4096, 16384]} = 192
+                  tensors, 6.44 G elements;
+    "llama70b" -- the synthetic 70 B-parameter stack, 80 x {[8192, 8192] x 2, [1024, 8192] x 2, [28672, 8192] x 2,
+                  [8192, 28672]} = 560 tensors, 68.7 G elements.   layers: 0 = the model's own depth."""
+    if name == "opt6.7b":
+        per = [(4096, 4096)] * 4 + [(16384, 4096), (4096, 16384)]
+        return per * (layers or 32)
+    if name == "llama70b":
+        per = [(8192, 8192)] * 2 + [(1024, 8192)] * 2 + [(28672, 8192)] * 2 + [(8192, 28672)]
+        return per * (layers or 80)
+    raise ValueError("unknown model %r" % (name,))
+
+
+def shard_plan(name: str, rank: int, world: int, layers: int = 0) -> List[Tuple[int, int, int, int]]:
+    """The units rank `rank` of `world` owns, as (tensor index, first row, end row, cols):
+    "opt6.7b"  -- whole tensors, longest-processing-time packing by bytes (lpt_assign): configs[3], "sharded 8 x MI355X";
+    "llama70b" -- a contiguous row block of EVERY tensor (row_block, pair-safe): configs[4], the 70 B row blocks -- each
+                  rank streams 1/world of every matrix.
+    No unit is shared and none is left out; nothing crosses ranks on the data path (per-row alpha: a row block carries its
+    own scales; OliVe pairs live inside a row because every row length is even)."""
+    shapes = model_linear_shapes(name, layers)
+    if name == "opt6.7b":
+        mine = lpt_assign([r * c for r, c in shapes], world)[rank]
+        return [(i, 0, shapes[i][0], shapes[i][1]) for i in mine]
+    out = []
+    for i, (r, c) in enumerate(shapes):
+        b, e = row_block(r, rank, world, pair_safe_row_len=c)
+        if e > b:
+            out.append((i, b, e, c))
+    return out
+
+
 # ---- OliVe pairs on a row-sharded tensor with an ODD element count ------------------------------------------------
 # Pairs (2k, 2k+1) live on the FLAT tensor and `torch.roll` wraps (OQ:313-318): with an odd element count the last
 # element has no partner of its own and is zeroed iff element 0 is an outlier.  When rows are sharded, element 0 lives

@@ -102,6 +102,15 @@ class Harness:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(self, value):
+        """One float per rank, known to every rank (a one-hot vector summed over ranks: no collective beyond all_reduce)."""
+        if self.dist is None:
+            return [float(value)]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.dev)
+        t[self.rank] = float(value)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
     def timed(self, step, steps, warmup, on_start=None, on_stop=None):
         """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both sides;
         returns the MAX over ranks of the wall-clock time of the bracketed region."""
@@ -126,9 +135,13 @@ class Harness:
             self.dist.destroy_process_group()
 
 
-def report(h, args, elems_per_step_per_gpu, elapsed, extra):
+def per_rank_stats(values, digits=2):
+    return {"min": round(min(values), digits), "mean": round(sum(values) / len(values), digits), "max": round(max(values), digits)}
+
+
+def report(h, args, elems_per_step_all_ranks, elapsed, extra, scaling="weak"):
     """The one JSON line (rank 0).  value = units ALL ranks processed / the slowest rank's time."""
-    total = h.world * elems_per_step_per_gpu * args.steps
+    total = elems_per_step_all_ranks * args.steps
     res = {
         "metric": METRIC,
         "value": round(total / elapsed / 1e9, 3),
@@ -138,7 +151,7 @@ def report(h, args, elems_per_step_per_gpu, elapsed, extra):
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -244,7 +257,7 @@ def cpu_baseline_torch(seconds_budget=6.0):
 # ------------------------------------------------------------------------------------------------
 # HBM traffic of the dominant kernel, measured (rank 0, N = 1): two rocprofv3 --pmc child runs of this very file
 # ------------------------------------------------------------------------------------------------
-def measure_traffic(nbuf, kernel_substr="k_fq_hbatch", timeout_s=240):
+def measure_traffic(nbuf, kernel_substr="k_fq_hbatch", timeout_s=240, child_args=()):
     """FETCH_SIZE and WRITE_SIZE of the batched kernel, one counter per pass as MI355X_MICROARCH.md's HBM section
     prescribes (`rocprofv3 --pmc <C> --kernel-trace`, nothing else), each pass a child `bench.py --traffic-child` that
     builds the same workload and issues 3 launches.  Units and the gfx950 correction as in that guide: both counters are
@@ -264,9 +277,13 @@ def measure_traffic(nbuf, kernel_substr="k_fq_hbatch", timeout_s=240):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="antq_pmc_", dir="/tmp")
         try:
-            env = dict(os.environ, TMPDIR="/tmp")
+            # (the child is a plain one-GPU run on this rank's GPU, whatever launcher started us)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                                                                    "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                                    "TORCHELASTIC_RUN_ID")}
+            env["TMPDIR"] = "/tmp"
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-                   os.path.abspath(__file__), "--traffic-child", "--nbuf", str(nbuf)]
+                   os.path.abspath(__file__), "--traffic-child", "--nbuf", str(nbuf)] + list(child_args)
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             got = []
@@ -311,42 +328,42 @@ def spawn_ranks(n):
 
 
 def selftest_main(args):
-    """Stub workload for the CPU test of the rank harness: rank r sleeps (r + 1) ms per step."""
+    """Stub workload for the CPU test of the rank harness: rank r sleeps (r + 1) ms per step.  Everything around the
+    workload is the real thing: the sharding of the named workload (host bookkeeping), barriers, MAX over ranks, the
+    per-rank gather, the report."""
     h = Harness(args.gpus, selftest=True)
-    units = 1000000
+    scaling = "weak"
+    if args.workload == "headline":
+        units = 1000000
+        cfg = {"workload": "stub: rank r sleeps (r+1) ms per step"}
+    else:
+        from ant_quantization_amd import sharding
+        mine = sharding.shard_plan(args.workload, h.rank, h.world, layers=args.layers)
+        units = sum((e - b) * c for _, b, e, c in mine)
+        scaling = "strong"
+        cfg = {"workload": "stub over the %s shard plan: rank r sleeps (r+1) ms per step" % args.workload,
+               "units_of_rank0": len(mine)}
 
     def step():
         time.sleep(1e-3 * (h.rank + 1))
 
     elapsed = h.timed(step, args.steps, args.warmup)
+    launch_us = h.gather(1e3 * (h.rank + 1))
+    units_all = h.gather(units)
     if h.rank == 0:
-        res = report(h, args, units, elapsed, {"data": "stub", "selftest": True,
-                                                "config": {"workload": "stub: rank r sleeps (r+1) ms per step"}})
+        cfg["elements_per_step_per_rank"] = [int(u) for u in units_all]
+        res = report(h, args, sum(units_all), elapsed, {
+            "data": "stub", "selftest": True, "config": cfg,
+            "roofline": {"bound": "hbm", "per_rank": {"launch_us": per_rank_stats(launch_us), "ranks": h.world}}}, scaling=scaling)
         print(json.dumps(res), flush=True)
     h.finish()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--nbuf", type=int, default=32, help="distinct 4096x4096 bf16 tensors per GPU (one step)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic falls back "
-                                                               "to the committed profiles/hbm_traffic.json value)")
-    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))             # no launcher around us: one process per GPU, started here
-    if os.environ.get("ANTQ_BENCH_SELFTEST") == "1":
-        return selftest_main(args)
-
-    h = Harness(args.gpus)
+# ------------------------------------------------------------------------------------------------
+# workloads: everything resident in HBM before the timed region; one STEP = one pass = ONE batched launch per rank
+# ------------------------------------------------------------------------------------------------
+def build_headline(args, h, _lib, grids):
     torch, dev, rank = h.torch, h.dev, h.rank
-    from ant_quantization_amd import _lib, grids
-
-    # ---- workload: resident in HBM before the timed region -----------------------------------
     gen = torch.Generator(device=dev)
     gen.manual_seed(6 + rank)
     plan = _lib.plan_for(grids.ant_flint(4, True))
@@ -359,20 +376,10 @@ def main():
         alphas.append(_lib.absmax(xs[i], ROWS, COLS, per_row=True))           # calibrated alpha = row abs-max
         outs.append(out_slab[i])
     h.sync()
-
     # One STEP = one pass of the hot path over the batch = ONE launch of the batched entry point
     # (antq_fakequant_batch: every workgroup looks its tensor up in a resident descriptor table).
     batch = _lib.Batch([(xs[i], outs[i], alphas[i], plan, 10.0, ROWS, COLS, True) for i in range(args.nbuf)])
     assert not batch.singles
-
-    def step():
-        batch.run()
-
-    if args.traffic_child:              # a counter pass of measure_traffic(): the batched launch and nothing else
-        for _ in range(3):
-            step()
-        h.sync()
-        return
 
     def step_per_tensor():          # the reference's granularity: one launch per tensor (reported beside it)
         for i in range(args.nbuf):
@@ -381,6 +388,98 @@ def main():
     def step_per_tensor_unordered():    # the same launches marked independent of their predecessors (weights at rest):
         for i in range(args.nbuf):      # ANTQ_FLAG_UNORDERED, no barrier bit on the dispatch packet
             _lib.fakequant(xs[i], alphas[i], plan, 10.0, ROWS, COLS, True, out=outs[i], unordered=True)
+
+    def check():
+        return bool(torch.equal(_lib.fakequant(outs[0], alphas[0], plan, 10.0, ROWS, COLS, True), outs[0]))
+
+    return dict(step=batch.run, elems=args.nbuf * ROWS * COLS, kernel="antq::k_fq_hbatch<bf16,false>", scaling="weak",
+                per_tensor=(step_per_tensor, step_per_tensor_unordered), check=check,
+                copy=(lambda: _lib.copy(x_slab, out_slab), lambda: out_slab.copy_(x_slab)),
+                workload="headline: %d x [4096,4096] bf16 weight tensors per GPU, ANT 4-bit signed flint grid, calibrated per-row "
+                         "alpha, steady-state _forward; one step = ONE batched launch (antq_fakequant_batch) over all %d "
+                         "tensors" % (args.nbuf, args.nbuf),
+                sharding="independent tensors per rank, no data-path collective", keep=(x_slab, out_slab, xs, alphas, outs, batch))
+
+
+def build_model(args, h, _lib, grids):
+    """BASELINE configs[3] (`--workload opt6.7b`: 192 Linear weights, whole tensors packed onto the ranks by bytes) and
+    configs[4] (`--workload llama70b`: the 70 B stack, a row block of every matrix per rank): OliVe 4-bit flint + outliers,
+    outlier-victim pairs (OQ:294-330), alpha = 3 sigma per row (OQ:193-197), bf16.  The TOTAL work is fixed: strong scaling.
+    Synthetic weights: randn * 0.02 with 0.1 % of the entries multiplied by U(8, 64)."""
+    import numpy as np
+    from ant_quantization_amd import sharding
+    torch, dev, rank = h.torch, h.dev, h.rank
+    mine = sharding.shard_plan(args.workload, rank, h.world, layers=args.layers)
+    gn, go = grids.olive_flint(4, True), grids.olive_outliers(4, True)
+    plan = _lib.plan_for(np.concatenate([gn, go]))
+    gen = torch.Generator(device=dev).manual_seed(4 + rank)
+    inplace = args.inplace or args.workload == "llama70b"
+    ws, alphas = [], []
+    for _, b, e, c in mine:
+        w = torch.randn(e - b, c, device=dev, dtype=torch.bfloat16, generator=gen) * 0.02
+        m = torch.rand(w.shape, device=dev, generator=gen) < 0.001
+        w[m] *= torch.empty(int(m.sum()), device=dev, dtype=torch.bfloat16).uniform_(8, 64, generator=gen)
+        del m
+        ws.append(w)
+        alphas.append(_lib.xmax_3sigma(w, w.shape[0], w.shape[1], per_row=True))      # OQ:193-197 on one read (antq_moments)
+    outs = ws if inplace else [torch.empty_like(w) for w in ws]
+    h.sync()
+    batch = _lib.Batch([(w, o, a, plan, 32.0, w.shape[0], w.shape[1], True) for w, o, a in zip(ws, outs, alphas)], ovp=True)
+    assert not batch.singles
+    elems = sum(w.numel() for w in ws)
+
+    def check():               # fake-quant of a fake-quantised tensor at the same scale is the tensor itself
+        o = outs[0][:64].clone()
+        return bool(torch.equal(_lib.fakequant(o, alphas[0][:64].contiguous(), plan, 32.0, 64, o.shape[1], True, ovp=True), o))
+
+    src = ws[0].reshape(-1)
+    dst = torch.empty_like(src)
+    what = {"opt6.7b": "configs[3]: OPT-6.7B, 192 Linear weights (6.44 G elements), whole tensors packed onto the ranks by bytes "
+                       "(sharding.lpt_assign)",
+            "llama70b": "configs[4]: synthetic 70 B-parameter Linear stack, 560 matrices (68.5 G elements), a contiguous row block "
+                        "of every matrix per rank (sharding.row_block)"}[args.workload]
+    return dict(step=batch.run, elems=elems, kernel="antq::k_fq_hbatch<bf16,true>", scaling="strong", per_tensor=None, check=check,
+                copy=(lambda: _lib.copy(src, dst), lambda: dst.copy_(src)), copy_bytes=2 * src.numel() * 2,
+                workload="%s%s; OliVe 4-bit flint + outliers with outlier-victim pairs, alpha = 3 sigma per row, bf16%s; one step = "
+                         "ONE batched launch per rank over its %d units" % (what, " (%d layers)" % args.layers if args.layers else "",
+                                                                           ", quantised in place" if inplace else "", len(ws)),
+                sharding="%d units on rank 0 of %d ranks, no data-path collective" % (len(ws), h.world),
+                keep=(ws, outs, alphas, batch, dst))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nbuf", type=int, default=32, help="distinct 4096x4096 bf16 tensors per GPU (one step)")
+    ap.add_argument("--workload", choices=["headline", "opt6.7b", "llama70b"], default="headline",
+                    help="headline (BASELINE metric: weak scaling) | opt6.7b (configs[3]) | llama70b (configs[4]): a whole model's "
+                         "Linear weights sharded over the ranks, strong scaling")
+    ap.add_argument("--layers", type=int, default=0, help="model workloads: decoder layers (0 = the model's own depth)")
+    ap.add_argument("--inplace", action="store_true", help="model workloads: out = x (llama70b always: 137 GB of weights)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic falls back "
+                                                               "to the committed profiles/hbm_traffic.json value)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))             # no launcher around us: one process per GPU, started here
+    if os.environ.get("ANTQ_BENCH_SELFTEST") == "1":
+        return selftest_main(args)
+
+    h = Harness(args.gpus)
+    torch, rank = h.torch, h.rank
+    from ant_quantization_amd import _lib, grids
+
+    W = build_headline(args, h, _lib, grids) if args.workload == "headline" else build_model(args, h, _lib, grids)
+    step = W["step"]
+
+    if args.traffic_child:              # a counter pass of measure_traffic(): the batched launch and nothing else
+        for _ in range(3):
+            step()
+        h.sync()
+        return
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -396,85 +495,102 @@ def main():
             last = ev0.elapsed_time(ev1) * 1e-3 / per_call
         return last
 
-    # ---- setup pass: the same work as one launch per tensor (k_fq_lane, the reference's granularity).
+    # ---- setup pass: the same work as one launch per tensor (the reference's granularity).
     # Reported beside the headline; it also keeps the GPU busy for >= 0.3 s before anything is timed,
     # which is what it takes for an idle MI355X to reach steady clocks (the first ~50 ms of load run
     # up to 20 % slower: tools/probe_clock_ramp.py).
-    pt_launch_s = event_time(step_per_tensor, 0.3, 5) / args.nbuf
-    ptu_launch_s = event_time(step_per_tensor_unordered, 0.15, 5) / args.nbuf
+    if W["per_tensor"]:
+        pt_launch_s = event_time(W["per_tensor"][0], 0.3, 5) / args.nbuf
+        ptu_launch_s = event_time(W["per_tensor"][1], 0.15, 5) / args.nbuf
+    else:
+        event_time(step, 0.3, 1)
 
     # ---- the timed region: HIP events on the launch stream (= torch's current stream) inside the barriers
     elapsed = h.timed(step, args.steps, args.warmup, on_start=ev0.record, on_stop=ev1.record)
-    # roofline of the dominant kernel (antq::k_fq_batch): the timed region is nothing but back-to-back
-    # launches of it on one stream, so its average launch duration = event time / launches.
+    # roofline of the dominant kernel: the timed region is nothing but back-to-back launches of it on one stream,
+    # so its average launch duration = event time / launches -- on EVERY rank, gathered below
     launch_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
-    algo_bytes = args.nbuf * ROWS * COLS * BYTES_PER_ELEM
-    achieved = algo_bytes / launch_s / 1e9
+    algo_bytes = W["elems"] * BYTES_PER_ELEM
+    launch_all = h.gather(launch_s)
+    bytes_all = h.gather(algo_bytes)
+    fracs = [b / t / 1e9 / HBM_PEAK_GBPS for b, t in zip(bytes_all, launch_all)]
+    worst = min(range(h.world), key=lambda r: fracs[r])
+    achieved = bytes_all[worst] / launch_all[worst] / 1e9           # the SLOWEST rank's kernel (N = 1: the only one)
 
     # ---- parity spot check of what was just measured (cheap, outside the timed region) --------
-    ok = bool(torch.equal(_lib.fakequant(outs[0], alphas[0], plan, 10.0, ROWS, COLS, True), outs[0]))
+    ok = W["check"]()
 
+    h.finish()                          # every rank is done; what follows is rank 0 describing its own GPU
     if rank != 0:
-        h.finish()
         return
 
-    # ---- empirical ceiling on the same bytes: plain copies x_slab -> out_slab, one launch each
-    copy_s = event_time(lambda: _lib.copy(x_slab, out_slab), 0.15, 10)
-    d2d_s = event_time(lambda: out_slab.copy_(x_slab), 0.15, 10)
-    ceiling = max(algo_bytes / copy_s, algo_bytes / d2d_s) / 1e9
+    # ---- empirical ceiling on the same bytes: plain copies in -> out, one launch each
+    copy_bytes = W.get("copy_bytes", algo_bytes)
+    copy_s = event_time(W["copy"][0], 0.15, 10)
+    d2d_s = event_time(W["copy"][1], 0.15, 10)
+    ceiling = max(copy_bytes / copy_s, copy_bytes / d2d_s) / 1e9
 
     traffic, traffic_note = None, None
-    if h.world == 1 and not args.no_traffic:
-        traffic, traffic_note = measure_traffic(args.nbuf)       # (the children build their own copy of the workload)
+    if not args.no_traffic:             # (at N > 1 too: the child passes are one-GPU runs on rank 0's GPU, after the job is over)
+        child = ["--workload", args.workload, "--layers", str(args.layers)] + (["--inplace"] if args.inplace else [])
+        if args.workload != "headline" and h.world > 1:
+            traffic_note = "not measured: a child pass cannot rebuild rank 0's share of a sharded model on its own"
+        else:
+            traffic, traffic_note = measure_traffic(args.nbuf, child_args=child,
+                                                    timeout_s=240 if args.workload == "headline" else 900)
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # rocprofv3 --pmc result, see profiles/README.md
-    if traffic is None and os.path.exists(tpath):
+    if traffic is None and args.workload == "headline" and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            per_tensor = tj.get("headline_bytes_per_tensor", tj.get("k_fq_batch_bf16_bytes_per_tensor"))
+            per_tensor = tj.get("headline_bytes_per_tensor")
             traffic = int(per_tensor * args.nbuf) if per_tensor else None
-            traffic_note = ("from profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                            "command (FETCH_SIZE x2 per the guide's gfx950 correction), NOT measured in this run (%s)" % traffic_note)
+            traffic_note = ("from profiles/hbm_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                            "command (FETCH_SIZE x2 per the guide's gfx950 correction), NOT measured in this run (%s)"
+                            % (tj.get("headline_kernel"), traffic_note))
         except Exception:
             traffic = None
 
-    res = report(h, args, args.nbuf * ROWS * COLS, elapsed, {
-        "config": {"workload": "headline: %d x [4096,4096] bf16 weight tensors per GPU, ANT 4-bit signed flint grid, "
-                               "calibrated per-row alpha, steady-state _forward; one step = ONE batched launch "
-                               "(antq_fakequant_batch) over all %d tensors" % (args.nbuf, args.nbuf),
-                   "io_dtype": "bf16", "elements_per_step_per_gpu": args.nbuf * ROWS * COLS,
-                   "sharding": "independent tensors per rank, no data-path collective",
-                   "idempotence_check": ok,
-                   "per_tensor_launches": {"what": "the same pass as ONE LAUNCH PER TENSOR (antq_fakequant, the reference's "
-                                                   "granularity), %d independent weight tensors back to back on one stream, "
-                                                   "each launch marked ANTQ_FLAG_UNORDERED (inputs at rest: its dispatch "
-                                                   "packet carries no barrier bit, so it may start while its predecessor "
-                                                   "drains); `ordered` = the same launches without the flag" % args.nbuf,
-                                           "kernel": "antq::k_fq_hrow<bf16,false,4> (16-bit-domain row table, one wavefront per workgroup)",
-                                           "launch_us": round(ptu_launch_s * 1e6, 2),
-                                           "gelem_per_s": round(ROWS * COLS / ptu_launch_s / 1e9, 1),
-                                           "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9, 1),
-                                           "frac": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9 / HBM_PEAK_GBPS, 4),
-                                           "ordered": {"kernel": "antq::k_fq_hrow<bf16,false,8> (one wavefront per row)",
-                                                       "launch_us": round(pt_launch_s * 1e6, 2),
-                                                       "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}}},
+    config = {"workload": W["workload"], "io_dtype": "bf16", "elements_per_step_per_gpu": W["elems"],
+              "elements_per_step_per_rank": [int(b // BYTES_PER_ELEM) for b in bytes_all],
+              "sharding": W["sharding"], "idempotence_check": ok}
+    if W["per_tensor"]:
+        config["per_tensor_launches"] = {
+            "what": "the same pass as ONE LAUNCH PER TENSOR (antq_fakequant, the reference's granularity), %d independent weight "
+                    "tensors back to back on one stream, each launch marked ANTQ_FLAG_UNORDERED (inputs at rest: its dispatch "
+                    "packet carries no barrier bit, so it may start while its predecessor drains); `ordered` = the same launches "
+                    "without the flag" % args.nbuf,
+            "kernel": "antq::k_fq_hrow<bf16,false,4> (16-bit-domain row table, one wavefront per workgroup)",
+            "launch_us": round(ptu_launch_s * 1e6, 2),
+            "gelem_per_s": round(ROWS * COLS / ptu_launch_s / 1e9, 1),
+            "achieved_GBps": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9, 1),
+            "frac": round(ROWS * COLS * BYTES_PER_ELEM / ptu_launch_s / 1e9 / HBM_PEAK_GBPS, 4),
+            "ordered": {"kernel": "antq::k_fq_hrow<bf16,false,8> (one wavefront per row)",
+                        "launch_us": round(pt_launch_s * 1e6, 2),
+                        "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}}
+    res = report(h, args, sum(bytes_all) / BYTES_PER_ELEM, elapsed, {
+        "config": config,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": "antq::k_fq_hbatch<bf16,false>", "launch_us": round(launch_s * 1e6, 2),
-                     "algorithmic_bytes_per_launch": algo_bytes,
-                     "copy_ceiling": {"antq_copy_GBps": round(algo_bytes / copy_s / 1e9, 1),
-                                      "hipMemcpyDtoD_GBps": round(algo_bytes / d2d_s / 1e9, 1),
+                     "kernel": W["kernel"], "launch_us": round(launch_all[worst] * 1e6, 2),
+                     "algorithmic_bytes_per_launch": int(bytes_all[worst]),
+                     "per_rank": {"what": "every rank's own launch duration (HIP events around its timed region) and its "
+                                          "algorithmic bytes / that duration / 8 TB/s; `achieved`, `frac`, `launch_us` above "
+                                          "are the slowest rank's (rank %d)" % worst,
+                                  "ranks": h.world, "launch_us": per_rank_stats([t * 1e6 for t in launch_all]),
+                                  "frac": per_rank_stats(fracs, 4)},
+                     "copy_ceiling": {"antq_copy_GBps": round(copy_bytes / copy_s / 1e9, 1),
+                                      "hipMemcpyDtoD_GBps": round(copy_bytes / d2d_s / 1e9, 1),
                                       "frac_of_copy_ceiling": round(achieved / ceiling, 4),
-                                      "what": "plain copy of the same %d bytes in -> out (one launch), timed after the "
-                                              "timed region" % (algo_bytes // 2)}},
-    })
-    if h.world == 1 and not args.no_cpu_baseline:      # reported baselines, N=1 only
+                                      "what": "plain copy of %d bytes in -> out (one launch) on rank 0's GPU, timed after the "
+                                              "timed region" % (copy_bytes // 2)}},
+    }, scaling=W["scaling"])
+    if h.world == 1 and not args.no_cpu_baseline and args.workload == "headline":      # reported baselines, N=1 only
         res["cpu_baseline"] = cpu_baseline()
         phys = _physical_cores()
         if phys and phys < (os.cpu_count() or 1):      # SMT box: the same port with one thread per physical core beside it
             res["cpu_baseline_physical_cores"] = cpu_baseline(seconds_budget=6.0, threads=phys)
         res["cpu_baseline_torch"] = cpu_baseline_torch()
     print(json.dumps(res), flush=True)
-    h.finish()
 
 
 if __name__ == "__main__":

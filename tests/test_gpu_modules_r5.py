@@ -323,3 +323,153 @@ def test_prewarm_leaves_the_global_rng_alone(antq_lib, dev):
     _lib.prewarm(dev, torch.float16)
     b = torch.randn(4, device=dev)
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# K1h (csrc/antq_k_hrow.h) along the SCALE axis
+# ---------------------------------------------------------------------------------------------------------------------------
+def _f32_bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _to16(v, dtype):
+    """Nearest 16-bit magnitude pattern of positive float32 values (sampling aid only: neighbours are added around it)."""
+    v = np.asarray(v, dtype=np.float32)
+    with np.errstate(all="ignore"):
+        if dtype == 1:
+            return np.minimum((_f32_bits(v).astype(np.uint64) + 0x8000) >> 16, 0x7f80).astype(np.uint32)
+        return np.minimum(v, 65504.0).astype(np.float16).view(np.uint16).astype(np.uint32)
+
+
+def _hrow_has_table(L, plan, alpha, gmax, dtype, ovp):
+    """Does the row of this scale get a slot table (hrow_build's `fast`), by the library's own host model of the path?"""
+    import ctypes
+    x = np.zeros(8, np.uint16)
+    out, path = np.empty(8, np.uint16), np.empty(8, np.uint8)
+    rc = L.antq_plan_eval_host_h(plan.host_ptr(), x.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(8), ctypes.c_float(alpha),
+                                 ctypes.c_float(gmax), ctypes.c_int(dtype), ctypes.c_uint(1 if ovp else 0),
+                                 out.ctypes.data_as(ctypes.c_void_p), path.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return bool(path[0] == 0)
+
+
+def _flip_scales(L, plan, gmax, dtype, ovp):
+    """Every float32 alpha at which the row's table appears or disappears, to the last bit: a coarse sweep of the whole
+    positive float32 range (four points per binade) and a bisection on the bit pattern between two points that disagree.
+    Returns [(last alpha of one kind, first alpha of the other)]."""
+    grid = np.concatenate([np.ldexp(np.float32(1.0 + j / 4.0), np.arange(-149, 128)) for j in range(4)]).astype(np.float32)
+    grid = np.unique(grid[np.isfinite(grid) & (grid > 0)])
+    state = [_hrow_has_table(L, plan, float(a), gmax, dtype, ovp) for a in grid]
+    flips = []
+    for i in range(len(grid) - 1):
+        if state[i] != state[i + 1]:
+            lo, hi = int(_f32_bits(grid[i])), int(_f32_bits(grid[i + 1]))
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if _hrow_has_table(L, plan, float(np.uint32(mid).view(np.float32)), gmax, dtype, ovp) == state[i]:
+                    lo = mid
+                else:
+                    hi = mid
+            flips.append((np.uint32(lo).view(np.float32), np.uint32(hi).view(np.float32)))
+    return flips
+
+
+def test_16bit_domain_row_kernels_along_the_scale_axis(antq_lib, oracle, dev):
+    """K1h's per-row table depends on the row's scale: which slot a threshold lands in, where the sentinel slot sits, whether
+    the row gets a table at all (hrow_build's `fast`, antq_k_hrow.h:92-116).  test_16bit_domain_row_kernels_on_every_pattern
+    covers every PATTERN at 16 scales; this one covers the SCALE axis: 256 log-uniform alphas plus the exact float32
+    neighbours (both sides, +- 1 ulp) of every alpha at which `fast` flips, each row holding the patterns that can go
+    wrong at its scale -- every slot boundary of the row's key range +- 1, every threshold's pattern +- 3, the row limit
+    +- 3, zeros / Inf / NaN / denormals / the largest finite values, and random patterns in random pair positions --
+    against the oracle's fp32 sequence rounded to 16 bits, bit for bit: one launch per tensor (4- and 8-vector tasks, ordered and
+    unordered), the batched launch, ANT and OliVe pairs, bf16 and f16."""
+    import torch
+    from conftest import golden
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    L = antq_lib.lib()
+    import ctypes
+    L.antq_plan_eval_host_h.restype = ctypes.c_int
+    rng = np.random.default_rng(77)
+    books = [("flint_b4_s", G["flint_b4_s"], None, False), ("int_b4_s", G["int_b4_s"], None, False),
+             ("flint_b4_u", G["flint_b4_u"], None, False), ("pot_b4_s", G["pot_b4_s"], None, False),
+             ("float_b5_s", G["float_b5_s"], None, False),
+             ("olive_flint_b4_s", np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]]), float(O["flint_b4_s"].max()), True),
+             ("olive_int_b4_s", np.concatenate([O["int_b4_s"], O["outlier_b4_s"]]), float(O["int_b4_s"].max()), True)]
+    knob = L.antq_debug_set
+    K = 4096
+    n_flip_rows = n_rows = 0
+    for name, g, gmax, olive in books:
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        gmax = float(g.max()) if gmax is None else gmax
+        plan = antq_lib.plan_for(g)
+        hdr = plan.host[:128].view(np.uint32)
+        assert plan.is_table and int(hdr[24]) == 3, name
+        n_thr, hshifts, tl_off = int(hdr[25]), int(hdr[27]), int(hdr[28])
+        T = plan.host[tl_off:tl_off + 16 * n_thr].view(np.float32).reshape(n_thr, 4)[:, 0].copy()
+        lim = min(float(plan.host[:128].view(np.float32)[13]) * 0.99999, float(plan.host[:128].view(np.float32)[17]))
+        for dtype, tdt in ((1, torch.bfloat16), (2, torch.float16)):
+            hshift = (hshifts >> (8 * (dtype - 1))) & 0xff
+            inf16 = 0x7f80 if dtype == 1 else 0x7c00
+            for ovp in ((False, True) if olive else (False,)):
+                flips = _flip_scales(L, plan, gmax, dtype, ovp)
+                assert flips, (name, dtype)            # (at the very least: scales too small / too large for any table)
+                lo_e, hi_e = (-10.0, 10.0) if dtype == 1 else (-6.5, 5.5)
+                alphas = list(np.float32(10.0) ** rng.uniform(lo_e, hi_e, 256).astype(np.float32))
+                for a, b in flips[:24]:
+                    for v in (a, b):
+                        bits = int(_f32_bits(v))
+                        alphas += [v, np.uint32(max(bits - 1, 1)).view(np.float32), np.uint32(bits + 1).view(np.float32)]
+                alphas = np.float32(alphas)
+                alphas = alphas[np.isfinite(alphas) & (alphas > 0)]
+                n_flip_rows += len(alphas) - 256
+                rows = len(alphas)
+                x16 = np.empty((rows, K), np.uint16)
+                special = np.uint16([0, 0x8000, inf16, inf16 | 0x8000, inf16 + 1, 0xffff, inf16 - 1, (inf16 - 1) | 0x8000, 1, 0x8001,
+                                     2, 0x7fff, inf16 >> 1, 0x3c00 if dtype == 2 else 0x3f80])
+                for r, a in enumerate(alphas):
+                    with np.errstate(all="ignore"):
+                        s = np.float32(a) / np.float32(gmax)
+                        u = np.abs(T).astype(np.float32) * s
+                        limx = np.float32(min(lim * float(s) * 0.999, 3.0e38))
+                    pu = _to16(u[np.isfinite(u) & (u > 0)], dtype).astype(np.int64)
+                    pl = int(_to16(np.float32([limx]), dtype)[0]) if limx > 0 else 0
+                    cand = [special.astype(np.int64)]
+                    for d in range(-3, 4):
+                        cand.append(pu + d)
+                        cand.append(np.int64([max(pl + d, 0)]))
+                    k0 = max((int(pu.min()) >> hshift) - 2, 0) if pu.size else 0
+                    k1 = min((pl >> hshift) + 2, (0x7fff >> hshift))
+                    if k1 - k0 <= 200:
+                        edges = (np.arange(k0, k1 + 1, dtype=np.int64) << hshift)
+                        cand += [edges, edges + 1, np.maximum(edges, 1) - 1]
+                    mag = np.unique(np.clip(np.concatenate(cand).astype(np.int64), 0, 0x7fff)).astype(np.uint16)
+                    both = np.concatenate([mag, mag | 0x8000, special])
+                    if both.size > K - 512:
+                        both = rng.choice(both, K - 512, replace=False)
+                    row = np.concatenate([both, rng.integers(0, 65536, K - both.size).astype(np.uint16)])
+                    x16[r] = rng.permutation(row)
+                xf = oracle.bf16_to_f32(x16) if dtype == 1 else x16.view(np.float16).astype(np.float32)
+                with np.errstate(all="ignore"):
+                    ref, _ = oracle.forward(xf, alphas, g, gmax, ovp)
+                    ref16 = oracle.f32_to_bf16(ref) if dtype == 1 else ref.astype(np.float16).view(np.uint16)
+                rf = oracle.bf16_to_f32(ref16) if dtype == 1 else ref16.view(np.float16).astype(np.float32)
+                xt = torch.from_numpy(x16.view(np.int16)).to(dev).view(tdt)
+                at = torch.from_numpy(alphas).to(dev)
+
+                def same(t, what):
+                    got = t.view(torch.int16).cpu().numpy().view(np.uint16).reshape(ref16.shape)
+                    gf = oracle.bf16_to_f32(got) if dtype == 1 else got.view(np.float16).astype(np.float32)
+                    bad = ~((got == ref16) | (np.isnan(gf) & np.isnan(rf)))
+                    assert not bad.any(), (name, str(tdt), ovp, what, int(bad.sum()), alphas[np.argwhere(bad)[:3, 0]].tolist(),
+                                           x16[bad][:3], got[bad][:3], ref16[bad][:3])
+
+                same(antq_lib.fakequant(xt, at, plan, gmax, rows, K, True, ovp=ovp), "one launch")
+                knob(0, 8)
+                same(antq_lib.fakequant(xt, at, plan, gmax, rows, K, True, ovp=ovp), "one launch, 8-vector tasks")
+                knob(0, 0)
+                same(antq_lib.fakequant(xt, at, plan, gmax, rows, K, True, ovp=ovp, out=torch.empty_like(xt), unordered=True), "unordered")
+                out = torch.empty_like(xt)
+                antq_lib.Batch([(xt, out, at, plan, gmax, rows, K, True)], ovp=ovp).run()
+                same(out, "batched")
+                n_rows += rows
+    assert n_flip_rows >= 60 and n_rows > 4000

@@ -121,11 +121,11 @@ def test_lpt_balance_and_row_blocks():
         sharding.row_block(8, 2, 2)
 
 
-def _run_bench(tmp_path, nproc, gpus, steps=12, warmup=2):
+def _run_bench(tmp_path, nproc, gpus, steps=12, warmup=2, extra=()):
     env = dict(os.environ, ANTQ_BENCH_SELFTEST="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(gpus),
-           "--steps", str(steps), "--warmup", str(warmup)]
+           "--steps", str(steps), "--warmup", str(warmup)] + list(extra)
     return subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
 
 
@@ -144,6 +144,55 @@ def test_bench_rank_harness_under_torchrun_world2(tmp_path):
     assert 2.0 <= res["ms_per_step"] < 20.0                              # the SLOWER rank's 2 ms, not rank 0's 1 ms
     # value = units of ALL ranks / the slowest rank's time
     assert abs(res["value"] - 2 * 1e6 * 12 / (res["ms_per_step"] * 1e-3 * 12) / 1e9) < 2e-3 * res["value"] + 1e-3
+    # every rank's own kernel time reaches the line (gathered, not rank 0's alone)
+    pr = res["roofline"]["per_rank"]
+    assert pr["ranks"] == 2 and pr["launch_us"] == {"min": 1000.0, "mean": 1500.0, "max": 2000.0}
+    assert res["config"]["elements_per_step_per_rank"] == [1000000, 1000000]
+
+
+@pytest.mark.parametrize("workload,layers,total", [("opt6.7b", 2, 2 * 100663296 * 2), ("llama70b", 1, 855638016)])
+def test_bench_sharded_model_workloads_under_torchrun_world2(tmp_path, workload, layers, total):
+    """BASELINE configs[3] / [4] as driver-runnable bench lines (`bench.py --workload opt6.7b | llama70b`): at world 2 the
+    shard plan (sharding.shard_plan: LPT packing of whole tensors / a row block of every matrix) gives the two ranks disjoint
+    shares that add up to the whole model, the work is fixed (`scaling: strong`) and `value` counts ALL ranks' elements
+    against the slowest rank's time."""
+    r = _run_bench(tmp_path, 2, 2, extra=["--workload", workload, "--layers", str(layers)])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    per = res["config"]["elements_per_step_per_rank"]
+    assert res["scaling"] == "strong" and res["n_gpus"] == 2 and len(per) == 2 and sum(per) == total
+    assert max(per) <= 1.01 * min(per)
+    assert abs(res["value"] - total / (res["ms_per_step"] * 1e-3) / 1e9) < 2e-3 * res["value"] + 1e-3
+    assert res["roofline"]["per_rank"]["ranks"] == 2
+
+
+def test_shard_plan_covers_every_unit_exactly_once():
+    """sharding.shard_plan for both sharded BASELINE workloads at world 1, 2, 3, 8: every (tensor, row) is owned by exactly one
+    rank; opt6.7b ranks own whole tensors with loads within one tensor of each other; llama70b ranks own a row block of every
+    matrix, balanced to within a row, cut so that no OliVe pair is split."""
+    from ant_quantization_amd import sharding
+    for name in ("opt6.7b", "llama70b"):
+        shapes = sharding.model_linear_shapes(name)
+        total = sum(r * c for r, c in shapes)
+        assert total == {"opt6.7b": 6442450944, "llama70b": 68451041280}[name]
+        for world in (1, 2, 3, 8):
+            owned = {}
+            loads = []
+            for rank in range(world):
+                units = sharding.shard_plan(name, rank, world)
+                loads.append(sum((e - b) * c for _, b, e, c in units))
+                for i, b, e, c in units:
+                    assert c == shapes[i][1] and 0 <= b < e <= shapes[i][0] and ((b * c) % 2 == 0)
+                    owned.setdefault(i, []).append((b, e))
+            assert sum(loads) == total
+            for i, blocks in owned.items():
+                blocks.sort()
+                assert blocks[0][0] == 0 and blocks[-1][1] == shapes[i][0]
+                assert all(blocks[k][1] == blocks[k + 1][0] for k in range(len(blocks) - 1))
+            assert sorted(owned) == list(range(len(shapes)))
+            assert max(loads) - min(loads) <= max(r * c for r, c in shapes)
 
 
 def test_bench_refuses_a_world_size_other_than_gpus(tmp_path):
