@@ -190,6 +190,8 @@ static int launch_hrow(const void *x, void *out, size_t rows, size_t vpr, const 
         // (tools/probe_per_tensor.py, profiles/r04_per_tensor_shapes.log)
         if (U == 4 && !t_unordered && vpr % 512u == 0u && rows * (vpr / 512u) >= 1024u && rows * (vpr / 512u) <= 4096u) U = 8;
         if ((g_knob_u >= 2 && g_knob_u <= 4) || g_knob_u == 8) U = g_knob_u;      // knob 0 (A/B)
+        const int W = (g_knob_waves == 4 || g_knob_waves == 1) ? g_knob_waves : 1;
+        if (W == 4 && U == 8) U = 4;               // (the 4-wavefront form exists for 2 / 3 / 4 vectors per lane: the task size below must be the launched kernel's)
         const size_t tpr = (vpr + (size_t)64 * U - 1) / ((size_t)64 * U);
         const size_t total = rows * tpr;
         if (total > 0x7fffffffull) return ANTQ_ERR_UNSUPPORTED;
@@ -197,7 +199,6 @@ static int launch_hrow(const void *x, void *out, size_t rows, size_t vpr, const 
         // 33.5 MB tensor is a single round and wants every slot (tools/probe_per_tensor.py)
         const bool big = total >= (size_t)4 * 8192;
         const unsigned pad = g_knob_hlds >= 0 ? (unsigned)g_knob_hlds : (big ? kHRowLdsPad : 0u);
-        const int W = (g_knob_waves == 4 || g_knob_waves == 1) ? g_knob_waves : 1;
         const dim3 g((unsigned)((total + W - 1) / W)), b(64 * W);
         const uint4 *tl = plan_tlist_dev(plan_host, plan_dev);
         const float *grid = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev));

@@ -5,7 +5,7 @@
 namespace antq {
 
 constexpr uint32_t kPlanMagic = 0x51544E41u;  // "ANTQ"
-constexpr uint32_t kPlanVersion = 9;
+constexpr uint32_t kPlanVersion = 10;     // 10: HThr::flags carries the scan-order indices of v_lo / v_hi
 
 constexpr uint32_t kPlanScan = 0;  // kernels run the literal scan for every element
 constexpr uint32_t kPlanLut = 1;   // table plan: one LDS lookup + one compare per element
@@ -77,7 +77,8 @@ struct HThr {
     float T;          // RN(x / s) >= T  ->  v_hi, else v_lo
     float v_lo;
     float v_hi;
-    uint32_t flags;   // bit 0: |v_lo| > 32, bit 1: |v_hi| > 32 (OliVe outlier test, OQ:314)
+    uint32_t flags;   // bit 0: |v_lo| > 32, bit 1: |v_hi| > 32 (OliVe outlier test, OQ:314); bits 8..17 / 18..27: the scan-order
+                      // grid index of v_lo / v_hi (the last duplicate: what the reference scan's `<=` keeps) -- the packed codec's codes
 };
 static_assert(sizeof(HThr) == 16, "HThr must be 16 bytes");
 constexpr uint32_t kHSlots = 128;         // slots per sign of the wave-private table (2 KiB per wavefront)

@@ -5,6 +5,7 @@
 
 #include "antq_device.h"
 #include "antq_k_approx.h"
+#include "antq_k_hrow.h"
 
 namespace antq {
 
@@ -311,6 +312,232 @@ k_encode4_xrow(const uint4 *__restrict__ x, uint32_t *__restrict__ codes, uint32
     }
 }
 
+// ------------------------------------------------------------------------------------
+// 16-bit-domain row encoder (round 5): the K1h treatment (antq_k_hrow.h) for the codes.  A bf16 / f16 element never leaves
+// its 16 bits: the wave-private slot table is keyed by the element's own (sign, exponent, top mantissa bits) and holds the
+// threshold PATTERN in word 0 and, in word 1, two BYTES instead of two output patterns:
+//     byte 0 = code of the region below the threshold (by magnitude), byte 1 = code at / above it
+//     code byte = nibble (scan-order index; an outlier: its index in the outlier list) | 0x10 if |v| > 32 (OQ:314)
+// Per element: v_bfe (key) + v_med3 (clamp) + v_alignbit (sign) + v_lshl_add (address) + ds_read_b64 + v_cmp +
+// v_cndmask_sdwa that drops the chosen byte straight into byte i of an accumulator -- the low elements of a vector's four
+// words collect in A, the high ones in B, and the vector's 32 bits of nibbles are A | B << 4 (one v_lshl_or); the pair rule is
+// five more word-wide logic operations on the 0x10 flags of all four pairs at once.  No conversion to fp32, no multiply
+// by 1 / s, no per-pair shifts and masks: 6.5 + ~1 VALU instructions per element against 16 in the fp32-domain row encoder.
+// The sentinel slot's threshold is the pattern of the table's DECISION limit (flim), not of the narrower straight-through
+// limit the fake-quant kernel needs: a far-clipped element keeps the extreme code of its sign on the fast path, and only
+// Inf / NaN / magnitudes beyond ~2^20 grid units reach the sentinel byte 0x80 -- such a lane redoes its vector literally.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t kHCodeSentinel = 0x80u;
+constexpr uint32_t kHCodeOutlier = 0x10u;
+
+template <bool OVP>
+__device__ __forceinline__ uint32_t hcode_byte(uint32_t j, bool outlier, uint32_t n_normal)
+{
+    uint32_t c = (OVP && j >= n_normal) ? j - n_normal : j;
+    c &= 15u;
+    if (OVP && outlier) c |= kHCodeOutlier;
+    return c;
+}
+
+// hrow_build (antq_k_hrow.h) with codes instead of output patterns; same slot geometry, same conditions for `fast`.
+template <typename T, bool OVP>
+__device__ __forceinline__ HRow hrow_build_codes(const HArgs &ha, const uint4 &thr, const Scale &sc, uint2 *tab, uint32_t lane,
+                                                 uint32_t n_normal)
+{
+    HRow R;
+    const float s = sc.s;
+    bool ok = sc.ok && (s > 0.0f);
+    const bool mine = lane < ha.n_thr;
+    const bool neg = lane < ha.n_neg;
+    const float limx = ha.lim * s * 0.999f;
+    const uint32_t lim16 = ok ? H16<T>::down(fminf(limx, 3.0e38f)) : 0u;
+    const uint32_t klim = lim16 >> ha.hshift;
+    // the sentinel slot decides on the pattern of the DECISION limit (>= lim16: keys beyond klim clamp into this slot)
+    const uint32_t flim16 = ok ? max(H16<T>::down(fminf(ha.flim * s * 0.999f, 3.0e38f)), lim16) : 0u;
+    bool tok;
+    const float Tt = mine ? u2f(thr.x) : 1.0f;
+    const float U = x_threshold(Tt, ok ? s : 1.0f, sc.rs, tok);
+    uint32_t t16 = neg ? H16<T>::down(-U) + 1u : H16<T>::up(U);
+    const uint32_t key = mine ? (t16 >> ha.hshift) : 0u;
+    const uint32_t o_lo = hcode_byte<OVP>((thr.w >> 8) & 0x3ffu, (thr.w & 1u) != 0u, n_normal);
+    const uint32_t o_hi = hcode_byte<OVP>((thr.w >> 18) & 0x3ffu, (thr.w & 2u) != 0u, n_normal);
+    const uint32_t first = neg ? o_hi : o_lo, second = neg ? o_lo : o_hi;      // by rising MAGNITUDE
+    const uint32_t k_prev = (uint32_t)__shfl((int)key, (int)((lane + 63u) & 63u), 64);
+    const uint32_t k_next = (uint32_t)__shfl((int)key, (int)((lane + 1u) & 63u), 64);
+    const bool last_of_side = neg ? (lane == 0u) : (lane + 1u == ha.n_thr);
+    const bool first_of_side = neg ? (lane + 1u == ha.n_neg) : (lane == ha.n_neg);
+    const uint32_t nxt = last_of_side ? klim : (neg ? k_prev : k_next);
+    const uint32_t kpos = ha.n_neg < ha.n_thr ? (uint32_t)__builtin_amdgcn_readlane((int)key, (int)ha.n_neg) : 0xffffffffu;
+    const uint32_t kneg = ha.n_neg > 0u ? (uint32_t)__builtin_amdgcn_readlane((int)key, (int)(ha.n_neg - 1u)) : 0xffffffffu;
+    const uint32_t kmin = min(kpos, kneg);
+    const bool lane_ok = !mine || (key < nxt);
+    ok = ok && (klim >= kmin) && (klim - kmin < kHSlots) && (__ballot(lane_ok) == ~0ull);
+    R.kmin = kmin; R.klim = klim; R.fast = ok;
+    if (!ok) return R;
+    auto slot = [&](uint32_t k, bool ng) -> uint2 & { return tab[((k - kmin) << 1) + (ng ? 1u : 0u)]; };
+    const uint32_t sbit = neg ? 0x80000000u : 0u;
+    if (mine) {
+        slot(key, neg) = make_uint2(sbit | (t16 << 16), first | (second << 8));
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (uint32_t k = key + 1u; k < nxt; k++) slot(k, neg) = make_uint2(kHNoThr, second | (second << 8));
+        if (first_of_side) {
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (uint32_t k = kmin; k < key; k++) slot(k, neg) = make_uint2(kHNoThr, first | (first << 8));
+        }
+        if (last_of_side) slot(klim, neg) = make_uint2(sbit | (flim16 << 16), second | (kHCodeSentinel << 8));
+    }
+    if (ha.n_neg == 0u || ha.n_neg == ha.n_thr) {
+        const bool ng = ha.n_neg == 0u;
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)first, ng ? 0 : (int)(ha.n_thr - 1u));
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (uint32_t k = kmin + lane; k < klim; k += 64u) slot(k, ng) = make_uint2(kHNoThr, o | (o << 8));
+        if (lane == 0u) slot(klim, ng) = make_uint2((ng ? 0x80000000u : 0u) | (flim16 << 16), o | (kHCodeSentinel << 8));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+    return R;
+}
+
+// The two elements of word I (0..3) of a vector: their code bytes into byte I of A (low element) and B (high element).
+#define ANTQ_HCODE_SEL(DST, SRCW, ENT, BYTE)                                                                                   \
+    asm("v_cmp_ge_u32 vcc, %1, %2\n\t"                                                                                         \
+        "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:" BYTE " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1"       \
+        : "+v"(DST) : "v"(SRCW), "v"((ENT).x), "v"((ENT).y) : "vcc")
+#define ANTQ_HCODE_SEL0(DST, SRCW, ENT)                                                                                        \
+    asm("v_cmp_ge_u32 vcc, %1, %2\n\t"                                                                                         \
+        "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1"              \
+        : "=v"(DST) : "v"(SRCW), "v"((ENT).x), "v"((ENT).y) : "vcc")
+template <int I>
+__device__ __forceinline__ void hcode_pair(uint32_t w, uint32_t tbase, uint32_t vkmin, uint32_t vklim, uint32_t kpos, uint32_t vkwid,
+                                           uint32_t &A, uint32_t &B)
+{
+    uint32_t th, tl, wl;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(th) : "v"(w), "s"(kpos), "v"(vkwid));
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(th) : "v"(th), "v"(vkmin), "v"(vklim));
+    wl = w << 16;
+    th = __builtin_amdgcn_alignbit(th, w, 31);
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(tl) : "v"(wl), "s"(kpos), "v"(vkwid));
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(tl) : "v"(tl), "v"(vkmin), "v"(vklim));
+    tl = __builtin_amdgcn_alignbit(tl, wl, 31);
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t eh = *(const __attribute__((address_space(3))) u32x2_t *)(uintptr_t)((th << 3) + tbase);
+    const u32x2_t el = *(const __attribute__((address_space(3))) u32x2_t *)(uintptr_t)((tl << 3) + tbase);
+    if constexpr (I == 0) { ANTQ_HCODE_SEL0(A, wl, el); ANTQ_HCODE_SEL0(B, w, eh); }        // (the first byte pads the rest with zeros)
+    if constexpr (I == 1) { ANTQ_HCODE_SEL(A, wl, el, "BYTE_1"); ANTQ_HCODE_SEL(B, w, eh, "BYTE_1"); }
+    if constexpr (I == 2) { ANTQ_HCODE_SEL(A, wl, el, "BYTE_2"); ANTQ_HCODE_SEL(B, w, eh, "BYTE_2"); }
+    if constexpr (I == 3) { ANTQ_HCODE_SEL(A, wl, el, "BYTE_3"); ANTQ_HCODE_SEL(B, w, eh, "BYTE_3"); }
+}
+#undef ANTQ_HCODE_SEL
+#undef ANTQ_HCODE_SEL0
+
+// A (low elements) / B (high elements) of the four pairs of a vector -> its 8 nibbles; OVP: the pair rule (OQ:313-320) on the
+// 0x10 flags of all four pairs at once: the even element is a victim when its odd partner is an outlier and it is not one
+// itself, the odd one when its even partner is an outlier; a victim's nibble becomes the identifier 15.
+template <bool OVP>
+__device__ __forceinline__ uint32_t hcode_pack(uint32_t A, uint32_t B)
+{
+    if (OVP) {
+        const uint32_t me = A & 0x10101010u, mo = B & 0x10101010u;
+        const uint32_t ve = mo & ~me;
+        A = (A & 0x0f0f0f0fu) | (ve - (ve >> 4));        // 0x10 -> 0x0f in the bytes of the victims
+        B = (B & 0x0f0f0f0fu) | (me - (me >> 4));
+    }
+    return A | (B << 4);
+}
+
+// The literal reference sequence for one vector (rare): d = x / s, scan, the code of the winner (no entry within 102400:
+// the code of the grid's zero), pair rule.
+template <typename T, bool OVP>
+__device__ __forceinline__ uint32_t hcode_exact(const uint4 &v, float s, const float *__restrict__ grid, uint32_t m, int n_normal,
+                                                int zero_code)
+{
+    uint32_t c[8];
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+        const uint32_t w = vec_word(v, i);
+        const float d0 = H16<T>::val(w & 0xffffu) / s, d1 = H16<T>::val(w >> 16) / s;
+        float q0 = 0.0f, q1 = 0.0f, m0 = 102400.0f, m1 = 102400.0f;
+        int j0 = ANTQ_IDX_NONE, j1 = ANTQ_IDX_NONE;
+#pragma unroll 1
+        for (uint32_t k = 0; k < m; k++) {
+            const float g = ld_global(grid + k);
+            const float s0 = fabsf(d0 - g), s1 = fabsf(d1 - g);
+            if (s0 <= m0) { m0 = s0; q0 = g; j0 = (int)k; }
+            if (s1 <= m1) { m1 = s1; q1 = g; j1 = (int)k; }
+        }
+        const uint32_t c0 = j0 == ANTQ_IDX_NONE ? (uint32_t)zero_code : code_of<OVP>((uint32_t)j0, q0, n_normal);
+        const uint32_t c1 = j1 == ANTQ_IDX_NONE ? (uint32_t)zero_code : code_of<OVP>((uint32_t)j1, q1, n_normal);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (i == k) { c[2 * k] = c0; c[2 * k + 1] = c1; }
+    }
+    return pack_codes<OVP>(c);
+}
+
+template <typename T, bool OVP, int VPT, int MEM = 0>          // MEM (experiment): bit 0 plain loads, bit 1 plain stores
+__global__ void __launch_bounds__(64)
+k_encode4_hrow(const uint4 *__restrict__ x, uint32_t *__restrict__ codes, uint32_t total_tasks, uint32_t vpr, uint32_t tpr,
+               const float *__restrict__ alpha, int per_row, float gmax, HArgs ha, const uint4 *__restrict__ tlist,
+               const float *__restrict__ grid, int n_normal, int zero_code)
+{
+    __shared__ __attribute__((aligned(16))) uint2 tab[kHSlots * 2];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    if (task >= total_tasks) return;
+    uint32_t row = task, g = 0;
+    if (tpr != 1) { row = task / tpr; g = task - row * tpr; }
+    uint4 thr = ld_global(tlist + min(lane, ha.n_thr - 1u));
+    const float a = ld_global(alpha + (per_row ? row : 0));
+    const uint32_t v0 = g * (64u * VPT) + lane;
+    const uint4 *p = x + (size_t)row * vpr;
+    uint4 v[VPT];
+#pragma unroll
+    for (int u = 0; u < VPT; u++) v[u] = (MEM & 1) ? ld_global(p + min(v0 + 64u * u, vpr - 1u)) : ld_stream(p + min(v0 + 64u * u, vpr - 1u));
+    __builtin_amdgcn_sched_barrier(0);                 // (see hrow_wave_task: the table is built while the loads are in flight)
+    asm volatile("" : "+v"(thr.x), "+v"(thr.y), "+v"(thr.z), "+v"(thr.w));
+    const Scale sc = row_scale(a, gmax, ha.inv_gmax);
+    const HRow R = hrow_build_codes<T, OVP>(ha, thr, sc, tab, lane, (uint32_t)n_normal);
+    const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)tab;
+    const uint32_t kpos = 16u + ha.hshift;
+    uint32_t vkmin = R.kmin, vklim = R.klim, vkwid = 15u - ha.hshift;
+    asm volatile("" : "+v"(vkmin), "+v"(vklim), "+v"(vkwid));          // (VGPR copies: gfx9 takes one SGPR per VOP3)
+    const uint32_t tbase = tab_addr - (R.kmin << 4);
+    uint32_t *out = codes + (size_t)row * vpr + v0;                    // one word of nibbles per 16-byte vector
+    uint32_t acc = 0u;
+    if (R.fast) {
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            uint32_t A, B;
+            hcode_pair<0>(v[u].x, tbase, vkmin, vklim, kpos, vkwid, A, B);
+            hcode_pair<1>(v[u].y, tbase, vkmin, vklim, kpos, vkwid, A, B);
+            hcode_pair<2>(v[u].z, tbase, vkmin, vklim, kpos, vkwid, A, B);
+            hcode_pair<3>(v[u].w, tbase, vkmin, vklim, kpos, vkwid, A, B);
+            acc |= A | B;
+            if (v0 + 64u * u < vpr) {
+                if (MEM & 2) out[64u * u] = hcode_pack<OVP>(A, B);
+                else __builtin_nontemporal_store(hcode_pack<OVP>(A, B), out + 64u * u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (__builtin_expect((acc & 0x80808080u) == 0u, 1)) return;
+    }
+    // rare: an element at or beyond the table's decision limit (Inf, NaN, absurd magnitudes), or a row without a table
+    const uint32_t slot0 = R.klim << ha.hshift;
+#pragma unroll 1
+    for (uint32_t u = 0; u < (uint32_t)VPT; u++) {
+        uint4 cur = v[0];
+#pragma unroll
+        for (int k = 1; k < VPT; k++)
+            if (u == (uint32_t)k) cur = v[k];
+        if (v0 + 64u * u < vpr) {
+            const uint32_t top = IO<T>::amax_acc(0u, cur);
+            if (!R.fast || max(top & 0xffffu, top >> 16) >= slot0)
+                __builtin_nontemporal_store(hcode_exact<T, OVP>(cur, sc.s, grid, ha.m, n_normal, zero_code), out + 64u * u);
+        }
+    }
+}
+
 // Decoder.  VEC: one 16-byte vector of output per thread and access (EPL = 4 fp32 / 8 bf16 elements = 2 / 4 bytes of
 // codes), 4 in flight: every store instruction of a wavefront covers 1 KiB contiguous.  Otherwise 8 elements per thread
 // with element stores.
@@ -391,6 +618,49 @@ static int launch_codec(bool enc, const void *x, void *codes_or_out, const uint8
     int zero_code = 0;
     for (int i = 0; i < (ovp ? n_normal : m); i++) if (grid_host[i] == 0.0f) zero_code = i;
     const dim3 gd((unsigned)blocks), bd(256);
+    if constexpr (!std::is_same<T, float>::value) {
+        // bf16 / f16 rows of >= 128 vectors with a 16-bit-domain plan: the K1h encoder (knob 9 = 0: the fp32-domain row encoder)
+        HArgs ha;
+        const size_t rl = per_row ? row_len : n;
+        const size_t vpr = rl / 8;
+        if (enc && vec && g_knob_h != 0 && vpr >= kRowKernelMinVpr && vpr <= 0xffffffffull &&
+            hargs_from_plan(plan_host, IO<T>::DTYPE, gmax, ha)) {
+            // vectors per lane and task: the largest of 8 / 4 / 3 / 2 that keeps the lanes of a row's tasks busy (the table is
+            // built once per task); knob 0 forces a size (A/B)
+            uint32_t U = 2;
+            double best = -1.0;
+            for (uint32_t u : {8u, 4u, 3u, 2u}) {
+                const size_t span = 64u * u, tasks = (vpr + span - 1) / span;
+                const double util = (double)vpr / (double)(tasks * span);
+                if (util > best + 0.02) { best = util; U = u; }
+            }
+            if ((g_knob_u >= 2 && g_knob_u <= 4) || g_knob_u == 8) U = (uint32_t)g_knob_u;
+            const size_t tpr = (vpr + 64 * U - 1) / (64 * U), total = (per_row ? rows : 1) * tpr;
+            if (total <= 0x7fffffffull) {
+                const uint4 *tl = plan_tlist_dev(plan_host, plan_dev);
+                const float *grid = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev));
+                const unsigned pad = g_knob_hlds >= 0 ? (unsigned)g_knob_hlds : 0u;
+#define ANTQ_ENCH(O, U_) hipLaunchKernelGGL((k_encode4_hrow<T, O, U_>), dim3((unsigned)total), dim3(64), pad, st, static_cast<const uint4 *>(x), \
+                                        static_cast<uint32_t *>(codes_or_out), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, \
+                                        gmax, ha, tl, grid, n_normal, zero_code)
+#define ANTQ_ENCHM(O, U_, M_) hipLaunchKernelGGL((k_encode4_hrow<T, O, U_, M_>), dim3((unsigned)total), dim3(64), pad, st, static_cast<const uint4 *>(x), \
+                                        static_cast<uint32_t *>(codes_or_out), (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, alpha, per_row, \
+                                        gmax, ha, tl, grid, n_normal, zero_code)
+                // whole 8 KiB tasks store their 256-byte code words through the cache (plain stores: 71.1 -> 76.5 % ANT, 70.4 ->
+                // 75.4 % OliVe on 16384 x 8192 bf16; nontemporal loads stay -- plain loads cost 4 points); knob 13 = 1: nontemporal
+                // stores (A/B).  profiles/r05_codec_h.log
+                if (U == 8 && g_knob_exp != 1) { if (ovp) ANTQ_ENCHM(true, 8, 2); else ANTQ_ENCHM(false, 8, 2); }
+                else
+                if (U == 8) { if (ovp) ANTQ_ENCH(true, 8); else ANTQ_ENCH(false, 8); }
+                else if (U == 4) { if (ovp) ANTQ_ENCH(true, 4); else ANTQ_ENCH(false, 4); }
+                else if (U == 3) { if (ovp) ANTQ_ENCH(true, 3); else ANTQ_ENCH(false, 3); }
+                else { if (ovp) ANTQ_ENCH(true, 2); else ANTQ_ENCH(false, 2); }
+#undef ANTQ_ENCH
+#undef ANTQ_ENCHM
+                return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+            }
+        }
+    }
     if (enc && vec && g_knob_x != 0 && g_knob_lane_rows != 2) {
         // rows of >= 128 vectors with an x-domain plan: the row-table encoder (knob 2 = 0 or knob 5 = 2: the element encoder, A/B)
         const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);

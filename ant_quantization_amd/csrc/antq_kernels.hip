@@ -20,6 +20,8 @@
 // float op below must round exactly as written).
 // This translation unit: nearest-value operator, affine quantiser, copy, abs-max, alpha gradient, packed 4-bit codec, knobs.
 // (antq_fq.hip: one tensor per launch; antq_batch.hip: batched launch; antq_search.hip: calibration.)
+#include <type_traits>
+
 #include "antq_host.h"
 #include "antq_k_fakequant.h"
 #include "antq_k_nearest.h"
@@ -41,6 +43,7 @@ thread_local int g_knob_h = 1;
 thread_local int g_knob_hlds = -1;
 thread_local int g_knob_dlds = -1;
 thread_local int g_knob_schunks = 0;
+thread_local int g_knob_exp = 0;
 
 }  // namespace antq
 
@@ -237,6 +240,7 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 10) g_knob_hlds = value;
     else if (key == 11) g_knob_dlds = value;
     else if (key == 12) g_knob_schunks = value;
+    else if (key == 13) g_knob_exp = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }

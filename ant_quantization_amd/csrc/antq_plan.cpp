@@ -485,7 +485,8 @@ extern "C" int antq_plan_build(const float *grid, int m, void *blob, size_t cap)
             t.T = T[i];
             t.v_lo = grid[dv[i].win];
             t.v_hi = grid[dv[i + 1].win];
-            t.flags = (fabsf(t.v_lo) > 32.0f ? 1u : 0u) | (fabsf(t.v_hi) > 32.0f ? 2u : 0u);
+            t.flags = (fabsf(t.v_lo) > 32.0f ? 1u : 0u) | (fabsf(t.v_hi) > 32.0f ? 2u : 0u) |
+                      ((uint32_t)dv[i].win << 8) | ((uint32_t)dv[i + 1].win << 18);      // scan-order indices (m <= 1024)
             tlist.push_back(t);
         }
         h.tlist_off = h.bytes;

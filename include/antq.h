@@ -405,10 +405,14 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
  *   key 6: wavefronts per workgroup (1 / 2 / 4) of the batched row-table launch and of the one-launch lane kernel (0 = heuristic)
  *   key 7: vectors per lane of the one-launch lane kernel (0 = heuristic)
  *   key 8: workgroup -> task map rotation of the batched row-table launch: 0 per job (default), 1 always, 2 never
- *   key 9: 0 disables the 16-bit-domain row kernels (bf16 / f16 rows of >= 128 vectors go back to the fp32-domain row table)
+ *   key 9: 0 disables the 16-bit-domain row kernels and the 16-bit-domain encoder (bf16 / f16 rows of >= 128 vectors go back to
+ *          the fp32-domain row table / row encoder)
  *   key 10: dynamic LDS bytes per workgroup of those kernels (occupancy A/B; -1 = default: 24 workgroups per CU)
  *   key 11: extra dynamic LDS bytes per workgroup of the batched lane-job kernels (occupancy A/B; -1 = default: fp32 static
- *           launches of >= 32768 workgroups are held at 6 workgroups = 24 wavefronts per CU, nothing otherwise) */
+ *           launches of >= 32768 workgroups are held at 6 workgroups = 24 wavefronts per CU, nothing otherwise)
+ *   key 12: clip search: number of candidate-list chunks (0 = cost model)
+ *   key 13: experiment switch of the kernel under development (0 = off; 1: the 16-bit-domain encoder's 8-vector tasks store
+ *           their codes nontemporally instead of through the cache) */
 int antq_debug_set(int key, int value);
 
 /* Load the library's GPU code objects for the current device now (HIP would load each of them at the first launch of one

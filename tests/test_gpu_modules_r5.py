@@ -473,3 +473,93 @@ def test_16bit_domain_row_kernels_along_the_scale_axis(antq_lib, oracle, dev):
                 same(out, "batched")
                 n_rows += rows
     assert n_flip_rows >= 60 and n_rows > 4000
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the 16-bit-domain encoder (csrc/antq_k_codec.h: k_encode4_hrow)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _codes_want(oracle, ridx, n_normal, ovp, zero_code):
+    want = ridx.astype(np.int64).copy()
+    if ovp:
+        want[ridx >= n_normal] -= n_normal
+    want[ridx == oracle.IDX_VICTIM] = 15
+    want[ridx == oracle.IDX_NONE] = zero_code
+    return want
+
+
+def test_16bit_domain_encoder_codes_on_every_pattern(antq_lib, oracle, dev):
+    """antq_encode4 on bf16 / f16 rows of >= 128 vectors (k_encode4_hrow: the slot table of K1h holding code bytes; the pair
+    rule on the 0x10 flags of four pairs at once): the codes ARE the oracle's scan-order indices (OQ:155-179: an outlier is its
+    index in the outlier list, a victim the identifier 15; no entry within 102400: the code of the grid's zero) for EVERY
+    one of the 65 536 input patterns, in order and shuffled (other pairs, other lanes), one row per scale -- ordinary ones,
+    zero, negative, NaN, Inf, denormal-range, overflowing --, through 8-, 4-, 3- and 2-vector tasks, ANT and OliVe; and equal
+    to the fp32-domain row encoder's (knob 9 = 0) and the element encoder's (knob 2 = 0) codes."""
+    import torch
+    from conftest import golden
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    rng = np.random.default_rng(43)
+    allpat = np.arange(65536, dtype=np.uint16)
+    books = [("flint_b4_s", G["flint_b4_s"], None, 0), ("int_b4_s", G["int_b4_s"], None, 0), ("flint_b4_u", G["flint_b4_u"], None, 0),
+             ("pot_b4_s", G["pot_b4_s"], None, 0), ("int_b3_u", G["int_b3_u"], None, 0),
+             ("olive_flint_b4_s", np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]]), float(O["flint_b4_s"].max()), O["flint_b4_s"].size),
+             ("olive_int_b4_s", np.concatenate([O["int_b4_s"], O["outlier_b4_s"]]), float(O["int_b4_s"].max()), O["int_b4_s"].size)]
+    # (OliVe's UNSIGNED 4-bit codebook has 16 normal values: with the identifier 15 reserved there is no packed form for it --
+    #  antq_encode4 refuses it, include/antq.h)
+    knob = antq_lib.lib().antq_debug_set
+    for name, g, gmax, nn in books:
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        gmax = float(g.max()) if gmax is None else gmax
+        olive = nn > 0
+        plan = antq_lib.plan_for(g)
+        assert plan.is_table and int(plan.host[:128].view(np.uint32)[24]) == 3, name
+        zs = np.flatnonzero((g[:nn] if olive else g) == 0)
+        zero_code = int(zs[-1]) if zs.size else 0
+        alphas = np.concatenate([np.float32([1.0, 0.06, 0.0, -0.05, np.nan, np.inf, 1e-30, 1e30, 65504.0, 6e-8]),
+                                 np.exp(rng.uniform(-20, 20, 6)).astype(np.float32)])
+        rows = len(alphas)
+        for tdt, npdt in ((torch.bfloat16, None), (torch.float16, np.float16)):
+            for pats in (allpat, rng.permutation(allpat)):
+                x16 = np.ascontiguousarray(np.broadcast_to(pats, (rows, 65536)))
+                xf = oracle.bf16_to_f32(x16) if npdt is None else x16.view(np.float16).astype(np.float32)
+                xt = torch.from_numpy(x16.view(np.int16)).to(dev).view(tdt)
+                at = torch.from_numpy(alphas).to(dev)
+                for ovp in ((True,) if olive else (False,)):
+                    with np.errstate(all="ignore"):
+                        _, ridx = oracle.forward(xf, alphas, g, gmax, ovp)
+                    want = _codes_want(oracle, ridx, nn, ovp, zero_code)
+
+                    def nib(codes, r, k):
+                        return torch.stack([(codes & 15), (codes >> 4)], 1).reshape(r, k).cpu().numpy().astype(np.int64)
+
+                    def enc(x, a, r, k):
+                        return antq_lib.encode4(x, a, plan, gmax, r, k, True, n_normal=nn, ovp=ovp)
+
+                    base = enc(xt, at, rows, 65536)
+                    got = nib(base, rows, 65536)
+                    bad = got != want
+                    assert not bad.any(), (name, str(tdt), ovp, int(bad.sum()), alphas[np.argwhere(bad)[:3, 0]].tolist(),
+                                           x16[bad][:3], got[bad][:3], want[bad][:3])
+                    for u in (4, 3, 2):
+                        knob(0, u)
+                        assert torch.equal(enc(xt, at, rows, 65536), base), (name, str(tdt), u)
+                    knob(0, 0)
+                    knob(9, 0)
+                    assert torch.equal(enc(xt, at, rows, 65536), base), (name, str(tdt), "fp32-domain row encoder")
+                    knob(9, 1)
+                    # the same elements as rows of 576 vectors (3-vector tasks) and of 128 vectors (2-vector tasks)
+                    for rl in (4608, 1024):
+                        n_keep = (65536 // rl) * rl
+                        xs = xt[:, :n_keep].contiguous().view(-1, rl)
+                        a2 = at.repeat_interleave(n_keep // rl)
+                        g2 = nib(enc(xs, a2, xs.shape[0], rl), rows, n_keep)
+                        assert np.array_equal(g2, want[:, :n_keep]), (name, str(tdt), rl)
+    # a per-tensor scale: ONE row however the tensor is shaped
+    g = np.ascontiguousarray(G["flint_b4_s"], dtype=np.float32)
+    plan = antq_lib.plan_for(g)
+    x16 = np.tile(rng.permutation(allpat), 4)
+    xt = torch.from_numpy(x16.view(np.int16)).to(dev).view(torch.bfloat16).view(64, 4096)
+    with np.errstate(all="ignore"):
+        _, ridx = oracle.forward(oracle.bf16_to_f32(x16).reshape(1, -1), np.float32([0.37]), g, 10.0, False)
+    codes = antq_lib.encode4(xt, torch.tensor([0.37], device=dev), plan, 10.0, 1, xt.numel(), False)
+    got = torch.stack([(codes & 15), (codes >> 4)], 1).reshape(-1).cpu().numpy().astype(np.int64)
+    assert np.array_equal(got, _codes_want(oracle, ridx.reshape(-1), 0, False, int(np.flatnonzero(g == 0)[-1])))
