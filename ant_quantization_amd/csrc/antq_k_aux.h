@@ -199,18 +199,19 @@ k_absmax(const void *__restrict__ x, float *__restrict__ amax, size_t rows, size
 
 // Small groups (a power of two <= 64 of 16-byte vectors per group, e.g. group-16): several groups per wavefront, four
 // vectors per lane, butterfly max over the group's lanes (DPP) -- a wavefront per 2-vector group would idle 62 lanes.
-template <typename T>
+// Streaming (nontemporal) loads: 16384^2 bf16 in groups of 16 64.9 -> 72.5 % of 8 TB/s, fp32 73.3 -> 79.8 %, one 33.5 MB tensor
+// 53.7 -> 56.2 %; eight vectors per lane instead of four: no better (72.0 / 77.9 %) -- profiles/r05_absmax_experiments.log.
+template <typename T, int U = 4, bool NT = true>
 __global__ void __launch_bounds__(256)
 k_absmax_groups(const uint4 *__restrict__ x, float *__restrict__ amax, size_t n_vec, uint32_t vpr, int vshift)
 {
-    constexpr int U = 4;
     const size_t first = ((size_t)blockIdx.x * U) * 256u + threadIdx.x;
     uint4 v[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const size_t vi = first + (size_t)u * 256u;
         v[u] = make_uint4(0, 0, 0, 0);
-        if (vi < n_vec) v[u] = x[vi];
+        if (vi < n_vec) v[u] = NT ? ld_stream(x + vi) : x[vi];
     }
     uint32_t m[U];
 #pragma unroll

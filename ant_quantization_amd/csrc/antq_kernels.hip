@@ -271,6 +271,8 @@ static int launch_absmax(const void *x, float *amax, size_t rows, size_t row_len
     //  with 256 workgroups, 90 / 109 / 113 / 117 us with 512 / 1024 / 2048 / 4096 -- the block-strided walk wants few, long streams; a chunked walk with
     //  1024 workgroups reads 33 MB in the per-row kernel's 7.5 us but then spends 15 us on its 1024 atomics to ONE address, which
     //  all arrive together: 23 us against this shape's 9.3)
+    // (round 5: the chunked walk with SIXTEEN wavefronts per workgroup -- 4096 contiguous streams, 256 atomics -- is slower still:
+    //  10.9 us for the 33.5 MB bf16 tensor, 1024-thread workgroups start slowly; profiles/r05_absmax_experiments.log, .patch)
     if (blocks > (per_row ? 4096u : 256u)) blocks = per_row ? 4096 : 256;
     if (blocks < 1) blocks = 1;
     // the whole-tensor maximum is an atomicMax of workgroup maxima into a zero (stream-ordered, capturable)
