@@ -8,8 +8,40 @@
 #include "antq_host.h"
 #include "antq_k_fakequant.h"
 #include "antq_k_search.h"
+#include "antq_k_hist.h"
+
+#include <type_traits>
 
 namespace antq {
+
+// ---- the histogram path (antq_k_hist.h): 16-bit tensors with ONE scale and no pair rule --------------------------------
+// Worth it once the direct kernels' n x (types x candidates) evaluations outweigh the fixed cost of the three launches (the
+// 65 536 x types x candidates literal evaluations of the scoring kernel and the slabs: ~50 us): knob 14 = 0 switches it off,
+// = 2 takes it for every eligible tensor (tests).
+template <typename T>
+static bool hist_eligible(size_t n, int nflat, bool ovp, const void *x)
+{
+    if constexpr (std::is_same<T, float>::value) return false;
+    if (g_knob_hist == 0 || ovp || n % 8 != 0 || n >= ((size_t)1 << 31) || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
+    return g_knob_hist == 2 || (double)n * (double)nflat >= 3.0e8;
+}
+template <typename T>
+static int launch_hist_search(const void *x, size_t n, const float *xmax, const float *ratios, int ncand, const HistTypes &ht,
+                              double *sse, void *ws, hipStream_t st)
+{
+    if constexpr (std::is_same<T, float>::value) {
+        return ANTQ_ERR_UNSUPPORTED;
+    } else {
+        const size_t nv = n / 8;
+        uint32_t G = (uint32_t)std::min<size_t>(std::max<size_t>(n / 65536, 16), (size_t)kHistMaxG);
+        uint32_t *slabs = static_cast<uint32_t *>(ws);
+        uint32_t *count = slabs + 2 * (size_t)kHistMaxG * kHistBins;
+        hipLaunchKernelGGL(k_hist16, dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs);
+        hipLaunchKernelGGL(k_hist_reduce, dim3(256), dim3(256), 0, st, slabs, G, count);
+        hipLaunchKernelGGL((k_hist_score<T>), dim3((unsigned)(ht.ntypes * ncand)), dim3(1024), 0, st, count, xmax, ratios, ncand, ht, sse);
+        return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+    }
+}
 
 // ---- grid of a clip-search launch -------------------------------------------------------------------------------------
 // A search workgroup (4 wavefronts) walks its share of the tensor once per candidate of its chunk of the candidate list
@@ -100,6 +132,15 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }
     if (!per_row) { row_len = rows * row_len; rows = 1; }
+    if (rows == 1 && hist_eligible<T>(row_len, ncand, OVP, x)) {
+        HistTypes ht;
+        memset(&ht, 0, sizeof(ht));
+        ht.ntypes = 1;
+        ht.grid[0] = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev));
+        ht.m[0] = (int)pa.m;
+        ht.gmax[0] = gmax;
+        return launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, st);
+    }
     const size_t vpr = row_len / EPL;
     if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
     // vectors per lane and task: the per-candidate work of a task that does not depend on its size (the row table for this
@@ -143,6 +184,19 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
     constexpr int EPL = IO<T>::EPL;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) return ANTQ_ERR_UNSUPPORTED;
     if (!per_row) { row_len = rows * row_len; rows = 1; }
+    if (rows == 1 && hist_eligible<T>(row_len, ntypes * ncand, OVP, x)) {
+        HistTypes ht;
+        memset(&ht, 0, sizeof(ht));
+        ht.ntypes = ntypes;
+        for (int t = 0; t < ntypes; t++) {
+            PlanArgs pa;
+            if (!plan_args_from_host(plan_host[t], pa)) return ANTQ_ERR_PLAN;
+            ht.grid[t] = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev[t]));
+            ht.m[t] = (int)pa.m;
+            ht.gmax[t] = gmax[t];
+        }
+        return launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, st);
+    }
     const size_t vpr = row_len / EPL;
     if (vpr < kRowKernelMinVpr || vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
     MultiArgs ma;
@@ -245,7 +299,8 @@ extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const
     }
 }
 
-extern "C" size_t antq_search_workspace_bytes(void) { return (size_t)kWsSlots * kPtCand * sizeof(double); }
+// (the direct kernels' workgroup partials, or -- never at the same time -- the histogram path's slabs and counts)
+extern "C" size_t antq_search_workspace_bytes(void) { return std::max((size_t)kWsSlots * kPtCand * sizeof(double), kHistWorkspaceBytes); }
 
 extern "C" int antq_search_pick(const double *sse, const float *xmax, const float *ratios, int ncand, size_t na,
                                 size_t row_len, float *best_score, float *best_alpha, void *stream)

@@ -411,6 +411,8 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
  *   key 11: extra dynamic LDS bytes per workgroup of the batched lane-job kernels (occupancy A/B; -1 = default: fp32 static
  *           launches of >= 32768 workgroups are held at 6 workgroups = 24 wavefronts per CU, nothing otherwise)
  *   key 12: clip search: number of candidate-list chunks (0 = cost model)
+ *   key 14: the histogram clip search of 16-bit tensors with one scale (antq_search_sse / _multi / antq_calibrate, no pair
+ *           rule): 0 off, 1 (default) when the tensor is large enough for it to pay, 2 for every eligible tensor
  *   key 13: experiment switch of the kernel under development (0 = off; 1: the 16-bit-domain encoder's 8-vector tasks store
  *           their codes nontemporally instead of through the cache) */
 int antq_debug_set(int key, int value);

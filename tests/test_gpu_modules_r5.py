@@ -563,3 +563,117 @@ def test_16bit_domain_encoder_codes_on_every_pattern(antq_lib, oracle, dev):
     codes = antq_lib.encode4(xt, torch.tensor([0.37], device=dev), plan, 10.0, 1, xt.numel(), False)
     got = torch.stack([(codes & 15), (codes >> 4)], 1).reshape(-1).cpu().numpy().astype(np.int64)
     assert np.array_equal(got, _codes_want(oracle, ridx.reshape(-1), 0, False, int(np.flatnonzero(g == 0)[-1])))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the histogram clip search of 16-bit per-tensor quantisers (csrc/antq_k_hist.h)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _hist_expected(oracle, x16, dtype, xmax, ratios, grid, gmax):
+    """sum_p count[p] * term(p) with the term from the ORACLE's forward on the 65 536 patterns (the reference's fp32 sequence),
+    counts from numpy: what the histogram path must produce up to the order of its double additions."""
+    pats = np.arange(65536, dtype=np.uint16)
+    vals = oracle.bf16_to_f32(pats) if dtype == 1 else pats.view(np.float16).astype(np.float32)
+    cnt = np.bincount(x16.reshape(-1).astype(np.int64), minlength=65536).astype(np.float64)
+    out = np.empty(ratios.size, np.float64)
+    with np.errstate(all="ignore"):
+        for c, r in enumerate(ratios):
+            a = np.float32(np.float32(xmax) * np.float32(r))
+            ref, _ = oracle.forward(vals.reshape(1, -1), np.float32([a]), grid, gmax, False)
+            df = np.abs(ref.reshape(-1) - vals).astype(np.float32)
+            term = (df * df).astype(np.float32).astype(np.float64)
+            out[c] = np.sum(np.where(cnt > 0, cnt * term, 0.0))
+    return out
+
+
+def test_histogram_clip_search_equals_direct_kernels_and_the_oracle(antq_lib, oracle, dev):
+    """antq_search_sse / antq_search_sse_multi / antq_calibrate of a bf16 / f16 tensor with ONE scale and no pair rule take the
+    histogram path (antq_k_hist.h; knob 14 = 2: for every eligible tensor): the sums equal (a) the oracle's per-pattern terms
+    weighted by the tensor's exact pattern counts to 1e-12 -- every element counted once, whatever the tensor's length (whole
+    chunks, ragged tails, fewer elements than one chunk), sign mix (ReLU outputs: half the elements on the zero pattern; -0;
+    all-negative tensors) and special values (Inf, NaN, denormals) --, (b) the direct kernels' sums (knob 14 = 0) to their
+    own fp32 partial-sum noise, with identical clip picks unless the direct scores tie, and (c) each other between the
+    single-type and the multi-type entry points, bit for bit.  The whole calibration (antq_calibrate, three codebooks) picks
+    the same type and alpha on both paths."""
+    import torch
+    from conftest import golden
+    G = golden("ant_grids.npz")
+    rng = np.random.default_rng(91)
+    knob = antq_lib.lib().antq_debug_set
+    lb, ub = 75, 150
+    ratios_np = np.asarray([np.float32(i * 0.01) for i in range(lb, ub)], dtype=np.float32)
+    ratios = torch.from_numpy(ratios_np).to(dev)
+    names = ["int_b4_s", "pot_b4_s", "flint_b4_s"]
+    grids_ = [np.ascontiguousarray(G[k], dtype=np.float32) for k in names]
+    plans = [antq_lib.plan_for(g) for g in grids_]
+    cases = [("normal", 8 * (1024 * 16 * 4 * 2 + 1024 * 5 + 77), 0), ("relu", 8 * (1024 * 16 * 4 + 3), 1),
+             ("tiny", 8 * 300, 0), ("negative", 8 * 1024 * 70, 2), ("specials", 8 * (1024 * 33 + 1), 3), ("big", 1 << 24, 1)]
+    try:
+        for dtype, tdt in ((1, torch.bfloat16), (2, torch.float16)):
+            for cname, n, kind in cases:
+                x = (rng.standard_normal(n) * 0.7).astype(np.float32)
+                if kind == 1:
+                    x = np.maximum(x, 0.0)
+                    x[::5] = -0.0
+                elif kind == 2:
+                    x = -np.abs(x) - 0.01
+                elif kind == 3:
+                    x[::1001] = np.inf
+                    x[7::1003] = 1e-40
+                    x[3::997] = -6e4
+                x16 = oracle.f32_to_bf16(x) if dtype == 1 else x.astype(np.float16).view(np.uint16)
+                xt = torch.from_numpy(x16.view(np.int16)).to(dev).view(tdt)
+                vals = oracle.bf16_to_f32(x16) if dtype == 1 else x16.view(np.float16).astype(np.float32)
+                fin = vals[np.isfinite(vals)]
+                xmax_np = np.float32(np.abs(fin).max())
+                xm = torch.tensor([xmax_np], device=dev)
+                res = {}
+                for mode in (2, 0):
+                    knob(14, mode)
+                    one = [antq_lib.search_sse(xt, 1, n, xm, False, ratios, p, 10.0) for p in plans]
+                    multi = antq_lib.search_sse_multi(xt, 1, n, xm, False, ratios, plans, [10.0] * 3)
+                    res[mode] = (torch.stack(one).cpu().numpy().reshape(3, -1), multi.cpu().numpy().reshape(3, -1) if multi is not None else None)
+                h_one, h_multi = res[2]
+                d_one, _ = res[0]
+                assert h_multi is not None and np.array_equal(h_one.view(np.uint64), h_multi.view(np.uint64)), (cname, dtype)
+                for t in range(3):
+                    if kind != 3:
+                        want = _hist_expected(oracle, x16, dtype, xmax_np, ratios_np, grids_[t], 10.0)
+                        np.testing.assert_allclose(h_one[t], want, rtol=1e-12, err_msg=str((cname, dtype, names[t])))
+                        np.testing.assert_allclose(h_one[t], d_one[t], rtol=2e-6, err_msg=str((cname, dtype, names[t])))
+                        ch, cd = int(np.argmin(h_one[t])), int(np.argmin(d_one[t]))
+                        assert ch == cd or abs(d_one[t][ch] - d_one[t][cd]) <= 2e-6 * d_one[t][cd], (cname, dtype, names[t], ch, cd)
+                    else:                                       # Inf in the tensor: every candidate's sum is NaN on both paths
+                        assert np.isnan(h_one[t]).all() and np.isnan(d_one[t]).all(), (cname, dtype)
+                if kind != 3:
+                    cal = {}
+                    for mode in (2, 0):
+                        knob(14, mode)
+                        alpha, score, typ, xmo = antq_lib.calibrate(xt, 1, n, False, plans, [10.0] * 3, lb, ub, 1, xmax="absmax")
+                        cal[mode] = (alpha.cpu().numpy(), score.cpu().numpy(), int(typ.item()), float(xmo.item()))
+                    assert cal[2][3] == cal[0][3] == float(xmax_np)
+                    np.testing.assert_allclose(cal[2][1], cal[0][1], rtol=2e-6)
+                    if cal[2][2] != cal[0][2]:
+                        assert abs(cal[0][1][cal[2][2]] - cal[0][1][cal[0][2]]) <= 2e-6 * cal[0][1][cal[0][2]]
+                    for t in range(3):
+                        if cal[2][0][t, 0] != cal[0][0][t, 0]:
+                            ch = int(np.argmin(np.abs(ratios_np * xmax_np - cal[2][0][t, 0])))
+                            cd = int(np.argmin(np.abs(ratios_np * xmax_np - cal[0][0][t, 0])))
+                            assert abs(d_one[t][ch] - d_one[t][cd]) <= 2e-6 * d_one[t][cd], (cname, dtype, names[t])
+        # what the default (knob 14 = 1) does: small tensors keep the direct kernels, large ones switch -- same sums either way
+        knob(14, 1)
+        n = 1 << 22
+        x16 = oracle.f32_to_bf16((rng.standard_normal(n) * 0.3).astype(np.float32))
+        xt = torch.from_numpy(x16.view(np.int16)).to(dev).view(torch.bfloat16)
+        xm = xt.float().abs().max().reshape(1)
+        auto = antq_lib.search_sse_multi(xt, 1, n, xm, False, ratios, plans, [10.0] * 3).cpu().numpy()
+        knob(14, 2)
+        forced = antq_lib.search_sse_multi(xt, 1, n, xm, False, ratios, plans, [10.0] * 3).cpu().numpy()
+        assert np.array_equal(auto.view(np.uint64), forced.view(np.uint64))          # 4 M x 225 evaluations: the histogram pays
+        # OliVe pairs, fp32 tensors and per-row quantisers never take it (the sums are those of the direct kernels)
+        x32 = torch.randn(1 << 20, device=dev)
+        a = antq_lib.search_sse(x32, 1, x32.numel(), x32.abs().max().reshape(1), False, ratios, plans[0], 10.0).cpu().numpy()
+        knob(14, 0)
+        b = antq_lib.search_sse(x32, 1, x32.numel(), x32.abs().max().reshape(1), False, ratios, plans[0], 10.0).cpu().numpy()
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    finally:
+        knob(14, 1)

@@ -16,6 +16,7 @@ from ant_quantization_amd.ant import quant_model as qm, quant_utils as qu  # noq
 
 dev = torch.device("cuda:0")
 mode = sys.argv[1] if len(sys.argv) > 1 else "flint"
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(sys.argv[2] if len(sys.argv) > 2 else "", torch.float32)     # model dtype
 args = types.SimpleNamespace(mode=mode, wbit=4, abit=4, w_up=150, a_up=150, w_low=75, a_low=75, percent=100, search=False)
 qu.set_quantizer(args)
 torch.manual_seed(0)
@@ -40,7 +41,7 @@ if os.environ.get("ANTQ_PREALLOC") == "1":
     blocks = [torch.empty(n, device=dev, dtype=torch.uint8) for n in (100 << 20, 100 << 20, 100 << 20, 26 << 20, 26 << 20, 26 << 20, 10 << 20, 10 << 20, 10 << 20, 3 << 20, 3 << 20, 2 << 20, 2 << 20, 2 << 20, 2 << 20)]
     del blocks
 for rep in range(2):
-    model = qm.quantize_model(BertModel(BertConfig()).eval()).to(dev).eval()
+    model = qm.quantize_model(BertModel(BertConfig()).eval()).to(dev).to(DT).eval()
     with torch.no_grad():
         qu.disable_quantization(model)
         model(ids); model(ids)
@@ -56,7 +57,7 @@ for rep in range(2):
         sys.stdout = sys.__stdout__
         if rep == 1:
             pr.disable()
-        print("mode %s: first forward %.1f ms%s" % (mode, (time.perf_counter() - t0) * 1e3, " (under cProfile)" if rep else ""))
+        print("mode %s %s: first forward %.1f ms%s" % (mode, str(DT)[6:], (time.perf_counter() - t0) * 1e3, " (under cProfile)" if rep else ""))
         t0 = time.perf_counter()
         model(ids); torch.cuda.synchronize()
         print("   second forward %.1f ms" % ((time.perf_counter() - t0) * 1e3))

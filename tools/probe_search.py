@@ -41,5 +41,29 @@ def main():
             name, n * nc / t1 / 1e9, t1 * 1e3, 3 * n * nc / t3 / 1e9, t3 * 1e3, tc * 1e3), flush=True)
 
 
+def hist():
+    """The histogram path (16-bit tensors, one scale, no pair rule; knob 14: 0 off / 2 always) against the direct kernels."""
+    dev = torch.device("cuda:0")
+    knob = _lib.lib().antq_debug_set
+    gs = [grids.ant_grid(t, 4, True) for t in ("int", "flint", "pot")]
+    plans = [_lib.plan_for(g) for g in gs]
+    gm = [10.0] * 3
+    for name, n, relu in (("BERT 64x128x3072 bf16 (GELU-like)", 64 * 128 * 3072, False), ("64x128x768 bf16", 64 * 128 * 768, False),
+                          ("64x128x3072 bf16 after ReLU", 64 * 128 * 3072, True), ("1 M bf16", 1 << 20, False), ("256 K bf16", 1 << 18, False)):
+        x = torch.randn(n, device=dev)
+        if relu:
+            x = torch.relu(x)
+        x = x.to(torch.bfloat16)
+        for mode in (0, 2):
+            knob(14, mode)
+            tc = timed(lambda: _lib.calibrate(x, 1, n, False, plans, gm, 75, 150, 1), 5)
+            t1 = timed(lambda: _lib.calibrate(x, 1, n, False, plans[1:2], gm[:1], 75, 150, 1), 5)
+            print("%-36s %s   antq_calibrate three types %7.3f ms   one type %7.3f ms" % (name, "histogram" if mode else "direct   ", tc * 1e3, t1 * 1e3), flush=True)
+    knob(14, 1)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "hist":
+        hist()
+        sys.exit(0)
     main()
