@@ -16,14 +16,18 @@ namespace antq {
 
 // ---- the histogram path (antq_k_hist.h): 16-bit tensors with ONE scale and no pair rule --------------------------------
 // Worth it once the direct kernels' n x (types x candidates) evaluations outweigh the fixed cost of the three launches (the
-// 65 536 x types x candidates literal evaluations of the scoring kernel and the slabs: ~50 us): knob 14 = 0 switches it off,
-// = 2 takes it for every eligible tensor (tests).
+// 65 536 x types x candidates literal evaluations of the scoring kernel and the slabs: ~50 us).  Measured break-even
+// (profiles/r05_hist_search.log): 1 M elements (three types 0.111 -> 0.060 ms, one type 0.048 -> 0.055 ms).  The rule looks at
+// the element count ONLY: a tensor's sums must not depend on how many types are searched with it (the single-read type
+// selection and one search per type form the very same sums: test_calibration_sums_are_bit_reproducible).  knob 14 = 0
+// switches the path off, = 2 takes it for every eligible tensor (tests).
 template <typename T>
 static bool hist_eligible(size_t n, int nflat, bool ovp, const void *x)
 {
     if constexpr (std::is_same<T, float>::value) return false;
     if (g_knob_hist == 0 || ovp || n % 8 != 0 || n >= ((size_t)1 << 31) || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
-    return g_knob_hist == 2 || (double)n * (double)nflat >= 3.0e8;
+    (void)nflat;
+    return g_knob_hist == 2 || n >= ((size_t)1 << 20);
 }
 template <typename T>
 static int launch_hist_search(const void *x, size_t n, const float *xmax, const float *ratios, int ncand, const HistTypes &ht,

@@ -19,6 +19,10 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "flint"
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(sys.argv[2] if len(sys.argv) > 2 else "", torch.float32)     # model dtype
 args = types.SimpleNamespace(mode=mode, wbit=4, abit=4, w_up=150, a_up=150, w_low=75, a_low=75, percent=100, search=False)
 qu.set_quantizer(args)
+if "ANTQ_HIST" in os.environ:                      # knob 14: 0 = the direct clip-search kernels only, 2 = the histogram path wherever eligible
+    from ant_quantization_amd import _lib as _l
+    _l.lib().antq_debug_set(14, int(os.environ["ANTQ_HIST"]))
+    print("knob 14 =", os.environ["ANTQ_HIST"])
 torch.manual_seed(0)
 ids = torch.randint(0, 30000, (64, 128), device=dev)
 if os.environ.get("ANTQ_PREWARM") == "1":
