@@ -219,6 +219,11 @@ int antq_alpha_grad(const void *x_dev, const void *out_dev, const void *gout_dev
  * antq_search_workspace_bytes() bytes of device memory owned by the caller, not
  * shared with a call running concurrently on another stream; contents are
  * scratch (no initialisation).  May be NULL for per_row with rows > 1.
+ * A bf16 / f16 tensor with ONE scale (per_row == 0 or rows == 1), no ANTQ_FLAG_OVP and at least 2^20 elements is scored on
+ * its 65 536-bin histogram (one pass counts the bit patterns, then every pattern with a non-zero count goes through the
+ * literal reference sequence for every candidate: count x term, summed in double in one fixed order): the same terms as the
+ * element-by-element kernels, added in another order (relative 1e-7 on a sum).  The workspace holds the histogram's slabs:
+ * always size it with antq_search_workspace_bytes() (32.25 MiB since ABI 5 / library round 5; 8 MiB before).
  * ------------------------------------------------------------------------- */
 size_t antq_search_workspace_bytes(void);
 int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
@@ -362,6 +367,8 @@ int antq_fakequant_batch(const void *batch_host, const void *batch_dev, void *st
  * and finite inputs within twice the outermost grid values; for arbitrary value lists the two may differ by one ulp.
  * Elements outside the scan's validity range (code would be ANTQ_IDX_NONE) encode as the
  * grid entry holding 0.0.  row_len must be a multiple of 8; x: F32 / BF16 / F16; codes: rows*row_len/2 bytes.
+ * (BF16 / F16 rows of at least 1024 elements are encoded in the tensor's own 16-bit domain: the per-row slot table of the
+ *  headline kernels holding code bytes instead of output patterns, antq_k_codec.h: k_encode4_hrow.)
  * ------------------------------------------------------------------------- */
 int antq_encode4(const void *x_dev, uint8_t *codes_dev, size_t rows, size_t row_len,
                  const float *alpha_dev, int alpha_per_row, float gmax,
