@@ -71,6 +71,10 @@ def lib():
                 L.antq_absmax.argtypes = [vp, vp, sz, sz, ci, ci, vp]
                 L.antq_absmax_into.argtypes = [vp, vp, sz, ci, vp]
                 L.antq_copy.argtypes = [vp, vp, sz, vp]
+                # development: ANTQ_DEBUG_KNOBS="14=2,0=8" applies antq_debug_set(key, value) pairs to the loading thread
+                # (the knobs are thread-local; tools/fuzz_campaign.sh forces code paths with it)
+                for kv in [k for k in os.environ.get("ANTQ_DEBUG_KNOBS", "").split(",") if "=" in k]:
+                    L.antq_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
                 _lib = L
     return _lib
 

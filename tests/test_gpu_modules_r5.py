@@ -677,3 +677,27 @@ def test_histogram_clip_search_equals_direct_kernels_and_the_oracle(antq_lib, or
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
     finally:
         knob(14, 1)
+
+
+def test_bench_sharded_workload_line_on_the_gpu(antq_lib, dev):
+    """`python bench.py --workload opt6.7b --layers 1` (BASELINE configs[3], shortened to one decoder layer): ONE JSON line,
+    strong scaling, the per-rank roofline block, algorithmic bytes = 4 B x the rank's elements, the kernel of the OliVe pairs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "opt6.7b", "--layers", "1", "--steps", "10",
+                          "--warmup", "3", "--no-traffic"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    elems = 4 * 4096 * 4096 + 2 * 16384 * 4096
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["steps"] == 10 and d["unit"] == "Gelem/s"
+    assert d["config"]["elements_per_step_per_rank"] == [elems] and d["config"]["idempotence_check"] is True
+    assert "configs[3]" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["algorithmic_bytes_per_launch"] == 4 * elems and "k_fq_hbatch<bf16,true>" in r["kernel"]
+    assert r["per_rank"]["ranks"] == 1 and r["per_rank"]["frac"]["min"] == r["per_rank"]["frac"]["max"] == r["frac"]
+    assert abs(d["value"] - elems / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"] and 0.3 < r["frac"] < 1.0

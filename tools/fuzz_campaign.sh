@@ -23,4 +23,9 @@ mkdir -p gpurun_out
   echo "== test_calibration_pass_fuzz_fast_schedule_equals_step_by_step, ${4:-150} seeds"
   ANTQ_FUZZ_SEEDS=${4:-150} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k calibration_pass_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+  echo "== the calibration fuzz tests again with the histogram clip search forced for every eligible tensor (ANTQ_DEBUG_KNOBS=14=2)"
+  ANTQ_DEBUG_KNOBS=14=2 ANTQ_FUZZ_SEEDS=${3:-300} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k "calibration_fuzz or quantizer_end_to_end or type_selection_on_one_read or sharded_per_tensor or bert_base_real_shapes" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+  ANTQ_DEBUG_KNOBS=14=2 ANTQ_FUZZ_SEEDS=${4:-150} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k calibration_pass_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
 } | tee gpurun_out/fuzz_campaign.log
