@@ -5,7 +5,11 @@ quantisers in it: packed in-projection weight and its input, out-projection weig
 (:525-529, :459, :663-668), for torchvision's ViT.  The wrapper here keeps the reference's parameter
 and quantiser names (state-dict compatibility) and writes the attention itself out in a dozen lines of
 plain PyTorch for the case the reference supports: self-attention (`key = value = query`, :665-666)
-with equal embedding dims.  The quantisers are the fused gfx950 ones.
+with equal embedding dims, including the two options of torch's attention its forward passes on (round 5): `add_bias_kv`
+(a learnt key / value row appended to the projected sequence, :375-388) and `add_zero_attn` (a zero key / value row
+appended per head, :417-425), with or without masks (the reference itself only runs them without: its vendored forward
+calls an undefined `pad` as soon as a mask meets either option, :382).  Distinct `kdim` / `vdim` raise here as they do
+there (NameError in its set_param, :566-569).  The quantisers are the fused gfx950 ones.
 """
 import math
 
@@ -30,8 +34,6 @@ class MultiheadAttentionQuantizer(nn.Module):
     def set_param(self, MA):
         if not MA._qkv_same_embed_dim:
             raise NotImplementedError("separate q/k/v projection weights (kdim/vdim != embed_dim) are not quantised")
-        if MA.bias_k is not None or MA.add_zero_attn:
-            raise NotImplementedError("add_bias_kv / add_zero_attn are not supported")
         self.embed_dim, self.num_heads, self.dropout = MA.embed_dim, MA.num_heads, MA.dropout
         self.kdim = self.vdim = MA.embed_dim
         self._qkv_same_embed_dim = True
@@ -49,8 +51,12 @@ class MultiheadAttentionQuantizer(nn.Module):
             self.register_parameter('out_proj_bias', None)
         else:
             self.out_proj_bias = nn.Parameter(MA.out_proj.bias.data.clone())
-        self.bias_k = self.bias_v = None
-        self.add_zero_attn = False
+        if MA.bias_k is not None:                          # add_bias_kv (:598-603)
+            self.bias_k = nn.Parameter(MA.bias_k.data.clone())
+            self.bias_v = nn.Parameter(MA.bias_v.data.clone())
+        else:
+            self.bias_k = self.bias_v = None
+        self.add_zero_attn = bool(MA.add_zero_attn)
 
     def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=True, attn_mask=None,
                 average_attn_weights=True):
@@ -66,17 +72,34 @@ class MultiheadAttentionQuantizer(nn.Module):
         L, N, E = x.shape
         H, hd = self.num_heads, self.head_dim
         q, k, v = F.linear(x, w_in, self.in_proj_bias).chunk(3, dim=-1)
+        if attn_mask is not None and attn_mask.dim() == 2:
+            attn_mask = attn_mask.unsqueeze(0)
+        if key_padding_mask is not None and not batched:
+            key_padding_mask = key_padding_mask.unsqueeze(0)
+        if self.bias_k is not None:                        # :375-388: one learnt row behind the keys / values, masks padded
+            k = torch.cat([k, self.bias_k.to(k.dtype).repeat(1, N, 1)])
+            v = torch.cat([v, self.bias_v.to(v.dtype).repeat(1, N, 1)])
+            if attn_mask is not None:
+                attn_mask = F.pad(attn_mask, (0, 1))
+            if key_padding_mask is not None:
+                key_padding_mask = F.pad(key_padding_mask, (0, 1))
         q = q.contiguous().view(L, N * H, hd).transpose(0, 1)
-        k = k.contiguous().view(L, N * H, hd).transpose(0, 1)
-        v = v.contiguous().view(L, N * H, hd).transpose(0, 1)
+        k = k.contiguous().view(k.shape[0], N * H, hd).transpose(0, 1)
+        v = v.contiguous().view(v.shape[0], N * H, hd).transpose(0, 1)
+        if self.add_zero_attn:                             # :417-425: a zero row per head
+            k = torch.cat([k, torch.zeros((N * H, 1, hd), dtype=k.dtype, device=k.device)], dim=1)
+            v = torch.cat([v, torch.zeros((N * H, 1, hd), dtype=v.dtype, device=v.device)], dim=1)
+            if attn_mask is not None:
+                attn_mask = F.pad(attn_mask, (0, 1))
+            if key_padding_mask is not None:
+                key_padding_mask = F.pad(key_padding_mask, (0, 1))
+        S = k.shape[1]
         scores = torch.bmm(q, k.transpose(1, 2)) / math.sqrt(hd)
         if attn_mask is not None:
             m = attn_mask
-            if m.dim() == 2:
-                m = m.unsqueeze(0)
             scores = scores.masked_fill(m, float("-inf")) if m.dtype == torch.bool else scores + m
         if key_padding_mask is not None:
-            kp = key_padding_mask.view(N, 1, 1, L).expand(-1, H, -1, -1).reshape(N * H, 1, L)
+            kp = key_padding_mask.view(N, 1, 1, S).expand(-1, H, -1, -1).reshape(N * H, 1, S)
             scores = scores.masked_fill(kp, float("-inf")) if kp.dtype == torch.bool else scores + kp
         attn = F.softmax(scores, dim=-1)
         if self.dropout > 0.0 and self.training:
@@ -86,7 +109,7 @@ class MultiheadAttentionQuantizer(nn.Module):
         out = F.linear(out, w_out, self.out_proj_bias).view(L, N, E)
         weights = None
         if need_weights:
-            weights = attn.view(N, H, L, L)
+            weights = attn.view(N, H, L, S)
             if average_attn_weights:
                 weights = weights.mean(dim=1)
             if not batched:

@@ -809,9 +809,53 @@ def gen_ckpt(outdir, tree):
     np.savez_compressed(os.path.join(outdir, "%s_ckpt.npz" % tree), **fx)
 
 
+def gen_mha_options(outdir):
+    """Round 5: the reference's MultiheadAttentionQuantizer with the options of torch's attention it forwards to the vendored
+    `multi_head_attention_forward` (multihead_attention.py:543-547, :598-606, :677-679): add_bias_kv, add_zero_attn, and both
+    together with batch_first.  (What cannot be recorded: distinct kdim / vdim -- the reference's set_param raises NameError
+    on them, :566-569 -- and either option together with an attention / key-padding mask: its vendored forward calls an
+    undefined `pad`, :382.)  Rewritten, calibrated and run by the reference
+    itself; stored like the `m__` / `mb__` records of ant_ckpt.npz."""
+    import torch
+    import torch.nn as nn
+    import torch.distributed as dist
+    _install_shim()
+    _stub_torchvision()
+    fx = {}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    sys.path.insert(0, os.path.join(REF, "ant_quantization", "antquant"))
+    import quant_modules as qm
+    import quant_model
+    import quant_utils
+    quant_utils.set_quantizer(_args(mode="ant-int-pot-flint", wbit=4, abit=4))
+    for tag, kw, masks in (("mk__", dict(add_bias_kv=True), False), ("mz__", dict(add_zero_attn=True), False),
+                           ("mkz__", dict(add_bias_kv=True, add_zero_attn=True, batch_first=True), False)):
+        torch.manual_seed(54)
+        ma = nn.Sequential(nn.MultiheadAttention(64, 4, **kw)).eval()
+        qma = quant_model.quantize_model(ma).eval()
+        quant_utils.enable_quantization(qma)
+        bf = kw.get("batch_first", False)
+        xm = torch.randn(3, 10, 64) if bf else torch.randn(10, 3, 64)
+        extra = {}
+        if masks:
+            kpm = torch.zeros(3, 10, dtype=torch.bool)
+            kpm[1, 7:] = True
+            kpm[2, 9:] = True
+            am = torch.randn(10, 10) * 0.5
+            extra = dict(key_padding_mask=kpm, attn_mask=am)
+            fx[tag + "key_padding_mask"] = kpm.numpy()
+            fx[tag + "attn_mask"] = am.numpy()
+        _record_model(tag, qma, xm, fx, qm, call=lambda m, t: m[0](t, t, t, **extra)[0])
+        with torch.no_grad():
+            fx[tag + "attn_weights"] = qma[0](xm, xm, xm, **extra)[1].numpy()
+    dist.destroy_process_group()
+    np.savez_compressed(os.path.join(outdir, "ant_mha_options.npz"), **fx)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long", "ant_ckpt", "olive_ckpt", "all"], default="all")
+    ap.add_argument("--tree", choices=["ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long", "ant_ckpt", "olive_ckpt", "ant_mha", "all"], default="all")
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--traces-only", action="store_true",
                     help="write only the *_traces.npz files (per-candidate MSE of the complete calibrations)")
@@ -821,7 +865,7 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
     if a.tree == "all":
-        for t in ("ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long") + (() if a.traces_only else ("ant_ckpt", "olive_ckpt")):
+        for t in ("ant", "ant_wide", "olive", "olive_wide", "ant_long", "olive_long") + (() if a.traces_only else ("ant_ckpt", "olive_ckpt", "ant_mha")):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", t, "--out", a.out] +
                                   (["--traces-only"] if a.traces_only else []))
         return
@@ -831,6 +875,8 @@ def main():
         gen_long(a.out, a.tree[:-5])
     elif a.tree in ("ant_ckpt", "olive_ckpt"):
         gen_ckpt(a.out, a.tree[:-5])
+    elif a.tree == "ant_mha":
+        gen_mha_options(a.out)
     elif a.tree == "ant":
         gen_ant(a.out)
     elif a.tree == "ant_wide":

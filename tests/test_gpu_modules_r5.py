@@ -701,3 +701,40 @@ def test_bench_sharded_workload_line_on_the_gpu(antq_lib, dev):
     assert r["algorithmic_bytes_per_launch"] == 4 * elems and "k_fq_hbatch<bf16,true>" in r["kernel"]
     assert r["per_rank"]["ranks"] == 1 and r["per_rank"]["frac"]["min"] == r["per_rank"]["frac"]["max"] == r["frac"]
     assert abs(d["value"] - elems / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"] and 0.3 < r["frac"] < 1.0
+
+
+def test_multihead_attention_options_vs_reference_fixture(antq_lib, dev, capsys):
+    """N4 / SURVEY row 7: MultiheadAttentionQuantizer with add_bias_kv, add_zero_attn and both (batch_first), each rewritten,
+    calibrated and run by the REFERENCE (tests/golden/ant_mha_options.npz, make_golden.py --tree ant_mha); its checkpoint is
+    loaded here (strict: same parameter names incl. bias_k / bias_v), the four quantisers reproduce the recorded tensors bit for
+    bit, output and attention weights (one more key column per option) agree within softmax / GEMM rounding."""
+    import torch
+    import torch.nn as nn
+    from conftest import golden
+    from test_gpu_parity import _check_recorded_quantizers, _ref_checkpoint
+    from ant_quantization_amd.ant import quant_model as qmod, quant_utils as qutil
+    from ant_quantization_amd.ant.multihead_attention import MultiheadAttentionQuantizer
+    fx = golden("ant_mha_options.npz")
+    qutil.set_quantizer(_args(mode="ant-int-pot-flint", wbit=4, abit=4))
+
+    def weight_of(model, qname):
+        mha = model.get_submodule(qname.rsplit(".", 1)[0])
+        return mha.in_proj_weight if "in_quant" in qname else mha.out_proj_weight
+
+    for pre, kw, cols in (("mk__", dict(add_bias_kv=True), 11), ("mz__", dict(add_zero_attn=True), 11),
+                          ("mkz__", dict(add_bias_kv=True, add_zero_attn=True, batch_first=True), 12)):
+        torch.manual_seed(7)
+        model = qmod.quantize_model(nn.Sequential(nn.MultiheadAttention(64, 4, **kw))).to(dev).eval()
+        assert type(model[0]) is MultiheadAttentionQuantizer
+        qutil.enable_quantization(model)
+        check = _ref_checkpoint(fx, [pre], dev, True)
+        qmod.load_ant_state_dict(model, check)
+        model.load_state_dict(check, strict=True)
+        capsys.readouterr()
+        _check_recorded_quantizers(fx, pre, model, dev, weight_of)
+        x = torch.from_numpy(fx[pre + "x"]).to(dev)
+        with torch.no_grad():
+            y, w = model[0](x, x, x)
+        assert "-bit" not in capsys.readouterr().out and w.shape[-1] == cols
+        np.testing.assert_allclose(y.cpu().numpy(), fx[pre + "y"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(w.cpu().numpy(), fx[pre + "attn_weights"], rtol=2e-4, atol=2e-6)

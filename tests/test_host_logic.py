@@ -762,3 +762,44 @@ def test_pinned_slot_pool_never_hands_out_a_slot_that_is_still_owned():
         s[0] = -1.0
     assert [int(s[0]) for s in held[1::2]] == list(range(1, 50, 2))
     pool.give(None)
+
+
+def test_multihead_attention_wrapper_equals_torch_attention_with_every_option():
+    """ant/multihead_attention.py with its quantisers switched off is torch's nn.MultiheadAttention (self-attention): the
+    options the reference forwards to its vendored torch 1.11 code -- add_bias_kv, add_zero_attn, batch_first, boolean and
+    float masks, unbatched input -- all give torch's own output and attention weights (CPU: no kernel is involved)."""
+    import types
+    import torch
+    import torch.nn as nn
+    from ant_quantization_amd.ant import quant_model as qmod, quant_utils as qutil
+    from ant_quantization_amd.ant.multihead_attention import MultiheadAttentionQuantizer
+    qutil.set_quantizer(types.SimpleNamespace(mode="flint", wbit=4, abit=4, w_up=150, a_up=150, w_low=75, a_low=75, percent=100,
+                                              search=False))
+    torch.manual_seed(3)
+    for kw in (dict(), dict(add_bias_kv=True), dict(add_zero_attn=True), dict(add_bias_kv=True, add_zero_attn=True, batch_first=True),
+               dict(bias=False, add_zero_attn=True)):
+        ma = nn.MultiheadAttention(32, 4, **kw).eval()
+        wrapped = qmod.quantize_model(nn.Sequential(ma)).eval()
+        assert type(wrapped[0]) is MultiheadAttentionQuantizer
+        qutil.disable_quantization(wrapped)
+        bf = kw.get("batch_first", False)
+        x = torch.randn(2, 7, 32) if bf else torch.randn(7, 2, 32)
+        kpm = torch.zeros(2, 7, dtype=torch.bool)
+        kpm[1, 5:] = True
+        for masks in (dict(), dict(key_padding_mask=kpm), dict(attn_mask=torch.randn(7, 7)),
+                      dict(attn_mask=torch.triu(torch.ones(7, 7, dtype=torch.bool), 1), key_padding_mask=kpm),
+                      dict(attn_mask=torch.randn(8, 7, 7) * 0.3)):
+            for avg in (True, False):
+                with torch.no_grad():
+                    y0, w0 = ma(x, x, x, need_weights=True, average_attn_weights=avg, **masks)
+                    y1, w1 = wrapped[0](x, x, x, need_weights=True, average_attn_weights=avg, **masks)
+                torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-6)
+                torch.testing.assert_close(w1, w0, rtol=1e-5, atol=1e-6)
+        xu = torch.randn(7, 32)                       # unbatched
+        with torch.no_grad():
+            y0, w0 = ma(xu, xu, xu)
+            y1, w1 = wrapped[0](xu, xu, xu)
+        torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(w1, w0, rtol=1e-5, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        qmod.quantize_model(nn.Sequential(nn.MultiheadAttention(32, 4, kdim=16, vdim=16)))
