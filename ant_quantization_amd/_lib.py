@@ -15,7 +15,7 @@ import torch  # must be imported before libantq.so so that ONE libamdhip64 is sh
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ANTQ_LIB") or os.path.join(_HERE, "libantq.so")   # ANTQ_LIB: A/B builds (dev)
 
-ABI_VERSION = 5         # include/antq.h ANTQ_ABI_VERSION this binding was written against
+ABI_VERSION = 6         # include/antq.h ANTQ_ABI_VERSION this binding was written against
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_OVP = 1
 FLAG_DYNAMIC = 2
@@ -57,7 +57,7 @@ def lib():
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
                              "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
                              "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma",
-                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h", "antq_calibrate_batch", "antq_absmax_into"):
+                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h", "antq_calibrate_batch", "antq_absmax_into", "antq_fakequant_f64"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 L.antq_search_workspace_bytes.restype = ctypes.c_size_t
@@ -420,6 +420,24 @@ def fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False, want_idx=
     return (out, idx) if want_idx else out
 
 
+def fakequant_f64(x, alpha, plan, gmax, rows, row_len, per_row, ovp=False):
+    """antq_fakequant_f64: the reference's float64 op sequence around its float-narrowing operator, fused.  x: float64,
+    contiguous; alpha: float64 tensor with rows (per_row) / 1 entries."""
+    _require_gpu(x, "x")
+    if x.dtype != torch.float64 or alpha.dtype != torch.float64 or not x.is_contiguous() or not alpha.is_contiguous():
+        raise AntqError("fakequant_f64 takes contiguous float64 tensors")
+    if rows * row_len != x.numel() or alpha.numel() != (rows if per_row else 1) or alpha.device != x.device:
+        raise AntqError("rows*row_len != numel, or alpha does not hold one value per row / one value")
+    out = torch.empty_like(x)
+    with _on_device(x.device):
+        rc = lib().antq_fakequant_f64(_vp(x), _vp(out), ctypes.c_size_t(rows), ctypes.c_size_t(row_len), _vp(alpha),
+                                      ctypes.c_int(1 if per_row else 0), ctypes.c_double(float(gmax)), ctypes.c_void_p(plan.host_addr),
+                                      ctypes.c_void_p(plan.dev(x.device).data_ptr()), ctypes.c_uint(FLAG_OVP if ovp else 0),
+                                      _stream(x.device))
+    _check(rc, "antq_fakequant_f64")
+    return out
+
+
 def fakequant_dynamic(x, plan, gmax, rows, row_len, ratio=1.0, ovp=False, want_idx=False, out=None,
                       want_alpha=True):
     _require_gpu(x, "x")
@@ -456,11 +474,16 @@ _zero_pools = {}          # device index -> [float32 zeros, next free slot]
 
 def _zero_slot(device):
     """A one-element float32 tensor holding 0 -- a slot of a pool zeroed once for 4096 calls, never handed out twice (the
-    whole-tensor abs-max then needs no launch of its own for that zero: antq_absmax_into)."""
+    whole-tensor abs-max then needs no launch of its own for that zero: antq_absmax_into).  One pool per (device, stream):
+    the fill is ordered before every use of its slots by the stream itself (a pool shared by streams could be used on one
+    before the other had zeroed it).  Never reached while a stream is capturing (absmax below)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    pool = _zero_pools.get(idx)
+    key = (idx, _stream_int(device))
+    pool = _zero_pools.get(key)
     if pool is None or pool[1] >= pool[0].numel():
-        pool = _zero_pools[idx] = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
+        if len(_zero_pools) >= 64:               # streams come and go
+            _zero_pools.clear()
+        pool = _zero_pools[key] = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
     pool[1] += 1
     return pool[0][pool[1] - 1:pool[1]]
 
@@ -548,7 +571,7 @@ def _workspace(device):
         with _lock:
             ws = _workspaces.get(key)
             if ws is None:
-                if len(_workspaces) >= 64:           # streams come and go: do not grow without bound
+                if len(_workspaces) >= 16:           # streams come and go: do not grow without bound (32 MiB each)
                     _workspaces.clear()
                 ws = _workspaces[key] = torch.empty(int(lib().antq_search_workspace_bytes()), dtype=torch.uint8, device=device)
     return ws

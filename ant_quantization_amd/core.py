@@ -60,9 +60,15 @@ _grid64_cache = {}
 def fake_quant_f64(x, alpha, plan, gmax, per_channel, ovp=False):
     """float64 tensors (a `.double()` model).  The reference's operator is dispatched for double and narrows to float
     INSIDE the kernel (KQ/quant_kernel.cu:51, :28), everything around it runs in double: that is exactly what happens
-    here -- the reference's own op sequence (AQ:535-551 / OQ:294-330) in torch float64 around `antq_nearest` (F64: same
-    narrowing), seven launches instead of one fused kernel.  Double precision is not a throughput path; autograd flows
-    through the torch ops as it does in the reference (ANT's straight-through graph)."""
+    here -- fused into one kernel when no gradient is wanted (antq_fakequant_f64), otherwise the reference's own op sequence
+    (AQ:535-551 / OQ:294-330) in torch float64 around `antq_nearest` (F64: same narrowing), seven launches, through which
+    autograd flows as it does in the reference (ANT's straight-through graph).  Both forms give the same bits."""
+    if not (torch.is_grad_enabled() and (x.requires_grad or alpha.requires_grad)) and x.is_cuda:
+        # no gradient wanted: the same sequence as ONE kernel (antq_fakequant_f64, round 5)
+        xc = x.detach().contiguous()
+        rows, row_len = view_rows(xc, per_channel)
+        a = alpha.detach().reshape(-1).to(torch.float64).contiguous()
+        return _lib.fakequant_f64(xc, a, plan, gmax, rows, row_len, per_channel, ovp=ovp).view(x.shape)
     key = (plan.grid.tobytes(), x.device.index)
     grid = _grid64_cache.get(key)
     if grid is None:

@@ -395,6 +395,35 @@ extern "C" int antq_absmax_into(const void *x, float *amax, size_t n, int dtype,
 }
 
 // ======================================================================================
+// Fused Quantizer._forward of a float64 tensor (antq_k_f64.h)
+// ======================================================================================
+#include "antq_k_f64.h"
+
+extern "C" int antq_fakequant_f64(const double *x, double *out, size_t rows, size_t row_len, const double *alpha,
+                                  int alpha_per_row, double gmax, const void *plan_host, const void *plan_dev, unsigned flags,
+                                  void *stream)
+{
+    if (rows == 0 || row_len == 0) return ANTQ_OK;
+    if (!x || !out || !alpha || !plan_host || !plan_dev) return ANTQ_ERR_ARG;
+    if (flags & ~ANTQ_FLAG_OVP) return ANTQ_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(x) % 8 || reinterpret_cast<uintptr_t>(out) % 8 || reinterpret_cast<uintptr_t>(alpha) % 8) return ANTQ_ERR_ALIGN;
+    PlanArgs pa;
+    if (!plan_args_from_host(plan_host, pa)) return ANTQ_ERR_PLAN;
+    const size_t n = rows * row_len, npairs = (n + 1) / 2;
+    size_t blocks = (npairs + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const size_t lds = lds_table(pa, false);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & ANTQ_FLAG_OVP)
+        hipLaunchKernelGGL((antq::k_fq_f64<true>), dim3((unsigned)blocks), dim3(256), lds, st, x, out, n, row_len, alpha,
+                           alpha_per_row ? 1 : 0, gmax, pa, plan_tab_ptr(plan_dev));
+    else
+        hipLaunchKernelGGL((antq::k_fq_f64<false>), dim3((unsigned)blocks), dim3(256), lds, st, x, out, n, row_len, alpha,
+                           alpha_per_row ? 1 : 0, gmax, pa, plan_tab_ptr(plan_dev));
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+// ======================================================================================
 // Packed 4-bit codec (antq_encode4 / antq_decode4)
 // ======================================================================================
 #include "antq_k_codec.h"

@@ -41,7 +41,7 @@ extern "C" {
  * 16-bit-domain kernels; ANTQ_PLAN_MAX_BYTES with it), the batch blob changed, antq_plan_eval_host_h and
  * antq_prefetch_kernels added.  5: antq_calibrate_batch / antq_calibrate_batch_workspace_bytes and antq_absmax_into added (nothing else changed).
  * A caller built against another version must not call in: the blobs / argument lists differ. */
-#define ANTQ_ABI_VERSION 5
+#define ANTQ_ABI_VERSION 6
 
 /* element types of x / out */
 #define ANTQ_F32  0
@@ -161,6 +161,17 @@ int antq_fakequant(const void *x_dev, void *out_dev, int16_t *idx_dev,
                    const float *alpha_dev, int alpha_per_row, float gmax,
                    const void *plan_host, const void *plan_dev,
                    unsigned flags, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * The same for a float64 tensor (a `.double()` model).  The reference's operator narrows to float INSIDE the kernel
+ * (quant_kernel.cu:51, :28) while the tensor ops around it run in double: scale = alpha / gmax, d = x / scale,
+ * q = grid[nearest(float(d))], [OVP], out = ((q - d) + d) * scale, all in double -- fused here (one read, one write).
+ * alpha_dev: doubles (a double model's alpha Parameter is double).  flags: ANTQ_FLAG_OVP only.  8-byte aligned pointers.
+ * Bit-identical to that op sequence; not a throughput path (16 B per element, a thread per flat pair).
+ * ------------------------------------------------------------------------- */
+int antq_fakequant_f64(const double *x_dev, double *out_dev, size_t rows, size_t row_len,
+                       const double *alpha_dev, int alpha_per_row, double gmax,
+                       const void *plan_host, const void *plan_dev, unsigned flags, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Same, with alpha computed in the kernel from the data (the initial alpha of

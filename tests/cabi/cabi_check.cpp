@@ -8,7 +8,7 @@
 // calibration entry points (antq_search_sse with its workspace, antq_search_pick, and antq_calibrate: all of it in one call),
 // and -- section 9 -- every ABI 4 / 5 entry: antq_nearest_plan, the host models antq_plan_eval_host[_a|_h], the 16-bit-domain row
 // kernels on bf16, antq_absmax_into, antq_search_sse_multi, antq_moments + antq_xmax_3sigma, antq_affine, antq_alpha_grad,
-// antq_calibrate_batch, antq_copy, antq_prefetch_kernels, antq_debug_set: every prototype of include/antq.h is called here.
+// antq_calibrate_batch, antq_fakequant_f64, antq_copy, antq_prefetch_kernels, antq_debug_set: every prototype of include/antq.h is called here.
 // Exit code 0 = every comparison bit-exact; prints one line per check.
 #include <hip/hip_runtime.h>
 
@@ -29,6 +29,7 @@ void antq_oracle_absmax_f32(const float *x, float *alpha, size_t rows, size_t ro
 int antq_oracle_search_mse_f32(const float *x, size_t rows, size_t row_len, int per_row, const float *x_max, int lb, int ub,
                                int step, const float *grid, int m, float gmax, int ovp, float *best_score, float *best_alpha,
                                float *trace);
+void antq_oracle_nearest_f64(const double *x, double *z, int32_t *idx, size_t n, const double *grid, int m);
 void antq_oracle_f32_to_bf16(const float *in, uint16_t *out, size_t n);
 void antq_oracle_forward_bf16(const uint16_t *x, uint16_t *out, int32_t *idx, size_t rows, size_t row_len, const float *alpha,
                               int alpha_per_row, const float *grid, int m, float gmax, int ovp);
@@ -598,6 +599,32 @@ int main()
         jobs3[1].ub = jobs3[1].lb - 5;                                        // an empty range is legal (AQ:299: the loop never runs) ...
         jobs3[1].ntypes = 0;                                                  // ... no codebook is not
         if (antq_calibrate_batch_workspace_bytes(jobs3, 3) != 0) { printf("bad job not rejected by the workspace query\n"); failures++; }
+    }
+
+    // 9k. antq_fakequant_f64: a double tensor through the fused kernel == the reference's double op sequence around its
+    //     float-narrowing operator (KQ/quant_kernel.cu:28, :51; AQ:535-551 / OQ:311-320), restated here on the oracle's scan
+    {
+        const size_t nd = rows * K - 1;                                       // odd element count: the pair rule's wrap
+        std::vector<double> xd(nd), ad(1, 0.0731), od(nd), dd(nd), gd(olive.size()), qd(nd);
+        for (size_t i = 0; i < nd; i++) xd[i] = (double)xf[i] * 1.000000123;
+        for (size_t i = 0; i < olive.size(); i++) gd[i] = (double)olive[i];
+        const double s = ad[0] / 32.0;
+        for (size_t i = 0; i < nd; i++) dd[i] = xd[i] / s;
+        std::vector<int32_t> qi(nd);
+        antq_oracle_nearest_f64(dd.data(), qd.data(), qi.data(), nd, gd.data(), (int)gd.size());
+        std::vector<uint8_t> mask(nd), vo(nd, 0), ve(nd, 0);
+        for (size_t i = 0; i < nd; i++) mask[i] = std::fabs(qd[i]) > 32.0;
+        for (size_t i = 1; i < nd; i += 2) vo[i] = mask[i - 1];
+        for (size_t i = 0; i < nd; i += 2) { const size_t j = (i + 1) % nd; ve[i] = mask[j] && !vo[j]; }
+        for (size_t i = 0; i < nd; i++) { const double q = qd[i] * ((ve[i] || vo[i]) ? 0.0 : 1.0); od[i] = ((q - dd[i]) + dd[i]) * s; }
+        DevBuf<double> dxd(nd), dod(nd), dad(1);
+        dxd.up(xd, st); dad.up(ad, st);
+        ANTQ_OK_(antq_fakequant_f64(dxd.p, dod.p, 1, nd, dad.p, 0, 32.0, plan2.data(), dplan2.p, ANTQ_FLAG_OVP, st));
+        const std::vector<double> got = dod.down(st);
+        size_t bad = 0;
+        for (size_t i = 0; i < nd; i++) bad += std::memcmp(&got[i], &od[i], 8) != 0 && !(std::isnan(got[i]) && std::isnan(od[i]));
+        printf("%-58s %s (%zu / %zu differ)\n", "antq_fakequant_f64, OliVe pairs, odd element count", bad ? "FAIL" : "ok", bad, nd);
+        if (bad) failures++;
     }
 
     // 9j. the rest of the surface: antq_copy, antq_prefetch_kernels, antq_debug_set (thread-local knob, result unchanged)

@@ -738,3 +738,39 @@ def test_multihead_attention_options_vs_reference_fixture(antq_lib, dev, capsys)
         assert "-bit" not in capsys.readouterr().out and w.shape[-1] == cols
         np.testing.assert_allclose(y.cpu().numpy(), fx[pre + "y"], rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(w.cpu().numpy(), fx[pre + "attn_weights"], rtol=2e-4, atol=2e-6)
+
+
+def test_fused_float64_forward_equals_the_composed_op_sequence(antq_lib, oracle, dev):
+    """antq_fakequant_f64 (one kernel) against core.fake_quant_f64's composed path (the reference's seven double ops around the
+    float-narrowing operator -- itself pinned to the oracle in test_float64_forward_is_the_reference_sequence_...), which a call
+    that wants gradients still takes: same bits, per channel and per tensor, ANT and OliVe pairs, odd element counts (the
+    wrap of the last element), Inf / NaN / huge values, zero / negative / NaN alphas."""
+    import torch
+    from conftest import golden
+    from ant_quantization_amd import core
+    G, O = golden("ant_grids.npz"), golden("olive_grids.npz")
+    gol = np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]])
+    rng = np.random.default_rng(65)
+    for shape in ((16, 256), (7, 33), (5, 3, 7, 7), (1, 4097), (33, 1)):
+        x = rng.standard_normal(shape) * 0.05
+        f = x.reshape(-1)
+        f[::19] *= 25
+        if f.size > 40:
+            f[3], f[8], f[11], f[12] = np.inf, np.nan, 1e300, -1e-310
+        xt = torch.from_numpy(x).to(dev)
+        for g, gmax, ovp in ((G["flint_b4_s"], 10.0, False), (G["int_b8_s"], 10.0, False), (gol, 32.0, True)):
+            plan = antq_lib.plan_for(np.ascontiguousarray(g, dtype=np.float32))
+            for per_channel in (True, False):
+                na = shape[0] if per_channel else 1
+                alpha = torch.from_numpy(np.abs(rng.standard_normal(na)) * 0.1 + 0.01).to(dev)
+                if na > 4:
+                    alpha[1], alpha[2], alpha[3] = 0.0, -0.05, float("nan")
+                a = alpha.reshape(-1, 1) if per_channel else alpha.reshape(())
+                with torch.no_grad():
+                    fused = core.fake_quant(xt, a, plan, gmax, per_channel, ovp=ovp)
+                xg = xt.clone().requires_grad_(True)
+                composed = core.fake_quant(xg, a, plan, gmax, per_channel, ovp=ovp)
+                assert composed.requires_grad and fused.dtype == torch.float64 and fused.shape == xt.shape
+                fb, cb = fused.cpu().numpy(), composed.detach().cpu().numpy()
+                same = (fb.view(np.uint64) == cb.view(np.uint64)) | (np.isnan(fb) & np.isnan(cb))
+                assert same.all(), (shape, ovp, per_channel, int((~same).sum()), fb[~same][:3], cb[~same][:3])
