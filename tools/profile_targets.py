@@ -67,6 +67,9 @@ def main():
     act = torch.nn.functional.gelu(torch.randn(64, 128, 3072, device=dev))
     am = core.row_absmax(act, False)
     runs.append(lambda: _lib.search_sse(act, 1, act.numel(), am, False, ratios, flint, 10.0))            # per-tensor (PT)
+    act16 = act.to(torch.bfloat16)                                                                       # round 5: the histogram path
+    am16 = core.row_absmax(act16, False)
+    runs.append(lambda: _lib.search_sse_multi(act16, 1, act16.numel(), am16, False, ratios, plans, [10.0] * 3))      # k_hist16 / _reduce / _score
     # packed 4-bit codec (fp32 and bf16, OliVe pairs)
     gn = grids.olive_flint(4, True).size
     codec = []
@@ -75,6 +78,8 @@ def main():
         codes = _lib.encode4(x, a, ol, 32.0, 4096, 4096, True, n_normal=gn, ovp=True)
         codec.append(lambda x=x, a=a: _lib.encode4(x, a, ol, 32.0, 4096, 4096, True, n_normal=gn, ovp=True))      # k_encode4
         codec.append(lambda x=x, a=a, c=codes: _lib.decode4(c, a, ol, 32.0, 4096, 4096, True, x.dtype, n_normal=gn, ovp=True))
+    a_ant = _lib.absmax(xs[0], 4096, 4096)
+    codec.append(lambda: _lib.encode4(xs[0], a_ant, flint, 10.0, 4096, 4096, True))                     # k_encode4_hrow, ANT
     runs += codec
     if os.environ.get("ANTQ_TARGETS") == "codec":
         runs = codec
