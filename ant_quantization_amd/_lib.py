@@ -557,13 +557,13 @@ def alpha_grad(x, out, gout, rows, row_len, per_row=True):
     return gsum
 
 
-_workspaces = {}            # (device index, raw stream) -> 8 MiB scratch; launches on one stream are ordered, so they may share it
+_workspaces = {}            # (device index, raw stream) -> scratch of antq_search_workspace_bytes() (32.25 MiB); launches on one stream are ordered, so they may share it
 
 
 def _workspace(device):
     """Scratch for the workgroup partials of a whole-tensor sum (antq_search_workspace_bytes), ONE per (device, stream):
     kernels that use it on the same stream run one after the other, so a QAT backward does not ask the caching allocator
-    for a fresh 8 MiB block per quantiser and step; different streams never share one."""
+    for a fresh block per quantiser and step; different streams never share one."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, _stream_int(device))
     ws = _workspaces.get(key)

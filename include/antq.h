@@ -234,7 +234,7 @@ int antq_alpha_grad(const void *x_dev, const void *out_dev, const void *gout_dev
  * its 65 536-bin histogram (one pass counts the bit patterns, then every pattern with a non-zero count goes through the
  * literal reference sequence for every candidate: count x term, summed in double in one fixed order): the same terms as the
  * element-by-element kernels, added in another order (relative 1e-7 on a sum).  The workspace holds the histogram's slabs:
- * always size it with antq_search_workspace_bytes() (32.25 MiB since ABI 5 / library round 5; 8 MiB before).
+ * always size it with antq_search_workspace_bytes() (32.25 MiB since ABI 6; 8 MiB before).
  * ------------------------------------------------------------------------- */
 size_t antq_search_workspace_bytes(void);
 int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
