@@ -15,6 +15,20 @@
 // kernels is only the ORDER of the additions (they add eight fp32 terms per vector before widening): relative 1e-7, three
 // orders of magnitude inside the tie band the parity tests allow a pick to move in (tests/calib_check.py, 2e-5).
 //
+// OliVe's pair rule (round 5b).  With outlier-victim pairs (OQ:311-320) an element's output also depends on whether its pair
+// partner quantises to an outlier: a victim's output is 0, its term fl32(x^2).  Outliers are the tails of the tensor, so
+//     sse[t, c] = sum_p count[p] * term(p; t, c)  +  sum over victims v of ( fl32(x_v^2) - term(p_v; t, c) )
+// where the victims of candidate (t, c) are found in a LIST of the pairs that hold an outlier-capable element -- a magnitude at
+// or above a conservative bound of the smallest outlier threshold of any candidate (the smallest scale, the codebook with
+// the lowest threshold).  k_hist16 writes that list while it counts: every wavefront of the non-negative workgroups compacts
+// the qualifying 32-bit words (a word IS a flat pair) of its chunks into its own segment by ballot / prefix popcount, so the
+// list's layout -- and with it the order of every double addition in the scoring kernel -- is the same on every run.  The
+// scoring kernel learns the exact outlier thresholds of its candidate from the main pass (the smallest magnitude pattern
+// per sign whose literal q has |q| > 32; q is monotone in x), then walks the list: two pattern compares per pair, one
+// literal evaluation per victim.  A segment that overflows (a tensor with more than ~8 % outlier-capable pairs) raises a flag:
+// the histogram kernels then write nothing and the direct kernels, enqueued behind them with that flag as their run condition,
+// do the search -- no host decision, no synchronisation.
+//
 //   k_hist16        1024-thread workgroups, each with a private 32 768-bin histogram of ONE sign in its 128 KiB of LDS (a
 //                   workgroup may own the whole 160 KiB of a CU): even workgroups count the non-negative patterns of their
 //                   chunk, odd ones the negative patterns; ds_add_u32 without return; the zero patterns -- half of a ReLU
@@ -33,16 +47,58 @@ namespace antq {
 constexpr uint32_t kHistBins = 32768;            // magnitude patterns of one sign
 constexpr int kHistMaxG = 128;                   // workgroups per sign (slabs: 2 * kHistMaxG * 128 KiB = 32 MiB)
 constexpr size_t kHistSlabBytes = (size_t)kHistBins * 4;
-constexpr size_t kHistWorkspaceBytes = 2 * (size_t)kHistMaxG * kHistSlabBytes + 2 * kHistSlabBytes;   // slabs, then count[65536]
+constexpr uint32_t kHistSegCap = 1024;           // pair words per wavefront segment (OliVe's pair rule)
+constexpr size_t kHistSlabsBytes = 2 * (size_t)kHistMaxG * kHistSlabBytes;
+constexpr size_t kHistCountOff = kHistSlabsBytes;                                   // count[65536]
+constexpr size_t kHistSegCountOff = kHistCountOff + 2 * kHistSlabBytes;             // seg_count[kHistMaxG * 16]
+constexpr size_t kHistFlagsOff = kHistSegCountOff + (size_t)kHistMaxG * 16 * 4;     // flags[64] (bit 0 of word 0: a segment overflowed)
+constexpr size_t kHistSegOff = kHistFlagsOff + 256;                                 // segments[kHistMaxG * 16][kHistSegCap]
+constexpr size_t kHistWorkspaceBytes = kHistSegOff + (size_t)kHistMaxG * 16 * kHistSegCap * 4;
 
-static __global__ void __launch_bounds__(1024)
-k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restrict__ slabs)
+// what the pair list needs to know (by value)
+struct HistPairs {
+    const float *xmax;         // device: the clip statistic (1 float)
+    const float *ratios;       // device: the clip ratios (the smallest one gives the smallest scale)
+    int ncand;
+    float tmin_over_gmax;      // min over the candidate codebooks of (smallest outlier decision threshold / gmax), times 0.999
+    uint32_t *seg;             // [G * 16][kHistSegCap]
+    uint32_t *seg_count;       // [G * 16]
+    int *flags;
+};
+
+template <typename T, bool PAIRS>
+__global__ void __launch_bounds__(1024)
+k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restrict__ slabs, HistPairs hp)
 {
     __shared__ __attribute__((aligned(16))) uint32_t bins[kHistBins];        // 128 KiB, static: one workgroup per CU
     const uint32_t sign = blockIdx.x & 1u, w = blockIdx.x >> 1;
     for (uint32_t i = threadIdx.x; i < kHistBins / 4; i += 1024u) reinterpret_cast<uint4 *>(bins)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     uint32_t zeros = 0;                                                      // this wavefront's count of the zero pattern (lane 0)
+    // PAIRS: the magnitude pattern at or above which an element may quantise to an outlier under SOME candidate (a lower
+    // bound: the list may hold pairs that never produce a victim, never the other way round); NaN / non-positive statistic:
+    // 0 -- everything qualifies, the segments overflow, the direct kernels take over
+    uint32_t theta = 0xffffffffu, nseg = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool lister = PAIRS && sign == 0u;
+    uint32_t *myseg = nullptr;
+    if (lister) {
+        float rmin = hp.ratios[0];
+        for (int c = 1; c < hp.ncand; c++) rmin = fminf(rmin, hp.ratios[c]);      // (fminf drops a NaN ratio: checked below)
+        for (int c = 0; c < hp.ncand; c++) rmin = hp.ratios[c] == hp.ratios[c] ? rmin : __builtin_nanf("");
+        const float tv = hp.xmax[0] * rmin * hp.tmin_over_gmax;
+        theta = (tv > 0.0f && tv < 3.0e38f) ? H16<T>::down(tv) : 0u;
+        myseg = hp.seg + ((size_t)w * 16u + (threadIdx.x >> 6)) * kHistSegCap;
+    }
+    auto list_pair = [&](uint32_t word, bool live) {
+        const bool hit = live && max(word & 0x7fffu, (word >> 16) & 0x7fffu) >= theta;
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const uint32_t off = nseg + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (hit && off < kHistSegCap) myseg[off] = word;
+            nseg += (uint32_t)__builtin_popcountll(m);
+        }
+    };
     auto count = [&](uint32_t h) {
         const bool mine = (h >> 15) == sign;
         const uint32_t mag = h & 0x7fffu;
@@ -60,6 +116,10 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
         const uint32_t ws[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
 #pragma unroll
         for (int k = 0; k < 16; k++) { count(ws[k] & 0xffffu); count(ws[k] >> 16); }
+        if (lister) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) list_pair(ws[k], true);
+        }
     }
     for (; cb < nv; cb += stride) {
         const size_t j = cb + threadIdx.x;
@@ -73,6 +133,14 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
             count(live ? (ws[k] & 0xffffu) : dead);
             count(live ? (ws[k] >> 16) : dead);
         }
+        if (lister) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) list_pair(ws[k], live);
+        }
+    }
+    if (lister && lane == 0u) {
+        hp.seg_count[(size_t)w * 16u + (threadIdx.x >> 6)] = min(nseg, kHistSegCap);
+        if (nseg > kHistSegCap) atomicOr(hp.flags, 1);
     }
     if ((threadIdx.x & 63u) == 0u && zeros) atomicAdd(&bins[0], zeros);
     __syncthreads();
@@ -98,18 +166,34 @@ struct HistTypes {
     int ntypes;
 };
 
-// sse[t * ncand + c] for one (t, c) per workgroup.  Terms in ascending pattern order per thread (p = tid, tid + 1024, ...),
-// then a fixed tree: the same bits on every run.
+// the literal reference sequence for one pattern: q (before any pair rule) and the term of the element's own output
 template <typename T>
+__device__ __forceinline__ float hist_term(uint32_t p, const Scale &sc, const float *g, int m, float &q)
+{
+    const float xv = H16<T>::val(p);
+    const float d = xv / sc.s;                   // AQ:541 / OQ:299
+    int jj;
+    q = scan_lds(d, g, m, jj);                   // quant_kernel.cu:25-37
+    const float tt = (q - d) + d;                // AQ:547 / OQ:323
+    const float df = fabsf(tt * sc.s - xv);      // AQ:549, :282
+    return df * df;
+}
+
+// sse[t * ncand + c] for one (t, c) per workgroup.  Terms in ascending pattern order per thread (p = tid, tid + 1024, ...),
+// then a fixed tree; PAIRS: the victims' corrections in the fixed order of the list's segments: the same bits on every run.
+template <typename T, bool PAIRS>
 __global__ void __launch_bounds__(1024)
 k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax, const float *__restrict__ ratios, int ncand,
-             HistTypes ht, double *__restrict__ sse)
+             HistTypes ht, double *__restrict__ sse, HistPairs hp, uint32_t n_seg)
 {
     __shared__ float g[ANTQ_MAX_GRID];
     __shared__ double part[16];
+    __shared__ uint32_t thr[4];                          // per sign: smallest / largest magnitude pattern that quantises to an outlier
+    if (PAIRS && (hp.flags[0] & 1)) return;              // the pair list overflowed: the direct kernels behind us do the search
     const int f = (int)blockIdx.x, t = f / ncand, c = f - t * ncand;
     const int m = ht.m[t];
     for (int i = (int)threadIdx.x; i < m; i += 1024) g[i] = ht.grid[t][i];
+    if (threadIdx.x < 4) thr[threadIdx.x] = threadIdx.x < 2 ? 0xffffffffu : 0u;
     __syncthreads();
     const float a = xmax[0] * ratios[c];                 // AQ:300  new_alpha = base_alpha * fl32(i * 0.01)
     const Scale sc = make_scale(a, ht.gmax[t]);
@@ -119,14 +203,44 @@ k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax,
         const uint32_t n = count[p];
         if (__ballot(n != 0u) == 0ull) continue;         // (whole exponent ranges no element of the tensor lies in)
         if (n != 0u) {
-            const float xv = H16<T>::val(p);
-            const float d = xv / sc.s;                   // AQ:541
-            int jj;
-            const float q = scan_lds(d, g, m, jj);       // quant_kernel.cu:25-37
-            const float tt = (q - d) + d;                // AQ:547
-            const float df = fabsf(tt * sc.s - xv);      // AQ:549, :282
-            acc += (double)n * (double)(df * df);
+            float q;
+            const float term = hist_term<T>(p, sc, g, m, q);
+            acc += (double)n * (double)term;
+            if (PAIRS && fabsf(q) > 32.0f) {                                            // OQ:314
+                atomicMin(&thr[p >> 15], p & 0x7fffu);
+                atomicMax(&thr[2u + (p >> 15)], p & 0x7fffu);
+            }
         }
+    }
+    if (PAIRS) {
+        __syncthreads();
+        // (q is monotone in x up to the scan's horizon -- beyond it no entry lies within 102400 and q is 0 again: the
+        //  outliers of a sign are the magnitudes in [lo, hi] among the patterns the tensor holds)
+        const uint32_t lo0 = thr[0], lo1 = thr[1], hi0 = thr[2], hi1 = thr[3];
+        const uint32_t lane = threadIdx.x & 63u;
+        double corr = 0.0;
+#pragma unroll 1
+        for (uint32_t sgi = threadIdx.x >> 6; sgi < n_seg; sgi += 16u) {
+            const uint32_t cnt = hp.seg_count[sgi];
+            const uint32_t *sp = hp.seg + (size_t)sgi * kHistSegCap;
+#pragma unroll 1
+            for (uint32_t i = lane; i < cnt; i += 64u) {
+                const uint32_t wd = sp[i], pe = wd & 0xffffu, po = wd >> 16;
+                const uint32_t ge = pe & 0x7fffu, go = po & 0x7fffu;
+                const bool me = (pe >> 15) ? (ge >= lo1 && ge <= hi1) : (ge >= lo0 && ge <= hi0);
+                const bool mo = (po >> 15) ? (go >= lo1 && go <= hi1) : (go >= lo0 && go <= hi0);
+                // OQ:313-320: the odd element is a victim when its even partner is an outlier; the even one when its odd
+                // partner is an outlier and it is not one itself
+                if (me || mo) {
+                    const uint32_t v = me ? po : pe;
+                    float q;
+                    const float term = hist_term<T>(v, sc, g, m, q);
+                    const float xv = H16<T>::val(v);
+                    corr += (double)(xv * xv) - (double)term;           // a victim's output is 0: its term is fl32(|0 - x|^2)
+                }
+            }
+        }
+        acc += corr;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
@@ -138,6 +252,9 @@ k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax,
         sse[f] = s;
     }
 }
+
+// the flag word of the pair list, zeroed ahead of k_hist16
+static __global__ void k_hist_clear_flags(int *flags) { if (threadIdx.x < 64) flags[threadIdx.x] = 0; }
 
 }  // namespace antq
 

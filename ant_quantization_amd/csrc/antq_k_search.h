@@ -34,8 +34,9 @@ struct WaveAcc {
 
 // out[f] = sum over the n_wg workgroup partials of candidate f, in a fixed order (strided per thread, then a tree)
 static __global__ void __launch_bounds__(256)
-k_sum_partials(const double *__restrict__ ws, uint32_t n_wg, int chunk, double *__restrict__ out)
+k_sum_partials(const double *__restrict__ ws, uint32_t n_wg, int chunk, double *__restrict__ out, const int *__restrict__ run_if = nullptr)
 {
+    if (run_if && !*run_if) return;             // (behind a histogram search with a pair list: only when that list overflowed)
     const int f = (int)blockIdx.x;
     const int y = f / chunk, c = f - y * chunk;
     const double *p = ws + ((size_t)y * n_wg) * kPtCand + c;
@@ -91,9 +92,10 @@ __global__ void __launch_bounds__(256)
 k_search_sse(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
              const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand, float gmax,
              double *__restrict__ sse, double *__restrict__ ws, PlanArgs pa, const uint4 *__restrict__ plan_tab,
-             int cand_chunk, XArgs xa)
+             int cand_chunk, XArgs xa, const int *__restrict__ run_if = nullptr)
 {
     constexpr int EPL = IO<T>::EPL;
+    if (run_if && !*run_if) return;             // (see k_sum_partials)
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     __shared__ __attribute__((aligned(16))) uint4 wtab_all[XD ? 4 : 1][XD ? 256 : 1];
     const uint32_t lane = threadIdx.x & 63u;
@@ -214,9 +216,10 @@ template <typename T, bool OVP, int U, bool PT>
 __global__ void __launch_bounds__(256, (IO<T>::EPL == 8 && U == 4) ? 4 : 1)
 k_search_sse_multi(const uint4 *__restrict__ x, uint32_t total_tasks, uint32_t vpr, uint32_t tpr, size_t rows,
                    const float *__restrict__ xmax, int per_row, const float *__restrict__ ratios, int ncand,
-                   double *__restrict__ sse, double *__restrict__ ws, MultiArgs ma, int flat_chunk)
+                   double *__restrict__ sse, double *__restrict__ ws, MultiArgs ma, int flat_chunk, const int *__restrict__ run_if = nullptr)
 {
     constexpr int EPL = IO<T>::EPL;
+    if (run_if && !*run_if) return;             // (see k_sum_partials)
     __shared__ __attribute__((aligned(16))) uint4 wtab_all[4][256];
     __shared__ __attribute__((aligned(16))) uint4 s_ent[kMaxTypes][128];
     __shared__ double wacc[4][kPtCand];

@@ -22,27 +22,59 @@ namespace antq {
 // selection and one search per type form the very same sums: test_calibration_sums_are_bit_reproducible).  knob 14 = 0
 // switches the path off, = 2 takes it for every eligible tensor (tests).
 template <typename T>
-static bool hist_eligible(size_t n, int nflat, bool ovp, const void *x)
+static bool hist_eligible(size_t n, bool ovp, const void *x)
 {
     if constexpr (std::is_same<T, float>::value) return false;
-    if (g_knob_hist == 0 || ovp || n % 8 != 0 || n >= ((size_t)1 << 31) || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
-    (void)nflat;
-    return g_knob_hist == 2 || n >= ((size_t)1 << 20);
+    if (g_knob_hist == 0 || (ovp && g_knob_hist == 3) || n % 8 != 0 || n >= ((size_t)1 << 31) || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
+    return g_knob_hist >= 2 || n >= ((size_t)1 << 20);
 }
+// OliVe's pair rule: a lower bound (in units of gmax) of the smallest |d| that quantises to an outlier, from the plan's
+// threshold list (the thresholds between a normal value and an outlier, either sign).  false: the plan has no such list.
+static bool hist_outlier_bound(const void *plan_host, float gmax, float &bound)
+{
+    const PlanHeader *h = static_cast<const PlanHeader *>(plan_host);
+    if (h->kind != kPlanLut || !h->hdom || !(gmax > 0.0f)) return false;
+    const HThr *tl = plan_tlist(plan_host);
+    float tmin = INFINITY;
+    for (uint32_t i = 0; i < h->h_nthr; i++) {
+        const bool lo_out = (tl[i].flags & 1u) != 0u, hi_out = (tl[i].flags & 2u) != 0u;
+        if (lo_out != hi_out) tmin = std::min(tmin, fabsf(tl[i].T));
+    }
+    if (!(tmin < INFINITY)) tmin = 3.0e38f;              // (a codebook without outliers: nothing ever qualifies)
+    bound = tmin / gmax * 0.999f;
+    return true;
+}
+// The histogram search.  pairs: with OliVe's pair rule; *run_if then receives the device flag the caller's direct launches
+// take as their run condition (set iff the pair list overflowed; the histogram kernels then wrote nothing).
 template <typename T>
 static int launch_hist_search(const void *x, size_t n, const float *xmax, const float *ratios, int ncand, const HistTypes &ht,
-                              double *sse, void *ws, hipStream_t st)
+                              double *sse, void *ws, bool pairs, float tmin_over_gmax, const int **run_if, hipStream_t st)
 {
     if constexpr (std::is_same<T, float>::value) {
         return ANTQ_ERR_UNSUPPORTED;
     } else {
         const size_t nv = n / 8;
         uint32_t G = (uint32_t)std::min<size_t>(std::max<size_t>(n / 65536, 16), (size_t)kHistMaxG);
-        uint32_t *slabs = static_cast<uint32_t *>(ws);
-        uint32_t *count = slabs + 2 * (size_t)kHistMaxG * kHistBins;
-        hipLaunchKernelGGL(k_hist16, dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs);
-        hipLaunchKernelGGL(k_hist_reduce, dim3(256), dim3(256), 0, st, slabs, G, count);
-        hipLaunchKernelGGL((k_hist_score<T>), dim3((unsigned)(ht.ntypes * ncand)), dim3(1024), 0, st, count, xmax, ratios, ncand, ht, sse);
+        char *w = static_cast<char *>(ws);
+        uint32_t *slabs = reinterpret_cast<uint32_t *>(w);
+        uint32_t *count = reinterpret_cast<uint32_t *>(w + kHistCountOff);
+        HistPairs hp;
+        hp.xmax = xmax; hp.ratios = ratios; hp.ncand = ncand; hp.tmin_over_gmax = tmin_over_gmax;
+        hp.seg = reinterpret_cast<uint32_t *>(w + kHistSegOff);
+        hp.seg_count = reinterpret_cast<uint32_t *>(w + kHistSegCountOff);
+        hp.flags = reinterpret_cast<int *>(w + kHistFlagsOff);
+        const unsigned nflat = (unsigned)(ht.ntypes * ncand);
+        if (pairs) {
+            hipLaunchKernelGGL(k_hist_clear_flags, dim3(1), dim3(64), 0, st, hp.flags);
+            hipLaunchKernelGGL((k_hist16<T, true>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp);
+            hipLaunchKernelGGL(k_hist_reduce, dim3(256), dim3(256), 0, st, slabs, G, count);
+            hipLaunchKernelGGL((k_hist_score<T, true>), dim3(nflat), dim3(1024), 0, st, count, xmax, ratios, ncand, ht, sse, hp, G * 16u);
+            *run_if = hp.flags;                  // non-zero iff a segment of the pair list overflowed
+        } else {
+            hipLaunchKernelGGL((k_hist16<T, false>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp);
+            hipLaunchKernelGGL(k_hist_reduce, dim3(256), dim3(256), 0, st, slabs, G, count);
+            hipLaunchKernelGGL((k_hist_score<T, false>), dim3(nflat), dim3(1024), 0, st, count, xmax, ratios, ncand, ht, sse, hp, 0u);
+        }
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }
 }
@@ -136,14 +168,17 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }
     if (!per_row) { row_len = rows * row_len; rows = 1; }
-    if (rows == 1 && hist_eligible<T>(row_len, ncand, OVP, x)) {
+    const int *run_if = nullptr;                 // device flag: run the direct kernels only if it is set (pair-list overflow)
+    float bound = 0.0f;
+    if (rows == 1 && hist_eligible<T>(row_len, OVP, x) && (!OVP || hist_outlier_bound(plan_host, gmax, bound))) {
         HistTypes ht;
         memset(&ht, 0, sizeof(ht));
         ht.ntypes = 1;
         ht.grid[0] = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev));
         ht.m[0] = (int)pa.m;
         ht.gmax[0] = gmax;
-        return launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, st);
+        const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st);
+        if (rc != ANTQ_OK || !OVP) return rc;
     }
     const size_t vpr = row_len / EPL;
     if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
@@ -168,14 +203,14 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
         if (sg.chunks == 0) return ANTQ_ERR_UNSUPPORTED;                                                           \
         hipLaunchKernelGGL((k_search_sse<T, OVP, U_, PT_, XD_>), dim3((unsigned)sg.blocks, (unsigned)sg.chunks), dim3(256), \
                            (XD_) ? 0 : lds, st, xv, (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row,  \
-                           ratios, ncand, gmax, sse, ws, pa, plan_tab_ptr(plan_dev), sg.chunk, xa);                 \
+                           ratios, ncand, gmax, sse, ws, pa, plan_tab_ptr(plan_dev), sg.chunk, xa, run_if);         \
     } while (0)
 #define ANTQ_LAUNCH_SU(PT_, XD_) do { if (U == 8) ANTQ_LAUNCH_S(PT_, XD_, 8); else ANTQ_LAUNCH_S(PT_, XD_, 4); } while (0)
     if (pt) { if (xd) ANTQ_LAUNCH_SU(true, true); else ANTQ_LAUNCH_SU(true, false); }
     else    { if (xd) ANTQ_LAUNCH_SU(false, true); else ANTQ_LAUNCH_SU(false, false); }
 #undef ANTQ_LAUNCH_SU
 #undef ANTQ_LAUNCH_S
-    if (pt) hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)sg.blocks, sg.chunk, sse);
+    if (pt) hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)sg.blocks, sg.chunk, sse, run_if);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
@@ -188,18 +223,26 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
     constexpr int EPL = IO<T>::EPL;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) return ANTQ_ERR_UNSUPPORTED;
     if (!per_row) { row_len = rows * row_len; rows = 1; }
-    if (rows == 1 && hist_eligible<T>(row_len, ntypes * ncand, OVP, x)) {
+    const int *run_if = nullptr;
+    if (rows == 1 && hist_eligible<T>(row_len, OVP, x)) {
         HistTypes ht;
         memset(&ht, 0, sizeof(ht));
         ht.ntypes = ntypes;
+        float bound = 3.0e38f;
+        bool ok = true;
         for (int t = 0; t < ntypes; t++) {
             PlanArgs pa;
             if (!plan_args_from_host(plan_host[t], pa)) return ANTQ_ERR_PLAN;
             ht.grid[t] = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev[t]));
             ht.m[t] = (int)pa.m;
             ht.gmax[t] = gmax[t];
+            float b = 0.0f;
+            if (OVP) { ok = ok && hist_outlier_bound(plan_host[t], gmax[t], b); bound = std::min(bound, b); }
         }
-        return launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, st);
+        if (ok) {
+            const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st);
+            if (rc != ANTQ_OK || !OVP) return rc;
+        }
     }
     const size_t vpr = row_len / EPL;
     if (vpr < kRowKernelMinVpr || vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
@@ -232,11 +275,11 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
         sg = search_grid(PT_ ? total : rows, PT_ ? 1 : tpr, PT_, nflat, resident_);                                       \
         if (sg.chunks == 0) return ANTQ_ERR_UNSUPPORTED;                                                                  \
         hipLaunchKernelGGL((k_search_sse_multi<T, OVP, U_, PT_>), dim3((unsigned)sg.blocks, (unsigned)sg.chunks), dim3(256), 0, st, \
-                           xv, (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, sg.chunk); \
+                           xv, (uint32_t)total, (uint32_t)vpr, (uint32_t)tpr, rows, xmax, per_row, ratios, ncand, sse, ws, ma, sg.chunk, run_if); \
     } while (0)
     if (pt) {
         if (U == 8) ANTQ_LAUNCH_M(true, 8); else ANTQ_LAUNCH_M(true, 4);
-        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nflat), dim3(256), 0, st, ws, (uint32_t)sg.blocks, sg.chunk, sse);
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nflat), dim3(256), 0, st, ws, (uint32_t)sg.blocks, sg.chunk, sse, run_if);
     } else {
         if (U == 8) ANTQ_LAUNCH_M(false, 8); else ANTQ_LAUNCH_M(false, 4);
     }

@@ -774,3 +774,89 @@ def test_fused_float64_forward_equals_the_composed_op_sequence(antq_lib, oracle,
                 fb, cb = fused.cpu().numpy(), composed.detach().cpu().numpy()
                 same = (fb.view(np.uint64) == cb.view(np.uint64)) | (np.isnan(fb) & np.isnan(cb))
                 assert same.all(), (shape, ovp, per_channel, int((~same).sum()), fb[~same][:3], cb[~same][:3])
+
+
+def test_histogram_clip_search_with_outlier_victim_pairs(antq_lib, oracle, dev):
+    """The histogram clip search under OliVe's pair rule (OQ:311-320): sum_p count[p] term(p) plus the victims' corrections
+    from the list of outlier-capable pairs.  Against (a) the ORACLE's forward with the pair rule on the whole tensor, per
+    candidate (terms fl32(|out - x|^2), added in double): 1e-9 -- every victim found, none invented, whatever the pair is
+    made of (outlier + normal, two outliers, a value beyond the scan's horizon -- q = 0, not an outlier --, a zero partner); (b) the direct kernels (knob 14 = 0):
+    their own partial-sum noise, same picks unless they tie; (c) itself: five runs, identical bits (the list's layout does not
+    depend on which wavefront finished first).  A tensor whose pair list overflows falls back to the direct kernels on the
+    device: bit-identical sums, no error, no synchronisation."""
+    import torch
+    from conftest import golden
+    O = golden("olive_grids.npz")
+    rng = np.random.default_rng(92)
+    knob = antq_lib.lib().antq_debug_set
+    books = [(np.concatenate([O["flint_b4_s"], O["outlier_b4_s"]]).astype(np.float32), float(O["flint_b4_s"].max())),
+             (np.concatenate([O["int_b4_s"], O["outlier_b4_s"]]).astype(np.float32), float(O["int_b4_s"].max()))]
+    plans = [antq_lib.plan_for(g) for g, _ in books]
+    gmaxs = [gm for _, gm in books]
+    ratios_np = np.asarray([np.float32(i * 0.01) for i in range(80, 250, 10)], dtype=np.float32)
+    ratios = torch.from_numpy(ratios_np).to(dev)
+    try:
+        for dtype, tdt in ((1, torch.bfloat16), (2, torch.float16)):
+            for cname, n, frac in (("sparse outliers", 8 * (1024 * 16 * 4 + 1024 * 3 + 5), 0.004), ("many outliers", 1 << 18, 0.05),
+                                   ("specials", 8 * 1024 * 40, 0.003)):
+                x = (rng.standard_normal(n) * 0.05).astype(np.float32)
+                idx = rng.choice(n, int(n * frac), replace=False)
+                x[idx] *= rng.uniform(6, 60, idx.size).astype(np.float32)
+                x[idx[:20] ^ 1] = x[idx[:20]] * 1.5                              # pairs of two outliers
+                xmax_np = np.float32(3.0 * x.std())                              # (the clip statistic is an input here)
+                if cname == "specials":
+                    x[idx[20:24]] = 3e4                                          # beyond the scan's horizon: q = 0, NOT an outlier
+                    x[idx[30] ^ 1] = 0.0
+                x16 = oracle.f32_to_bf16(x) if dtype == 1 else x.astype(np.float16).view(np.uint16)
+                vals = oracle.bf16_to_f32(x16) if dtype == 1 else x16.view(np.float16).astype(np.float32)
+                xt = torch.from_numpy(x16.view(np.int16)).to(dev).view(tdt)
+                xm = torch.tensor([xmax_np], device=dev)
+                res = {}
+                for mode in (2, 0):
+                    knob(14, mode)
+                    one = [antq_lib.search_sse(xt, 1, n, xm, False, ratios, p, gm, ovp=True) for p, gm in zip(plans, gmaxs)]
+                    multi = antq_lib.search_sse_multi(xt, 1, n, xm, False, ratios, plans, gmaxs, ovp=True)
+                    res[mode] = (torch.stack(one).cpu().numpy().reshape(2, -1), multi.cpu().numpy().reshape(2, -1))
+                h_one, h_multi = res[2]
+                d_one, d_multi = res[0]
+                # (single- and multi-type calls list the outlier-capable pairs from different bounds -- the lowest threshold of
+                #  the codebooks searched together -- so the victims' corrections are added in another order, or one of the two
+                #  overflows its list and is answered by the direct kernels: equal to rounding, not bit for bit)
+                np.testing.assert_allclose(h_one, h_multi, rtol=1e-11 if frac < 0.01 else 2e-6, err_msg=str((cname, dtype)))
+                for t, (g, gm) in enumerate(books):
+                    want = np.empty(ratios_np.size)
+                    with np.errstate(all="ignore"):
+                        for c, r in enumerate(ratios_np):
+                            a = np.float32(np.float32(xmax_np) * np.float32(r))
+                            ref, ridx = oracle.forward(vals.reshape(1, -1), np.float32([a]), g, gm, True)
+                            df = np.abs(ref.reshape(-1) - vals).astype(np.float32)
+                            want[c] = float(np.sum((df * df).astype(np.float32).astype(np.float64)))
+                            if c == 0:
+                                assert (ridx == oracle.IDX_VICTIM).sum() > 10, (cname, dtype)
+                    np.testing.assert_allclose(h_one[t], want, rtol=1e-9 if frac < 0.01 else 2e-6, equal_nan=True, err_msg=str((cname, dtype, t)))
+                    np.testing.assert_allclose(h_multi[t], want, rtol=1e-9 if frac < 0.01 else 2e-6, equal_nan=True, err_msg=str((cname, dtype, t)))
+                    np.testing.assert_allclose(d_one[t], want, rtol=2e-6, equal_nan=True, err_msg=str((cname, dtype, t, "direct")))
+                    if np.isfinite(want).all():
+                        ch, cd = int(np.argmin(h_one[t])), int(np.argmin(d_one[t]))
+                        assert ch == cd or abs(d_one[t][ch] - d_one[t][cd]) <= 2e-6 * d_one[t][cd]
+                knob(14, 2)
+                for _ in range(4):
+                    again = antq_lib.search_sse_multi(xt, 1, n, xm, False, ratios, plans, gmaxs, ovp=True).cpu().numpy().reshape(2, -1)
+                    assert np.array_equal(again.view(np.uint64), h_multi.view(np.uint64)), (cname, dtype, "not reproducible")
+        # overflow of the pair list: a clip statistic of ONE sigma makes a third of the elements outlier-capable -> the direct
+        # kernels answer, same bits
+        n = 1 << 20
+        x = (rng.standard_normal(n) * 0.05).astype(np.float32)
+        x16 = oracle.f32_to_bf16(x)
+        xt = torch.from_numpy(x16.view(np.int16)).to(dev).view(torch.bfloat16)
+        xm = torch.tensor([np.float32(0.05)], device=dev)
+        knob(14, 2)
+        over = antq_lib.search_sse_multi(xt, 1, n, xm, False, ratios, plans, gmaxs, ovp=True).cpu().numpy()
+        over1 = antq_lib.search_sse(xt, 1, n, xm, False, ratios, plans[0], gmaxs[0], ovp=True).cpu().numpy()
+        knob(14, 0)
+        direct = antq_lib.search_sse_multi(xt, 1, n, xm, False, ratios, plans, gmaxs, ovp=True).cpu().numpy()
+        direct1 = antq_lib.search_sse(xt, 1, n, xm, False, ratios, plans[0], gmaxs[0], ovp=True).cpu().numpy()
+        assert np.isfinite(over).all() and np.array_equal(over.view(np.uint64), direct.view(np.uint64))
+        assert np.array_equal(over1.view(np.uint64), direct1.view(np.uint64))
+    finally:
+        knob(14, 1)

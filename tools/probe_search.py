@@ -59,6 +59,20 @@ def hist():
             tc = timed(lambda: _lib.calibrate(x, 1, n, False, plans, gm, 75, 150, 1), 5)
             t1 = timed(lambda: _lib.calibrate(x, 1, n, False, plans[1:2], gm[:1], 75, 150, 1), 5)
             print("%-36s %s   antq_calibrate three types %7.3f ms   one type %7.3f ms" % (name, "histogram" if mode else "direct   ", tc * 1e3, t1 * 1e3), flush=True)
+    # OliVe: two codebooks (int / flint + outliers), 3-sigma statistic, outlier-victim pairs, ratios range(95... as OQ: lb..ub step 2)
+    on = [np.concatenate([grids.olive_grid(t, 4, True), grids.olive_outliers(4, True)]) for t in ("int", "flint")]
+    oplans = [_lib.plan_for(g) for g in on]
+    ogm = [float(grids.olive_grid(t, 4, True).max()) for t in ("int", "flint")]
+    for name, n, frac in (("OliVe 64x128x3072 bf16, 0.3 % outliers", 64 * 128 * 3072, 0.003), ("OliVe 2048x4096 bf16, 1 % outliers", 2048 * 4096, 0.01),
+                          ("OliVe 1 M bf16, 0.3 % outliers", 1 << 20, 0.003)):
+        x = torch.randn(n, device=dev) * 0.05
+        m = torch.rand(n, device=dev) < frac
+        x[m] *= torch.empty(int(m.sum()), device=dev).uniform_(8, 60)
+        x = x.to(torch.bfloat16)
+        for mode in (0, 2):
+            knob(14, mode)
+            tc = timed(lambda: _lib.calibrate(x, 1, n, False, oplans, ogm, 75, 250, 2, xmax="3sigma", ovp=True), 5)
+            print("%-40s %s   antq_calibrate two types x 88 ratios, pairs %7.3f ms" % (name, "histogram" if mode else "direct   ", tc * 1e3), flush=True)
     knob(14, 1)
 
 
