@@ -22,11 +22,18 @@ namespace antq {
 // selection and one search per type form the very same sums: test_calibration_sums_are_bit_reproducible).  knob 14 = 0
 // switches the path off, = 2 takes it for every eligible tensor (tests).
 template <typename T>
-static bool hist_eligible(size_t n, bool ovp, const void *x)
+static bool hist_eligible(size_t n, bool ovp, const void *x, int nflat)
 {
     if constexpr (std::is_same<T, float>::value) return false;
     if (g_knob_hist == 0 || (ovp && g_knob_hist == 3) || n % 8 != 0 || n >= ((size_t)1 << 31) || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
-    return g_knob_hist >= 2 || n >= ((size_t)1 << 20);
+    if (g_knob_hist == 2) return true;
+    // With the pair rule every candidate also walks the list of outlier-capable pairs (~1 % of the pairs of a 3-sigma-clipped
+    // tensor) and the direct kernels are enqueued behind as gated no-ops: it pays from ~1e9 element x candidate evaluations
+    // (25 M elements x 176: 1.63 -> 0.37 ms; 1 M x 176: 0.102 -> 0.114 ms; profiles/r05_hist_search.log).  Those sums are equal
+    // to rounding across call forms anyway (the list depends on the codebooks searched together), so the rule may look at the
+    // candidate count; without the pair rule it must not (see above).
+    if (ovp) return n >= ((size_t)1 << 22) && (double)n * (double)nflat >= 1.0e9;
+    return n >= ((size_t)1 << 20);
 }
 // OliVe's pair rule: a lower bound (in units of gmax) of the smallest |d| that quantises to an outlier, from the plan's
 // threshold list (the thresholds between a normal value and an outlier, either sign).  false: the plan has no such list.
@@ -170,7 +177,7 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     if (!per_row) { row_len = rows * row_len; rows = 1; }
     const int *run_if = nullptr;                 // device flag: run the direct kernels only if it is set (pair-list overflow)
     float bound = 0.0f;
-    if (rows == 1 && hist_eligible<T>(row_len, OVP, x) && (!OVP || hist_outlier_bound(plan_host, gmax, bound))) {
+    if (rows == 1 && hist_eligible<T>(row_len, OVP, x, ncand) && (!OVP || hist_outlier_bound(plan_host, gmax, bound))) {
         HistTypes ht;
         memset(&ht, 0, sizeof(ht));
         ht.ntypes = 1;
@@ -224,7 +231,7 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) return ANTQ_ERR_UNSUPPORTED;
     if (!per_row) { row_len = rows * row_len; rows = 1; }
     const int *run_if = nullptr;
-    if (rows == 1 && hist_eligible<T>(row_len, OVP, x)) {
+    if (rows == 1 && hist_eligible<T>(row_len, OVP, x, ntypes * ncand)) {
         HistTypes ht;
         memset(&ht, 0, sizeof(ht));
         ht.ntypes = ntypes;

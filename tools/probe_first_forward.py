@@ -12,12 +12,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from transformers import BertConfig, BertModel  # noqa: E402
 
-from ant_quantization_amd.ant import quant_model as qm, quant_utils as qu  # noqa: E402
+TREE = os.environ.get("ANTQ_TREE", "ant")              # ant | olive
+import importlib  # noqa: E402
+qm = importlib.import_module("ant_quantization_amd.%s.quant_model" % TREE)
+qu = importlib.import_module("ant_quantization_amd.%s.quant_utils" % TREE)
 
 dev = torch.device("cuda:0")
 mode = sys.argv[1] if len(sys.argv) > 1 else "flint"
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(sys.argv[2] if len(sys.argv) > 2 else "", torch.float32)     # model dtype
-args = types.SimpleNamespace(mode=mode, wbit=4, abit=4, w_up=150, a_up=150, w_low=75, a_low=75, percent=100, search=False)
+args = types.SimpleNamespace(mode=mode, wbit=4, abit=4, w_up=150 if TREE == "ant" else 250, a_up=150 if TREE == "ant" else 250, w_low=75, a_low=75,
+                             percent=100, search=False, no_outlier=False)
 qu.set_quantizer(args)
 if "ANTQ_HIST" in os.environ:                      # knob 14: 0 = the direct clip-search kernels only, 2 = the histogram path wherever eligible
     from ant_quantization_amd import _lib as _l
@@ -61,7 +65,7 @@ for rep in range(2):
         sys.stdout = sys.__stdout__
         if rep == 1:
             pr.disable()
-        print("mode %s %s: first forward %.1f ms%s" % (mode, str(DT)[6:], (time.perf_counter() - t0) * 1e3, " (under cProfile)" if rep else ""))
+        print("%s mode %s %s: first forward %.1f ms%s" % (TREE, mode, str(DT)[6:], (time.perf_counter() - t0) * 1e3, " (under cProfile)" if rep else ""))
         t0 = time.perf_counter()
         model(ids); torch.cuda.synchronize()
         print("   second forward %.1f ms" % ((time.perf_counter() - t0) * 1e3))
