@@ -557,7 +557,7 @@ def alpha_grad(x, out, gout, rows, row_len, per_row=True):
     return gsum
 
 
-_workspaces = {}            # (device index, raw stream) -> scratch of antq_search_workspace_bytes() (32.25 MiB); launches on one stream are ordered, so they may share it
+_workspaces = {}            # (device index, raw stream) -> scratch of antq_search_workspace_bytes() (40.3 MiB); launches on one stream are ordered, so they may share it
 
 
 def _workspace(device):
@@ -571,7 +571,7 @@ def _workspace(device):
         with _lock:
             ws = _workspaces.get(key)
             if ws is None:
-                if len(_workspaces) >= 16:           # streams come and go: do not grow without bound (32 MiB each)
+                if len(_workspaces) >= 16:           # streams come and go: do not grow without bound (40 MiB each)
                     _workspaces.clear()
                 ws = _workspaces[key] = torch.empty(int(lib().antq_search_workspace_bytes()), dtype=torch.uint8, device=device)
     return ws
