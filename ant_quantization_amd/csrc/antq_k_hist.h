@@ -160,20 +160,30 @@ k_hist_reduce(const uint32_t *__restrict__ slabs, uint32_t G, uint32_t *__restri
 }
 
 struct HistTypes {
-    const float *grid[4];      // device pointers: m floats each (the plan blob's copy of the grid)
-    int m[4];
+    PlanArgs pa[4];            // the codebooks' plans: the d-domain table decides where it is valid (same value as the scan,
+    const uint4 *plan_tab[4];  //   proven by the plan builder's self-check and every kernel's parity tests), the literal scan elsewhere
     float gmax[4];
     int ntypes;
 };
 
-// the literal reference sequence for one pattern: q (before any pair rule) and the term of the element's own output
+// the reference sequence for one pattern: q (before any pair rule) and the term of the element's own output.  The nearest
+// grid value of d comes from the plan's table where d lies inside its domain (one LDS read instead of an m-step scan whose
+// every step waits for the previous one: the scoring kernel is latency-bound), from the literal scan otherwise.
 template <typename T>
-__device__ __forceinline__ float hist_term(uint32_t p, const Scale &sc, const float *g, int m, float &q)
+__device__ __forceinline__ float hist_term(uint32_t p, const Scale &sc, const PlanArgs &pa, const PlanLds &L, float &q)
 {
     const float xv = H16<T>::val(p);
     const float d = xv / sc.s;                   // AQ:541 / OQ:299
-    int jj;
-    q = scan_lds(d, g, m, jj);                   // quant_kernel.cu:25-37
+    if (pa.kind == kPlanLut && fabsf(d) < pa.fastlim) {          // false for NaN / Inf / beyond the table's domain
+        const float dd[1] = {d};
+        float qq[1];
+        int jj[1];
+        lut_lookup<1, false>(pa, L, dd, qq, jj);
+        q = qq[0];
+    } else {
+        int jj;
+        q = scan_lds(d, L.grid, (int)pa.m, jj);  // quant_kernel.cu:25-37
+    }
     const float tt = (q - d) + d;                // AQ:547 / OQ:323
     const float df = fabsf(tt * sc.s - xv);      // AQ:549, :282
     return df * df;
@@ -186,13 +196,15 @@ __global__ void __launch_bounds__(1024)
 k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax, const float *__restrict__ ratios, int ncand,
              HistTypes ht, double *__restrict__ sse, HistPairs hp, uint32_t n_seg)
 {
-    __shared__ float g[ANTQ_MAX_GRID];
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];     // the codebook's plan table (stage_plan)
     __shared__ double part[16];
     __shared__ uint32_t thr[4];                          // per sign: smallest / largest magnitude pattern that quantises to an outlier
     if (PAIRS && (hp.flags[0] & 1)) return;              // the pair list overflowed: the direct kernels behind us do the search
     const int f = (int)blockIdx.x, t = f / ncand, c = f - t * ncand;
-    const int m = ht.m[t];
-    for (int i = (int)threadIdx.x; i < m; i += 1024) g[i] = ht.grid[t][i];
+    const PlanArgs pa = ht.pa[t];
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = ht.plan_tab[t][threadIdx.x];
+    const PlanLds L = stage_plan(pa, ht.plan_tab[t], smem, tab0);
     if (threadIdx.x < 4) thr[threadIdx.x] = threadIdx.x < 2 ? 0xffffffffu : 0u;
     __syncthreads();
     const float a = xmax[0] * ratios[c];                 // AQ:300  new_alpha = base_alpha * fl32(i * 0.01)
@@ -204,7 +216,7 @@ k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax,
         if (__ballot(n != 0u) == 0ull) continue;         // (whole exponent ranges no element of the tensor lies in)
         if (n != 0u) {
             float q;
-            const float term = hist_term<T>(p, sc, g, m, q);
+            const float term = hist_term<T>(p, sc, pa, L, q);
             acc += (double)n * (double)term;
             if (PAIRS && fabsf(q) > 32.0f) {                                            // OQ:314
                 atomicMin(&thr[p >> 15], p & 0x7fffu);
@@ -234,7 +246,7 @@ k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax,
                 if (me || mo) {
                     const uint32_t v = me ? po : pe;
                     float q;
-                    const float term = hist_term<T>(v, sc, g, m, q);
+                    const float term = hist_term<T>(v, sc, pa, L, q);
                     const float xv = H16<T>::val(v);
                     corr += (double)(xv * xv) - (double)term;           // a victim's output is 0: its term is fl32(|0 - x|^2)
                 }

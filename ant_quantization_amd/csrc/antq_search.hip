@@ -28,11 +28,11 @@ static bool hist_eligible(size_t n, bool ovp, const void *x, int nflat)
     if (g_knob_hist == 0 || (ovp && g_knob_hist == 3) || n % 8 != 0 || n >= ((size_t)1 << 31) || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
     if (g_knob_hist == 2) return true;
     // With the pair rule every candidate also walks the list of outlier-capable pairs (~1 % of the pairs of a 3-sigma-clipped
-    // tensor) and the direct kernels are enqueued behind as gated no-ops: it pays from ~1e9 element x candidate evaluations
-    // (25 M elements x 176: 1.63 -> 0.37 ms; 1 M x 176: 0.102 -> 0.114 ms; profiles/r05_hist_search.log).  Those sums are equal
-    // to rounding across call forms anyway (the list depends on the codebooks searched together), so the rule may look at the
-    // candidate count; without the pair rule it must not (see above).
-    if (ovp) return n >= ((size_t)1 << 22) && (double)n * (double)nflat >= 1.0e9;
+    // tensor) and the direct kernels are enqueued behind as gated no-ops: it pays from ~3e8 element x candidate evaluations
+    // (25 M elements x 176: 1.63 -> 0.21 ms; 8 M x 176: 0.57 -> 0.19; 1 M x 176: 0.100 -> 0.083; profiles/r05_hist_search.log).
+    // Those sums are equal to rounding across call forms anyway (the list depends on the codebooks searched together), so the
+    // rule may look at the candidate count; without the pair rule it must not (see above).
+    if (ovp) return n >= ((size_t)1 << 21) && (double)n * (double)nflat >= 3.0e8;
     return n >= ((size_t)1 << 20);
 }
 // OliVe's pair rule: a lower bound (in units of gmax) of the smallest |d| that quantises to an outlier, from the plan's
@@ -71,16 +71,18 @@ static int launch_hist_search(const void *x, size_t n, const float *xmax, const 
         hp.seg_count = reinterpret_cast<uint32_t *>(w + kHistSegCountOff);
         hp.flags = reinterpret_cast<int *>(w + kHistFlagsOff);
         const unsigned nflat = (unsigned)(ht.ntypes * ncand);
+        size_t lds = 0;
+        for (int t = 0; t < ht.ntypes; t++) lds = std::max(lds, (size_t)ht.pa[t].tab_units * 16);
         if (pairs) {
             hipLaunchKernelGGL(k_hist_clear_flags, dim3(1), dim3(64), 0, st, hp.flags);
             hipLaunchKernelGGL((k_hist16<T, true>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp);
             hipLaunchKernelGGL(k_hist_reduce, dim3(256), dim3(256), 0, st, slabs, G, count);
-            hipLaunchKernelGGL((k_hist_score<T, true>), dim3(nflat), dim3(1024), 0, st, count, xmax, ratios, ncand, ht, sse, hp, G * 16u);
+            hipLaunchKernelGGL((k_hist_score<T, true>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp, G * 16u);
             *run_if = hp.flags;                  // non-zero iff a segment of the pair list overflowed
         } else {
             hipLaunchKernelGGL((k_hist16<T, false>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp);
             hipLaunchKernelGGL(k_hist_reduce, dim3(256), dim3(256), 0, st, slabs, G, count);
-            hipLaunchKernelGGL((k_hist_score<T, false>), dim3(nflat), dim3(1024), 0, st, count, xmax, ratios, ncand, ht, sse, hp, 0u);
+            hipLaunchKernelGGL((k_hist_score<T, false>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp, 0u);
         }
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }
@@ -181,8 +183,8 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
         HistTypes ht;
         memset(&ht, 0, sizeof(ht));
         ht.ntypes = 1;
-        ht.grid[0] = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev));
-        ht.m[0] = (int)pa.m;
+        ht.pa[0] = pa;
+        ht.plan_tab[0] = plan_tab_ptr(plan_dev);
         ht.gmax[0] = gmax;
         const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st);
         if (rc != ANTQ_OK || !OVP) return rc;
@@ -240,8 +242,8 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
         for (int t = 0; t < ntypes; t++) {
             PlanArgs pa;
             if (!plan_args_from_host(plan_host[t], pa)) return ANTQ_ERR_PLAN;
-            ht.grid[t] = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev[t]));
-            ht.m[t] = (int)pa.m;
+            ht.pa[t] = pa;
+            ht.plan_tab[t] = plan_tab_ptr(plan_dev[t]);
             ht.gmax[t] = gmax[t];
             float b = 0.0f;
             if (OVP) { ok = ok && hist_outlier_bound(plan_host[t], gmax[t], b); bound = std::min(bound, b); }
