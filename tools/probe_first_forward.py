@@ -69,4 +69,4 @@ for rep in range(2):
         t0 = time.perf_counter()
         model(ids); torch.cuda.synchronize()
         print("   second forward %.1f ms" % ((time.perf_counter() - t0) * 1e3))
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats(os.environ.get("ANTQ_SORT", "cumulative")).print_stats(45)
