@@ -95,7 +95,7 @@ class CalibrationMixin:
     * `mse`, the log value of the reference (AQ:519-520), is formed when somebody reads it.
     """
     _sign_probe = None
-    _calib_ready = None           # (weight key, spec, type, alpha, score, rows) from weight_bank.AutoBank.precalibrate
+    _calib_ready = None           # (weight key, spec, type pick (lazy), alpha [types, rows], score [types], rows) from weight_bank.AutoBank.precalibrate
     _calib_ctx = None             # the model's weight_bank.AutoBank (weight AND input quantisers): log order, deferred picks
     _pending = None               # (event, pinned slot, spec): a type pick made on the device, not yet known to the host
     _spec_out = None              # the calibrating forward's output of a quantiser whose pick is pending
@@ -118,7 +118,9 @@ class CalibrationMixin:
         ready, self._calib_ready = self._calib_ready, None
         if ready is not None and ready[0] == _lib_tensor_key(tensor) and self._hm_get('has_inited_quant_para') == 0:
             with torch.no_grad():
-                self._calib_apply(*ready[1:])
+                key, spec, pick, alpha, score, rows = ready
+                t = pick.get() if hasattr(pick, "get") else int(pick)       # (waits for the pick's own batch call only)
+                self._calib_apply(spec, t, alpha[t], score[t:t + 1], rows)
 
     def _emit(self, line):
         """The reference's calibration log line (`print(mode, end="\\t"); print("%d-bit \\t %s," ...)`), kept in the order the
