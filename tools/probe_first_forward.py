@@ -61,11 +61,13 @@ for rep in range(2):
             pr.enable()
         sys.stdout = open(os.devnull, "w")
         model(ids)
+        t_host = time.perf_counter()
         torch.cuda.synchronize()
         sys.stdout = sys.__stdout__
         if rep == 1:
             pr.disable()
-        print("%s mode %s %s: first forward %.1f ms%s" % (TREE, mode, str(DT)[6:], (time.perf_counter() - t0) * 1e3, " (under cProfile)" if rep else ""))
+        print("%s mode %s %s: first forward %.1f ms%s (host returned after %.1f ms: the rest is the GPU finishing)" % (
+            TREE, mode, str(DT)[6:], (time.perf_counter() - t0) * 1e3, " (under cProfile)" if rep else "", (t_host - t0) * 1e3))
         t0 = time.perf_counter()
         model(ids); torch.cuda.synchronize()
         print("   second forward %.1f ms" % ((time.perf_counter() - t0) * 1e3))
