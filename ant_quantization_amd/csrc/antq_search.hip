@@ -194,11 +194,18 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     // vectors per lane and task: the per-candidate work of a task that does not depend on its size (the row table for this
     // scale, ~60 instructions incl. the exact f64 threshold moves; the scale's division; the 64-lane sum of the squared
     // errors) is shared by twice the elements with 8 (tools/probe_search.py); short rows keep 4 (fewer idle lanes)
-    const int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : ((vpr >= 512 && EPL == 4) ? 8 : 4);   // (16-bit: 4 measured faster)
+    int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : ((vpr >= 512 && EPL == 4) ? 8 : 4);   // (16-bit: 4 measured faster)
+    // Short rows (round 5): a row of 96 vectors (768 bf16 elements: 60 of BERT-base's 72 Linear weights) in a 4-vector task
+    // leaves 62 % of the lane slots idle; rows of at most 128 / 64 vectors take 2 / 1 vectors per lane (per-row searches
+    // only; knob 0 = 4 restores the 4-vector tasks for an A/B)
+    const bool pt = rows == 1;
+    if (!pt && vpr < kRowKernelMinVpr) {             // (below 128 vectors there is no per-row x-domain table: `xd` is false)
+        if (g_knob_u == 0) U = vpr <= 64 ? 1 : 2;
+        else if (g_knob_u == 1 || g_knob_u == 2) U = g_knob_u;
+    }
     const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
-    const bool pt = rows == 1;
     // per tensor: tasks over all wavefronts; per row: one wavefront per row (it walks the row's tasks in order)
     const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
     const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr;
@@ -216,6 +223,7 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     } while (0)
 #define ANTQ_LAUNCH_SU(PT_, XD_) do { if (U == 8) ANTQ_LAUNCH_S(PT_, XD_, 8); else ANTQ_LAUNCH_S(PT_, XD_, 4); } while (0)
     if (pt) { if (xd) ANTQ_LAUNCH_SU(true, true); else ANTQ_LAUNCH_SU(true, false); }
+    else if (U <= 2) { if (U == 2) ANTQ_LAUNCH_S(false, false, 2); else ANTQ_LAUNCH_S(false, false, 1); }
     else    { if (xd) ANTQ_LAUNCH_SU(false, true); else ANTQ_LAUNCH_SU(false, false); }
 #undef ANTQ_LAUNCH_SU
 #undef ANTQ_LAUNCH_S

@@ -27,6 +27,9 @@ def main():
                                         ("4096x4096 bf16 per row", (4096, 4096), torch.bfloat16, True),
                                         ("4096x4096 fp32 per tensor", (4096, 4096), torch.float32, False),
                                         ("3072x768 fp32 per row", (3072, 768), torch.float32, True),
+                                        ("768x768 bf16 per row", (768, 768), torch.bfloat16, True),
+                                        ("3072x768 bf16 per row", (3072, 768), torch.bfloat16, True),
+                                        ("512x576 bf16 per row (conv 3x3x64)", (512, 576), torch.bfloat16, True),
                                         ("768x3072 fp32 per row", (768, 3072), torch.float32, True),
                                         ("16384x4096 bf16 per row", (16384, 4096), torch.bfloat16, True)):
         x = (torch.randn(*shape, device=dev) * 0.02).to(dtype)
@@ -35,7 +38,7 @@ def main():
         xm = _lib.absmax(x, rows, K, per_row=per_row)
         n = x.numel()
         t1 = timed(lambda: _lib.search_sse(x, r_, k_, xm, per_row, ratios, plans[1], 10.0), 5)
-        t3 = timed(lambda: _lib.search_sse_multi(x, r_, k_, xm, per_row, ratios, plans, gm), 5)
+        t3 = timed(lambda: _lib.search_sse_multi(x, r_, k_, xm, per_row, ratios, plans, gm), 5) if K * x.element_size() >= 2048 else float("nan")
         tc = timed(lambda: _lib.calibrate(x, rows, K, per_row, plans, gm, 75, 145, 1), 5)
         print("%-28s one type %7.1f G/s (%6.3f ms)   three types, one read %7.1f G/s (%6.3f ms)   antq_calibrate %6.3f ms" % (
             name, n * nc / t1 / 1e9, t1 * 1e3, 3 * n * nc / t3 / 1e9, t3 * 1e3, tc * 1e3), flush=True)
