@@ -14,6 +14,8 @@
 
 namespace antq {
 
+constexpr unsigned kSearchMinVpr = 64;      // rows of at least this many vectors: x-domain search kernels, single-read type selection
+
 // ---- the histogram path (antq_k_hist.h): 16-bit tensors with ONE scale and no pair rule --------------------------------
 // Worth it once the direct kernels' n x (types x candidates) evaluations outweigh the fixed cost of the three launches (the
 // 65 536 x types x candidates literal evaluations of the scoring kernel and the slabs: ~50 us).  Measured break-even
@@ -199,16 +201,15 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     // leaves 62 % of the lane slots idle; rows of at most 128 / 64 vectors take 2 / 1 vectors per lane (per-row searches
     // only; knob 0 = 4 restores the 4-vector tasks for an A/B)
     const bool pt = rows == 1;
-    if (!pt && vpr < kRowKernelMinVpr) {             // (below 128 vectors there is no per-row x-domain table: `xd` is false)
-        if (g_knob_u == 0) U = vpr <= 64 ? 1 : 2;
-        else if (g_knob_u == 1 || g_knob_u == 2) U = g_knob_u;
-    }
+    if (!pt && vpr < kRowKernelMinVpr && g_knob_u == 0) U = vpr < kSearchMinVpr ? 1 : 2;
     const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
     // per tensor: tasks over all wavefronts; per row: one wavefront per row (it walks the row's tasks in order)
     const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
-    const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kRowKernelMinVpr;
+    // (the per-candidate x-domain table from 64 vectors per row on -- the fake-quant row kernels want 128: their table is
+    //  built once per task, this one once per task AND candidate, but it replaces ~8 instructions per element and candidate)
+    const bool xd = (g_knob_x != 0) && pa.kind == kPlanLut && ph->xdom && vpr >= kSearchMinVpr && (pt || U != 1);
     const XArgs xa = xargs_from_plan(plan_host, pa);
     const uint4 *xv = static_cast<const uint4 *>(x);
     SearchGrid sg{0, 0, 0};
@@ -223,7 +224,8 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
     } while (0)
 #define ANTQ_LAUNCH_SU(PT_, XD_) do { if (U == 8) ANTQ_LAUNCH_S(PT_, XD_, 8); else ANTQ_LAUNCH_S(PT_, XD_, 4); } while (0)
     if (pt) { if (xd) ANTQ_LAUNCH_SU(true, true); else ANTQ_LAUNCH_SU(true, false); }
-    else if (U <= 2) { if (U == 2) ANTQ_LAUNCH_S(false, false, 2); else ANTQ_LAUNCH_S(false, false, 1); }
+    else if (U == 2) { if (xd) ANTQ_LAUNCH_S(false, true, 2); else ANTQ_LAUNCH_S(false, false, 2); }
+    else if (U == 1) ANTQ_LAUNCH_S(false, false, 1);
     else    { if (xd) ANTQ_LAUNCH_SU(false, true); else ANTQ_LAUNCH_SU(false, false); }
 #undef ANTQ_LAUNCH_SU
 #undef ANTQ_LAUNCH_S
@@ -262,7 +264,7 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
         }
     }
     const size_t vpr = row_len / EPL;
-    if (vpr < kRowKernelMinVpr || vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
+    if (vpr < kSearchMinVpr || vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
     MultiArgs ma;
     memset(&ma, 0, sizeof(ma));
     ma.ntypes = ntypes;
@@ -278,11 +280,12 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
         ma.gmax[t] = gmax[t];
     }
     // (as in launch_search; 16-bit data stays at 4: with 8 the kernel needs 169 registers -- 2 waves per SIMD instead of 3)
-    const int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : ((vpr >= 512 && EPL == 4) ? 8 : 4);
+    int U = (g_knob_u == 4 || g_knob_u == 8) ? g_knob_u : ((vpr >= 512 && EPL == 4) ? 8 : 4);
+    const bool pt = rows == 1;
+    if (!pt && vpr < kRowKernelMinVpr && g_knob_u == 0) U = 2;          // (as in launch_search: the same sums as one search per type)
     const size_t tpr = (vpr + 64 * U - 1) / (64 * U);
     const size_t total = rows * tpr;
     if (total > 0xfffffff0ull) return ANTQ_ERR_UNSUPPORTED;
-    const bool pt = rows == 1;
     const int nflat = ntypes * ncand;
     const uint4 *xv = static_cast<const uint4 *>(x);
     SearchGrid sg{0, 0, 0};
@@ -298,7 +301,7 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
         if (U == 8) ANTQ_LAUNCH_M(true, 8); else ANTQ_LAUNCH_M(true, 4);
         hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nflat), dim3(256), 0, st, ws, (uint32_t)sg.blocks, sg.chunk, sse, run_if);
     } else {
-        if (U == 8) ANTQ_LAUNCH_M(false, 8); else ANTQ_LAUNCH_M(false, 4);
+        if (U == 8) ANTQ_LAUNCH_M(false, 8); else if (U == 2) ANTQ_LAUNCH_M(false, 2); else ANTQ_LAUNCH_M(false, 4);
     }
 #undef ANTQ_LAUNCH_M
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;

@@ -250,7 +250,7 @@ int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
  *     sse[t, c, r]  = sum_col ( fl32|fakequant_t(x; xmax[r] * ratios[c])[r,col] - x[r,col]| )^2
  * sse_dev: [ntypes, ncand, rows] doubles (per_row) or [ntypes, ncand], not initialised; workspace_dev as for
  * antq_search_sse (same order-fixed sums).  gmax_host, plan_host, plan_dev: host arrays of ntypes entries.  Every plan must have the x-domain path (all ANT / OliVe codebooks up to 128
- * buckets) and rows must be whole 16-byte vectors, at least 128 of them (2 KiB): otherwise ANTQ_ERR_UNSUPPORTED and the
+ * buckets) and rows must be whole 16-byte vectors, at least 64 of them (1 KiB): otherwise ANTQ_ERR_UNSUPPORTED and the
  * caller issues one antq_search_sse per type. */
 int antq_search_sse_multi(const void *x_dev, size_t rows, size_t row_len, const float *xmax_dev, int per_row,
                           const float *ratios_dev, int ncand, int ntypes, const float *gmax_host,

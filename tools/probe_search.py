@@ -38,7 +38,7 @@ def main():
         xm = _lib.absmax(x, rows, K, per_row=per_row)
         n = x.numel()
         t1 = timed(lambda: _lib.search_sse(x, r_, k_, xm, per_row, ratios, plans[1], 10.0), 5)
-        t3 = timed(lambda: _lib.search_sse_multi(x, r_, k_, xm, per_row, ratios, plans, gm), 5) if K * x.element_size() >= 2048 else float("nan")
+        t3 = timed(lambda: _lib.search_sse_multi(x, r_, k_, xm, per_row, ratios, plans, gm), 5) if K * x.element_size() >= 1024 else float("nan")
         tc = timed(lambda: _lib.calibrate(x, rows, K, per_row, plans, gm, 75, 145, 1), 5)
         print("%-28s one type %7.1f G/s (%6.3f ms)   three types, one read %7.1f G/s (%6.3f ms)   antq_calibrate %6.3f ms" % (
             name, n * nc / t1 / 1e9, t1 * 1e3, 3 * n * nc / t3 / 1e9, t3 * 1e3, tc * 1e3), flush=True)
