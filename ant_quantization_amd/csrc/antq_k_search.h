@@ -388,12 +388,18 @@ k_search_sse_scalar(const void *__restrict__ x, size_t rows, size_t row_len, con
 // over its lanes (a lane walks c = lane, lane + 64, ... in ascending order), then a lexicographic minimum over the lanes.
 // (One thread per row walked 76 dependent f64 divisions: 18-26 us for a per-tensor quantiser, 150 times per BERT-base
 //  calibration pass.)
+// blockIdx.y: the candidate type (antq_calibrate picks for all its types in one launch: sse / best_score / best_alpha of type t
+// start t * type_stride_sse / t * na further on; the single-type entry point launches with gridDim.y = 1)
 static __global__ void __launch_bounds__(256)
 k_search_pick(const double *__restrict__ sse, const float *__restrict__ xmax, const float *__restrict__ ratios,
-              int ncand, size_t na, double row_len, float *__restrict__ best_score, float *__restrict__ best_alpha)
+              int ncand, size_t na, double row_len, float *__restrict__ best_score, float *__restrict__ best_alpha,
+              size_t type_stride_sse = 0)
 {
     const size_t r = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (r >= na) return;
+    sse += (size_t)blockIdx.y * type_stride_sse;
+    best_score += (size_t)blockIdx.y * na;
+    best_alpha += (size_t)blockIdx.y * na;
     const int lane = (int)(threadIdx.x & 63u);
     float best = 1e10f;
     int bc = 0x7fffffff;
@@ -431,35 +437,43 @@ k_calib_none(const float *__restrict__ xmax, size_t na, int ntypes, float *__res
     for (int t = 0; t < ntypes; t++) { best_score[(size_t)t * na + r] = 1e10f; alpha[(size_t)t * na + r] = xmax[r]; }
 }
 
-// score of a type = the sum of its rows' best MSE (search_mse returns best_score.sum(), AQ:326): one workgroup per type,
-// double accumulators, one fixed order (thread-strided partials, then a tree over the 256 threads)
+// score of a type = the sum of its rows' best MSE (search_mse returns best_score.sum(), AQ:326): double accumulators, one fixed
+// order (thread-strided partials, then a tree over the 256 threads); then the type with the smallest score, the first one on
+// ties, NaN last (np.argsort(mse)[0], AQ:413-415).  One workgroup walks the types one after the other (round 5: one launch
+// instead of two; the same additions in the same order as before).
 static __global__ void __launch_bounds__(256)
-k_calib_type_score(const float *__restrict__ best_score, size_t na, float *__restrict__ score)
+k_calib_type_score_pick(const float *__restrict__ best_score, size_t na, int ntypes, float *__restrict__ score, int32_t *__restrict__ type)
 {
     __shared__ double part[256];
-    const float *p = best_score + (size_t)blockIdx.x * na;
-    double s = 0.0;
-    for (size_t r = threadIdx.x; r < na; r += 256u) s += (double)p[r];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t w = 128u; w > 0u; w >>= 1) {
-        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __shared__ float sc[64];
+    for (int t = 0; t < ntypes; t++) {
+        const float *p = best_score + (size_t)t * na;
+        double s = 0.0;
+        for (size_t r = threadIdx.x; r < na; r += 256u) s += (double)p[r];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (uint32_t w = 128u; w > 0u; w >>= 1) {
+            if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float v = (float)part[0];
+            score[t] = v;
+            if (t < 64) sc[t] = v;
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) score[blockIdx.x] = (float)part[0];
-}
-
-// the type with the smallest score, the first one on ties, NaN last (np.argsort(mse)[0], AQ:413-415)
-static __global__ void k_calib_type_pick(const float *__restrict__ score, int ntypes, int32_t *__restrict__ type)
-{
-    int best = 0;
-    bool have = false;
-    for (int t = 0; t < ntypes; t++) {
-        const float v = score[t];
-        if (v != v) continue;
-        if (!have || v < score[best]) { best = t; have = true; }
+    if (threadIdx.x == 0) {
+        int best = 0;
+        bool have = false;
+        for (int t = 0; t < ntypes; t++) {
+            const float v = t < 64 ? sc[t] : score[t];
+            if (v != v) continue;
+            const float b = best < 64 ? sc[best] : score[best];
+            if (!have || v < b) { best = t; have = true; }
+        }
+        type[0] = best;
     }
-    type[0] = best;
 }
 
 }  // namespace antq

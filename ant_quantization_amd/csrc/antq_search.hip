@@ -467,16 +467,14 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
             }
             if (rc != ANTQ_OK) return rc;
         }
-        // 3. per row: the first strict minimum (AQ:299-306)
-        for (int t = 0; t < ntypes; t++) {
-            rc = antq_search_pick(sse + (size_t)t * per_type, xmax, ratios, ncand, na, n_per, best + (size_t)t * na,
-                                  alpha + (size_t)t * na, stream);
-            if (rc != ANTQ_OK) return rc;
-        }
+        // 3. per row: the first strict minimum (AQ:299-306), every type in one launch (blockIdx.y)
+        const size_t pblocks = (na + 3) / 4;
+        if (pblocks > 0x7fffffffull || ntypes > 65535) return ANTQ_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(k_search_pick, dim3((unsigned)pblocks, (unsigned)ntypes), dim3(256), 0, st, sse, xmax, ratios, ncand, na,
+                           (double)n_per, best, alpha, per_type);
     }
     // 4. per tensor: the type with the smallest sum of best MSEs (AQ:326, :413-415)
-    hipLaunchKernelGGL(k_calib_type_score, dim3((unsigned)ntypes), dim3(256), 0, st, best, na, score);
-    hipLaunchKernelGGL(k_calib_type_pick, dim3(1), dim3(1), 0, st, score, ntypes, type);
+    hipLaunchKernelGGL(k_calib_type_score_pick, dim3(1), dim3(256), 0, st, best, na, ntypes, score, type);
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
