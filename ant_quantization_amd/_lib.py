@@ -557,7 +557,7 @@ def alpha_grad(x, out, gout, rows, row_len, per_row=True):
     return gsum
 
 
-_workspaces = {}            # (device index, raw stream) -> scratch of antq_search_workspace_bytes() (40.3 MiB); launches on one stream are ordered, so they may share it
+_workspaces = {}            # (device index, raw stream) -> scratch of antq_search_workspace_bytes() (48.3 MiB); launches on one stream are ordered, so they may share it
 
 
 def _workspace(device):

@@ -51,9 +51,10 @@ constexpr uint32_t kHistSegCap = 1024;           // pair words per wavefront seg
 constexpr size_t kHistSlabsBytes = 2 * (size_t)kHistMaxG * kHistSlabBytes;
 constexpr size_t kHistCountOff = kHistSlabsBytes;                                   // count[65536]
 constexpr size_t kHistSegCountOff = kHistCountOff + 2 * kHistSlabBytes;             // seg_count[kHistMaxG * 16]
-constexpr size_t kHistFlagsOff = kHistSegCountOff + (size_t)kHistMaxG * 16 * 4;     // flags[64] (bit 0 of word 0: a segment overflowed)
+constexpr size_t kHistFlagsOff = kHistSegCountOff + (size_t)kHistMaxG * 16 * 4;     // flags[64] (bit 0 of word 0: a segment overflowed; word 1: length of list[])
 constexpr size_t kHistSegOff = kHistFlagsOff + 256;                                 // segments[kHistMaxG * 16][kHistSegCap]
-constexpr size_t kHistWorkspaceBytes = kHistSegOff + (size_t)kHistMaxG * 16 * kHistSegCap * 4;
+constexpr size_t kHistListOff = kHistSegOff + (size_t)kHistMaxG * 16 * kHistSegCap * 4;   // list[]: the segments, packed (k_hist_reduce)
+constexpr size_t kHistWorkspaceBytes = kHistListOff + (size_t)kHistMaxG * 16 * kHistSegCap * 4;
 
 // what the pair list needs to know (by value)
 struct HistPairs {
@@ -64,6 +65,7 @@ struct HistPairs {
     uint32_t *seg;             // [G * 16][kHistSegCap]
     uint32_t *seg_count;       // [G * 16]
     int *flags;
+    uint32_t *list;            // the segments one after the other (their order: the order of the scoring kernel's additions)
 };
 
 template <typename T, bool PAIRS>
@@ -148,15 +150,59 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
     for (uint32_t k = threadIdx.x; k < kHistBins / 4; k += 1024u) slab[k] = reinterpret_cast<const uint4 *>(bins)[k];
 }
 
-// count[sign * 32768 + b] = sum over the G slabs of that sign
-static __global__ void __launch_bounds__(256)
-k_hist_reduce(const uint32_t *__restrict__ slabs, uint32_t G, uint32_t *__restrict__ count)
+// count[sign * 32768 + b] = sum over the G slabs of that sign.  A workgroup owns 256 consecutive bins of one sign: every
+// wavefront adds a quarter of the slabs (16-byte loads, four bins per lane, eight in flight), lane-wise sums through LDS.
+// PAIRS: the workgroups also pack the pair list -- workgroup b copies segments [b * spw, (b + 1) * spw) behind the words of
+// all earlier segments (their counts summed by every workgroup for itself: at most 2048 integers), so the scoring kernel
+// walks ONE contiguous list with independent loads instead of 2048 short ones behind their counts.
+template <bool PAIRS>
+__global__ void __launch_bounds__(256)
+k_hist_reduce(const uint32_t *__restrict__ slabs, uint32_t G, uint32_t *__restrict__ count, HistPairs hp, uint32_t n_seg)
 {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;                      // 0 .. 65535
-    const uint32_t sign = p >> 15, b = p & 0x7fffu;
-    uint32_t s = 0;
-    for (uint32_t w = 0; w < G; w++) s += slabs[((size_t)(2u * w + sign)) * kHistBins + b];
-    count[p] = s;
+    __shared__ uint4 part[4][64];
+    __shared__ uint32_t pre[4];
+    const uint32_t sign = blockIdx.x >> 7, base = (blockIdx.x & 127u) * 256u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint4 *src = reinterpret_cast<const uint4 *>(slabs + (size_t)sign * kHistBins + base) + lane;
+    constexpr size_t kStep = 2 * (size_t)kHistBins / 4;                       // uint4s from slab (2w + sign) to slab (2(w + 1) + sign)
+    uint4 s = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t w = wv;
+    for (; w + 28u < G; w += 32u) {
+        uint4 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = src[(size_t)(w + 4u * k) * kStep];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s.x += a[k].x; s.y += a[k].y; s.z += a[k].z; s.w += a[k].w; }
+    }
+    for (; w < G; w += 4u) {
+        const uint4 a = src[(size_t)w * kStep];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    part[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0u) {
+        const uint4 b = part[1][lane], c = part[2][lane], d = part[3][lane];
+        s.x += b.x + c.x + d.x; s.y += b.y + c.y + d.y; s.z += b.z + c.z + d.z; s.w += b.w + c.w + d.w;
+        reinterpret_cast<uint4 *>(count + (size_t)sign * kHistBins + base)[lane] = s;
+    }
+    if (PAIRS) {
+        if (hp.flags[0] & 1) return;                     // overflow: the direct kernels do the search
+        const uint32_t spw = (n_seg + 255u) / 256u, first = min(blockIdx.x * spw, n_seg), last = min(first + spw, n_seg);
+        uint32_t o = 0;
+        for (uint32_t i = threadIdx.x; i < first; i += 256u) o += hp.seg_count[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
+        if (lane == 0u) pre[wv] = o;
+        __syncthreads();
+        o = pre[0] + pre[1] + pre[2] + pre[3];
+        for (uint32_t sg = first; sg < last; sg++) {
+            const uint32_t cnt = hp.seg_count[sg];
+            const uint32_t *sp = hp.seg + (size_t)sg * kHistSegCap;
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256u) hp.list[o + i] = sp[i];
+            o += cnt;
+        }
+        if (last == n_seg && first < n_seg && threadIdx.x == 0u) hp.flags[1] = (int)o;      // (the workgroup of the last segment)
+    }
 }
 
 struct HistTypes {
@@ -190,11 +236,11 @@ __device__ __forceinline__ float hist_term(uint32_t p, const Scale &sc, const Pl
 }
 
 // sse[t * ncand + c] for one (t, c) per workgroup.  Terms in ascending pattern order per thread (p = tid, tid + 1024, ...),
-// then a fixed tree; PAIRS: the victims' corrections in the fixed order of the list's segments: the same bits on every run.
+// then a fixed tree; PAIRS: the victims' corrections in the fixed order of the packed list: the same bits on every run.
 template <typename T, bool PAIRS>
 __global__ void __launch_bounds__(1024)
 k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax, const float *__restrict__ ratios, int ncand,
-             HistTypes ht, double *__restrict__ sse, HistPairs hp, uint32_t n_seg)
+             HistTypes ht, double *__restrict__ sse, HistPairs hp)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];     // the codebook's plan table (stage_plan)
     __shared__ double part[16];
@@ -210,17 +256,24 @@ k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax,
     const float a = xmax[0] * ratios[c];                 // AQ:300  new_alpha = base_alpha * fl32(i * 0.01)
     const Scale sc = make_scale(a, ht.gmax[t]);
     double acc = 0.0;
+    // (eight counts in flight per lane: one at a time the loop was a chain of 64 L2 latencies, 22 us whatever the tensor)
 #pragma unroll 1
-    for (uint32_t p = threadIdx.x; p < 65536u; p += 1024u) {
-        const uint32_t n = count[p];
-        if (__ballot(n != 0u) == 0ull) continue;         // (whole exponent ranges no element of the tensor lies in)
-        if (n != 0u) {
-            float q;
-            const float term = hist_term<T>(p, sc, pa, L, q);
-            acc += (double)n * (double)term;
-            if (PAIRS && fabsf(q) > 32.0f) {                                            // OQ:314
-                atomicMin(&thr[p >> 15], p & 0x7fffu);
-                atomicMax(&thr[2u + (p >> 15)], p & 0x7fffu);
+    for (uint32_t p0 = threadIdx.x; p0 < 65536u; p0 += 8u * 1024u) {
+        uint32_t nn[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) nn[k] = count[p0 + 1024u * k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t p = p0 + 1024u * k, n = nn[k];
+            if (__ballot(n != 0u) == 0ull) continue;     // (whole exponent ranges no element of the tensor lies in)
+            if (n != 0u) {
+                float q;
+                const float term = hist_term<T>(p, sc, pa, L, q);
+                acc += (double)n * (double)term;
+                if (PAIRS && fabsf(q) > 32.0f) {                                        // OQ:314
+                    atomicMin(&thr[p >> 15], p & 0x7fffu);
+                    atomicMax(&thr[2u + (p >> 15)], p & 0x7fffu);
+                }
             }
         }
     }
@@ -229,28 +282,32 @@ k_hist_score(const uint32_t *__restrict__ count, const float *__restrict__ xmax,
         // (q is monotone in x up to the scan's horizon -- beyond it no entry lies within 102400 and q is 0 again: the
         //  outliers of a sign are the magnitudes in [lo, hi] among the patterns the tensor holds)
         const uint32_t lo0 = thr[0], lo1 = thr[1], hi0 = thr[2], hi1 = thr[3];
-        const uint32_t lane = threadIdx.x & 63u;
         double corr = 0.0;
-#pragma unroll 1
-        for (uint32_t sgi = threadIdx.x >> 6; sgi < n_seg; sgi += 16u) {
-            const uint32_t cnt = hp.seg_count[sgi];
-            const uint32_t *sp = hp.seg + (size_t)sgi * kHistSegCap;
-#pragma unroll 1
-            for (uint32_t i = lane; i < cnt; i += 64u) {
-                const uint32_t wd = sp[i], pe = wd & 0xffffu, po = wd >> 16;
-                const uint32_t ge = pe & 0x7fffu, go = po & 0x7fffu;
-                const bool me = (pe >> 15) ? (ge >= lo1 && ge <= hi1) : (ge >= lo0 && ge <= hi0);
-                const bool mo = (po >> 15) ? (go >= lo1 && go <= hi1) : (go >= lo0 && go <= hi0);
-                // OQ:313-320: the odd element is a victim when its even partner is an outlier; the even one when its odd
-                // partner is an outlier and it is not one itself
-                if (me || mo) {
-                    const uint32_t v = me ? po : pe;
-                    float q;
-                    const float term = hist_term<T>(v, sc, pa, L, q);
-                    const float xv = H16<T>::val(v);
-                    corr += (double)(xv * xv) - (double)term;           // a victim's output is 0: its term is fl32(|0 - x|^2)
-                }
+        auto victim = [&](uint32_t wd) {
+            const uint32_t pe = wd & 0xffffu, po = wd >> 16;
+            const uint32_t ge = pe & 0x7fffu, go = po & 0x7fffu;
+            const bool me = (pe >> 15) ? (ge >= lo1 && ge <= hi1) : (ge >= lo0 && ge <= hi0);
+            const bool mo = (po >> 15) ? (go >= lo1 && go <= hi1) : (go >= lo0 && go <= hi0);
+            // OQ:313-320: the odd element is a victim when its even partner is an outlier; the even one when its odd
+            // partner is an outlier and it is not one itself
+            if (me || mo) {
+                const uint32_t v = me ? po : pe;
+                float q;
+                const float term = hist_term<T>(v, sc, pa, L, q);
+                const float xv = H16<T>::val(v);
+                corr += (double)(xv * xv) - (double)term;           // a victim's output is 0: its term is fl32(|0 - x|^2)
             }
+        };
+        // the packed list, eight words in flight per lane; a lane's additions in list order
+        const uint32_t total = (uint32_t)hp.flags[1];
+#pragma unroll 1
+        for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 8u * 1024u) {
+            uint32_t wd[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) wd[k] = i0 + 1024u * k < total ? hp.list[i0 + 1024u * k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (i0 + 1024u * k < total) victim(wd[k]);
         }
         acc += corr;
     }

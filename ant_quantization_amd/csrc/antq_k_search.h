@@ -422,9 +422,10 @@ k_search_pick(const double *__restrict__ sse, const float *__restrict__ xmax, co
 
 // antq_calibrate's small steps.  The candidate ratios: fl32(i * 0.01), i * 0.01 evaluated in double as Python does (AQ:296).
 static __global__ void __launch_bounds__(256)
-k_calib_ratios(float *__restrict__ ratios, int lb, int step, int ncand)
+k_calib_ratios(float *__restrict__ ratios, int lb, int step, int ncand, float *__restrict__ zero = nullptr)
 {
     const int c = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (zero && c == 0) *zero = 0.0f;                // (the accumulator of a whole-tensor abs-max that follows: one launch less)
     if (c < ncand) ratios[c] = (float)((double)(lb + c * step) * 0.01);
 }
 

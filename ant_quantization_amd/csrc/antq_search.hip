@@ -18,8 +18,9 @@ constexpr unsigned kSearchMinVpr = 64;      // rows of at least this many vector
 
 // ---- the histogram path (antq_k_hist.h): 16-bit tensors with ONE scale and no pair rule --------------------------------
 // Worth it once the direct kernels' n x (types x candidates) evaluations outweigh the fixed cost of the three launches (the
-// 65 536 x types x candidates literal evaluations of the scoring kernel and the slabs: ~50 us).  Measured break-even
-// (profiles/r05_hist_search.log): 1 M elements (three types 0.111 -> 0.060 ms, one type 0.048 -> 0.055 ms).  The rule looks at
+// 65 536 x types x candidates literal evaluations of the scoring kernel and the slabs: ~30 us).  Measured
+// (profiles/r05_hist_search.log): 1 M elements three types 0.106 -> 0.035 ms, one type 0.046 -> 0.033 ms; 256 K elements
+// 0.043 -> 0.034 / 0.031 -> 0.033 ms.  The rule looks at
 // the element count ONLY: a tensor's sums must not depend on how many types are searched with it (the single-read type
 // selection and one search per type form the very same sums: test_calibration_sums_are_bit_reproducible).  knob 14 = 0
 // switches the path off, = 2 takes it for every eligible tensor (tests).
@@ -30,12 +31,12 @@ static bool hist_eligible(size_t n, bool ovp, const void *x, int nflat)
     if (g_knob_hist == 0 || (ovp && g_knob_hist == 3) || n % 8 != 0 || n >= ((size_t)1 << 31) || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
     if (g_knob_hist == 2) return true;
     // With the pair rule every candidate also walks the list of outlier-capable pairs (~1 % of the pairs of a 3-sigma-clipped
-    // tensor) and the direct kernels are enqueued behind as gated no-ops: it pays from ~3e8 element x candidate evaluations
-    // (25 M elements x 176: 1.63 -> 0.21 ms; 8 M x 176: 0.57 -> 0.19; 1 M x 176: 0.100 -> 0.083; profiles/r05_hist_search.log).
+    // tensor) and the direct kernels are enqueued behind as gated no-ops: it pays from ~1.5e8 element x candidate evaluations
+    // (25 M elements x 176: 1.63 -> 0.12 ms; 8 M x 176: 0.57 -> 0.10; 1 M x 176: 0.098 -> 0.057; profiles/r05_hist_search.log).
     // Those sums are equal to rounding across call forms anyway (the list depends on the codebooks searched together), so the
     // rule may look at the candidate count; without the pair rule it must not (see above).
-    if (ovp) return n >= ((size_t)1 << 21) && (double)n * (double)nflat >= 3.0e8;
-    return n >= ((size_t)1 << 20);
+    if (ovp) return n >= ((size_t)1 << 20) && (double)n * (double)nflat >= 1.5e8;
+    return n >= ((size_t)1 << 19);
 }
 // OliVe's pair rule: a lower bound (in units of gmax) of the smallest |d| that quantises to an outlier, from the plan's
 // threshold list (the thresholds between a normal value and an outlier, either sign).  false: the plan has no such list.
@@ -72,19 +73,20 @@ static int launch_hist_search(const void *x, size_t n, const float *xmax, const 
         hp.seg = reinterpret_cast<uint32_t *>(w + kHistSegOff);
         hp.seg_count = reinterpret_cast<uint32_t *>(w + kHistSegCountOff);
         hp.flags = reinterpret_cast<int *>(w + kHistFlagsOff);
+        hp.list = reinterpret_cast<uint32_t *>(w + kHistListOff);
         const unsigned nflat = (unsigned)(ht.ntypes * ncand);
         size_t lds = 0;
         for (int t = 0; t < ht.ntypes; t++) lds = std::max(lds, (size_t)ht.pa[t].tab_units * 16);
         if (pairs) {
             hipLaunchKernelGGL(k_hist_clear_flags, dim3(1), dim3(64), 0, st, hp.flags);
             hipLaunchKernelGGL((k_hist16<T, true>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp);
-            hipLaunchKernelGGL(k_hist_reduce, dim3(256), dim3(256), 0, st, slabs, G, count);
-            hipLaunchKernelGGL((k_hist_score<T, true>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp, G * 16u);
+            hipLaunchKernelGGL((k_hist_reduce<true>), dim3(256), dim3(256), 0, st, slabs, G, count, hp, G * 16u);
+            hipLaunchKernelGGL((k_hist_score<T, true>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp);
             *run_if = hp.flags;                  // non-zero iff a segment of the pair list overflowed
         } else {
             hipLaunchKernelGGL((k_hist16<T, false>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp);
-            hipLaunchKernelGGL(k_hist_reduce, dim3(256), dim3(256), 0, st, slabs, G, count);
-            hipLaunchKernelGGL((k_hist_score<T, false>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp, 0u);
+            hipLaunchKernelGGL((k_hist_reduce<false>), dim3(256), dim3(256), 0, st, slabs, G, count, hp, 0u);
+            hipLaunchKernelGGL((k_hist_score<T, false>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp);
         }
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }
@@ -438,7 +440,13 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
     const int pr = alpha_per_row ? 1 : 0;
     int rc = ANTQ_OK;
     // 1. the clip statistic: abs-max (ANT, AQ:289 / :308), mean +- 3 sigma (OliVe, OQ:193-197 / :213-218), or the caller's
-    if (xmax_mode == ANTQ_XMAX_ABSMAX) rc = antq_absmax(x, xmax, rows, row_len, pr, dtype, stream);
+    //    (the candidate ratios do not depend on the data: their kernel goes first and also zeroes the accumulator of a
+    //     whole-tensor abs-max)
+    float *const zero = (xmax_mode == ANTQ_XMAX_ABSMAX && !pr && ncand > 0) ? xmax : nullptr;
+    if (ncand > 0)
+        hipLaunchKernelGGL(k_calib_ratios, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ratios, lb, step, ncand, zero);
+    if (xmax_mode == ANTQ_XMAX_ABSMAX)
+        rc = zero ? antq_absmax_into(x, xmax, rows * row_len, dtype, stream) : antq_absmax(x, xmax, rows, row_len, pr, dtype, stream);
     else if (xmax_mode == ANTQ_XMAX_3SIGMA) {
         rc = antq_moments(x, rows, row_len, pr, dtype, sums, ws_search, stream);
         if (rc == ANTQ_OK) rc = antq_xmax_3sigma(sums, na, n_per, dtype, xmax, stream);
@@ -449,7 +457,6 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
     if (ncand == 0) {
         hipLaunchKernelGGL(k_calib_none, dim3(nab), dim3(256), 0, st, xmax, na, ntypes, best, alpha);
     } else {
-        hipLaunchKernelGGL(k_calib_ratios, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ratios, lb, step, ncand);
         // 2. sum of squared errors of every (type, candidate) per row: kMaxTypes types per read of the tensor where the
         //    single-read kernel applies, one read per type otherwise
         const size_t per_type = (size_t)ncand * na;

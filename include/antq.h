@@ -230,13 +230,13 @@ int antq_alpha_grad(const void *x_dev, const void *out_dev, const void *gout_dev
  * antq_search_workspace_bytes() bytes of device memory owned by the caller, not
  * shared with a call running concurrently on another stream; contents are
  * scratch (no initialisation).  May be NULL for per_row with rows > 1.
- * A bf16 / f16 tensor with ONE scale (per_row == 0 or rows == 1) and at least 2^20 elements is scored on its 65 536-bin
+ * A bf16 / f16 tensor with ONE scale (per_row == 0 or rows == 1) and at least 2^19 elements (2^20 with ANTQ_FLAG_OVP) is scored on its 65 536-bin
  * histogram (one pass counts the bit patterns, then every pattern with a non-zero count goes through the literal reference
  * sequence for every candidate: count x term, summed in double in one fixed order): the same terms as the element-by-element
  * kernels, added in another order (relative 1e-7 on a sum).  With ANTQ_FLAG_OVP the pass also lists the pairs that hold an
  * outlier-capable element and the scoring corrects the victims' terms from that list; a tensor with too many such pairs
  * (> ~8 %) is searched by the element-by-element kernels instead (decided on the device, no synchronisation).  The workspace
- * holds the slabs and the list: always size it with antq_search_workspace_bytes() (40.3 MiB since ABI 6; 8 MiB before).
+ * holds the slabs and the list: always size it with antq_search_workspace_bytes() (48.3 MiB since ABI 6; 8 MiB before).
  * ------------------------------------------------------------------------- */
 size_t antq_search_workspace_bytes(void);
 int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
