@@ -860,3 +860,51 @@ def test_histogram_clip_search_with_outlier_victim_pairs(antq_lib, oracle, dev):
         assert np.array_equal(over1.view(np.uint64), direct1.view(np.uint64))
     finally:
         knob(14, 1)
+
+
+@pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_graph_replay_after_a_weight_change_with_the_bank_refreshed_outside(antq_lib, dev, tree):
+    """a graph captured on clean resident weights holds no weight launch; after a weight change ONE
+    `bank.refresh()` outside the graph (the resident buffers keep their addresses) makes the replay equal to the eager
+    forward of the changed model -- which the reference's cache-nothing schedule (AQ:613-617) would compute."""
+    import torch
+    import torch.nn as nn
+    qmod, qutil = _trees(tree)
+    qutil.set_quantizer(_args(mode="flint", wbit=4, abit=4))
+    torch.manual_seed(3)
+    net = nn.Sequential(nn.Linear(128, 256), nn.GELU(), nn.Linear(256, 256), nn.GELU(), nn.Linear(256, 32))
+    model = qmod.quantize_model(net).to(dev).eval()
+    qutil.enable_quantization(model)
+    static_x = torch.randn(32, 128, device=dev)
+    with torch.no_grad():
+        model(static_x)                                  # calibration
+        model(static_x)                                  # the bank attaches and fills
+    bank = model._antq_auto_bank.bank
+    assert bank is not None and bank.launches == 1
+    addrs = [e["out"].data_ptr() for e in bank.entries.values()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        model(static_x)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        static_y = model(static_x)
+    assert bank.launches == 1                            # nothing launched for the weights inside the capture
+    for step in range(3):
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() == 2:
+                    p.mul_(1.0 + 0.05 * (step + 1))      # a weight update between two replays
+        bank.refresh()                                   # one launch, outside the graph
+        assert [e["out"].data_ptr() for e in bank.entries.values()] == addrs
+        xn = torch.randn(32, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(step))
+        static_x.copy_(xn)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref_model = copy.deepcopy(model)                 # (a copy starts without a bank; the graph's bank stays attached)
+        qutil.set_weight_bank(ref_model, False)          # the reference's schedule: every layer re-quantises its weight
+        with torch.no_grad():
+            ref = ref_model(xn)
+        assert torch.equal(static_y, ref), (tree, step)
+        assert model._antq_auto_bank.bank is bank
