@@ -31,6 +31,7 @@ extern thread_local int g_knob_rot;            // 1: rotate the workgroup -> tas
 extern thread_local int g_knob_lane_u;        // vectors per lane of the one-launch-per-tensor lane kernel: 0 = default (A/B)
 extern thread_local int g_knob_h;             // 0 disables the 16-bit-domain row kernels (antq_k_hrow.h; A/B measurements)
 extern thread_local int g_knob_hist;          // clip search of 16-bit per-tensor quantisers on the tensor's histogram: 0 off, 1 when it pays, 2 always (tests)
+extern thread_local int g_knob_hist_xmax;     // antq_calibrate: the abs-max statistic of a histogram-searched tensor from the counting pass (1) or from its own pass (0)
 extern thread_local int g_knob_exp;           // experiment switch of the kernel under development (A/B; 0 = off)
 extern thread_local int g_knob_schunks;       // clip search: candidate-list chunks (blockIdx.y) forced to this many (A/B; 0 = cost model)
 extern thread_local int g_knob_dlds;          // extra dynamic LDS bytes of the d-domain batched kernels' workgroups (occupancy A/B)

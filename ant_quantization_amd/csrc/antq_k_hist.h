@@ -68,11 +68,17 @@ struct HistPairs {
     uint32_t *list;            // the segments one after the other (their order: the order of the scoring kernel's additions)
 };
 
-template <typename T, bool PAIRS>
+// XM: the tensor's abs-max on the way (antq_calibrate with the abs-max statistic: the separate pass over the tensor is not
+// run) -- the non-negative workgroups keep the packed maximum of the 16-bit magnitudes they read and close with one
+// atomicMax on the bits of the value as a float (non-negative floats order like unsigned integers, NaN above Inf: the very
+// value k_absmax leaves, which folds the same converted patterns); *xmax_out is zeroed ahead of the launch.
+template <typename T, bool PAIRS, bool XM = false>
 __global__ void __launch_bounds__(1024)
-k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restrict__ slabs, HistPairs hp)
+k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restrict__ slabs, HistPairs hp, float *__restrict__ xmax_out = nullptr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t bins[kHistBins];        // 128 KiB, static: one workgroup per CU
+    __shared__ uint32_t wmax[16];
+    uint32_t pkmax = 0;                                                      // XM: two 16-bit magnitude maxima
     const uint32_t sign = blockIdx.x & 1u, w = blockIdx.x >> 1;
     for (uint32_t i = threadIdx.x; i < kHistBins / 4; i += 1024u) reinterpret_cast<uint4 *>(bins)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
@@ -118,6 +124,7 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
         const uint32_t ws[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
 #pragma unroll
         for (int k = 0; k < 16; k++) { count(ws[k] & 0xffffu); count(ws[k] >> 16); }
+        if (XM && sign == 0u) pkmax = IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(IO<T>::amax_acc(pkmax, a0), a1), a2), a3);
         if (lister) {
 #pragma unroll
             for (int k = 0; k < 16; k++) list_pair(ws[k], true);
@@ -135,6 +142,7 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
             count(live ? (ws[k] & 0xffffu) : dead);
             count(live ? (ws[k] >> 16) : dead);
         }
+        if (XM && sign == 0u) pkmax = IO<T>::amax_acc(pkmax, a);             // (a lane past the end holds zeros)
         if (lister) {
 #pragma unroll
             for (int k = 0; k < 4; k++) list_pair(ws[k], live);
@@ -145,7 +153,19 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
         if (nseg > kHistSegCap) atomicOr(hp.flags, 1);
     }
     if ((threadIdx.x & 63u) == 0u && zeros) atomicAdd(&bins[0], zeros);
+    if (XM && sign == 0u) {
+        const uint32_t m = wave_max_u32(IO<T>::amax_bits(pkmax));            // (the bits of the maximum as a float)
+        if (lane == 0u) wmax[threadIdx.x >> 6] = m;
+    }
     __syncthreads();
+    if (XM && sign == 0u && threadIdx.x == 0u) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m = max(m, wmax[k]);
+        const uint32_t bits = m;
+        unsigned int *dst = reinterpret_cast<unsigned int *>(xmax_out);
+        if (bits && bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+    }
     uint4 *slab = reinterpret_cast<uint4 *>(slabs + (size_t)blockIdx.x * kHistBins);
     for (uint32_t k = threadIdx.x; k < kHistBins / 4; k += 1024u) slab[k] = reinterpret_cast<const uint4 *>(bins)[k];
 }

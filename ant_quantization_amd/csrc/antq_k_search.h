@@ -420,6 +420,52 @@ k_search_pick(const double *__restrict__ sse, const float *__restrict__ xmax, co
     }
 }
 
+// k_search_pick for every type + the type's score + the type pick in ONE launch when the tensor has ONE scale (na == 1: every
+// activation quantiser): wavefront w picks for types w, w + 4, ...; the score of a type with one row IS its row's best MSE
+// ((float)(double)best); then the first smallest score, NaN last.  Same comparisons, same results as the two kernels.
+static __global__ void __launch_bounds__(256)
+k_calib_pick_one_scale(const double *__restrict__ sse, const float *__restrict__ xmax, const float *__restrict__ ratios, int ncand,
+                       double row_len, int ntypes, float *__restrict__ best_score, float *__restrict__ best_alpha,
+                       float *__restrict__ score, int32_t *__restrict__ type)
+{
+    __shared__ float sc[64];
+    const int lane = (int)(threadIdx.x & 63u);
+    for (int t = (int)(threadIdx.x >> 6); t < ntypes; t += 4) {
+        const double *p = sse + (size_t)t * (size_t)ncand;
+        float best = 1e10f;
+        int bc = 0x7fffffff;
+        for (int c = lane; c < ncand; c += 64) {
+            const float s = (float)(p[c] / row_len);
+            if (s < best) { best = s; bc = c; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oc = __shfl_xor(bc, off, 64);
+            if (ob < best || (ob == best && oc < bc)) { best = ob; bc = oc; }
+        }
+        if (lane == 0) {
+            const float xm = xmax[0];
+            best_score[t] = best;
+            best_alpha[t] = bc == 0x7fffffff ? xm : xm * ratios[bc];
+            score[t] = best;
+            if (t < 64) sc[t] = best;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int bt = 0;
+        bool have = false;
+        for (int t = 0; t < ntypes; t++) {
+            const float v = t < 64 ? sc[t] : score[t];
+            if (v != v) continue;
+            const float b = bt < 64 ? sc[bt] : score[bt];
+            if (!have || v < b) { bt = t; have = true; }
+        }
+        type[0] = bt;
+    }
+}
+
 // antq_calibrate's small steps.  The candidate ratios: fl32(i * 0.01), i * 0.01 evaluated in double as Python does (AQ:296).
 static __global__ void __launch_bounds__(256)
 k_calib_ratios(float *__restrict__ ratios, int lb, int step, int ncand, float *__restrict__ zero = nullptr)

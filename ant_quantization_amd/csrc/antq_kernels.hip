@@ -45,6 +45,7 @@ thread_local int g_knob_dlds = -1;
 thread_local int g_knob_schunks = 0;
 thread_local int g_knob_exp = 0;
 thread_local int g_knob_hist = 1;
+thread_local int g_knob_hist_xmax = 1;
 
 }  // namespace antq
 
@@ -243,6 +244,7 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 12) g_knob_schunks = value;
     else if (key == 13) g_knob_exp = value;
     else if (key == 14) g_knob_hist = value;
+    else if (key == 15) g_knob_hist_xmax = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }

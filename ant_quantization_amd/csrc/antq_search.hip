@@ -56,6 +56,11 @@ static bool hist_outlier_bound(const void *plan_host, float gmax, float &bound)
 }
 // The histogram search.  pairs: with OliVe's pair rule; *run_if then receives the device flag the caller's direct launches
 // take as their run condition (set iff the pair list overflowed; the histogram kernels then wrote nothing).
+// antq_calibrate with the abs-max statistic on a tensor the histogram search will take (its own eligibility test, below):
+// the statistic's accumulator (zeroed, stream-ordered) that the counting pass has to fill -- the separate abs-max pass over
+// the tensor is not run.  Consumed by the first histogram search of the call; antq_calibrate fails loudly if nobody took it.
+static thread_local float *g_hist_xmax_out = nullptr;
+
 template <typename T>
 static int launch_hist_search(const void *x, size_t n, const float *xmax, const float *ratios, int ncand, const HistTypes &ht,
                               double *sse, void *ws, bool pairs, float tmin_over_gmax, const int **run_if, hipStream_t st)
@@ -79,12 +84,17 @@ static int launch_hist_search(const void *x, size_t n, const float *xmax, const 
         for (int t = 0; t < ht.ntypes; t++) lds = std::max(lds, (size_t)ht.pa[t].tab_units * 16);
         if (pairs) {
             hipLaunchKernelGGL(k_hist_clear_flags, dim3(1), dim3(64), 0, st, hp.flags);
-            hipLaunchKernelGGL((k_hist16<T, true>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp);
+            hipLaunchKernelGGL((k_hist16<T, true>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp, nullptr);
             hipLaunchKernelGGL((k_hist_reduce<true>), dim3(256), dim3(256), 0, st, slabs, G, count, hp, G * 16u);
             hipLaunchKernelGGL((k_hist_score<T, true>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp);
             *run_if = hp.flags;                  // non-zero iff a segment of the pair list overflowed
         } else {
-            hipLaunchKernelGGL((k_hist16<T, false>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp);
+            float *const xo = g_hist_xmax_out;
+            g_hist_xmax_out = nullptr;
+            if (xo)
+                hipLaunchKernelGGL((k_hist16<T, false, true>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp, xo);
+            else
+                hipLaunchKernelGGL((k_hist16<T, false>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp, nullptr);
             hipLaunchKernelGGL((k_hist_reduce<false>), dim3(256), dim3(256), 0, st, slabs, G, count, hp, 0u);
             hipLaunchKernelGGL((k_hist_score<T, false>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp);
         }
@@ -442,10 +452,19 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
     // 1. the clip statistic: abs-max (ANT, AQ:289 / :308), mean +- 3 sigma (OliVe, OQ:193-197 / :213-218), or the caller's
     //    (the candidate ratios do not depend on the data: their kernel goes first and also zeroes the accumulator of a
     //     whole-tensor abs-max)
-    float *const zero = (xmax_mode == ANTQ_XMAX_ABSMAX && !pr && ncand > 0) ? xmax : nullptr;
+    //    A 16-bit tensor with ONE scale that the histogram search will take gets its abs-max from the counting pass.
+    bool xmax_in_hist = false;
+    if (na == 1 && xmax_mode == ANTQ_XMAX_ABSMAX && !(flags & ANTQ_FLAG_OVP) && ncand > 0 && g_knob_hist_xmax)
+        xmax_in_hist = dtype == ANTQ_BF16 ? hist_eligible<bf16_tag>(n_per, false, x, 0)
+                     : dtype == ANTQ_F16  ? hist_eligible<f16_tag>(n_per, false, x, 0) : false;
+    struct Pending {                               // (whatever way this call ends, nothing stays handed over)
+        ~Pending() { g_hist_xmax_out = nullptr; }
+    } pending_guard;
+    float *const zero = (xmax_mode == ANTQ_XMAX_ABSMAX && ncand > 0 && (!pr || xmax_in_hist)) ? xmax : nullptr;
     if (ncand > 0)
         hipLaunchKernelGGL(k_calib_ratios, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ratios, lb, step, ncand, zero);
-    if (xmax_mode == ANTQ_XMAX_ABSMAX)
+    if (xmax_in_hist) g_hist_xmax_out = xmax;
+    else if (xmax_mode == ANTQ_XMAX_ABSMAX)
         rc = zero ? antq_absmax_into(x, xmax, rows * row_len, dtype, stream) : antq_absmax(x, xmax, rows, row_len, pr, dtype, stream);
     else if (xmax_mode == ANTQ_XMAX_3SIGMA) {
         rc = antq_moments(x, rows, row_len, pr, dtype, sums, ws_search, stream);
@@ -473,6 +492,13 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
                 }
             }
             if (rc != ANTQ_OK) return rc;
+        }
+        if (g_hist_xmax_out) return ANTQ_ERR_LAUNCH;     // (the histogram search did not run although its own rule said it would)
+        if (na == 1) {
+            // 3 + 4 for a tensor with one scale: picks, scores and the type pick in one launch
+            hipLaunchKernelGGL(k_calib_pick_one_scale, dim3(1), dim3(256), 0, st, sse, xmax, ratios, ncand, (double)n_per, ntypes, best,
+                               alpha, score, type);
+            return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
         }
         // 3. per row: the first strict minimum (AQ:299-306), every type in one launch (blockIdx.y)
         const size_t pblocks = (na + 3) / 4;

@@ -434,6 +434,8 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
  *   key 14: the histogram clip search of 16-bit tensors with one scale (antq_search_sse / _multi / antq_calibrate, no pair
  *           rule, or OliVe's pairs through a list of the outlier-capable pairs): 0 off, 1 (default) when the tensor is large
  *           enough for it to pay, 2 for every eligible tensor, 3 as 1 but never with the pair rule
+ *   key 15: antq_calibrate with the abs-max statistic on a tensor the histogram search takes: 1 (default) the counting pass
+ *           also finds the maximum (no separate abs-max pass), 0 the abs-max pass runs as everywhere else (A/B; same value)
  *   key 13: experiment switch of the kernel under development (0 = off; 1: the 16-bit-domain encoder's 8-vector tasks store
  *           their codes nontemporally instead of through the cache) */
 int antq_debug_set(int key, int value);

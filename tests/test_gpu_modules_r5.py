@@ -908,3 +908,72 @@ def test_graph_replay_after_a_weight_change_with_the_bank_refreshed_outside(antq
             ref = ref_model(xn)
         assert torch.equal(static_y, ref), (tree, step)
         assert model._antq_auto_bank.bank is bank
+
+
+def test_calibrate_one_scale_absmax_from_the_counting_pass_and_one_pick_launch(antq_lib, dev):
+    """antq_calibrate of a tensor with ONE scale (every activation quantiser, AQ:308 / :328-415): (a) on the histogram path
+    the abs-max statistic comes out of the counting pass (knob 15 = 1, the default) -- same x_max, alphas, scores and type,
+    bit for bit, as with the separate abs-max pass (knob 15 = 0), whatever the length (whole chunks, ragged tails, less than
+    one chunk), sign mix and special values (Inf, NaN: x_max NaN like torch.max); (b) the per-type pick, the type's score and
+    the type pick share one launch: equal to antq_search_pick per type on the same sums and to argsort(score)[0] (first
+    minimum, NaN last) -- for fp32 tensors (direct kernels) as well."""
+    import torch
+    from ant_quantization_amd import grids
+    knob = antq_lib.lib().antq_debug_set
+    rng = np.random.default_rng(17)
+    plans = [antq_lib.plan_for(grids.ant_grid(t, 4, True)) for t in ("int", "flint", "pot")]
+    gm = [10.0] * 3
+    lb, ub = 75, 150
+    ratios = torch.from_numpy(np.asarray([np.float32(i * 0.01) for i in range(lb, ub)], dtype=np.float32)).to(dev)
+
+    def bits(t):
+        return t.contiguous().view(torch.int32).cpu().numpy()
+
+    cases = [("normal", 8 * (1024 * 16 * 4 * 2 + 1024 * 5 + 77), 0), ("relu", 8 * (1024 * 16 * 4 + 3), 1), ("tiny", 8 * 300, 0),
+             ("negative", 8 * 1024 * 70, 2), ("inf", 8 * (1024 * 33 + 1), 3), ("nan", 8 * (1024 * 9 + 5), 4), ("big", 1 << 23, 0),
+             ("max in the last lane", 8 * (1024 * 16 + 1), 5)]
+    try:
+        for tdt in (torch.bfloat16, torch.float16, torch.float32):
+            for cname, n, kind in cases:
+                x = (rng.standard_normal(n) * 0.7).astype(np.float32)
+                if kind == 1:
+                    x = np.maximum(x, 0.0)
+                elif kind == 2:
+                    x = -np.abs(x) - 0.01
+                elif kind == 3:
+                    x[rng.integers(0, n, 3)] = np.inf
+                elif kind == 4:
+                    x[rng.integers(0, n, 2)] = np.nan
+                    x[7] = np.inf
+                elif kind == 5:
+                    x[-1] = -37.5                        # the maximum sits in the ragged tail, negative
+                xt = torch.from_numpy(x).to(dev).to(tdt)
+                res = {}
+                for k15 in (0, 1):
+                    knob(14, 2)                          # the histogram path for every eligible tensor (16-bit ones)
+                    knob(15, k15)
+                    res[k15] = antq_lib.calibrate(xt, 1, n, False, plans, gm, lb, ub, 1)
+                a0, s0, t0, m0 = res[0]
+                a1, s1, t1, m1 = res[1]
+                tag = (str(tdt), cname)
+                assert np.array_equal(bits(m0), bits(m1)), tag
+                assert np.array_equal(bits(a0), bits(a1)) and np.array_equal(bits(s0), bits(s1)) and int(t0) == int(t1), tag
+                ref = xt.float().abs().max()
+                if kind == 4:
+                    assert bool(torch.isnan(m1).all()), tag
+                else:
+                    assert float(m1) == float(ref), tag
+                # (b) the pick launch against the public per-type pick on the same sums
+                sse = antq_lib.search_sse_multi(xt, 1, n, m1, False, ratios, plans, gm)          # [types, candidates]
+                sc = []
+                for t in range(3):
+                    best, al = antq_lib.search_pick(sse[t].reshape(-1, 1).contiguous(), m1, ratios, n)
+                    assert np.array_equal(bits(best), bits(s1[t:t + 1])), (tag, t)
+                    assert np.array_equal(bits(al), bits(a1[t])), (tag, t)
+                    sc.append(float(best))
+                order = [t for t in range(3) if sc[t] == sc[t]]
+                want = min(order, key=lambda t: sc[t]) if order else 0
+                assert int(t1) == want, (tag, sc, int(t1))
+    finally:
+        knob(14, 1)
+        knob(15, 1)
