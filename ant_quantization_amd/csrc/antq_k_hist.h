@@ -79,7 +79,10 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
     __shared__ __attribute__((aligned(16))) uint32_t bins[kHistBins];        // 128 KiB, static: one workgroup per CU
     __shared__ uint32_t wmax[16];
     uint32_t pkmax = 0;                                                      // XM: two 16-bit magnitude maxima
-    const uint32_t sign = blockIdx.x & 1u, w = blockIdx.x >> 1;
+    // The two workgroups of a chunk stream (one per sign) sit 8 apart in the grid: workgroup b runs on XCD b mod 8, so both read
+    // through the SAME L2 and the tensor leaves HBM once (neighbours 2w / 2w + 1 sat on different XCDs: 2.0 x the tensor's
+    // bytes fetched, profiles/r05_pmc_hist.txt).  G is a multiple of 8.
+    const uint32_t sign = (blockIdx.x >> 3) & 1u, w = ((blockIdx.x >> 4) << 3) + (blockIdx.x & 7u);
     for (uint32_t i = threadIdx.x; i < kHistBins / 4; i += 1024u) reinterpret_cast<uint4 *>(bins)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     uint32_t zeros = 0;                                                      // this wavefront's count of the zero pattern (lane 0)
@@ -88,6 +91,9 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
     // 0 -- everything qualifies, the segments overflow, the direct kernels take over
     uint32_t theta = 0xffffffffu, nseg = 0;
     const uint32_t lane = threadIdx.x & 63u;
+    // (the lister falls behind its partner, whose lines have left the L2 by then: 1.9 x the tensor fetched with the pair rule.
+    //  Splitting the listing between the two -- 1.0 x -- measured 3-6 % SLOWER: the pass is VALU-bound with the list,
+    //  profiles/r05_hist_split_listing.patch)
     const bool lister = PAIRS && sign == 0u;
     uint32_t *myseg = nullptr;
     if (lister) {
@@ -166,7 +172,7 @@ k_hist16(const uint4 *__restrict__ x, size_t nv, uint32_t G, uint32_t *__restric
         unsigned int *dst = reinterpret_cast<unsigned int *>(xmax_out);
         if (bits && bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
     }
-    uint4 *slab = reinterpret_cast<uint4 *>(slabs + (size_t)blockIdx.x * kHistBins);
+    uint4 *slab = reinterpret_cast<uint4 *>(slabs + (size_t)(2u * w + sign) * kHistBins);
     for (uint32_t k = threadIdx.x; k < kHistBins / 4; k += 1024u) slab[k] = reinterpret_cast<const uint4 *>(bins)[k];
 }
 

@@ -70,6 +70,7 @@ static int launch_hist_search(const void *x, size_t n, const float *xmax, const 
     } else {
         const size_t nv = n / 8;
         uint32_t G = (uint32_t)std::min<size_t>(std::max<size_t>(n / 65536, 16), (size_t)kHistMaxG);
+        G = (G + 7u) & ~7u;                          // (k_hist16's workgroup -> (chunk stream, sign) map works in groups of 16)
         char *w = static_cast<char *>(ws);
         uint32_t *slabs = reinterpret_cast<uint32_t *>(w);
         uint32_t *count = reinterpret_cast<uint32_t *>(w + kHistCountOff);

@@ -69,7 +69,16 @@ def main():
     runs.append(lambda: _lib.search_sse(act, 1, act.numel(), am, False, ratios, flint, 10.0))            # per-tensor (PT)
     act16 = act.to(torch.bfloat16)                                                                       # round 5: the histogram path
     am16 = core.row_absmax(act16, False)
-    runs.append(lambda: _lib.search_sse_multi(act16, 1, act16.numel(), am16, False, ratios, plans, [10.0] * 3))      # k_hist16 / _reduce / _score
+    hist = [lambda: _lib.search_sse_multi(act16, 1, act16.numel(), am16, False, ratios, plans, [10.0] * 3)]         # k_hist16 / _reduce / _score
+    hist.append(lambda: _lib.calibrate(act16, 1, act16.numel(), False, plans, [10.0] * 3, 75, 150, 1))                # k_hist16<.,false,true>: abs-max on the way
+    op = [_lib.plan_for(np.concatenate([grids.olive_grid(t, 4, True), grids.olive_outliers(4, True)])) for t in ("int", "flint")]
+    ogm = [float(grids.olive_grid(t, 4, True).max()) for t in ("int", "flint")]
+    xo = torch.randn(64 * 128 * 3072, device=dev) * 0.05
+    mo = torch.rand(xo.numel(), device=dev) < 0.003
+    xo[mo] *= torch.empty(int(mo.sum()), device=dev).uniform_(8, 60)
+    xo = xo.to(torch.bfloat16)
+    hist.append(lambda: _lib.calibrate(xo, 1, xo.numel(), False, op, ogm, 75, 250, 2, xmax="3sigma", ovp=True))       # the pair-rule variants
+    runs += hist
     # packed 4-bit codec (fp32 and bf16, OliVe pairs)
     gn = grids.olive_flint(4, True).size
     codec = []
@@ -83,6 +92,8 @@ def main():
     runs += codec
     if os.environ.get("ANTQ_TARGETS") == "codec":
         runs = codec
+    if os.environ.get("ANTQ_TARGETS") == "hist":
+        runs = hist
     for r in runs:
         for _ in range(REPS):
             r()
