@@ -881,3 +881,36 @@ class Batch:
                 _check(rc, "antq_fakequant_batch")
         for x, out, alpha, plan, gmax, rows, row_len, per_row in self.singles:
             fakequant(x, alpha, plan, gmax, rows, row_len, per_row, ovp=self.ovp, out=out)
+
+    def kernels(self):
+        """The launches run() issues, read off the descriptor header the library built (csrc/antq_k_batch.h BatchHeader,
+        the dispatch of antq_fakequant_batch in csrc/antq_batch.hip): [(kernel name, workgroups)], + one entry per single.
+        For reports (bench.py config.configs[].kernel) -- nothing on the launch path reads it."""
+        out = []
+        if self.host is not None:
+            h = self.host[:80].view(np.uint32)
+            fam, pad = [int(v) for v in h[8:17]], int(h[17])
+            t = {F32: "float", BF16: "bf16", F16: "f16"}[self.dtype]
+            o = "true" if self.ovp else "false"
+            dyn = "true" if int(h[3]) & FLAG_DYNAMIC else "false"
+            if pad & 1:
+                out.append(("antq::k_fq_batch_all<%s,%s>" % (t, o), fam[0]))
+            elif fam[0]:
+                w = 1 if ((pad >> 8) & 7) == 1 else 4
+                out.append(("antq::k_fq_batch<%s,%s,%d>" % (t, o, w), fam[0] * (4 // w)))
+            if fam[5]:
+                out.append(("antq::k_fq_hbatch<%s,%s>" % (t, o), fam[5] * 4))
+            for f, v in ((6, 1), (7, 4), (8, 16)):
+                if fam[f] and not (pad & 1):
+                    out.append(("antq::k_fq_hbatch_dyn<%s,%s,%d>" % (t, o, v), fam[f]))
+            if not (pad & 1):
+                if fam[1]:
+                    out.append(("antq::k_fq_batch_d<%s,%s,true,%s>" % (t, o, dyn), fam[1]))
+                if fam[2]:
+                    out.append(("antq::k_fq_batch_d<%s,%s,false,%s>" % (t, o, dyn), fam[2]))
+                if fam[3]:
+                    out.append(("antq::k_fq_batch_dyn<%s,%s>" % (t, o), fam[3]))
+                if fam[4]:
+                    out.append(("antq::k_fq_batch_dyn16<%s,%s>" % (t, o), fam[4]))
+        out += [("antq_fakequant (own launch)", 0)] * len(self.singles)
+        return out

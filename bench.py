@@ -257,12 +257,14 @@ def cpu_baseline_torch(seconds_budget=6.0):
 # ------------------------------------------------------------------------------------------------
 # HBM traffic of the dominant kernel, measured (rank 0, N = 1): two rocprofv3 --pmc child runs of this very file
 # ------------------------------------------------------------------------------------------------
-def measure_traffic(nbuf, kernel_substr="k_fq_hbatch", timeout_s=240, child_args=()):
+def measure_traffic(nbuf, kernels=("k_fq_hbatch",), timeout_s=240, child_args=()):
     """FETCH_SIZE and WRITE_SIZE of the batched kernel, one counter per pass as MI355X_MICROARCH.md's HBM section
     prescribes (`rocprofv3 --pmc <C> --kernel-trace`, nothing else), each pass a child `bench.py --traffic-child` that
     builds the same workload and issues 3 launches.  Units and the gfx950 correction as in that guide: both counters are
     KiB; FETCH_SIZE tallies the 128-byte requests of 16 B / lane streaming reads at 64 B and is doubled.
-    Returns (bytes per launch, note) or (None, why not)."""
+    `kernels`: regular expressions, one per kernel of interest (the child may launch several: the headline child also
+    runs the OliVe twin of the batch); Returns ({pattern: bytes per launch}, {pattern: note}) or (None, why not)."""
+    import re
     import csv
     import glob
     import shutil
@@ -286,22 +288,24 @@ def measure_traffic(nbuf, kernel_substr="k_fq_hbatch", timeout_s=240, child_args
                    os.path.abspath(__file__), "--traffic-child", "--nbuf", str(nbuf)] + list(child_args)
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            got = []
-            for f in files:
-                for row in csv.DictReader(open(f)):
-                    if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                        got.append(float(row["Counter_Value"]))
-            if not got:
-                return None, "rocprofv3 --pmc %s gave no row for %s (rc %d)" % (counter, kernel_substr, r.returncode)
-            vals[counter] = sum(got) / len(got)
+            rows = [row for f in files for row in csv.DictReader(open(f)) if row.get("Counter_Name") == counter]
+            for pat in kernels:
+                got = [float(row["Counter_Value"]) for row in rows if re.search(pat, row.get("Kernel_Name", ""))]
+                if not got:
+                    return None, "rocprofv3 --pmc %s gave no row for %s (rc %d)" % (counter, pat, r.returncode)
+                vals[(pat, counter)] = sum(got) / len(got)
         except Exception as ex:           # noqa: BLE001  (a missing profiler must not cost the bench its line)
             return None, "rocprofv3 --pmc %s failed: %r" % (counter, ex)
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    total = int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0))
-    return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child passes of `bench.py "
-                   "--traffic-child`, 3 launches each; FETCH_SIZE %.1f KiB x 2 per the guide's gfx950 correction + WRITE_SIZE "
-                   "%.1f KiB)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+    total, notes = {}, {}
+    for pat in kernels:
+        fs, ws = vals[(pat, "FETCH_SIZE")], vals[(pat, "WRITE_SIZE")]
+        total[pat] = int(round((2.0 * fs + ws) * 1024.0))
+        notes[pat] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child passes of `bench.py "
+                      "--traffic-child`, 3 launches each; FETCH_SIZE %.1f KiB x 2 per the guide's gfx950 correction + WRITE_SIZE "
+                      "%.1f KiB)" % (fs, ws))
+    return total, notes
 
 
 # ------------------------------------------------------------------------------------------------
@@ -447,6 +451,189 @@ def build_model(args, h, _lib, grids):
                 keep=(ws, outs, alphas, batch, dst))
 
 
+# ------------------------------------------------------------------------------------------------
+# config.configs[]: the OliVe twin of the headline + every BASELINE config, each event-timed on its own after the
+# headline's timed region (rank 0, N = 1).  Everything resident before its timing starts; HIP events on the launch stream.
+# ------------------------------------------------------------------------------------------------
+def plant_outliers(torch, w, gen, every=1000):
+    """SURVEY 8d C3/C4 distribution: 0.1 % of the entries multiplied by U(8, 64) -- one entry in every run of `every`
+    consecutive flat elements, at a random offset inside the run (distinct positions, no mask pass over the tensor)."""
+    flat = w.view(-1)
+    k = flat.numel() // every
+    if k == 0:
+        return
+    idx = torch.arange(k, device=w.device) * every + torch.randint(0, every, (k,), device=w.device, generator=gen)
+    f = torch.empty(k, device=w.device, dtype=torch.float32).uniform_(8, 64, generator=gen)
+    flat[idx] = (flat[idx].float() * f).to(w.dtype)
+
+
+def build_headline_olive(torch, dev, _lib, olive_plan, nbuf):
+    """The OliVe twin of the headline batch: nbuf x [4096,4096] bf16, randn * 0.02 with 0.1 % of the entries multiplied by
+    U(8, 64), alpha = max|mean +- 3 std| per row (OQ:193-197); ONE batched launch with the pair rule (OQ:311-320)."""
+    gen = torch.Generator(device=dev).manual_seed(60)
+    xs = torch.empty(nbuf, ROWS, COLS, dtype=torch.bfloat16, device=dev)
+    os_ = torch.empty_like(xs)
+    al = []
+    for i in range(nbuf):
+        xs[i] = (torch.randn(ROWS, COLS, device=dev, generator=gen) * 0.02).to(torch.bfloat16)
+        plant_outliers(torch, xs[i], gen)
+        al.append(_lib.xmax_3sigma(xs[i], ROWS, COLS, per_row=True))
+    bt = _lib.Batch([(xs[i], os_[i], al[i], olive_plan, 32.0, ROWS, COLS, True) for i in range(nbuf)], ovp=True)
+    return xs, os_, al, bt
+
+
+def resnet50_shapes():
+    """The 54 weight tensors of torchvision's ResNet-50 (53 convolutions + fc), SURVEY 8a / Appendix C: 25 502 912 elements."""
+    s, inp = [(64, 3, 7, 7)], 64
+    for planes, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
+        for b in range(blocks):
+            s += [(planes, inp, 1, 1), (planes, planes, 3, 3), (planes * 4, planes, 1, 1)]
+            if b == 0:
+                s.append((planes * 4, inp, 1, 1))
+            inp = planes * 4
+    return s + [(1000, 2048)]
+
+
+def bert_base_shapes():
+    """The 74 Linear weights of BERT-base (12 x {q, k, v, out, fc1, fc2} + pooler + classifier): 85.5 M elements."""
+    return ([(768, 768)] * 4 + [(3072, 768), (768, 3072)]) * 12 + [(768, 768), (2, 768)]
+
+
+def run_configs(h, _lib, grids, want):
+    """-> list of entries {name, what, kernel, launches_per_pass, elements, bytes_per_elem, launch_us (= one pass),
+    gelem_per_s, achieved_GBps, frac}.  `want`: names to run (None = all)."""
+    import numpy as np
+    from ant_quantization_amd import sharding
+    torch, dev = h.torch, h.dev
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = []
+
+    def timed(fn):
+        """Seconds per pass at steady clocks: >= 40 ms of warm-up passes, then >= 40 ms (and >= 10) timed passes."""
+        fn()
+        torch.cuda.synchronize()
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        once = max(e0.elapsed_time(e1) * 1e-3, 1e-6)
+        for _ in range(min(5000, int(0.04 / once) + 1)):
+            fn()
+        reps = max(10, min(5000, int(0.04 / once) + 1))
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps, reps
+
+    def entry(name, what, kernels, elems, bpe, fn, **extra):
+        secs, reps = timed(fn)
+        e = {"name": name, "what": what, "kernel": " + ".join(k for k, _ in kernels), "launches_per_pass": len(kernels),
+             "grid": [g for _, g in kernels], "elements": int(elems), "bytes_per_elem": bpe, "timed_passes": reps,
+             "launch_us": round(secs * 1e6, 2), "gelem_per_s": round(elems / secs / 1e9, 1),
+             "achieved_GBps": round(elems * bpe / secs / 1e9, 1), "algorithmic_bytes": int(elems * bpe),
+             "frac": round(elems * bpe / secs / 1e9 / HBM_PEAK_GBPS, 4)}
+        e.update(extra)
+        out.append(e)
+        return e
+
+    def on(name):
+        return want is None or name in want
+
+    flint = _lib.plan_for(grids.ant_flint(4, True))
+    gn, go = grids.olive_flint(4, True), grids.olive_outliers(4, True)
+    olive = _lib.plan_for(np.concatenate([gn, go]))
+
+    # (i) the headline batch through the OliVe outlier-victim kernel (OQ:294-330)
+    if on("headline_olive"):
+        xs, os_, al, bt = build_headline_olive(torch, dev, _lib, olive, 32)
+        e = entry("headline_olive", "the headline batch (32 x [4096,4096] bf16) through the OliVe path: 4-bit flint + abfloat outliers, "
+                  "outlier-victim pairs, 0.1 % planted outliers (x U(8,64)), alpha = 3 sigma per row; ONE batched launch",
+                  bt.kernels(), 32 * ROWS * COLS, 4, bt.run)
+        o0 = os_[0].clone()
+        e["idempotence_check"] = bool(torch.equal(_lib.fakequant(o0, al[0], olive, 32.0, ROWS, COLS, True, ovp=True), o0))
+        s0 = (al[0] / 32.0).view(-1, 1)
+        e["outlier_frac_of_output"] = round(float((os_[0].float().abs() > s0 * 40.0).float().mean()), 6)
+        e["victim_frac_of_output"] = round(float(((os_[0] == 0) & (xs[0].float().abs() > s0)).float().mean()), 6)
+        del xs, os_, al, bt, o0
+
+    # (ii) configs[1]: ResNet-50, all 54 weight tensors, ANT 4-bit flint, per-channel and group = 16, fp32, one batched launch
+    if on("C1"):
+        gen = torch.Generator(device=dev).manual_seed(1)
+        ws = [torch.randn(*s, device=dev, generator=gen) * float(np.sqrt(2.0 / (s[0] * np.prod(s[2:], dtype=np.int64))))
+              for s in resnet50_shapes()]
+        outs = [torch.empty_like(w) for w in ws]
+        elems = sum(w.numel() for w in ws)
+        for nm, G in (("per-channel", 0), ("group-16", 16)):
+            jobs = []
+            for w, o in zip(ws, outs):
+                rows, K = (w.shape[0], w.numel() // w.shape[0]) if not G else (w.numel() // G, G)
+                jobs.append((w, o, _lib.absmax(w, rows, K), flint, 10.0, rows, K, True))
+            bt = _lib.Batch(jobs)
+            entry("C1_resnet50_%s_f32" % nm, "configs[1]: ResNet-50, 54 weight tensors (25.5 M elements), ANT 4-bit flint, %s scales "
+                  "(alpha = abs-max), fp32; ONE batched launch over all 54" % nm, bt.kernels(), elems, 8, bt.run)
+        del ws, outs, jobs, bt
+
+    # (iii) configs[2]: BERT-base, 74 Linear weights batched + the [64,128,3072] post-GELU activation per tensor; fp32 and bf16
+    if on("C2"):
+        for dt, bpe, tag in ((torch.float32, 8, "f32"), (torch.bfloat16, 4, "bf16")):
+            gen = torch.Generator(device=dev).manual_seed(2)
+            ws = [(torch.randn(*s, device=dev, generator=gen) * 0.02).to(dt) for s in bert_base_shapes()]
+            outs = [torch.empty_like(w) for w in ws]
+            bt = _lib.Batch([(w, o, _lib.absmax(w, w.shape[0], w.shape[1]), flint, 10.0, w.shape[0], w.shape[1], True)
+                             for w, o in zip(ws, outs)])
+            entry("C2_bert_weights_%s" % tag, "configs[2]: BERT-base, 74 Linear weights (85.5 M elements), steady state after the type "
+                  "pick (flint), per-channel alpha, %s; ONE batched launch" % tag, bt.kernels(), sum(w.numel() for w in ws), bpe, bt.run)
+            gen = torch.Generator(device=dev).manual_seed(3)
+            x = torch.nn.functional.gelu(torch.randn(64, 128, 3072, device=dev, generator=gen)).to(dt)
+            ax = _lib.absmax(x, 1, x.numel(), per_row=False)
+            ox = torch.empty_like(x)
+            entry("C2_bert_activation_%s" % tag, "configs[2]: the [64,128,3072] post-GELU activation (25.2 M elements), one scale "
+                  "for the tensor (signed flint after the sign flip), %s; one launch (antq_fakequant)" % tag,
+                  [("antq_fakequant, per tensor", 0)], x.numel(), bpe,
+                  lambda: _lib.fakequant(x, ax, flint, 10.0, 1, x.numel(), False, out=ox))
+            del ws, outs, bt, x, ox
+
+    # (iv) configs[3]: OPT-6.7B, rank 0's share of 8 (24 whole tensors by LPT), OliVe pairs, bf16 and fp32
+    if on("C3"):
+        mine = sharding.shard_plan("opt6.7b", 0, 8)
+        for dt, bpe, tag in ((torch.bfloat16, 4, "bf16"), (torch.float32, 8, "f32")):
+            gen = torch.Generator(device=dev).manual_seed(4)
+            ws = []
+            for _, b, e_, c in mine:
+                w = (torch.randn(e_ - b, c, device=dev, generator=gen) * 0.02).to(dt)
+                plant_outliers(torch, w, gen)
+                ws.append(w)
+            outs = [torch.empty_like(w) for w in ws]
+            al = [_lib.xmax_3sigma(w, w.shape[0], w.shape[1], per_row=True) for w in ws]
+            bt = _lib.Batch([(w, o, a, olive, 32.0, w.shape[0], w.shape[1], True) for w, o, a in zip(ws, outs, al)], ovp=True)
+            entry("C3_opt6.7b_rank0of8_%s" % tag, "configs[3]: OPT-6.7B, the 24 weight tensors rank 0 of 8 owns (LPT by bytes, 805 M "
+                  "elements), OliVe 4-bit flint + outliers, outlier-victim pairs, alpha = 3 sigma per row, %s; ONE batched launch" % tag,
+                  bt.kernels(), sum(w.numel() for w in ws), bpe, bt.run)
+            del ws, outs, al, bt
+
+    # (v) configs[4]: the 70 B-parameter bf16 stack, rank 0's row block of every matrix at 8 ranks (17.1 GB in, 17.1 GB out)
+    if on("C4"):
+        mine = sharding.shard_plan("llama70b", 0, 8)
+        gen = torch.Generator(device=dev).manual_seed(5)
+        ws = []
+        for _, b, e_, c in mine:
+            w = torch.randn(e_ - b, c, device=dev, dtype=torch.bfloat16, generator=gen) * 0.02
+            plant_outliers(torch, w, gen)
+            ws.append(w)
+        outs = [torch.empty_like(w) for w in ws]
+        al = [_lib.xmax_3sigma(w, w.shape[0], w.shape[1], per_row=True) for w in ws]
+        bt = _lib.Batch([(w, o, a, olive, 32.0, w.shape[0], w.shape[1], True) for w, o, a in zip(ws, outs, al)], ovp=True)
+        entry("C4_llama70b_rank0of8_bf16", "configs[4]: synthetic 70 B-parameter Linear stack, rank 0's row block of each of the 560 "
+              "matrices at 8 ranks (%.2f G elements, %.1f GB in + the same out, out of place), OliVe 4-bit flint + outliers, "
+              "outlier-victim pairs, alpha = 3 sigma per row, bf16; ONE batched launch"
+              % (sum(w.numel() for w in ws) / 1e9, sum(w.numel() for w in ws) * 2 / 1e9), bt.kernels(),
+              sum(w.numel() for w in ws), 4, bt.run)
+        del ws, outs, al, bt
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -461,6 +648,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic falls back "
                                                                "to the committed profiles/hbm_traffic.json value)")
+    ap.add_argument("--configs", default="all", help="headline workload at N = 1: which config.configs[] entries to time after "
+                                                     "the headline region: all | none | comma list of headline_olive,C1,C2,C3,C4")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -475,9 +664,15 @@ def main():
     W = build_headline(args, h, _lib, grids) if args.workload == "headline" else build_model(args, h, _lib, grids)
     step = W["step"]
 
-    if args.traffic_child:              # a counter pass of measure_traffic(): the batched launch and nothing else
+    if args.traffic_child:              # a counter pass of measure_traffic(): the batched launch(es) and nothing else
         for _ in range(3):
             step()
+        if args.workload == "headline":     # ... and the OliVe twin of the batch (config.configs[0]), same pass
+            import numpy as np
+            olive = _lib.plan_for(np.concatenate([grids.olive_flint(4, True), grids.olive_outliers(4, True)]))
+            twin = build_headline_olive(torch, h.dev, _lib, olive, args.nbuf)
+            for _ in range(3):
+                twin[3].run()
         h.sync()
         return
 
@@ -530,14 +725,24 @@ def main():
     d2d_s = event_time(W["copy"][1], 0.15, 10)
     ceiling = max(copy_bytes / copy_s, copy_bytes / d2d_s) / 1e9
 
-    traffic, traffic_note = None, None
+    want = None if args.configs == "all" else [c for c in args.configs.split(",") if c and c != "none"]
+    do_configs = h.world == 1 and args.workload == "headline" and (want is None or want)
+    K_ANT, K_OVP = r"k_fq_hbatch<[^>]*false>", r"k_fq_hbatch<[^>]*true>"
+    traffic, traffic_note, traffic_olive = None, None, (None, None)
     if not args.no_traffic:             # (at N > 1 too: the child passes are one-GPU runs on rank 0's GPU, after the job is over)
         child = ["--workload", args.workload, "--layers", str(args.layers)] + (["--inplace"] if args.inplace else [])
         if args.workload != "headline" and h.world > 1:
             traffic_note = "not measured: a child pass cannot rebuild rank 0's share of a sharded model on its own"
         else:
-            traffic, traffic_note = measure_traffic(args.nbuf, child_args=child,
-                                                    timeout_s=240 if args.workload == "headline" else 900)
+            pats = (K_ANT, K_OVP) if args.workload == "headline" else ("k_fq_hbatch",)
+            got, notes = measure_traffic(args.nbuf, kernels=pats, child_args=child,
+                                         timeout_s=240 if args.workload == "headline" else 900)
+            if got is None:
+                traffic_note = notes
+            else:
+                traffic, traffic_note = got[pats[0]], notes[pats[0]]
+                if len(pats) > 1:
+                    traffic_olive = (got[pats[1]], notes[pats[1]])
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # rocprofv3 --pmc result, see profiles/README.md
     if traffic is None and args.workload == "headline" and os.path.exists(tpath):
         try:
@@ -567,6 +772,13 @@ def main():
             "ordered": {"kernel": "antq::k_fq_hrow<bf16,false,8> (one wavefront per row)",
                         "launch_us": round(pt_launch_s * 1e6, 2),
                         "frac": round(ROWS * COLS * BYTES_PER_ELEM / pt_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}}
+    if do_configs:
+        config["configs"] = run_configs(h, _lib, grids, want)
+        for e in config["configs"]:
+            if e["name"] == "headline_olive" and args.nbuf == 32:
+                e["traffic"], e["traffic_source"] = traffic_olive
+                if e["traffic"]:
+                    e["traffic_over_algorithmic"] = round(e["traffic"] / e["algorithmic_bytes"], 4)
     res = report(h, args, sum(bytes_all) / BYTES_PER_ELEM, elapsed, {
         "config": config,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -588,7 +800,7 @@ def main():
         res["cpu_baseline"] = cpu_baseline()
         phys = _physical_cores()
         if phys and phys < (os.cpu_count() or 1):      # SMT box: the same port with one thread per physical core beside it
-            res["cpu_baseline_physical_cores"] = cpu_baseline(seconds_budget=6.0, threads=phys)
+            res["cpu_baseline_physical_cores"] = cpu_baseline(seconds_budget=2.0, threads=phys)
         res["cpu_baseline_torch"] = cpu_baseline_torch()
     print(json.dumps(res), flush=True)
 
