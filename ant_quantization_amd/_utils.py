@@ -73,7 +73,8 @@ def make_walkers(Q):
                     from .weight_bank import FlushHook
                     auto = AutoBank(model)
                     object.__setattr__(model, "_antq_auto_bank", auto)                 # (not a submodule, not state)
-                    model.register_forward_hook(FlushHook(auto))                       # (type picks made on the device: named here)
+                    if not any(isinstance(h, FlushHook) for h in model._forward_hooks.values()):      # (a copy brings its own)
+                        model.register_forward_hook(FlushHook())                       # (end of forward: picks named, bank spent)
                 except Exception:              # noqa: BLE001  (exotic containers: the per-layer schedule simply stays)
                     pass
         walk.__name__ = method
@@ -84,16 +85,28 @@ def make_walkers(Q):
 
 
 def make_set_weights_at_rest(Q):
-    def set_weights_at_rest(model, flag=True):
-        """Ours, opt-in (inference on frozen weights): mark every weight quantiser's launch as independent of the work
-        queued before it on the stream -- its weight and alpha are at rest, so the kernel may start while earlier kernels
-        drain (ANTQ_FLAG_UNORDERED: one launch per 33.5 MB tensor 61 -> 75 % of the HBM roofline).  Do NOT set it while
-        something still writes the weights (training, `.data` edits in flight): the quantiser could read them early."""
+    def set_weights_at_rest(model, flag=True, resident=True):
+        """Ours, opt-in (inference on frozen weights): the caller promises that nothing writes the weights or alphas behind
+        torch's back (no raw `.data` edits) while the flag is on.  Two things then happen:
+          * resident=True (default): the model's weight bank keeps its quantised copies across forwards -- a no-grad forward
+            on unchanged weights launches NOTHING for them (weight_bank, "RESIDENT"); version counters, train() / eval()
+            calls and training forwards still trigger a refresh.  With flag=False the bank returns to the default,
+            the reference's schedule: every forward re-quantises (one launch).
+          * every weight quantiser the bank does not serve (bank switched off, no memory for the copies, or resident=False:
+            the bank steps aside altogether) marks its own launch as independent of the work queued before it on the stream
+            -- the kernel may start while earlier kernels drain (ANTQ_FLAG_UNORDERED: one launch per 33.5 MB tensor
+            65 -> 77 % of the HBM roofline)."""
         for module in model.modules():
             if isinstance(module, Q):
                 module.weights_at_rest = bool(flag)
-        if flag:
+        ab = getattr(model, "_antq_auto_bank", None)
+        if flag and not resident:
             set_weight_bank(model, False)      # (an explicit choice of per-layer launches: the automatic bank steps aside)
+        elif ab is not None:
+            ab.resident = bool(flag)
+            if ab.bank is not None:
+                ab.bank.resident = bool(flag)
+                ab.bank.dirty = True
     return set_weights_at_rest
 
 
@@ -110,7 +123,8 @@ def set_weight_bank(model, flag=True):
         from .weight_bank import FlushHook
         ab = AutoBank(model)
         object.__setattr__(model, "_antq_auto_bank", ab)
-        model.register_forward_hook(FlushHook(ab))
+        if not any(isinstance(h, FlushHook) for h in model._forward_hooks.values()):
+            model.register_forward_hook(FlushHook())
     else:
         ab.enabled = True
 

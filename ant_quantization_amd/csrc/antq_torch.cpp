@@ -251,6 +251,24 @@ void batch_run(uintptr_t batch_host, const at::Tensor &batch_dev)
              "antq_fakequant_batch");
 }
 
+// weight_bank.WeightBank.refresh, default schedule (one batched re-quantisation of every weight per no-grad forward): the
+// descriptor tables hold raw addresses, so before launching make sure every weight / alpha tensor still lives where the
+// tables say (a dtype / device move, load_state_dict(assign=True), a rebound `.data`) and that no codebook buffer was
+// edited (versions[i] >= 0: tensor i must also still carry that version counter; -1: contents may change, that is the
+// point).  Returns false -- nothing launched -- otherwise: the Python side rebuilds its tables.
+// batches: (host blob address, device blob).
+bool bank_refresh(const std::vector<at::Tensor> &tensors, const std::vector<uintptr_t> &addrs,
+                  const std::vector<int64_t> &versions, const std::vector<std::pair<uintptr_t, at::Tensor>> &batches)
+{
+    if (tensors.size() != addrs.size() || tensors.size() != versions.size()) return false;
+    for (size_t i = 0; i < tensors.size(); i++) {
+        if (reinterpret_cast<uintptr_t>(tensors[i].data_ptr()) != addrs[i]) return false;
+        if (versions[i] >= 0 && (tensors[i].is_inference() || (int64_t)tensors[i]._version() != versions[i])) return false;
+    }
+    for (const auto &b : batches) batch_run(b.first, b.second);
+    return true;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -263,5 +281,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("rows"), py::arg("row_len"), py::arg("per_row"), py::arg("flags"), py::arg("out") = py::none(),
           py::arg("want_idx") = false);
     m.def("batch_run", &batch_run);
+    m.def("bank_refresh", &bank_refresh);
     m.def("abi_version", []() { return antq_abi_version(); });
 }

@@ -3,31 +3,32 @@
 The reference re-quantises each layer's weight on every forward, one small kernel sequence per layer
 (AQ:608-611, :641-644; OQ:413-416, :443-446).  For ResNet-50 that is 54 launches of a few tens of KB to
 a few MB each -- launch-bound, 7 % of the HBM roofline here -- while the same bytes through ONE
-multi-tensor launch (`antq_fakequant_batch`) reach 65 %, and 79 % for LLM-sized tensors.
+multi-tensor launch (`antq_fakequant_batch`) reach 75 %, and 80 % for LLM-sized tensors.
 
 `WeightBank(model)` collects the steady-state weight quantisers of the wrapper layers, quantises all
-their weights in one launch into resident buffers, and hands each layer its buffer on forward.  The
+their weights in one launch into bank-owned buffers, and hands each layer its buffer on forward.  The
 result is the same tensor the per-layer kernel would have produced (same kernels underneath, parity
-tested bit-exact); what changes is WHEN the work happens:
+tested bit-exact).  Two schedules:
 
-  * weights and alphas are stamped by (`data_ptr`, `_version`); a layer whose stamp is stale triggers one
-    refresh of the whole bank (so a QAT-style optimiser step costs one launch per step, not one per layer);
-  * a forward that needs gradients through the quantiser bypasses the bank (autograd path, AQ:544-549) AND marks the
-    whole bank dirty, and so does every `module.train()` / `.eval()` call on a wrapped layer: whoever trains between two
-    evaluations -- including optimisers that write through `.data` and never move a version counter, like the reference's
-    own BertAdam (`p.data.add_(-update_with_lr)`, BERT/optimization.py:161) -- gets freshly quantised weights on the
-    first no-grad forward afterwards (ONE launch), as the reference's cache-nothing schedule would (AQ:613-617, :642-646);
-  * THE ONE CASE LEFT TO THE CALLER: an in-place edit through `.data` (`w.data.mul_()`, `w.data.copy_()`) between two
-    no-grad forwards with no training forward and no train()/eval() call in between moves neither address nor version
-    counter and cannot be seen from here -- call `bank.invalidate()` (or `quant_utils.set_weight_bank(model, False)`,
-    which never caches) after such an edit.
+  * DEFAULT (what `enable_quantization(model)` arms, AutoBank): the reference's schedule in one launch.  Nothing is
+    cached across forwards: EVERY forward that does not need gradients through the quantisers re-quantises every weight
+    -- one batched launch (0.16 ms for BERT-base), issued by the first weight quantiser the forward reaches, capturable
+    into a hipGraph (a replayed graph re-quantises too).  "A new forward" = the model's forward returned since the last
+    refresh (forward hook), or a layer asks for its weight a second time since then (layers called directly, a module
+    used twice in one forward), or a stamp (address / version of weight and alpha, codebook) moved.  So a raw
+    `w.data.mul_()` between two no-grad forwards is seen, exactly as in the reference (AQ:613-617, :642-646).
+  * RESIDENT (`quant_utils.set_weights_at_rest(model, True)`, or `WeightBank(model)` built by hand): inference on frozen
+    weights.  The quantised copies stay; a forward on unchanged weights launches NOTHING for them.  Weights and alphas
+    are stamped by (`data_ptr`, `_version`); a stale stamp, a training forward, a `train()` / `.eval()` call on a wrapped
+    layer (optimisers that write through `.data`, like the reference's BertAdam, BERT/optimization.py:161) all trigger
+    one refresh at the next no-grad forward.  What this mode cannot see is a raw `.data` edit with none of those around
+    it -- which is what "at rest" promises does not happen; `bank.invalidate()` says it did.
 
-Attachment: `enable_quantization(model)` (quant_utils) arms an AutoBank -- once every weight quantiser of the model is
-calibrated, the next forward that does not need gradients through the quantisers builds the bank by itself, and from then
-on a forward on unchanged weights launches NOTHING for them (the stamps above decide).  Costs: one resident quantised copy
-of every weight, and the tensor a layer receives is that resident buffer (rewritten at the next refresh) rather than a fresh
-one.  `quant_utils.set_weight_bank(model, False)` (or ANTQ_WEIGHT_BANK=0 in the environment) restores the reference's
-per-layer schedule exactly; `WeightBank(model)` by hand still works.
+In both, a forward that needs gradients through the quantiser bypasses the bank (autograd path, AQ:544-549).
+
+Costs: one bank-owned quantised copy of every weight, and the tensor a layer receives is that buffer (rewritten at the
+next refresh) rather than a fresh one.  `quant_utils.set_weight_bank(model, False)` (or ANTQ_WEIGHT_BANK=0 in the
+environment) restores the reference's per-layer launches exactly.
 """
 import os
 import warnings
@@ -65,8 +66,10 @@ class _LazyPick:
 
 
 class WeightBank:
-    def __init__(self, model):
+    def __init__(self, model, resident=True):
         self.model = model
+        self.resident = bool(resident)   # False: the reference's schedule (module docstring), what AutoBank builds by default
+        self._served = set()       # id(quantiser) handed its buffer since the last refresh (non-resident schedule)
         self.entries = {}          # id(quantiser) -> dict
         self._batches = []
         self._ptr_key = None
@@ -81,7 +84,7 @@ class WeightBank:
                     self.skipped.append((name, reason))
                     continue
                 rows, row_len = (w.shape[0], w.numel() // w.shape[0]) if q.is_perchannel else (1, w.numel())
-                self.entries[id(q)] = dict(name=name, q=q, mod=mod, rows=rows, row_len=row_len,
+                self.entries[id(q)] = dict(name=name, q=q, mod=mod, rows=rows, row_len=row_len, w=w, a=None, plan=None, gmax=None,
                                            out=torch.empty_like(w, memory_format=torch.contiguous_format), stamp=None)
                 q._bank = self
         except BaseException:      # (out of memory half way through: leave nothing attached)
@@ -90,7 +93,7 @@ class WeightBank:
         if not self.entries:
             raise _lib.AntqError("WeightBank: no calibrated weight quantiser found (run one forward to calibrate first)")
 
-    def __deepcopy__(self, memo):       # (a copy of the model starts without a bank: its AutoBank -- if any -- builds its own)
+    def __deepcopy__(self, memo):       # (a copy of the model starts without a bank; FlushHook re-arms an AutoBank for it)
         return None
 
     def __reduce__(self):
@@ -153,12 +156,40 @@ class WeightBank:
         self._batches = [_lib.Batch(jobs, ovp=ovp) for (_, _, ovp), jobs in groups.items()]
         self._keep = keep
         self._ptr_key = self._pointers()
+        # what lookup() compares per layer (default schedule) and the compiled refresh: the tensors whose addresses the
+        # tables hold, and those addresses
+        ts, vs = [], []
+        for e in self.entries.values():
+            e["w"], e["a"], e["plan"], e["gmax"] = e["mod"].weight, e["q"]._parameters.get("alpha"), e["q"]._plan, e["q"]._gmax
+            ts += [e["w"], e["q"].alpha]
+            vs += [-1, -1]
+            for g in (e["q"].quant_grid, getattr(e["q"], "outliers", None)):      # (the codebook buffers: an in-place edit
+                if isinstance(g, torch.Tensor):                                   #  must rebuild the plan)
+                    ts.append(g)
+                    vs.append(-1 if torch.is_inference(g) else g._version)
+        self._fast = None
+        if _lib.ext() is not None and hasattr(_lib.ext(), "bank_refresh") and not any(b.singles for b in self._batches) \
+                and not any(e["alpha_copy"] for e in self.entries.values()):
+            self._fast = (ts, [t.data_ptr() for t in ts], vs,
+                          [(b.host.ctypes.data, b.dev) for b in self._batches if b.host is not None])
 
     def _pointers(self):
-        return tuple((e["mod"].weight.data_ptr(), e["mod"].weight.dtype, e["q"].alpha.data_ptr(), id(e["q"]._plan),
+        return tuple((e["mod"].weight.data_ptr(), e["mod"].weight.dtype, e["q"].alpha.data_ptr(), id(e["q"]._ensure_plan()),
                       e["q"]._gmax) for e in self.entries.values())
 
     # ------------------------------------------------------------------ the one launch
+    def _refresh_fast(self):
+        """Default schedule, every forward: one compiled call checks that no weight / alpha moved and launches the batches
+        (~20 us of host time for BERT-base's 73 layers; refresh() below walks them in Python: ~0.4 ms).  A codebook change
+        is caught per layer in lookup(); version counters do not matter here -- every forward re-quantises anyway."""
+        f = self._fast
+        if f is None or not _lib.ext().bank_refresh(f[0], f[1], f[2], f[3]):
+            return False
+        self.launches += 1
+        self.dirty = False
+        self._served.clear()
+        return True
+
     @torch.no_grad()
     def refresh(self):
         need_build = self._ptr_key != self._pointers() or any(e.get("alpha_copy") for e in self.entries.values())
@@ -168,6 +199,7 @@ class WeightBank:
             b.run()
         self.launches += 1
         self.dirty = False
+        self._served.clear()
         for e in self.entries.values():
             e["stamp"] = self._stamp(e["q"], e["mod"].weight)
 
@@ -176,8 +208,14 @@ class WeightBank:
         weight, or None when this forward has to take the per-layer path.  `training`: the caller's forward wants gradients
         for the weight or alpha (looked at before tensor_forward entered no_grad, OQ:332); None = decide here."""
         e = self.entries.get(id(q))
-        if e is None or tensor is not e["mod"].weight:
+        if e is None:
             return None
+        if tensor is not e["w"]:
+            if tensor is not e["mod"].weight:
+                return None                    # (the quantiser applied to some other tensor: its own launch)
+            e["w"] = tensor                    # the layer's Parameter object was replaced: new tables
+            self._fast = self._ptr_key = None
+            self.dirty = True
         if training is None:
             training = torch.is_grad_enabled() and (tensor.requires_grad or q.alpha.requires_grad)
         if training:
@@ -187,12 +225,23 @@ class WeightBank:
             return None
         if not q._steady or not (q.is_enable and q.is_enable_weight):
             return None
-        if self.dirty or e["stamp"] != self._stamp(q, tensor):
-            try:
-                self.refresh()
-            except torch.cuda.OutOfMemoryError:
-                self._give_up("out of memory while refreshing the resident weights")
-                return None
+        try:
+            if self.resident:
+                # only what the stamps / dirty flag say has changed
+                if self.dirty or e["stamp"] != self._stamp(q, tensor):
+                    self.refresh()
+            else:
+                # the reference's schedule: a new forward has begun (module docstring) -> every weight again, one launch
+                if q._plan is not e["plan"] or q._gmax != e["gmax"] or q._parameters.get("alpha") is not e["a"]:
+                    self._fast = None          # (a new codebook / alpha Parameter for this layer: tables rebuilt by refresh())
+                    self.dirty = True
+                if self.dirty or id(q) in self._served:
+                    if not self._refresh_fast():
+                        self.refresh()
+                self._served.add(id(q))
+        except torch.cuda.OutOfMemoryError:
+            self._give_up("out of memory while refreshing the bank's weights")
+            return None
         return e["out"]
 
     def _give_up(self, why):
@@ -214,6 +263,7 @@ class AutoBank:
         self._model = weakref.ref(model)
         self.bank = None
         self.enabled = os.environ.get("ANTQ_WEIGHT_BANK", "1") != "0"
+        self.resident = False      # quant_utils.set_weights_at_rest(model, True): the bank keeps its copies across forwards
         self.first = None          # the quantiser whose forward comes first in registration order: the only one that pokes
         self.failed = 0
         self.reason = None         # why the bank was switched off by itself, if it was (memory)
@@ -233,6 +283,7 @@ class AutoBank:
             if self.first is None:
                 self.first = weakref.ref(q)
             q._auto_bank = self
+            self.resident = self.resident or bool(getattr(q, "weights_at_rest", False))    # (set_weights_at_rest came first)
 
     def __deepcopy__(self, memo):
         return None
@@ -340,7 +391,7 @@ class AutoBank:
                 self.reason = "resident copies need %d MB, %d MB free on %s" % (n >> 20, free >> 20, dev)
                 return
         try:
-            bank = WeightBank(model)
+            bank = WeightBank(model, resident=self.resident)
         except _lib.AntqError:
             self.failed += 1
             return
@@ -356,19 +407,30 @@ class AutoBank:
 
 
 class FlushHook:
-    """Forward hook of the model enable_quantization armed: AutoBank.flush() when its forward returns.  Holds the AutoBank
-    weakly; a deep copy of the model gets the very same (then harmless) hook object."""
+    """Forward hook of the model enable_quantization armed, run when its forward returns: AutoBank.flush() (deferred type
+    picks get their log lines), and -- default schedule -- the bank's copies are spent: the next forward re-quantises.
+    Stateless (the AutoBank is looked up on the module), so a deep copy / an unpickled copy of an armed model carries a
+    working hook; such a copy has lost its AutoBank (never copied or pickled) and gets a fresh one here, after its first
+    forward."""
 
-    def __init__(self, auto):
-        self._auto = weakref.ref(auto)
+    def __init__(self, auto=None):
+        pass
 
     def __deepcopy__(self, memo):
         return self
 
     def __call__(self, module, inputs, output):
-        auto = self._auto()
-        if auto is not None and auto.queue:
+        auto = module.__dict__.get("_antq_auto_bank")
+        if auto is None:
+            try:
+                auto = AutoBank(module)
+                object.__setattr__(module, "_antq_auto_bank", auto)
+            except Exception:          # noqa: BLE001  (exotic containers: the per-layer schedule simply stays)
+                return
+        if auto.queue:
             auto.flush()
+        if auto.bank is not None and not auto.bank.resident:
+            auto.bank.dirty = True
         from . import core
         if core.search_memo.entries:
             core.search_memo.clear()       # (shared activations are shared within ONE forward: nothing outlives it)

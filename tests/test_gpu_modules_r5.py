@@ -48,12 +48,14 @@ def _bert_adam_step(model, lr=0.05, wd=0.01):
         assert p._version == v0
 
 
+@pytest.mark.parametrize("schedule", ["default", "resident"])
 @pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
 @pytest.mark.parametrize("tree", ["ant", "olive"])
-def test_run_glue_epoch_loop_with_data_writing_optimiser(antq_lib, dev, tree, dtype_name, capsys):
+def test_run_glue_epoch_loop_with_data_writing_optimiser(antq_lib, dev, tree, dtype_name, schedule, capsys):
     """calibrate -> eval -> [train steps whose optimiser writes p.data.add_() on weights and alphas -> eval] x 3, the default
     module path (AutoBank armed by enable_quantization) against the reference's schedule on the same parameters:
-    bit-identical outputs after every epoch, and ONE bank refresh per evaluation phase."""
+    bit-identical outputs after every epoch.  Default schedule: ONE bank launch per no-grad forward (the reference
+    re-quantises every weight on every forward, AQ:613-617); resident (set_weights_at_rest): ONE per evaluation phase."""
     import torch
     import torch.nn as nn
     qmod, qutil = _trees(tree)
@@ -64,6 +66,9 @@ def test_run_glue_epoch_loop_with_data_writing_optimiser(antq_lib, dev, tree, dt
     model = qmod.quantize_model(net).to(dev).to(dt)
     capsys.readouterr()
     qutil.enable_quantization(model)
+    resident = schedule == "resident"
+    if resident:
+        qutil.set_weights_at_rest(model, True)
     ab = model._antq_auto_bank
     x = torch.randn(64, 256, device=dev).to(dt)
     xt = torch.randn(32, 256, device=dev).to(dt)
@@ -71,9 +76,10 @@ def test_run_glue_epoch_loop_with_data_writing_optimiser(antq_lib, dev, tree, dt
     with torch.no_grad():
         model(x)                              # calibration
         y_prev = model(x)                     # epoch-0 evaluation: the bank attaches
-        assert ab.bank is not None and ab.bank.launches == 1
+        assert ab.bank is not None and ab.bank.launches == 1 and ab.bank.resident == resident
         model(x)
-        assert ab.bank.launches == 1          # unchanged weights under no_grad: nothing is launched for them
+        # resident: unchanged weights under no_grad, nothing is launched for them; default: one launch per forward
+        assert ab.bank.launches == (1 if resident else 2)
     for epoch in range(3):
         bank = ab.bank
         before = bank.launches
@@ -88,7 +94,7 @@ def test_run_glue_epoch_loop_with_data_writing_optimiser(antq_lib, dev, tree, dt
             y_bank = model(x)
             assert bank.launches == before + 1
             y_again = model(x)
-            assert bank.launches == before + 1 and torch.equal(y_bank, y_again)
+            assert bank.launches == before + (1 if resident else 2) and torch.equal(y_bank, y_again)
             ref = copy.deepcopy(model)                            # no bank travels with a copy: per-layer schedule
             assert all(m.quant_weight._bank is None for m in ref.modules() if hasattr(m, "quant_weight"))
             y_ref = ref(x)
@@ -104,10 +110,13 @@ def test_run_glue_epoch_loop_with_data_writing_optimiser(antq_lib, dev, tree, dt
 
 
 @pytest.mark.parametrize("tree", ["ant", "olive"])
-def test_train_eval_transition_alone_refreshes_and_plain_data_edit_needs_invalidate(antq_lib, dev, tree, capsys):
-    """(1) model.train() / model.eval() with `.data` writes in between but NO forward at all (an EMA copy, a checkpoint
-    averaged into place): the first no-grad forward re-quantises.  (2) The documented remaining case: `w.data.mul_()`
-    between two no-grad forwards, nothing else -- invisible to (address, version) stamps; `bank.invalidate()` is the caller's."""
+def test_plain_data_edit_between_two_no_grad_forwards_is_seen_by_default(antq_lib, dev, tree, capsys):
+    """The reference caches nothing: every forward re-quantises every weight (AQ:613-617, :642-646), so `w.data.mul_()`
+    between two no-grad forwards -- no train() / eval(), no training forward, no version counter moved -- changes the next
+    output.  The default module path (one batched refresh per no-grad forward) does the same, bit-identical to a fresh copy
+    of the model; layers called directly (not through the model's forward) see their edits too.  Only the opt-in resident
+    mode (set_weights_at_rest: "nothing writes the weights behind torch's back") keeps its copies: there the same edit
+    needs bank.invalidate(), while train() / eval() transitions still refresh."""
     import torch
     import torch.nn as nn
     qmod, qutil = _trees(tree)
@@ -122,27 +131,49 @@ def test_train_eval_transition_alone_refreshes_and_plain_data_edit_needs_invalid
         model(x)
         y0 = model(x)
         bank = model._antq_auto_bank.bank
-        assert bank is not None and bank.launches == 1
+        assert bank is not None and bank.launches == 1 and not bank.resident
+        v0 = lin[1].weight._version
+        lin[1].weight.data.mul_(0.5)                                  # the edit nothing can see ...
+        assert lin[1].weight._version == v0
+        y1 = model(x)
+        assert bank.launches == 2 and not torch.equal(y1, y0)         # ... is seen: this forward re-quantised
+        fresh = copy.deepcopy(model)
+        qutil.set_weight_bank(fresh, False)                           # the reference's per-layer schedule on a fresh copy
+        assert torch.equal(y1, fresh(x))
+        # layers called directly, twice, with an edit in between: the second call re-quantises (no model forward around it)
+        h = torch.randn(8, 128, device=dev)
+        a0 = lin[0](h)
+        lin[0].weight.data.mul_(1.5)
+        a1 = lin[0](h)
+        assert not torch.equal(a0, a1) and torch.equal(a1, copy.deepcopy(lin[0])(h))
+        # resident mode, opt-in: (1) train() / eval() around `.data` writes with no forward at all (an EMA copy, a checkpoint
+        # averaged into place) refresh; (2) the bare edit is the caller's promise not to happen -- invalidate() says it did
+        qutil.set_weights_at_rest(model, True)
+        y2 = model(x)
+        n = bank.launches
+        assert model._antq_auto_bank.bank is bank and bank.resident and torch.equal(model(x), y2) and bank.launches == n
         model.train()
         lin[0].weight.data.mul_(1.5)
         model.eval()
-        y1 = model(x)
-        assert bank.launches == 2 and not torch.equal(y0, y1)
-        assert torch.equal(y1, copy.deepcopy(model)(x))
-        # (2)
+        y3 = model(x)
+        assert bank.launches == n + 1 and not torch.equal(y3, y2)
         lin[1].weight.data.mul_(0.5)
         y_stale = model(x)
-        assert bank.launches == 2 and torch.equal(y_stale, y1)        # documented: this edit cannot be seen ...
+        assert bank.launches == n + 1 and torch.equal(y_stale, y3)
         bank.invalidate()
-        y2 = model(x)
-        assert bank.launches == 3 and not torch.equal(y2, y1)         # ... until the caller says so
-        assert torch.equal(y2, copy.deepcopy(model)(x))
+        y4 = model(x)
+        assert bank.launches == n + 2 and not torch.equal(y4, y3)
+        qutil.set_weights_at_rest(model, False)                       # back to the default: every forward re-quantises
+        assert not bank.resident and torch.equal(model(x), y4) and bank.launches == n + 3
+        lin[1].weight.data.mul_(2.0)
+        assert not torch.equal(model(x), y4) and bank.launches == n + 4
     capsys.readouterr()
 
 
+@pytest.mark.parametrize("resident", [True, False])
 @pytest.mark.parametrize("tree", ["ant", "olive"])
-def test_weights_at_rest_mode_after_a_training_step(antq_lib, dev, tree, capsys):
-    """set_weights_at_rest (opt-in, bf16 model: alpha kept as a float32 copy keyed by (address, version)): a training step
+def test_weights_at_rest_mode_after_a_training_step(antq_lib, dev, tree, resident, capsys):
+    """set_weights_at_rest (opt-in; resident bank, or per-layer unordered launches with resident=False; bf16 model: alpha kept as a float32 copy keyed by (address, version)): a training step
     that writes weight and alpha through `.data`, then evaluation -- the copy of alpha is re-read and the first launch is
     ordered, outputs bit-identical to a fresh copy of the model without the mode."""
     import torch
@@ -153,7 +184,7 @@ def test_weights_at_rest_mode_after_a_training_step(antq_lib, dev, tree, capsys)
     model = qmod.quantize_model(nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 8))).to(dev).to(torch.bfloat16)
     capsys.readouterr()
     qutil.enable_quantization(model)
-    qutil.set_weights_at_rest(model, True)
+    qutil.set_weights_at_rest(model, True, resident=resident)
     x = torch.randn(16, 256, device=dev).to(torch.bfloat16)
     model.eval()
     with torch.no_grad():
@@ -268,9 +299,9 @@ def test_weight_bank_memory_gate_and_failure_are_permanent(antq_lib, dev, capsys
     real = torch.empty_like
 
     class Counting(weight_bank.WeightBank):
-        def __init__(self, model):
+        def __init__(self, model, **kw):
             built.append(1)
-            super().__init__(model)
+            super().__init__(model, **kw)
 
     def failing(t, *a, **k):
         if state["armed"]:
@@ -863,8 +894,53 @@ def test_histogram_clip_search_with_outlier_victim_pairs(antq_lib, oracle, dev):
 
 
 @pytest.mark.parametrize("tree", ["ant", "olive"])
+def test_graph_of_the_default_schedule_requantises_on_every_replay(antq_lib, dev, tree):
+    """Default schedule: the forward's ONE batched weight launch is part of the captured graph, so a replay after ANY weight
+    change -- an in-place update or a raw `.data` edit -- computes what the reference's cache-nothing forward would
+    (AQ:613-617), with nothing to call in between."""
+    import torch
+    import torch.nn as nn
+    qmod, qutil = _trees(tree)
+    qutil.set_quantizer(_args(mode="flint", wbit=4, abit=4))
+    torch.manual_seed(4)
+    net = nn.Sequential(nn.Linear(128, 256), nn.GELU(), nn.Linear(256, 256), nn.GELU(), nn.Linear(256, 32))
+    model = qmod.quantize_model(net).to(dev).eval()
+    qutil.enable_quantization(model)
+    static_x = torch.randn(32, 128, device=dev)
+    with torch.no_grad():
+        model(static_x)                                  # calibration
+        model(static_x)                                  # the bank attaches
+    bank = model._antq_auto_bank.bank
+    assert bank is not None and not bank.resident
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        model(static_x)
+    torch.cuda.current_stream().wait_stream(side)
+    n = bank.launches
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        static_y = model(static_x)
+    assert bank.launches == n + 1                        # the refresh was captured
+    for step in range(3):
+        for p in model.parameters():
+            if p.dim() == 2:
+                p.data.mul_(1.0 + 0.05 * (step + 1))     # no version counter moves, nothing is told
+        xn = torch.randn(32, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(step))
+        static_x.copy_(xn)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref_model = copy.deepcopy(model)
+        qutil.set_weight_bank(ref_model, False)          # the reference's schedule: every layer re-quantises its weight
+        with torch.no_grad():
+            ref = ref_model(xn)
+        assert torch.equal(static_y, ref), (tree, step)
+    assert bank.launches == n + 1                        # (replays launch from the graph, not from Python)
+
+
+@pytest.mark.parametrize("tree", ["ant", "olive"])
 def test_graph_replay_after_a_weight_change_with_the_bank_refreshed_outside(antq_lib, dev, tree):
-    """a graph captured on clean resident weights holds no weight launch; after a weight change ONE
+    """INTEGRATION.md, resident mode (set_weights_at_rest): a graph captured on clean resident weights holds no weight launch; after a weight change ONE
     `bank.refresh()` outside the graph (the resident buffers keep their addresses) makes the replay equal to the eager
     forward of the changed model -- which the reference's cache-nothing schedule (AQ:613-617) would compute."""
     import torch
@@ -875,12 +951,13 @@ def test_graph_replay_after_a_weight_change_with_the_bank_refreshed_outside(antq
     net = nn.Sequential(nn.Linear(128, 256), nn.GELU(), nn.Linear(256, 256), nn.GELU(), nn.Linear(256, 32))
     model = qmod.quantize_model(net).to(dev).eval()
     qutil.enable_quantization(model)
+    qutil.set_weights_at_rest(model, True)               # opt-in: resident copies, no weight launch while nothing changes
     static_x = torch.randn(32, 128, device=dev)
     with torch.no_grad():
         model(static_x)                                  # calibration
         model(static_x)                                  # the bank attaches and fills
     bank = model._antq_auto_bank.bank
-    assert bank is not None and bank.launches == 1
+    assert bank is not None and bank.launches == 1 and bank.resident
     addrs = [e["out"].data_ptr() for e in bank.entries.values()]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

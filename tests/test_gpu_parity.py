@@ -972,7 +972,7 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
     with torch.no_grad():
         y0 = model(x)                       # calibration
         y1 = model(x)
-        qutil.set_weights_at_rest(model, True)
+        qutil.set_weights_at_rest(model, True, resident=False)
         assert all(m.weights_at_rest for m in model.modules() if hasattr(m, "weights_at_rest"))
         for _ in range(5):
             junk = torch.randn(4096, 4096, device=dev) @ torch.randn(4096, 64, device=dev)      # work in flight on the stream
@@ -982,7 +982,7 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
         assert torch.equal(model(x), y1) and torch.equal(y0, y1)
         # weights rewritten by work STILL IN FLIGHT (an in-place update, a device-side load_state_dict): the version counter
         # moves, so the first forward afterwards launches ordered -- and later ones, unordered again, agree with it
-        qutil.set_weights_at_rest(model, True)
+        qutil.set_weights_at_rest(model, True, resident=False)
         model(x)
         lins = [m for m in model.modules() if isinstance(getattr(m, "weight", None), torch.Tensor) and hasattr(m, "quant_weight")]
         new_w = [torch.randn_like(m.weight) * 0.05 for m in lins]
@@ -996,7 +996,7 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
             y_b = model(x)                                          # unordered again
             qutil.set_weights_at_rest(model, False)
             y_ref = model(x)
-            qutil.set_weights_at_rest(model, True)
+            qutil.set_weights_at_rest(model, True, resident=False)
             assert torch.equal(y_a, y_ref) and torch.equal(y_b, y_ref), rep
     # a model moved to bf16 AFTER calibration: alpha is a bf16 Parameter now and is converted to float32 on every forward
     # (a kernel in flight right before the launch) -- such launches stay ordered
@@ -1007,7 +1007,7 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
         mb = mb.bfloat16()
         xb = x.bfloat16()
         ref_b = mb(xb)
-        qutil.set_weights_at_rest(mb, True)
+        qutil.set_weights_at_rest(mb, True, resident=False)
         for _ in range(4):
             junk = torch.randn(4096, 4096, device=dev) @ torch.randn(4096, 64, device=dev)
             assert torch.equal(mb(xb), ref_b)
@@ -1018,13 +1018,13 @@ def test_weights_at_rest_forward_is_bit_identical(antq_lib, dev, tree, capsys):
         y_new = mb(xb)
         qutil.set_weights_at_rest(mb, False)
         assert torch.equal(mb(xb), y_new) and not torch.equal(y_new, ref_b)
-        qutil.set_weights_at_rest(mb, True)
+        qutil.set_weights_at_rest(mb, True, resident=False)
         assert torch.equal(mb(xb), y_new)
     # the flag set BEFORE the first (calibrating) forward: calibration writes alpha a moment before the launch
     net2 = nn.Sequential(nn.Linear(1024, 512), nn.GELU(), nn.Linear(512, 64))
     m2 = qmod.quantize_model(net2).to(dev).eval()
     qutil.enable_quantization(m2)
-    qutil.set_weights_at_rest(m2, True)
+    qutil.set_weights_at_rest(m2, True, resident=False)
     with torch.no_grad():
         z0 = m2(x)
         z1 = m2(x)
@@ -1057,7 +1057,7 @@ def test_weights_at_rest_under_inference_mode_and_on_temporaries(antq_lib, dev, 
             model = model.to(dt)
             xd = x.to(dt)
             ref = model(xd)
-        qutil.set_weights_at_rest(model, True)
+        qutil.set_weights_at_rest(model, True, resident=False)
         with torch.inference_mode():
             for _ in range(4):
                 assert torch.equal(model(xd), ref)
@@ -3381,12 +3381,14 @@ def test_sharded_per_tensor_calibration_two_ranks_on_one_device(antq_lib, oracle
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["default", "resident"])
 @pytest.mark.parametrize("tree", ["ant", "olive"])
-def test_auto_weight_bank_is_the_default_and_bit_identical(antq_lib, dev, tree, capsys):
+def test_auto_weight_bank_is_the_default_and_bit_identical(antq_lib, dev, tree, schedule, capsys):
     """enable_quantization(model) arms weight_bank.AutoBank: after the calibrating forward every later forward that needs no
-    gradient serves ALL weight quantisers from one resident batch -- no weight launch at all while weights and alphas are
-    unchanged, ONE launch after they change -- with outputs bit-identical to the per-layer schedule (set_weight_bank(model,
-    False) = the reference's).  A ResNet-shaped stack (conv rows of 27 / 576 / 1152 / 4608 elements, ragged conv1) and a
+    gradient serves ALL weight quantisers from one batched launch -- default schedule: ONE launch per forward (the
+    reference re-quantises every weight on every forward); resident (set_weights_at_rest): no weight launch at all while
+    weights and alphas are unchanged, ONE launch after they change -- with outputs bit-identical to the per-layer schedule
+    (set_weight_bank(model, False) = the reference's).  A ResNet-shaped stack (conv rows of 27 / 576 / 1152 / 4608 elements, ragged conv1) and a
     BERT-shaped one (768 / 3072-wide Linear layers), fp32 and bf16; training-mode forwards with gradients bypass the bank."""
     import importlib
     import torch
@@ -3403,8 +3405,12 @@ def test_auto_weight_bank_is_the_default_and_bit_identical(antq_lib, dev, tree, 
         for dt in (torch.float32, torch.bfloat16):
             model = qmod.quantize_model(net).to(dev).eval()
             qutil.enable_quantization(model)
+            resident = schedule == "resident"
+            per = 0 if resident else 1                          # bank launches per no-grad forward on unchanged weights
+            if resident:
+                qutil.set_weights_at_rest(model, True)
             ab = model._antq_auto_bank
-            assert ab is not None and ab.enabled and ab.bank is None
+            assert ab is not None and ab.enabled and ab.bank is None and ab.resident == resident
             with torch.no_grad():
                 y0 = model(x)                                   # calibration: per-layer path, nothing attached yet
                 assert ab.bank is None
@@ -3416,7 +3422,7 @@ def test_auto_weight_bank_is_the_default_and_bit_identical(antq_lib, dev, tree, 
                 assert len(ab.bank.entries) == nq
                 y2 = model(xd)
                 y3 = model(xd)
-                assert ab.bank.launches == 1                    # unchanged weights: no weight launch at all
+                assert ab.bank.launches == 1 + 2 * per          # resident, unchanged weights: no weight launch at all
                 assert torch.equal(y1, y2) and torch.equal(y2, y3)
                 qutil.set_weight_bank(model, False)             # the reference's schedule
                 assert ab.bank is None and all(m.quant_weight._bank is None for m in model.modules() if hasattr(m, "quant_weight"))
@@ -3428,10 +3434,10 @@ def test_auto_weight_bank_is_the_default_and_bit_identical(antq_lib, dev, tree, 
                 y4 = model(xd)
                 assert ab.bank is not None and ab.bank.launches == 1 and not torch.equal(y4, y1)
                 y5 = model(xd)
-                assert ab.bank.launches == 1 and torch.equal(y4, y5)
+                assert ab.bank.launches == 1 + per and torch.equal(y4, y5)
                 lin[1].quant_weight.alpha.mul_(0.9)
                 y6 = model(xd)
-                assert ab.bank.launches == 2
+                assert ab.bank.launches == 2 + per
                 qutil.set_weight_bank(model, False)
                 assert torch.equal(model(xd), y6)
                 qutil.set_weight_bank(model, True)

@@ -28,7 +28,7 @@ KS=$(find /tmp/prof_drv -name '*kernel_stats.csv' | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/${TAG}_bench_driver_cmd_kernel_stats.csv"
 python3 - "$KT" > "$OUT/${TAG}_bench_driver_cmd_launches.txt" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_fq_hbatch" in r["Kernel_Name"] or "k_fq_batch" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_fq_hbatch<antq::bf16_tag, false>" in r["Kernel_Name"]]     # the headline kernel
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 prev_end = None
 print("# per-launch durations of %s under rocprofv3 --kernel-trace, bench.py --gpus 1 --steps 20 --warmup 5" % rows[0]["Kernel_Name"][:60])
