@@ -14,6 +14,7 @@ code that edits `bit` / `has_inited_quant_para` / `quant_grid` that way must cal
 (INTEGRATION.md, section 2).  The operator-level drop-in (`quant_cuda.quant`) does not rely on keys at all: its kernel
 verifies the grid on the device.
 """
+import threading
 import weakref
 
 import torch
@@ -62,22 +63,50 @@ class _PinnedSlots:
     """Pinned host floats for device->host copies nobody wants to wait for at issue time.  A slot belongs to whoever took it
     until it is given back (`give`): a type pick parked until the end of the model's forward is never overwritten by a
     later layer's probe, however many layers the model has (GPT-2 XL / OPT: 192 linears, two slots each).  The pool grows
-    by one pinned chunk whenever the free list runs dry; a slot nobody gives back costs four bytes."""
+    by one pinned chunk whenever the free list runs dry.  Process-global and shared by threads (nn.DataParallel replicas,
+    multi-threaded serving): take / give hold a lock.  A slot taken on behalf of an `owner` (a quantiser) returns by itself
+    when the owner is collected without having given it back -- a model deleted half way through a calibrating forward, an
+    exception between take() and the read -- so nothing leaks."""
 
     def __init__(self, chunk=256, alloc=None):
         self.chunk, self.free, self.chunks = chunk, [], []
         self._alloc = alloc or (lambda n: torch.zeros(n, dtype=torch.float32).pin_memory())
+        self._lock = threading.Lock()
+        self._out = {}             # id(slot) -> (slot, finalizer or None): slots currently taken
 
-    def take(self):
-        if not self.free:
-            buf = self._alloc(self.chunk)
-            self.chunks.append(buf)
-            self.free.extend(buf[i:i + 1] for i in range(self.chunk - 1, -1, -1))
-        return self.free.pop()
+    def take(self, owner=None):
+        with self._lock:
+            if not self.free:
+                buf = self._alloc(self.chunk)
+                self.chunks.append(buf)
+                self.free.extend(buf[i:i + 1] for i in range(self.chunk - 1, -1, -1))
+            slot = self.free.pop()
+            fin = weakref.finalize(owner, self._reclaim, id(slot)) if owner is not None else None
+            if fin is not None:
+                fin.atexit = False
+            self._out[id(slot)] = (slot, fin)
+            return slot
 
     def give(self, slot):
-        if slot is not None:
-            self.free.append(slot)
+        if slot is None:
+            return
+        with self._lock:
+            ent = self._out.pop(id(slot), None)
+            if ent is None:
+                return                              # (already back: reclaimed, or given twice)
+            if ent[1] is not None:
+                ent[1].detach()
+            self.free.append(ent[0])
+
+    def _reclaim(self, key):
+        with self._lock:
+            ent = self._out.pop(key, None)
+            if ent is not None:
+                self.free.append(ent[0])
+
+    def outstanding(self):
+        with self._lock:
+            return len(self._out)
 
 
 _slots = _PinnedSlots()
@@ -167,7 +196,7 @@ class CalibrationMixin:
         for t, (p, gm) in enumerate(zip(plans, spec["gmaxs"])):
             core.fake_quant(x, alpha[t], p, gm, False, ovp=spec["ovp"], out=outs[t])
         self._spec_out = outs.index_select(0, idx)[0].view(data.shape)
-        slot = _slots.take()
+        slot = _slots.take(self)
         slot.copy_(typ.float(), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(data.device))
@@ -199,7 +228,7 @@ class CalibrationMixin:
             return
         self._drop_probe()
         with torch.no_grad():
-            slot = _slots.take()
+            slot = _slots.take(self)
             slot.copy_(tensor.detach().min().float().reshape(1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(tensor.device))

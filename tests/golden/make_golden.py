@@ -96,6 +96,44 @@ def _save(outdir, name, arrays):
     np.savez_compressed(os.path.join(outdir, name), **arrays)
 
 
+# Round 6: beside every recorded float32 score, the same score with the REDUCTION done in float64 over the
+# reference's own float32 per-element terms ((q - x).abs().pow(p), AQ:280-285 / OQ:181-187: element-wise fp32, then mean).
+# |fp32 score - fp64 score| / score is the reference's own reduction noise: the only thing that may legitimately move a clip
+# or type pick between two correct implementations.  Written to separate *_traces64.npz files (the round 1-5
+# fixtures stay byte-identical); tests/calib_check.py derives its near-tie tolerance from them.
+S64 = []          # parallel to whichever `scores` list is being filled: one float64 vector per mse_loss call
+
+
+def _score64(qt, st, p, is_perchannel):
+    import torch
+    e = (qt - st).abs().pow(p)                     # the reference's float32 element terms, bit for bit
+    if is_perchannel:
+        return e.view(qt.shape[0], -1).double().mean(-1).reshape(-1).numpy()
+    return e.double().mean().reshape(-1).numpy()
+
+
+def _reset(scores):
+    del scores[:]
+    del S64[:]
+
+
+def _calibration_trace64(ncand):
+    blocks = (len(S64) - 1) // ncand
+    return np.stack(S64[(blocks - 1) * ncand:blocks * ncand]).astype(np.float64)
+
+
+def _put_trace(tr, k, scores, ncand):
+    assert len(S64) == len(scores), (len(S64), len(scores))
+    tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, ncand)
+    tr.setdefault("__64", {})[k + "__trace64"] = _calibration_trace64(ncand)
+
+
+def _save_traces(outdir, name, tr):
+    t64 = tr.pop("__64", {})
+    _save(outdir, name, tr)
+    np.savez_compressed(os.path.join(outdir, name.replace("_traces.npz", "_traces64.npz")), **t64)
+
+
 def _calibration_trace(scores, ncand):
     """What a complete `TensorQuantizer(x)` calibration leaves in the mse_loss recorder: for every type of an
     `ant-...` list one search (ncand calls), then the search on the installed grid (ncand calls), then the one call
@@ -116,6 +154,7 @@ def _record_mse_loss(qm):
     def rec_mse(self, qt, st, p=2.0, is_perchannel=True):
         r = orig(self, qt, st, p, is_perchannel)
         scores.append(r.detach().reshape(-1).clone().numpy())
+        S64.append(_score64(qt.detach(), st.detach(), p, is_perchannel))
         return r
 
     qm.Quantizer.mse_loss = rec_mse
@@ -266,13 +305,14 @@ def gen_ant(outdir):
     _save(outdir, "ant_forward.npz", fwd)
 
     # ---- (5) search_mse traces ----------------------------------------------
-    srch = {}
+    srch, srch64 = {}, {}
     scores = []
     orig_mse = qm.Quantizer.mse_loss
 
     def rec_mse(self, qt, st, p=2.0, is_perchannel=True):
         r = orig_mse(self, qt, st, p, is_perchannel)
         scores.append(r.detach().reshape(-1).clone().numpy())
+        S64.append(_score64(qt.detach(), st.detach(), p, is_perchannel))
         return r
 
     qm.Quantizer.mse_loss = rec_mse
@@ -283,11 +323,12 @@ def gen_ant(outdir):
         for name, x, is_input, signed in [("w", w, False, True), ("a", a, True, True), ("au", a.abs(), True, False)]:
             q = mk(t, 4, signed, is_input=is_input)
             q.quant_grid.data = {"int": q.int_value, "flint": q.flint_value, "pot": q.pot_value}[t]()
-            del scores[:]
+            _reset(scores)
             with torch.no_grad():
                 best, alpha, ratio = q.search_mse(x)
             k = "%s_%s" % (name, t)
             srch[k + "_trace"] = np.stack(scores)
+            srch64[k + "_trace64"] = np.stack(S64).astype(np.float64)
             srch[k + "_best_sum"] = np.float32(best.item() if hasattr(best, "item") else best)
             srch[k + "_alpha"] = alpha.numpy().reshape(-1)
             srch[k + "_ratio"] = np.float32(ratio)
@@ -310,7 +351,7 @@ def gen_ant(outdir):
             q = mk(mode, 4, not is_input, is_input=is_input)
             if not is_input:
                 q.alpha.data = torch.ones(x.shape[0], 1)
-            del scores[:]
+            _reset(scores)
             out = q(x)
             k = "%s__%s" % (name, mode)
             sel[k + "__mode"] = np.array(q.mode)
@@ -320,7 +361,7 @@ def gen_ant(outdir):
             sel[k + "__out"] = out.detach().numpy()
             sel[k + "__mse"] = np.float32(q.mse.item())
             sel[k + "__ncand"] = np.int32(len(scores))
-            tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, 75)
+            _put_trace(tr, k, scores, 75)
         sel[name + "__x"] = x.numpy()
     # 8-bit forces int (AQ:482-483) with lb=95 (AQ:296-297)
     x = cases["w_gauss"][0]
@@ -331,7 +372,8 @@ def gen_ant(outdir):
     sel["w_gauss__b8__alpha"] = q.alpha.data.numpy().reshape(-1)
     sel["w_gauss__b8__out"] = out.detach().numpy()
     _save(outdir, "ant_select.npz", sel)
-    _save(outdir, "ant_select_traces.npz", tr)
+    _save_traces(outdir, "ant_select_traces.npz", tr)
+    np.savez_compressed(os.path.join(outdir, "ant_search_traces64.npz"), **srch64)
     qm.Quantizer.mse_loss = orig_mse
 
     # ---- (6b) 'outlier' baseline mode (int4 body + int16 outliers by percentile, AQ:417-465) ----
@@ -477,13 +519,14 @@ def gen_olive(outdir):
     _save(outdir, "olive_forward.npz", fwd)
 
     # ---- search_mse + full quantiser ---------------------------------------------
-    srch = {}
+    srch, srch64 = {}, {}
     scores = []
     orig_mse = qm.Quantizer.mse_loss
 
     def rec_mse(self, qt, st, p=2.0, is_perchannel=True):
         r = orig_mse(self, qt, st, p, is_perchannel)
         scores.append(r.detach().reshape(-1).clone().numpy())
+        S64.append(_score64(qt.detach(), st.detach(), p, is_perchannel))
         return r
 
     qm.Quantizer.mse_loss = rec_mse
@@ -498,10 +541,11 @@ def gen_olive(outdir):
                 q = mk(t, 4, True, is_input=is_input, no_outlier=no_outlier)
                 q.outliers.data = q.outlier_value()
                 q.quant_grid.data = q.int_value() if t == "int" else q.flint_value()
-                del scores[:]
+                _reset(scores)
                 best, alpha, ratio = q.search_mse(x)
                 k = "%s_%s_%s" % (name, t, "noout" if no_outlier else "ovp")
                 srch[k + "_trace"] = np.stack(scores)
+                srch64[k + "_trace64"] = np.stack(S64).astype(np.float64)
                 srch[k + "_best_sum"] = np.float32(best.item() if hasattr(best, "item") else best)
                 srch[k + "_alpha"] = alpha.numpy().reshape(-1)
                 srch[k + "_ratio"] = np.float32(ratio)
@@ -511,7 +555,7 @@ def gen_olive(outdir):
             q = mk(mode, 4, not is_input, is_input=is_input)
             if not is_input:
                 q.alpha.data = torch.ones(x.shape[0], 1)
-            del scores[:]
+            _reset(scores)
             out = q(x)
             k = "full_%s__%s" % (name, mode)
             srch[k + "__mode"] = np.array(q.mode)
@@ -522,10 +566,11 @@ def gen_olive(outdir):
             srch[k + "__out"] = out.numpy()
             srch[k + "__mse"] = np.float32(q.mse.item())
             srch[k + "__ncand"] = np.int32(len(scores))
-            tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, len(range(75, 250, 2)))
+            _put_trace(tr, k, scores, len(range(75, 250, 2)))
     qm.Quantizer.mse_loss = orig_mse
     _save(outdir, "olive_search.npz", srch)
-    _save(outdir, "olive_search_traces.npz", tr)
+    tr.setdefault("__64", {}).update(srch64)
+    _save_traces(outdir, "olive_search_traces.npz", tr)
 
 
 # ----------------------------------------------------------------------------
@@ -566,10 +611,10 @@ def gen_ant_wide(outdir):
                 q.name = "golden"
                 if not is_input:
                     q.alpha.data = torch.ones(x.shape[0], 1)
-                del scores[:]
+                _reset(scores)
                 out = q(x)
                 k = "%s__%s__b%d__%d_%d" % (name, mode, bit, lo, up)
-                tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, up - (95 if bit > 6 else lo))
+                _put_trace(tr, k, scores, up - (95 if bit > 6 else lo))
                 keys.append(k)
                 sel[k + "__mode"] = np.array(q.mode)
                 sel[k + "__signed"] = np.array(bool(q.is_signed))
@@ -579,7 +624,7 @@ def gen_ant_wide(outdir):
                 sel[k + "__mse"] = np.float32(q.mse.item())
     sel["keys"] = np.array(keys)
     _save(outdir, "ant_select_wide.npz", sel)
-    _save(outdir, "ant_select_wide_traces.npz", tr)
+    _save_traces(outdir, "ant_select_wide_traces.npz", tr)
     dist.destroy_process_group()
 
 
@@ -617,10 +662,10 @@ def gen_olive_wide(outdir):
                     q.name = "golden"
                     if not is_input:
                         q.alpha.data = torch.ones(x.shape[0], 1)
-                    del scores[:]
+                    _reset(scores)
                     out = q(x)
                     k = "%s__%s__b%d__%d_%d__%s" % (name, mode, bit, lo, up, "noout" if no_outlier else "ovp")
-                    tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, len(range(lo, up, 2)))
+                    _put_trace(tr, k, scores, len(range(lo, up, 2)))
                     keys.append(k)
                     sel[k + "__mode"] = np.array(q.mode)
                     sel[k + "__signed"] = np.array(bool(q.is_signed))
@@ -631,7 +676,7 @@ def gen_olive_wide(outdir):
                     sel[k + "__mse"] = np.float32(q.mse.item())
     sel["keys"] = np.array(keys)
     _save(outdir, "olive_select_wide.npz", sel)
-    _save(outdir, "olive_select_wide_traces.npz", tr)
+    _save_traces(outdir, "olive_select_wide_traces.npz", tr)
 
 
 # ----------------------------------------------------------------------------
@@ -676,7 +721,7 @@ def gen_long(outdir, tree):
             q.name = "golden"
             if not is_input:
                 q.alpha.data = torch.ones(x.shape[0], 1)
-            del scores[:]
+            _reset(scores)
             out = q(x)
             k = "%s__%s__b%d__%d_%d" % (name, mode, bit, lo, up)
             if tree == "olive":
@@ -689,10 +734,12 @@ def gen_long(outdir, tree):
             sel[k + "__grid"] = q.quant_grid.data.numpy()
             sel[k + "__out"] = out.detach().numpy()
             sel[k + "__mse"] = np.float32(q.mse.item())
-            tr[k + "__trace"], tr[k + "__type_sums"] = _calibration_trace(scores, len(range(lo, up, step)))
+            _put_trace(tr, k, scores, len(range(lo, up, step)))
     sel["keys"] = np.array(keys)
     np.savez_compressed(os.path.join(outdir, "%s_select_long.npz" % tree), **sel)
+    t64 = tr.pop("__64", {})
     np.savez_compressed(os.path.join(outdir, "%s_select_long_traces.npz" % tree), **tr)
+    np.savez_compressed(os.path.join(outdir, "%s_select_long_traces64.npz" % tree), **t64)
 
 
 # ----------------------------------------------------------------------------

@@ -9,7 +9,26 @@ import types
 import numpy as np
 import pytest
 
+import calib_check
 from calib_check import check_alpha_picks, check_type_pick, ratios_of
+
+
+def _pick_report(what, n_same, n_rows, ledger_from):
+    """print and assert how the clip picks of an end-to-end fixture suite compare with the reference's:
+    identical-pick fraction >= 0.99, every other row certified a tie within calib_check.NEAR_TIE_RTOL (= twice the
+    reference's measured reduction noise); the largest gap actually used goes to the log (and to gpurun_out/ for DESIGN)."""
+    gaps = [e[3] for e in calib_check.LEDGER[ledger_from:]]
+    line = "%s: %d / %d rows with the reference's own pick (%.4f), largest certified gap %.3g of %.3g allowed" % (
+        what, n_same, n_rows, n_same / max(n_rows, 1), max(gaps + [0.0]), calib_check.NEAR_TIE_RTOL)
+    print(line)
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "calib_picks.log"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    assert n_same >= 0.99 * n_rows, line
+
 from conftest import golden
 
 pytestmark = pytest.mark.gpu
@@ -415,6 +434,7 @@ def test_quantizer_end_to_end_vs_reference_fixtures(antq_lib, dev, tree, capsys)
         kw = dict(w_up=250, a_up=250)
         fmt = "full_%s__%s"
     n_rows = n_same = 0
+    led0 = len(calib_check.LEDGER)
     for name, mode in cases:
         k = fmt % (name, mode)
         x_np = sel[name + ("__x" if tree == "ant" else "_x")]
@@ -433,8 +453,8 @@ def test_quantizer_end_to_end_vs_reference_fixtures(antq_lib, dev, tree, capsys)
         n_same += int(same.sum())
         np.testing.assert_allclose(q.mse.item(), sel[k + "__mse"], rtol=2e-3)
         assert float(q.has_inited_quant_para) == 1.0
-    assert n_same >= 0.9 * n_rows            # informative only: every differing row was certified a tie above
     printed = capsys.readouterr().out
+    _pick_report("end to end, %s fixtures" % tree, n_same, n_rows, led0)
     assert "4-bit \t golden," in printed       # the log line format print_result.sh parses
 
 
@@ -1648,6 +1668,7 @@ def test_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
     from ant_quantization_amd.ant import quant_modules as qm
     sel, tr = golden("ant_select_wide.npz"), golden("ant_select_wide_traces.npz")
     n_rows = n_same = n_cases = 0
+    led0 = len(calib_check.LEDGER)
     for k in [str(v) for v in sel["keys"]]:
         name, mode, b, win = k.split("__")
         bit, (lo, up) = int(b[1:]), map(int, win.split("_"))
@@ -1667,8 +1688,9 @@ def test_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
         n_rows += same.size
         n_same += int(same.sum())
         np.testing.assert_allclose(q.mse.item(), sel[k + "__mse"], rtol=3e-3, err_msg=k)
-    assert n_cases >= 88 and n_same >= 0.95 * n_rows, (n_cases, n_same, n_rows)
+    assert n_cases >= 88, n_cases
     capsys.readouterr()
+    _pick_report("end to end, ant wide fixture set", n_same, n_rows, led0)
 
 
 def test_olive_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
@@ -1679,6 +1701,7 @@ def test_olive_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
     from ant_quantization_amd.olive import quant_modules as qm
     sel, tr = golden("olive_select_wide.npz"), golden("olive_select_wide_traces.npz")
     n_rows = n_same = n_cases = 0
+    led0 = len(calib_check.LEDGER)
     for k in [str(v) for v in sel["keys"]]:
         name, mode, b, win, om = k.split("__")
         bit, (lo, up) = int(b[1:]), map(int, win.split("_"))
@@ -1699,8 +1722,9 @@ def test_olive_quantizer_end_to_end_wide_fixture_set(antq_lib, dev, capsys):
         n_rows += same.size
         n_same += int(same.sum())
         np.testing.assert_allclose(q.mse.item(), sel[k + "__mse"], rtol=5e-3, err_msg=k)
-    assert n_cases >= 88 and n_same >= 0.9 * n_rows, (n_cases, n_same, n_rows)
+    assert n_cases >= 88, n_cases
     capsys.readouterr()
+    _pick_report("end to end, olive wide fixture set", n_same, n_rows, led0)
 
 
 @pytest.mark.parametrize("tree", ["ant", "olive"])

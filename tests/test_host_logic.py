@@ -762,6 +762,38 @@ def test_pinned_slot_pool_never_hands_out_a_slot_that_is_still_owned():
         s[0] = -1.0
     assert [int(s[0]) for s in held[1::2]] == list(range(1, 50, 2))
     pool.give(None)
+    # (1) two threads taking at once never see the same slot or an IndexError; (2) a slot taken for an owner
+    # that dies without giving it back returns by itself; giving twice is harmless
+    import gc
+    import threading
+    pool2 = _PinnedSlots(chunk=4, alloc=lambda n: torch.zeros(n))
+    got, errs = [[], []], []
+
+    def worker(k):
+        try:
+            for _ in range(500):
+                got[k].append(pool2.take())
+        except Exception as ex:          # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and len({s.data_ptr() for s in got[0] + got[1]}) == 1000 and pool2.outstanding() == 1000
+    for s in got[0] + got[1]:
+        pool2.give(s)
+    pool2.give(got[0][0])
+    assert pool2.outstanding() == 0 and len(pool2.free) == len(pool2.chunks) * 4
+
+    class Owner:
+        pass
+    o = Owner()
+    s1, s2 = pool2.take(o), pool2.take(o)
+    pool2.give(s1)
+    assert pool2.outstanding() == 1
+    del o
+    gc.collect()
+    assert pool2.outstanding() == 0 and len(pool2.free) == len(pool2.chunks) * 4
 
 
 def test_multihead_attention_wrapper_equals_torch_attention_with_every_option():

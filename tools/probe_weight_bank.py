@@ -78,14 +78,20 @@ def run(name, base, inp, dtype):
         ab = model._antq_auto_bank
         bank = ab.bank
         assert bank is not None and not bank.resident
-        n0 = bank.launches
-        t_default = timed(lambda: model(inp))
-        per_fwd = (bank.launches - n0) / (3 + 3 * 20)
-        qu.set_weights_at_rest(model, True)
-        model(inp)
-        n1 = bank.launches
-        t_resident = timed(lambda: model(inp))
-        assert bank.launches == n1
+        # default and resident alternate (5 rounds, best of each): a host-bound forward drifts by several % over seconds
+        t_default = t_resident = 1e9
+        per_fwd = 0.0
+        for _ in range(5):
+            qu.set_weights_at_rest(model, False)
+            model(inp)
+            n0 = bank.launches
+            t_default = min(t_default, timed(lambda: model(inp)))
+            per_fwd = (bank.launches - n0) / (3 + 3 * 20)
+            qu.set_weights_at_rest(model, True)
+            model(inp)
+            n1 = bank.launches
+            t_resident = min(t_resident, timed(lambda: model(inp)))
+            assert bank.launches == n1
         qu.set_weights_at_rest(model, False)
         qu.set_weight_bank(model, False)
         t_layer = timed(lambda: model(inp))
