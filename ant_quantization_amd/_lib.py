@@ -15,7 +15,7 @@ import torch  # must be imported before libantq.so so that ONE libamdhip64 is sh
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ANTQ_LIB") or os.path.join(_HERE, "libantq.so")   # ANTQ_LIB: A/B builds (dev)
 
-ABI_VERSION = 6         # include/antq.h ANTQ_ABI_VERSION this binding was written against
+ABI_VERSION = 7         # include/antq.h ANTQ_ABI_VERSION this binding was written against
 F32, BF16, F16, F64 = 0, 1, 2, 3
 FLAG_OVP = 1
 FLAG_DYNAMIC = 2
@@ -57,7 +57,8 @@ def lib():
                              "antq_copy", "antq_batch_build", "antq_fakequant_batch", "antq_encode4", "antq_decode4",
                              "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
                              "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma",
-                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h", "antq_calibrate_batch", "antq_absmax_into", "antq_fakequant_f64"):
+                             "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h", "antq_calibrate_batch", "antq_absmax_into", "antq_fakequant_f64",
+                             "antq_absmax_t", "antq_alpha_grad_t"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 L.antq_search_workspace_bytes.restype = ctypes.c_size_t
@@ -70,6 +71,9 @@ def lib():
                 L.antq_nearest.argtypes = [vp, vp, vp, sz, vp, ci, ci, vp]
                 L.antq_absmax.argtypes = [vp, vp, sz, sz, ci, ci, vp]
                 L.antq_absmax_into.argtypes = [vp, vp, sz, ci, vp]
+                L.antq_absmax_t.argtypes = [vp, vp, sz, ci, vp, vp]
+                L.antq_alpha_grad_t.argtypes = [vp, vp, vp, sz, vp, ci, vp, vp]
+                L.antq_alpha_grad.argtypes = [vp, vp, vp, sz, sz, ci, vp, vp, ci, vp]
                 L.antq_copy.argtypes = [vp, vp, sz, vp]
                 # development: ANTQ_DEBUG_KNOBS="14=2,0=8" applies antq_debug_set(key, value) pairs to the loading thread
                 # (the knobs are thread-local; tools/fuzz_campaign.sh forces code paths with it)
@@ -469,6 +473,26 @@ def fakequant_dynamic(x, plan, gmax, rows, row_len, ratio=1.0, ovp=False, want_i
     return out, (alpha if want_alpha else None), idx
 
 
+REDUCE_WS_BYTES = 65536   # include/antq.h ANTQ_REDUCE_WS_BYTES
+_reduce_blocks = {}       # (device index, raw stream) -> the ticket block of antq_absmax_t / antq_alpha_grad_t
+
+
+def _reduce_ws(device):
+    """The caller-owned ticket block of the one-launch whole-tensor reductions: zeroed ONCE here, left zeroed by every call;
+    ONE per (device, stream) -- calls on one stream run one after the other and may share it, two streams never do."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _stream_int(device))
+    ws = _reduce_blocks.get(key)
+    if ws is None:
+        with _lock:
+            ws = _reduce_blocks.get(key)
+            if ws is None:
+                if len(_reduce_blocks) >= 64:        # streams come and go
+                    _reduce_blocks.clear()
+                ws = _reduce_blocks[key] = torch.zeros(REDUCE_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 _zero_pools = {}          # device index -> [float32 zeros, next free slot]
 
 
@@ -480,12 +504,13 @@ def _zero_slot(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, _stream_int(device))
     pool = _zero_pools.get(key)
-    if pool is None or pool[1] >= pool[0].numel():
+    if pool is None or pool[1] >= len(pool[0]):
         if len(_zero_pools) >= 64:               # streams come and go
             _zero_pools.clear()
-        pool = _zero_pools[key] = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
+        # (the 4096 one-element views are cut once per refill, in C++: ~0.15 us per call instead of a Python slice)
+        pool = _zero_pools[key] = [torch.zeros(4096, dtype=torch.float32, device=device).split(1), 0]
     pool[1] += 1
-    return pool[0][pool[1] - 1:pool[1]]
+    return pool[0][pool[1] - 1]
 
 
 def absmax(x, rows, row_len, per_row=True):
@@ -495,8 +520,16 @@ def absmax(x, rows, row_len, per_row=True):
         raise AntqError("unsupported dtype %s" % x.dtype)
     if not per_row and not torch.cuda.is_current_stream_capturing():
         # one launch: the maximum is accumulated into a slot that already holds 0 (a captured graph would replay into the
-        # same slot, so captures keep the self-initialising entry below)
+        # same slot, so captures keep the self-initialising entry below).  The streaming kernel of round 6 reads a 33.5 MB
+        # bf16 tensor in 6.5 us -- less than the ctypes path's host time, hence the compiled call
         amax = _zero_slot(x.device)
+        e = _ext_mod if _ext_mod is not False else ext()
+        if e is not None and hasattr(e, "absmax_into") and x.is_contiguous():
+            try:
+                e.absmax_into(x, amax)
+            except RuntimeError as err:
+                raise AntqError(str(err).split("\n")[0]) from None
+            return amax
         with _on_device(x.device):
             rc = lib().antq_absmax_into(x.data_ptr(), amax.data_ptr(), rows * row_len, dt, _stream_int(x.device))
         if rc:
@@ -549,11 +582,15 @@ def alpha_grad(x, out, gout, rows, row_len, per_row=True):
     if dt is None or dt == F64 or out.dtype != x.dtype or gout.dtype != x.dtype:
         raise AntqError("alpha_grad: x / out / gout must share one of float32 / bfloat16 / float16")
     gsum = torch.empty(rows if per_row else 1, dtype=torch.float64, device=x.device)
-    ws = None if per_row else _workspace(x.device)
     with _on_device(x.device):
-        _check(lib().antq_alpha_grad(_vp(x), _vp(out), _vp(gout), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
-                                     ctypes.c_int(1 if per_row else 0), _vp(gsum), _vp(ws), ctypes.c_int(dt),
-                                     _stream(x.device)), "antq_alpha_grad")
+        if per_row or torch.cuda.is_current_stream_capturing():
+            ws = None if per_row else _workspace(x.device)
+            _check(lib().antq_alpha_grad(_vp(x), _vp(out), _vp(gout), ctypes.c_size_t(rows), ctypes.c_size_t(row_len),
+                                         ctypes.c_int(1 if per_row else 0), _vp(gsum), _vp(ws), ctypes.c_int(dt),
+                                         _stream(x.device)), "antq_alpha_grad")
+        else:           # one scale for the tensor: ONE launch (fixed-order tree through the stream's ticket block, ABI 7)
+            _check(lib().antq_alpha_grad_t(x.data_ptr(), out.data_ptr(), gout.data_ptr(), rows * row_len, gsum.data_ptr(), dt,
+                                           _reduce_ws(x.device).data_ptr(), _stream_int(x.device)), "antq_alpha_grad_t")
     return gsum
 
 

@@ -26,6 +26,7 @@
 #include "antq_k_fakequant.h"
 #include "antq_k_nearest.h"
 #include "antq_k_aux.h"
+#include "antq_k_reduce.h"
 #include "antq_k_search.h"   // k_sum_partials: the fixed-order sum of workgroup partials (alpha gradient per tensor)
 
 namespace antq {
@@ -46,6 +47,9 @@ thread_local int g_knob_schunks = 0;
 thread_local int g_knob_exp = 0;
 thread_local int g_knob_hist = 1;
 thread_local int g_knob_hist_xmax = 1;
+thread_local int g_knob_rows_stream = 1;
+thread_local int g_knob_tk_group = 0;     // A/B: workgroups per ticket group of the one-launch reductions (0 = default)
+thread_local int g_knob_tk_blocks = 0;    // A/B: workgroups of the one-launch reductions (0 = default)
 
 }  // namespace antq
 
@@ -245,6 +249,9 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 13) g_knob_exp = value;
     else if (key == 14) g_knob_hist = value;
     else if (key == 15) g_knob_hist_xmax = value;
+    else if (key == 16) g_knob_rows_stream = value;
+    else if (key == 17) g_knob_tk_group = value;
+    else if (key == 18) g_knob_tk_blocks = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }
@@ -268,6 +275,19 @@ static int launch_absmax(const void *x, float *amax, size_t rows, size_t row_len
                                n_vec, (uint32_t)vpr, vshift);
             return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
         }
+    }
+    if (per_row && vec_ok && g_knob_rows_stream && rows <= 0x7fffffffull) {
+        // rows of 128 / 256 / 512 / 1024 vectors: one single-wavefront workgroup per row, the whole row in flight (streaming)
+        const size_t vpr = row_len / EPL;
+        const dim3 g((unsigned)(rows < 262144u ? rows : 262144u)), b(64);
+        const uint4 *xv = static_cast<const uint4 *>(x);
+        bool done = true;
+        if (vpr == 128) hipLaunchKernelGGL((k_absmax_rows<T, 2>), g, b, 0, st, xv, amax, (uint32_t)rows);
+        else if (vpr == 256) hipLaunchKernelGGL((k_absmax_rows<T, 4>), g, b, 0, st, xv, amax, (uint32_t)rows);
+        else if (vpr == 512) hipLaunchKernelGGL((k_absmax_rows<T, 8>), g, b, 0, st, xv, amax, (uint32_t)rows);
+        else if (vpr == 1024) hipLaunchKernelGGL((k_absmax_rows<T, 16>), g, b, 0, st, xv, amax, (uint32_t)rows);
+        else done = false;
+        if (done) return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }
     size_t waves = per_row ? rows : (rows * row_len + 64 * EPL * 4 - 1) / (64 * EPL * 4);
     size_t blocks = (waves + 3) / 4;
@@ -392,6 +412,67 @@ extern "C" int antq_absmax_into(const void *x, float *amax, size_t n, int dtype,
     case ANTQ_F32: return launch_absmax<float>(x, amax, 1, n, 0, st, false);
     case ANTQ_BF16: return launch_absmax<bf16_tag>(x, amax, 1, n, 0, st, false);
     case ANTQ_F16: return launch_absmax<f16_tag>(x, amax, 1, n, 0, st, false);
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+}
+
+// ======================================================================================
+// Whole-tensor reductions in one launch (antq_k_reduce.h, ABI 7)
+// ======================================================================================
+namespace antq {
+template <typename T>
+static int launch_absmax_t(const void *x, float *amax, size_t n, void *ws, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const int vec_ok = reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    size_t blocks = (n + 64 * EPL * 4 * 4 - 1) / (64 * EPL * 4 * 4);
+    const size_t cap = g_knob_tk_blocks > 0 ? (size_t)g_knob_tk_blocks : 256;
+    if (blocks > cap) blocks = cap;              // one workgroup per CU: few, long streams (see launch_absmax)
+    if (blocks < 1) blocks = 1;
+    const uint32_t group = g_knob_tk_group > 0 ? (uint32_t)g_knob_tk_group : 16u;
+    hipLaunchKernelGGL((k_absmax_t<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, amax, n, vec_ok, ws, group);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+template <typename T>
+static int launch_alpha_grad_t(const void *x, const void *out, const void *gout, double *gsum, size_t n, void *ws, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const int vec_ok = (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gout)) % 16 == 0;
+    size_t blocks = (n + 64 * EPL * 2 * 4 - 1) / (64 * EPL * 2 * 4);       // a chunk of 128 vectors per wavefront
+    // (16 x 4096^2, profiles/r06_aux_kernels.log: bf16 128 / 256 / 512 / 1024 workgroups 41 / 64.2 / 65.6 / 65.7 %, fp32 49 /
+    //  77.0 / 75.0 / 74.2 %; workgroups per ticket group 8 .. 64: no difference, one group for all: 56 / 43 %)
+    const size_t cap = g_knob_tk_blocks > 0 ? (size_t)g_knob_tk_blocks : (sizeof(T) == 4 ? 256 : 512);
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const uint32_t group = g_knob_tk_group > 0 ? (uint32_t)g_knob_tk_group : 32u;
+    hipLaunchKernelGGL((k_alpha_grad_t<T>), dim3((unsigned)blocks), dim3(256), 0, st, x, out, gout, gsum, n, vec_ok, ws, group);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+}  // namespace antq
+
+extern "C" int antq_absmax_t(const void *x, float *amax, size_t n, int dtype, void *reduce_ws, void *stream)
+{
+    if (!x || !amax || !reduce_ws || n == 0) return ANTQ_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(reduce_ws) % 16) return ANTQ_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case ANTQ_F32: return launch_absmax_t<float>(x, amax, n, reduce_ws, st);
+    case ANTQ_BF16: return launch_absmax_t<bf16_tag>(x, amax, n, reduce_ws, st);
+    case ANTQ_F16: return launch_absmax_t<f16_tag>(x, amax, n, reduce_ws, st);
+    default: return ANTQ_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int antq_alpha_grad_t(const void *x, const void *out, const void *gout, size_t n, double *gsum, int dtype,
+                                 void *reduce_ws, void *stream)
+{
+    if (!x || !out || !gout || !gsum || !reduce_ws || n == 0) return ANTQ_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(reduce_ws) % 16) return ANTQ_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case ANTQ_F32: return launch_alpha_grad_t<float>(x, out, gout, gsum, n, reduce_ws, st);
+    case ANTQ_BF16: return launch_alpha_grad_t<bf16_tag>(x, out, gout, gsum, n, reduce_ws, st);
+    case ANTQ_F16: return launch_alpha_grad_t<f16_tag>(x, out, gout, gsum, n, reduce_ws, st);
     default: return ANTQ_ERR_UNSUPPORTED;
     }
 }

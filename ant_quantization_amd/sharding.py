@@ -210,11 +210,17 @@ def _all_reduce(t, op, group):
 
 def sharded_absmax(x_block, group=None, ops=GpuBlockOps):
     """abs-max of the whole row-sharded tensor as a 1-element float32 tensor on every rank: local abs-max, all_reduce(MAX)
-    (AQ/quant_modules.py:308-324: x_max of a per-tensor quantiser).  NaN propagates like torch.max: a NaN block maximum
-    is sent as +Inf-plus (its bit pattern orders above every finite value) -- here simply through the float MAX, which
-    keeps NaN on every backend this runs on when any rank holds one."""
+    (AQ/quant_modules.py:308-324: x_max of a per-tensor quantiser).  NaN propagates like torch.max, BY CONSTRUCTION: what
+    crosses the ranks is the float's bit pattern with the sign cleared, as int32, reduced with the INTEGER maximum -- the
+    ordering the kernel's own atomicMax uses (csrc/antq_k_aux.h): non-negative floats order like their patterns, +Inf
+    (0x7f800000) above every finite value, every NaN (0x7f800001 ..) above +Inf.  No backend's floating-point MAX is
+    trusted with a NaN (IEEE maxNum drops it; RCCL's float MAX was never run on one here -- DESIGN section 7)."""
+    import torch
     import torch.distributed as dist
-    return _all_reduce(ops.absmax(x_block).reshape(1).clone(), dist.ReduceOp.MAX, group)
+    local = ops.absmax(x_block).reshape(1).to(torch.float32).clone()
+    bits = local.view(torch.int32) & 0x7FFFFFFF
+    _all_reduce(bits, dist.ReduceOp.MAX, group)
+    return bits.view(torch.float32)
 
 
 def sharded_three_sigma(x_block, n_total, group=None, ops=GpuBlockOps):

@@ -40,8 +40,10 @@ extern "C" {
  * added (nothing else changed).  4 (round 4): the plan blob grew (version 9: 128-byte header + the threshold list of the
  * 16-bit-domain kernels; ANTQ_PLAN_MAX_BYTES with it), the batch blob changed, antq_plan_eval_host_h and
  * antq_prefetch_kernels added.  5: antq_calibrate_batch / antq_calibrate_batch_workspace_bytes and antq_absmax_into added (nothing else changed).
+ * 7 (round 6): antq_absmax_t / antq_alpha_grad_t (whole-tensor reductions in ONE launch through a caller-owned ticket block,
+ * ANTQ_REDUCE_WS_BYTES) and antq_calibrate_install added (nothing else changed).
  * A caller built against another version must not call in: the blobs / argument lists differ. */
-#define ANTQ_ABI_VERSION 6
+#define ANTQ_ABI_VERSION 7
 
 /* element types of x / out */
 #define ANTQ_F32  0
@@ -201,6 +203,23 @@ int antq_absmax(const void *x_dev, float *amax_dev, size_t rows, size_t row_len,
  * (a tensor that arrives in pieces, a row-sharded quantiser's local blocks).  Same combination rule as antq_absmax
  * (integer atomicMax on the float's bits: order-independent, NaN wins). */
 int antq_absmax_into(const void *x_dev, float *amax_dev, size_t n, int dtype, void *stream);
+
+/* Whole-tensor reductions in ONE launch with nothing to zero per call (ABI 7).  reduce_ws_dev: ANTQ_REDUCE_WS_BYTES of
+ * device memory owned by the caller, 16-byte aligned, ZEROED ONCE after allocation (hipMemsetAsync); every call leaves it
+ * zeroed again, so calls issued one after the other on ONE stream share one block -- two streams never do.  Inside:
+ * last-arriver tickets, one counter per group of workgroups (no more than 32 atomics ever queue on one address) and the
+ * workgroup / group partials, folded in index order: results do not depend on which workgroup finishes last.
+ *   antq_absmax_t     : *amax_dev = max_i |x[i]| over n elements, WRITTEN (not accumulated; amax_dev need not be
+ *                       initialised).  Same value as antq_absmax(per_row = 0), NaN wins.  A 33.5 MB bf16 tensor: 9.3 us
+ *                       (antq_absmax: zeroing launch + 256 atomics on one address) -> see profiles/r06_aux_kernels.log.
+ *   antq_alpha_grad_t : *gsum_dev = sum_i fl32(gout[i] * fl32(out[i] - x[i])) in double, the per-tensor form of
+ *                       antq_alpha_grad as one launch (that entry point: a second launch adds the partials).  Sums are
+ *                       formed in one fixed tree -- bit-reproducible, but not the tree of antq_alpha_grad: the two may
+ *                       differ in the last bits of the double. */
+#define ANTQ_REDUCE_WS_BYTES 65536
+int antq_absmax_t(const void *x_dev, float *amax_dev, size_t n, int dtype, void *reduce_ws_dev, void *stream);
+int antq_alpha_grad_t(const void *x_dev, const void *out_dev, const void *gout_dev, size_t n, double *gsum_dev, int dtype,
+                      void *reduce_ws_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Backward of antq_fakequant with respect to alpha (QAT: alpha is a Parameter, AQ:39; the autograd graph of

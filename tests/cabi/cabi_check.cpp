@@ -8,7 +8,8 @@
 // calibration entry points (antq_search_sse with its workspace, antq_search_pick, and antq_calibrate: all of it in one call),
 // and -- section 9 -- every ABI 4 / 5 entry: antq_nearest_plan, the host models antq_plan_eval_host[_a|_h], the 16-bit-domain row
 // kernels on bf16, antq_absmax_into, antq_search_sse_multi, antq_moments + antq_xmax_3sigma, antq_affine, antq_alpha_grad,
-// antq_calibrate_batch, antq_fakequant_f64, antq_copy, antq_prefetch_kernels, antq_debug_set: every prototype of include/antq.h is called here.
+// antq_calibrate_batch, antq_fakequant_f64, antq_copy, antq_prefetch_kernels, antq_debug_set, and ABI 7's antq_absmax_t /
+// antq_alpha_grad_t: every prototype of include/antq.h is called here.
 // Exit code 0 = every comparison bit-exact; prints one line per check.
 #include <hip/hip_runtime.h>
 
@@ -545,6 +546,50 @@ int main()
             printf("%-58s %s (%zu of %zu off)\n", per_row ? "antq_alpha_grad per row" : "antq_alpha_grad per tensor", bad ? "FAIL" : "ok", bad, na);
             if (bad) failures++;
         }
+    }
+
+    // 9h'. ABI 7: the same two whole-tensor reductions in ONE launch each through a ticket block zeroed once
+    //      (antq_absmax_t writes the maximum: the slot starts as garbage; antq_alpha_grad_t: one fixed-order tree), three
+    //      calls back to back through the SAME block (every call leaves it zeroed), then the block is checked to be zero
+    {
+        DevBuf<uint8_t> dred(ANTQ_REDUCE_WS_BYTES);
+        HIP_OK(hipMemsetAsync(dred.p, 0, ANTQ_REDUCE_WS_BYTES, st));
+        std::vector<float> want(1);
+        antq_oracle_absmax_f32(xf.data(), want.data(), 1, n, 0, 1.0f);
+        for (int rep = 0; rep < 3; rep++) {
+            DevBuf<float> dslot(1);
+            HIP_OK(hipMemsetAsync(dslot.p, 0x7f, 4, st));          // garbage: the entry point WRITES its result
+            ANTQ_OK_(antq_absmax_t(dxf.p, dslot.p, n - (size_t)rep, ANTQ_F32, dred.p, st));
+            std::vector<float> w2(1);
+            antq_oracle_absmax_f32(xf.data(), w2.data(), 1, n - (size_t)rep, 0, 1.0f);
+            same_bits("antq_absmax_t (one launch, ticket block)", dslot.down(st), w2);
+        }
+        std::vector<float> gout(n);
+        for (size_t i = 0; i < n; i++) gout[i] = nd(rng) * 50.0f;
+        DevBuf<float> dg(n);
+        dg.up(gout, st);
+        ANTQ_OK_(antq_fakequant(dxf.p, dout.p, nullptr, rows, K, dalpha.p, 1, 10.0f, plan.data(), dplan.p, 0, ANTQ_F32, st));
+        const std::vector<float> o = dout.down(st);
+        DevBuf<double> dgs(1);
+        ANTQ_OK_(antq_alpha_grad_t(dxf.p, dout.p, dg.p, n, dgs.p, ANTQ_F32, dred.p, st));
+        const std::vector<double> g1 = dgs.down(st);
+        ANTQ_OK_(antq_alpha_grad_t(dxf.p, dout.p, dg.p, n, dgs.p, ANTQ_F32, dred.p, st));
+        const std::vector<double> g2 = dgs.down(st);
+        double wantg = 0.0, mag = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            const float diff = o[i] - xf[i];
+            const float term = gout[i] * diff;
+            wantg += (double)term;
+            mag += std::fabs((double)term);
+        }
+        const bool okg = std::fabs(g1[0] - wantg) <= 1e-6 * mag + 1e-30 && std::memcmp(&g1[0], &g2[0], 8) == 0;
+        printf("%-58s %s\n", "antq_alpha_grad_t (one launch, bit-reproducible)", okg ? "ok" : "FAIL");
+        if (!okg) failures++;
+        const std::vector<uint8_t> red = dred.down(st);
+        size_t nz = 0;
+        for (size_t i = 0; i < 16384; i++) nz += red[i] != 0;     // (the counter region: what must be zero between calls)
+        printf("%-58s %s\n", "ticket block left zeroed by every call", nz ? "FAIL" : "ok");
+        if (nz) failures++;
     }
 
     // 9i. antq_calibrate_batch: three quantisers (per row, per tensor, per row on a sub-tensor) in ONE call == one

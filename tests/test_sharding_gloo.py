@@ -399,3 +399,54 @@ def test_sharded_per_tensor_calibration_world2():
                 assert abs(float(tr[ci]) - float(tr.min())) <= 1e-6 * float(tr.min()), (t, al, ar)
         assert a["type"] == a["type_ref"] or abs(a["score_ref"][a["type"]] - min(a["score_ref"])) <= 1e-6 * min(a["score_ref"])
         np.testing.assert_allclose(a["score"], a["score_ref"], rtol=1e-5)
+
+
+def _nan_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from ant_quantization_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops = OracleBlockOps(orc_module(), {})
+    out = []
+    # (which rank holds what): NaN on one rank only, on the other, on both; +Inf against a finite block; -NaN payloads;
+    # plain finite blocks (the larger wins exactly); an all-zero tensor
+    cases = [([1.0, -3.5], [2.0, float("nan")]), ([float("nan"), 0.5], [7.0, 1.0]), ([float("nan")], [float("nan")]),
+             ([float("inf"), 1.0], [3.0e38, 2.0]), ([-float("inf")], [float("nan")]), ([1.5, -2.25], [-2.5, 0.125]),
+             ([0.0, -0.0], [0.0, 0.0])]
+    for blocks in cases:
+        xb = torch.tensor(blocks[rank], dtype=torch.float32).reshape(1, -1)
+        if blocks is cases[4] and rank == 1:
+            xb = torch.tensor([0xFFC00001 - (1 << 32)], dtype=torch.int32).view(torch.float32).reshape(1, 1)   # a NEGATIVE NaN with payload
+        r = sharding.sharded_absmax(xb, ops=ops)
+        out.append(float(r[0]))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def orc_module():
+    from oracle import antq_oracle
+    return antq_oracle
+
+
+def test_sharded_absmax_keeps_nan_by_construction_world2():
+    """the abs-max of a row-sharded tensor crosses the ranks as an int32 bit pattern under the INTEGER
+    maximum (NaN above +Inf above every finite value: the kernel's own atomicMax ordering), so a NaN held by any one rank
+    reaches every rank -- like torch.max on the whole tensor -- whatever a backend's float MAX does with NaN."""
+    import math
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        v = res[r]
+        assert math.isnan(v[0]) and math.isnan(v[1]) and math.isnan(v[2]) and math.isnan(v[4]), v
+        assert v[3] == float("inf") and v[5] == 2.5 and v[6] == 0.0, v
