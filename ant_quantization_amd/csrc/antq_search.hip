@@ -9,6 +9,7 @@
 #include "antq_k_fakequant.h"
 #include "antq_k_search.h"
 #include "antq_k_hist.h"
+#include "antq_k_sweep.h"
 
 #include <type_traits>
 
@@ -169,6 +170,71 @@ static SearchGrid search_grid(size_t units, size_t unit_work, bool pt, int n, in
     return best;
 }
 
+// ---- the threshold sweep (antq_k_sweep.h): per-row scales, every codebook with a threshold list ------------------------
+// ANTQ_ERR_UNSUPPORTED: not this launch (the caller goes on to the direct kernels).  Where it is taken (knob 19 = 1, the
+// default): rows of 2048 .. 65536 elements and codebooks of at most 20 thresholds.  Measured, 70 candidates x 3 ANT codebooks
+// (profiles/r06_sweep_search.log): 4096 x 4096 fp32 1.29 -> 0.71 ms, 4096 x 16384 5.07 -> 2.27 ms; rows of 3072: 0.213 -> 0.201,
+// rows of 768: no gain -- the per-row set-up (thresholds x candidates moved into the x domain, the scans along the candidate
+// axis, ~17 KB of LDS per wavefront) is worth ~1500 elements' work; above 65536 elements the fixed-point sums could pass 62
+// bits.  OliVe's 28-29 thresholds and 75 .. 250 clip range (half a dozen thresholds sweep across every element) run 0.6-0.8 x
+// the direct kernels' speed: not taken.  knob 19 = 2 takes every eligible launch from 256 elements per row (tests).
+static bool sweep_type_ok(const void *plan_host, float gmax)
+{
+    const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
+    return ph->kind == kPlanLut && ph->hdom && ph->h_nthr > 0 && ph->h_nthr <= (g_knob_sweep == 2 ? (uint32_t)kSweepMaxThr : 20u) && gmax > 0.0f;
+}
+template <typename T, bool OVP>
+static bool sweep_shape_ok(const void *x, size_t rows, size_t row_len, int ncand, int ntypes)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (!g_knob_sweep || rows < 2 || ncand < 1 || ntypes < 1 || ntypes > kMaxTypes) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sweep == 2 ? 256u : 2048u) || row_len > 65536) return false;
+    return !(OVP && (row_len & 1));                                  // (pairs would straddle rows)
+}
+
+template <typename T, bool OVP>
+static int launch_sweep(const void *x, size_t rows, size_t row_len, const float *xmax, const float *ratios, int ncand, int ntypes,
+                        const float *gmax, const void *const *plan_host, const void *const *plan_dev, double *sse, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (!sweep_shape_ok<T, OVP>(x, rows, row_len, ncand, ntypes)) return ANTQ_ERR_UNSUPPORTED;
+    SweepType ty[kMaxTypes];
+    memset(ty, 0, sizeof(ty));
+    // candidate lists longer than the kernel's tables (128) go out in pieces: a candidate's sums are formed from exact integer
+    // counts, so they do not depend on which other candidates share its launch (as long as no element changes between the
+    // step-function and the literal class, which the smallest scale of the piece decides)
+    const uint32_t cp_max = (uint32_t)std::min(ncand, kSweepMaxCand) + 1u;
+    for (int t = 0; t < ntypes; t++) {
+        const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host[t]);
+        if (!sweep_type_ok(plan_host[t], gmax[t])) return ANTQ_ERR_UNSUPPORTED;
+        const HThr *tl = plan_tlist(plan_host[t]);
+        ty[t].tlist = reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev[t]) + ph->tlist_off);
+        ty[t].grid = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev[t]));
+        ty[t].n_thr = ph->h_nthr;
+        ty[t].m = ph->m;
+        ty[t].gmax = gmax[t];
+        const float flim = ph->fastlim * 0.99999f;
+        ty[t].lim = flim < ph->xlim ? flim : ph->xlim;
+        ty[t].kout_pos = ty[t].kout_neg = -1;
+        for (uint32_t k = 0; k < ph->h_nthr; k++) {
+            const bool lo_out = (tl[k].flags & 1u) != 0u, hi_out = (tl[k].flags & 2u) != 0u;
+            if (k > 0 && !(tl[k].T > tl[k - 1].T)) return ANTQ_ERR_UNSUPPORTED;                   // (ascending: what the kernel's searches assume)
+            if (!lo_out && hi_out) { if (ty[t].kout_pos >= 0 || !(tl[k].T > 0.0f)) return ANTQ_ERR_UNSUPPORTED; ty[t].kout_pos = (int)k; }
+            if (lo_out && !hi_out) { if (ty[t].kout_neg >= 0 || !(tl[k].T < 0.0f)) return ANTQ_ERR_UNSUPPORTED; ty[t].kout_neg = (int)k; }
+        }
+        if (sweep_lds_bytes(ph->h_nthr, cp_max) > 64 * 1024) return ANTQ_ERR_UNSUPPORTED;
+    }
+    const unsigned blocks = (unsigned)std::min<size_t>(rows, (size_t)1 << 20);
+    for (int t = 0; t < ntypes; t++)             // one codebook per launch: [ncand][rows] doubles each
+        for (int c0 = 0; c0 < ncand; c0 += kSweepMaxCand) {
+            const int nc = std::min(kSweepMaxCand, ncand - c0);
+            hipLaunchKernelGGL((k_search_sweep<T, OVP>), dim3(blocks), dim3(64), sweep_lds_bytes(ty[t].n_thr, (uint32_t)nc + 1u), st,
+                               static_cast<const uint4 *>(x), (uint32_t)(row_len / EPL), rows, xmax, ratios + c0,
+                               sse + ((size_t)t * (size_t)ncand + (size_t)c0) * rows, ty[t], (uint32_t)nc, (uint32_t)nc + 1u);
+        }
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
 template <typename T, bool OVP>
 static int launch_search(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                          const float *ratios, int ncand, float gmax, const PlanArgs &pa, const void *plan_host,
@@ -190,6 +256,11 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
         if (!per_row)
             hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)blocks, kPtCand, sse);
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+    }
+    if (per_row && rows > 1) {                   // per-row scales: the threshold sweep where it applies (antq_k_sweep.h)
+        const void *ph1[1] = {plan_host}, *pd1[1] = {plan_dev};
+        const int rc = launch_sweep<T, OVP>(x, rows, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, st);
+        if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
     }
     if (!per_row) { row_len = rows * row_len; rows = 1; }
     const int *run_if = nullptr;                 // device flag: run the direct kernels only if it is set (pair-list overflow)
@@ -254,6 +325,15 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
 {
     constexpr int EPL = IO<T>::EPL;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) return ANTQ_ERR_UNSUPPORTED;
+    if (per_row && rows > 1) {                   // per-row scales: the threshold sweep where it applies (antq_k_sweep.h)
+        const int rc = launch_sweep<T, OVP>(x, rows, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, st);
+        if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
+        // a codebook's sums must not depend on which other codebooks are searched with it: if one search per type would send
+        // SOME of these types through the sweep, the caller has to issue one search per type (it does on this return code)
+        if (sweep_shape_ok<T, OVP>(x, rows, row_len, ncand, 1))
+            for (int t = 0; t < ntypes; t++)
+                if (sweep_type_ok(plan_host[t], gmax[t])) return ANTQ_ERR_UNSUPPORTED;
+    }
     if (!per_row) { row_len = rows * row_len; rows = 1; }
     const int *run_if = nullptr;
     if (rows == 1 && hist_eligible<T>(row_len, OVP, x, ntypes * ncand)) {

@@ -2660,7 +2660,20 @@ def test_calibration_sums_are_bit_reproducible(antq_lib, dev):
             halves = torch.cat([antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[:75].contiguous(), flint, 10.0),
                                 antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[75:].contiguous(), flint, 10.0)])
             if per_row and rows > 1:
-                assert torch.equal(full, halves)
+                # (round 6: rows of 2048 elements and more take the threshold sweep, whose split of the elements into
+                #  step-function and literal ones follows the SMALLEST scale of the launch's candidates -- with a list that starts
+                #  at ratio 0.01 the two halves classify differently and agree to the closed form's rounding, 1e-8, not to the
+                #  bit; still the same bits on every run.  The direct kernels, knob 19 = 0, are split-independent to the bit.)
+                torch.testing.assert_close(full, halves, rtol=1e-7, atol=0)
+                antq_lib.lib().antq_debug_set(19, 0)
+                try:
+                    f0 = antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150, flint, 10.0)
+                    h0 = torch.cat([antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[:75].contiguous(), flint, 10.0),
+                                    antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[75:].contiguous(), flint, 10.0)])
+                finally:
+                    antq_lib.lib().antq_debug_set(19, 1)
+                assert torch.equal(f0, h0)
+                torch.testing.assert_close(full, f0, rtol=1e-7, atol=0)
             else:
                 torch.testing.assert_close(full, halves, rtol=1e-12, atol=0)
     finally:

@@ -36,15 +36,15 @@ FLOORS = {
     "batch_d_group16_bf16": 0.92,
     "hbatch_dyn_rows_bf16": 0.94,
     "batch_rows_f32": 0.95,
-    "encode4_bf16": 0.59,
-    "decode4_bf16": 0.60,
+    "encode4_bf16": 0.50,
+    "decode4_bf16": 0.50,
     "absmax_rows_bf16": 0.76,
     "absmax_tensor_bf16": 0.58,
     "moments_rows_bf16": 0.53,
     "alpha_grad_rows_bf16": 0.99,
     "alpha_grad_tensor_bf16": 0.88,
     "affine_f32": 0.91,
-    "search_sse_rows_f32": 1.50,
+    "search_sse_rows_f32": 2.80,
     "calibrate_tensor_bf16_hist": 0.16,
 }
 _measured = {}
