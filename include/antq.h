@@ -41,7 +41,7 @@ extern "C" {
  * 16-bit-domain kernels; ANTQ_PLAN_MAX_BYTES with it), the batch blob changed, antq_plan_eval_host_h and
  * antq_prefetch_kernels added.  5: antq_calibrate_batch / antq_calibrate_batch_workspace_bytes and antq_absmax_into added (nothing else changed).
  * 7 (round 6): antq_absmax_t / antq_alpha_grad_t (whole-tensor reductions in ONE launch through a caller-owned ticket block,
- * ANTQ_REDUCE_WS_BYTES) and antq_calibrate_install added (nothing else changed).
+ * ANTQ_REDUCE_WS_BYTES) added (nothing else changed).
  * A caller built against another version must not call in: the blobs / argument lists differ. */
 #define ANTQ_ABI_VERSION 7
 
