@@ -58,7 +58,7 @@ def lib():
                              "antq_search_pick", "antq_alpha_grad", "antq_nearest_plan", "antq_nearest_hinted",
                              "antq_search_sse_multi", "antq_plan_eval_host_a", "antq_moments", "antq_xmax_3sigma",
                              "antq_calibrate", "antq_prefetch_kernels", "antq_plan_eval_host_h", "antq_calibrate_batch", "antq_absmax_into", "antq_fakequant_f64",
-                             "antq_absmax_t", "antq_alpha_grad_t"):
+                             "antq_absmax_t", "antq_alpha_grad_t", "antq_calibrate_install"):
                     getattr(L, name).restype = ctypes.c_int
                 L.antq_batch_capacity.restype = ctypes.c_size_t
                 L.antq_search_workspace_bytes.restype = ctypes.c_size_t
@@ -74,6 +74,7 @@ def lib():
                 L.antq_absmax_t.argtypes = [vp, vp, sz, ci, vp, vp]
                 L.antq_alpha_grad_t.argtypes = [vp, vp, vp, sz, vp, ci, vp, vp]
                 L.antq_alpha_grad.argtypes = [vp, vp, vp, sz, sz, ci, vp, vp, ci, vp]
+                L.antq_calibrate_install.argtypes = [vp, vp, sz, ci, ci, vp, vp, vp, cu, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp]
                 L.antq_copy.argtypes = [vp, vp, sz, vp]
                 # development: ANTQ_DEBUG_KNOBS="14=2,0=8" applies antq_debug_set(key, value) pairs to the loading thread
                 # (the knobs are thread-local; tools/fuzz_campaign.sh forces code paths with it)
@@ -142,7 +143,12 @@ def prewarm(device, dtype=torch.float32):
         s1.copy_(x.min().float().reshape(1), non_blocking=True)
         torch.ones_like(al), al.clone()
         # the device-side type pick of input quantisers (_mirror.CalibrationMixin._calibrate_deferred): its gathers and casts
-        a3, _, typ, _ = calibrate(x, 1, x.numel(), False, plans_a, [10.0, 10.0], 95, 100, 1, xmax="absmax")
+        a3, s3, typ, _ = calibrate(x, 1, x.numel(), False, plans_a, [10.0, 10.0], 95, 100, 1, xmax="absmax")
+        stack = torch.zeros(2, 16, device=device)
+        calibrate_install(x, torch.empty_like(x), plans_a, [10.0, 10.0], typ, a3.reshape(-1), s3.reshape(-1), stack,
+                          torch.empty(16, device=device), torch.empty(1, device=device), torch.empty(1, device=device))
+        calibrate_install(x, torch.empty_like(x), [plan_o, plan_o], [float(on.max())] * 2, typ, a3.reshape(-1), s3.reshape(-1), stack,
+                          torch.empty(16, device=device), torch.empty(1, device=device), torch.empty(1, device=device), ovp=True)
         idx = typ.long()
         a3.index_select(0, idx).reshape(())
         torch.stack([x, x]).index_select(0, idx)
@@ -716,6 +722,38 @@ def calibrate(x, rows, row_len, per_row, plans, gmaxs, lb, ub, step, xmax="absma
                                   _vp(alpha), _vp(score), _vp(typ), _vp(ws), ctypes.c_size_t(nbytes), _stream(x.device))
     _check(rc, "antq_calibrate")
     return alpha, score, typ, xm
+
+
+_install_args = {}        # (plans..., gmaxs...) -> the three small ctypes arrays of antq_calibrate_install (built once per type list)
+
+
+def calibrate_install(x, out, plans, gmaxs, typ, alpha, score, grids_stack, grid_out, alpha_out, mse_out, ovp=False):
+    """antq_calibrate_install: from the device-side pick `typ` of calibrate() -- alpha_out / mse_out / grid_out <- the winner's
+    alpha, score and row of grids_stack [ntypes, grid_len] float32, and out <- the steady-state forward of x (one scale) with
+    the winner's codebook.  Two launches, no read-back.  False: this tensor is not eligible (ragged / unaligned: the caller
+    quantises with every candidate and gathers)."""
+    _require_gpu(x, "x")
+    dt = _DTYPES.get(x.dtype)
+    nt = len(plans)
+    if dt is None or dt == F64 or nt > 4 or not x.is_contiguous() or grids_stack.dtype != torch.float32 or grids_stack.shape[0] != nt:
+        return False
+    key = (tuple(id(p) for p in plans), tuple(gmaxs), x.device.index)
+    a = _install_args.get(key)
+    if a is None:
+        if len(_install_args) > 256:
+            _install_args.clear()
+        a = _install_args[key] = ((ctypes.c_float * nt)(*[float(g) for g in gmaxs]), (ctypes.c_void_p * nt)(*[p.host_addr for p in plans]),
+                                  (ctypes.c_void_p * nt)(*[p.dev(x.device).data_ptr() for p in plans]), list(plans))
+    with _on_device(x.device):
+        rc = lib().antq_calibrate_install(x.data_ptr(), out.data_ptr(), x.numel(), dt, nt, ctypes.addressof(a[0]), ctypes.addressof(a[1]),
+                                          ctypes.addressof(a[2]), FLAG_OVP if ovp else 0, typ.data_ptr(), alpha.data_ptr(), score.data_ptr(),
+                                          grids_stack.data_ptr(), grids_stack.shape[1], grid_out.data_ptr(), None, 0, None,
+                                          alpha_out.data_ptr(), mse_out.data_ptr(), _stream_int(x.device))
+    if rc == -2:                    # ANTQ_ERR_UNSUPPORTED
+        return False
+    if rc:
+        _check(rc, "antq_calibrate_install")
+    return True
 
 
 class _CalibJob(ctypes.Structure):           # include/antq.h: antq_calib_job

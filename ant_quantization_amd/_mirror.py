@@ -187,15 +187,36 @@ class CalibrationMixin:
             core.search_memo.put(data, key, (alpha, score, typ))
         else:
             alpha, score, typ = seen
-        idx = typ.long()
-        self.alpha.data = alpha.index_select(0, idx).reshape(())
-        self._install_selected(spec, idx)
-        self._searched = True
-        self._mse_later(score.index_select(0, idx), 1)
-        outs = torch.empty((len(plans),) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        for t, (p, gm) in enumerate(zip(plans, spec["gmaxs"])):
-            core.fake_quant(x, alpha[t], p, gm, False, ovp=spec["ovp"], out=outs[t])
-        self._spec_out = outs.index_select(0, idx)[0].view(data.shape)
+        # the installed state and this call's output from the device-side pick: two launches (antq_calibrate_install, round 6)
+        # -- alpha, mse and quant_grid gathered by the pick, ONE pass over the tensor with the picked codebook -- instead of a
+        # dozen small torch launches, a fake-quant pass per candidate and a gather of the whole tensor
+        rows_np = self._selectable_rows(spec)
+        installed = False
+        if rows_np is not None and x.dim() >= 1:
+            stack = core.device_grid_master(rows_np, x.device)
+            # (alpha and the codebook in storages of their own: an in-place edit of one must not move the other's version counter)
+            am = torch.empty(2, dtype=torch.float32, device=x.device)                  # [alpha, mse]
+            grid_out = torch.empty(stack.shape[1], dtype=torch.float32, device=x.device)
+            out = torch.empty_like(x)
+            installed = _lib.calibrate_install(x, out, plans, spec["gmaxs"], typ, alpha.reshape(-1), score.reshape(-1), stack,
+                                               grid_out, am[0:1], am[1:2], ovp=spec["ovp"])
+            if installed:
+                self.alpha.data = am[0].reshape(())
+                self.quant_grid.data = grid_out
+                self._after_install_selected(spec)
+                self._searched = True
+                self.mse = am[1]
+                self._spec_out = out.view(data.shape)
+        if not installed:
+            idx = typ.long()
+            self.alpha.data = alpha.index_select(0, idx).reshape(())
+            self._install_selected(spec, idx)
+            self._searched = True
+            self._mse_later(score.index_select(0, idx), 1)
+            outs = torch.empty((len(plans),) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            for t, (p, gm) in enumerate(zip(plans, spec["gmaxs"])):
+                core.fake_quant(x, alpha[t], p, gm, False, ovp=spec["ovp"], out=outs[t])
+            self._spec_out = outs.index_select(0, idx)[0].view(data.shape)
         slot = _slots.take(self)
         slot.copy_(typ.float(), non_blocking=True)
         ev = torch.cuda.Event()

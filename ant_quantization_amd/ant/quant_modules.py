@@ -434,6 +434,14 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         """quant_grid <- the codebook of the device-side pick (a row of the stacked candidates)."""
         self.quant_grid.data = self._to_grid(np.stack(spec["grids"])).index_select(0, idx)[0]
 
+    def _selectable_rows(self, spec):
+        """[ntypes, 2^bit] float32: what quant_grid holds for each candidate type (antq_calibrate_install gathers one row)."""
+        g = spec["grids"]
+        return np.stack(g) if len({len(v) for v in g}) == 1 else None
+
+    def _after_install_selected(self, spec):
+        pass
+
     def _adopt_plan(self, spec, t):
         self._plan = _lib.plan_for(spec["grids"][t])
         self._gmax = spec["gmaxs"][t]

@@ -240,6 +240,17 @@ def device_grid(values, device):
     return t.clone()
 
 
+def device_grid_master(values, device):
+    """The resident master copy itself (read-only use: a stack of candidate codebooks a kernel gathers a row from)."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    key = (v.tobytes(), device.type, device.index)
+    t = _grid_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(v.copy()).to(device)
+        _grid_cache[key] = t
+    return t
+
+
 _absmax_memo = [None]          # (tensor, (version, address, dtype, shape, strides), per_channel, result) of the last call
 
 

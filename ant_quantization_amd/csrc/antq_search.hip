@@ -592,6 +592,117 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+// ------------------------------------------------------------------------------------------------
+// antq_calibrate_install: the state and the output of a calibrating call whose type pick stays on the device
+// ------------------------------------------------------------------------------------------------
+namespace antq {
+struct SelPlans {
+    PlanArgs pa[kMaxTypes];
+    const uint4 *tab[kMaxTypes];
+    float gmax[kMaxTypes];
+    int ntypes;
+};
+
+static __global__ void __launch_bounds__(256)
+k_calib_install(const int32_t *__restrict__ type, int ntypes, const float *__restrict__ alpha, const float *__restrict__ score,
+                const float *__restrict__ grids, int grid_len, float *__restrict__ grid_out, const float *__restrict__ outl,
+                int outl_len, float *__restrict__ outl_out, float *__restrict__ alpha_out, float *__restrict__ mse_out)
+{
+    int t = type[0];
+    t = t < 0 ? 0 : (t >= ntypes ? ntypes - 1 : t);
+    for (int i = (int)threadIdx.x; i < grid_len; i += 256) grid_out[i] = grids[(size_t)t * grid_len + i];
+    if (outl && outl_out)
+        for (int i = (int)threadIdx.x; i < outl_len; i += 256) outl_out[i] = outl[(size_t)t * outl_len + i];
+    if (threadIdx.x == 0) {
+        alpha_out[0] = alpha[t];
+        if (mse_out) mse_out[0] = score[t];
+    }
+}
+
+// _forward of a tensor with ONE scale through the codebook the device picked: the d-domain element path (table where the
+// quotient lies inside it, literal scan elsewhere: quant_vec), the plan chosen by *type at run time.  Not a throughput
+// kernel -- it runs once per quantiser, in its calibrating forward -- but one pass instead of ntypes passes and a gather.
+template <typename T, bool OVP>
+__global__ void __launch_bounds__(256)
+k_fq_select(const uint4 *__restrict__ x, uint4 *__restrict__ out, size_t nv, const int32_t *__restrict__ type,
+            const float *__restrict__ alpha, SelPlans sp)
+{
+    constexpr int EPL = IO<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    int t = type[0];
+    t = t < 0 ? 0 : (t >= sp.ntypes ? sp.ntypes - 1 : t);
+    PlanArgs pa = sp.pa[0];
+    const uint4 *tab = sp.tab[0];
+    float gmax = sp.gmax[0];
+#pragma unroll
+    for (int k = 1; k < kMaxTypes; k++)
+        if (t == k) { pa = sp.pa[k]; tab = sp.tab[k]; gmax = sp.gmax[k]; }
+    uint4 tab0 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < pa.tab_units) tab0 = tab[threadIdx.x];
+    const PlanLds L = stage_plan(pa, tab, smem, tab0);
+    __syncthreads();
+    const Scale sc = make_scale(alpha[t], gmax);
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256u) {
+        const uint4 v = ld_stream(x + i);
+        float xf[EPL], of[EPL];
+        int j[EPL];
+        IO<T>::unpack(v, xf);
+        quant_vec<EPL, OVP, false>(pa, L, sc, xf, of, j);
+        st_stream(out + i, IO<T>::pack(of));
+    }
+}
+
+template <typename T>
+static int launch_install_forward(const void *x, void *out, size_t n, unsigned flags, const int32_t *type, const float *alpha,
+                                  const SelPlans &sp, size_t lds, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    const size_t nv = n / EPL;
+    const unsigned blocks = (unsigned)std::min<size_t>((nv + 255) / 256, 256 * 16);
+    if (flags & ANTQ_FLAG_OVP)
+        hipLaunchKernelGGL((k_fq_select<T, true>), dim3(blocks), dim3(256), lds, st, static_cast<const uint4 *>(x), static_cast<uint4 *>(out), nv, type, alpha, sp);
+    else
+        hipLaunchKernelGGL((k_fq_select<T, false>), dim3(blocks), dim3(256), lds, st, static_cast<const uint4 *>(x), static_cast<uint4 *>(out), nv, type, alpha, sp);
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+}  // namespace antq
+
+extern "C" int antq_calibrate_install(const void *x, void *out, size_t n, int dtype, int ntypes, const float *gmax_host,
+                                      const void *const *plan_host, const void *const *plan_dev, unsigned flags,
+                                      const int32_t *type, const float *alpha, const float *score, const float *grids,
+                                      int grid_len, float *grid_out, const float *outl, int outl_len, float *outl_out,
+                                      float *alpha_out, float *mse_out, void *stream)
+{
+    if (!x || !out || !gmax_host || !plan_host || !plan_dev || !type || !alpha || !score || !grids || !grid_out || !alpha_out ||
+        ntypes < 1 || grid_len < 1 || n == 0 || (flags & ~ANTQ_FLAG_OVP))
+        return ANTQ_ERR_ARG;
+    if (ntypes > kMaxTypes) return ANTQ_ERR_UNSUPPORTED;
+    const int epl = dtype == ANTQ_F32 ? 4 : 8;
+    if (dtype != ANTQ_F32 && dtype != ANTQ_BF16 && dtype != ANTQ_F16) return ANTQ_ERR_UNSUPPORTED;
+    if (n % (size_t)epl != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return ANTQ_ERR_UNSUPPORTED;
+    SelPlans sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.ntypes = ntypes;
+    size_t lds = 0;
+    for (int t = 0; t < kMaxTypes; t++) {
+        const int u = t < ntypes ? t : 0;
+        if (!plan_host[u] || !plan_dev[u]) return ANTQ_ERR_ARG;
+        if (!plan_args_from_host(plan_host[u], sp.pa[t])) return ANTQ_ERR_PLAN;
+        sp.tab[t] = plan_tab_ptr(plan_dev[u]);
+        sp.gmax[t] = gmax_host[u];
+        lds = std::max(lds, (size_t)sp.pa[t].tab_units * 16);
+    }
+    if (lds > 64 * 1024) return ANTQ_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_calib_install, dim3(1), dim3(256), 0, st, type, ntypes, alpha, score, grids, grid_len, grid_out, outl, outl_len,
+                       outl_out, alpha_out, mse_out);
+    switch (dtype) {
+    case ANTQ_F32: return launch_install_forward<float>(x, out, n, flags, type, alpha, sp, lds, st);
+    case ANTQ_BF16: return launch_install_forward<bf16_tag>(x, out, n, flags, type, alpha, sp, lds, st);
+    default: return launch_install_forward<f16_tag>(x, out, n, flags, type, alpha, sp, lds, st);
+    }
+}
+
 extern "C" size_t antq_calibrate_batch_workspace_bytes(const antq_calib_job *jobs, int n)
 {
     if (!jobs || n < 0) return 0;

@@ -361,6 +361,14 @@ class Quantizer(HostMirrorMixin, WeightsAtRestMixin, CalibrationMixin, nn.Module
         self.quant_grid.data = self._to_grid(np.stack(spec["normals"])).index_select(0, idx)[0]
         self.outliers.data = self._to_grid(spec["outl"])
 
+    def _selectable_rows(self, spec):
+        """[ntypes, n_normal] float32: the NORMAL codebook of each candidate type (the outliers are common to all)."""
+        g = spec["normals"]
+        return np.stack(g) if len({len(v) for v in g}) == 1 else None
+
+    def _after_install_selected(self, spec):
+        self.outliers.data = self._to_grid(spec["outl"])
+
     def _adopt_plan(self, spec, t):
         self._set_plan(spec["normals"][t], spec["outl"])
         self._grid_key = self._grid_now()

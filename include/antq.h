@@ -41,7 +41,7 @@ extern "C" {
  * 16-bit-domain kernels; ANTQ_PLAN_MAX_BYTES with it), the batch blob changed, antq_plan_eval_host_h and
  * antq_prefetch_kernels added.  5: antq_calibrate_batch / antq_calibrate_batch_workspace_bytes and antq_absmax_into added (nothing else changed).
  * 7 (round 6): antq_absmax_t / antq_alpha_grad_t (whole-tensor reductions in ONE launch through a caller-owned ticket block,
- * ANTQ_REDUCE_WS_BYTES) added (nothing else changed).
+ * ANTQ_REDUCE_WS_BYTES) and antq_calibrate_install added (nothing else changed).
  * A caller built against another version must not call in: the blobs / argument lists differ. */
 #define ANTQ_ABI_VERSION 7
 
@@ -312,6 +312,21 @@ int antq_calibrate(const void *x_dev, size_t rows, size_t row_len, int alpha_per
                    int ntypes, const float *gmax_host, const void *const *plan_host, const void *const *plan_dev,
                    unsigned flags, float *alpha_dev, float *score_dev, int32_t *type_dev,
                    void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* What _init_quant_para leaves behind (AQ:468-533, OQ:258-292) for a quantiser with ONE scale whose type was picked ON THE
+ * DEVICE by antq_calibrate -- without the host learning the pick (ABI 7).  With t = *type_dev, stream-ordered, two launches:
+ *   alpha_out[0] = alpha_dev[t];  mse_out[0] = score_dev[t] (the reference's log value, AQ:519-520);
+ *   grid_out[0 .. grid_len) = grids_dev[t][..] (the candidates' codebooks, padded to one length, stacked by the caller;
+ *   float32);  outl_out likewise from outl_dev (OliVe; NULL: none);
+ *   out = the steady-state _forward of x with codebook t at alpha_dev[t] (AQ:535-551 / OQ:294-330; ANTQ_FLAG_OVP: pairs) --
+ *   the calibrating call's own output, one pass over the tensor instead of one per candidate and a gather.
+ * The host needs the pick only to NAME the mode (it copies *type_dev to pinned memory and reads it when the model's forward
+ * has returned).  x: n elements, 16-byte aligned, n a multiple of the vector's element count (4 fp32 / 8 16-bit), otherwise
+ * ANTQ_ERR_UNSUPPORTED (the caller quantises with every candidate and gathers, as before).  ntypes <= 4. */
+int antq_calibrate_install(const void *x_dev, void *out_dev, size_t n, int dtype, int ntypes, const float *gmax_host,
+                           const void *const *plan_host, const void *const *plan_dev, unsigned flags, const int32_t *type_dev,
+                           const float *alpha_dev, const float *score_dev, const float *grids_dev, int grid_len, float *grid_out,
+                           const float *outl_dev, int outl_len, float *outl_out, float *alpha_out, float *mse_out, void *stream);
 
 /* The calibration of MANY quantisers in one call: job i is exactly antq_calibrate(jobs[i]...) -- same kernels, same order,
  * same bits -- all enqueued on `stream` one after the other through ONE workspace (antq_calibrate_batch_workspace_bytes: the

@@ -9,7 +9,7 @@
 // and -- section 9 -- every ABI 4 / 5 entry: antq_nearest_plan, the host models antq_plan_eval_host[_a|_h], the 16-bit-domain row
 // kernels on bf16, antq_absmax_into, antq_search_sse_multi, antq_moments + antq_xmax_3sigma, antq_affine, antq_alpha_grad,
 // antq_calibrate_batch, antq_fakequant_f64, antq_copy, antq_prefetch_kernels, antq_debug_set, and ABI 7's antq_absmax_t /
-// antq_alpha_grad_t: every prototype of include/antq.h is called here.
+// antq_alpha_grad_t / antq_calibrate_install: every prototype of include/antq.h is called here.
 // Exit code 0 = every comparison bit-exact; prints one line per check.
 #include <hip/hip_runtime.h>
 
@@ -343,6 +343,23 @@ int main()
                                                                              : "antq_calibrate (abs-max, 2 types, picks, type), per tensor",
                    bad ? "MISMATCH" : "ok", ty, osum[0], osum[1]);
             if (bad) failures++;
+            if (!per_row) {
+                // ABI 7: antq_calibrate_install -- from the pick that never left the device: alpha, score and codebook of the
+                // winner, and the calibrating call's own output == antq_fakequant with the winner's plan at the winner's alpha
+                std::vector<float> stack(32);
+                for (int k = 0; k < 16; k++) { stack[(size_t)k] = int4[(size_t)k]; stack[16 + (size_t)k] = flint[(size_t)k]; }
+                DevBuf<float> dstack(32), dgo(16), dao(1), dmo(1), dinst(n), dwant(n);
+                dstack.up(stack, st);
+                ANTQ_OK_(antq_calibrate_install(dxf.p, dinst.p, n, ANTQ_F32, 2, gm, ph, pd, 0, dty.p, dal.p, dsc.p, dstack.p, 16, dgo.p,
+                                                nullptr, 0, nullptr, dao.p, dmo.p, st));
+                ANTQ_OK_(antq_fakequant(dxf.p, dwant.p, nullptr, 1, n, dal.p + ty, 0, 10.0f, ph[ty], pd[ty], 0, ANTQ_F32, st));
+                same_bits("antq_calibrate_install: output == the winner's antq_fakequant", dinst.down(st), dwant.down(st));
+                const std::vector<float> go = dgo.down(st), ao = dao.down(st), mo = dmo.down(st);
+                const bool oki = std::memcmp(go.data(), stack.data() + 16 * (size_t)ty, 64) == 0 && std::memcmp(&ao[0], &al[(size_t)ty], 4) == 0 &&
+                                 std::memcmp(&mo[0], &sc[(size_t)ty], 4) == 0;
+                printf("%-62s %s\n", "antq_calibrate_install: alpha / score / codebook of the winner", oki ? "ok" : "FAIL");
+                if (!oki) failures++;
+            }
         }
     }
 
