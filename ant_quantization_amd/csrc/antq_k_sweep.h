@@ -82,11 +82,77 @@ __device__ __forceinline__ long long sweep_fixed(float xv, double F)
     return (long long)(__double_as_longlong(d) & 0x000fffffffffffffll) - 0x0008000000000000ll;
 }
 
-// One codebook per launch; one single-wavefront workgroup per row.  sse: this codebook's [ncand][rows] block.
-template <typename T, bool OVP>
+// cells of a per-tensor workgroup slab (64-bit each): Es, En, Hs[66], Hn[66] | doubles: Q, exc[128]
+__host__ __device__ inline uint32_t sweep_slab_cells(uint32_t nthr, uint32_t cp) { return 2u * nthr * cp + 132u + 129u; }
+
+// Phases 5 and 6 of the sweep: N_k(c), S_k(c) for every candidate (static suffix over the intervals + prefix of the events
+// along c: lanes along the candidate axis, a wavefront scan per threshold), then the closed form per candidate.  Q: the
+// wavefront's sum of x^2 already reduced over the lanes; exc0 / exc1: this lane's literal terms of candidates lane / lane + 64.
+// hrep: replicas of the static histogram to add up (kSweepRep for the row kernel, 1 for totals).
+__device__ __forceinline__ void sweep_finish(uint32_t lane, uint32_t nthr, uint32_t ncand, uint32_t cp, int *sEn, long long *sEs,
+                                             const unsigned int *sHn, const long long *sHs, int hrep, const float *sS, const float *sV,
+                                             double Q, double exc0, double exc1, double unit, double *__restrict__ out, size_t out_stride)
+{
+    auto lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    };
+    long long hn = 0, hs = 0;                                        // lane l: the histogram entry of interval l + 1
+    if (lane < nthr)
+        for (int r = 0; r < hrep; r++) { hn += (long long)sHn[r * 66 + lane + 1u]; hs += sHs[r * 66 + lane + 1u]; }
+    long long bn = hn, bs = hs;                                      // suffix sums over the lanes: B_k = sum_{j > k} H[j] at lane k
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long tn = __shfl_down(bn, off, 64), ts = __shfl_down(bs, off, 64);
+        if (lane + (uint32_t)off < 64u) { bn += tn; bs += ts; }
+    }
+    long long n_tot = __shfl(bn, 0, 64), s_tot = __shfl(bs, 0, 64);
+    for (int r = 0; r < hrep; r++) { n_tot += (long long)sHn[r * 66]; s_tot += sHs[r * 66]; }
+    for (uint32_t k = 0; k < nthr; k++) {
+        long long cn = __shfl(bn, (int)k, 64), cs = __shfl(bs, (int)k, 64);              // carry: starts at the static part
+        for (uint32_t c0 = 0; c0 < ncand; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            long long en = c < ncand ? (long long)sEn[k * cp + c] : 0, es = c < ncand ? sEs[k * cp + c] : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long tn = __shfl_up(en, off, 64), ts = __shfl_up(es, off, 64);
+                if (lane >= (uint32_t)off) { en += tn; es += ts; }
+            }
+            en += cn;
+            es += cs;
+            if (c < ncand) { sEn[k * cp + c] = (int)en; sEs[k * cp + c] = es; }
+            cn = __shfl(en, 63, 64);
+            cs = __shfl(es, 63, 64);
+        }
+    }
+    lds_sync();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t cc = lane + 64u * h;
+        if (cc < ncand) {
+            const float s = sS[cc];
+            double Op = (double)(sV[0] * s);
+            double sum = Q + (double)n_tot * Op * Op - 2.0 * Op * ((double)s_tot * unit);
+            for (uint32_t k = 0; k < nthr; k++) {
+                const double On = (double)(sV[k + 1u] * s);
+                const double N = (double)sEn[k * cp + cc], S = (double)sEs[k * cp + cc] * unit;
+                sum += (On * On - Op * Op) * N - 2.0 * (On - Op) * S;
+                Op = On;
+            }
+            sum += h ? exc1 : exc0;
+            out[(size_t)cc * out_stride] = sum;
+        }
+    }
+}
+
+// One codebook per launch; one single-wavefront workgroup per row (PT: per run of vectors of a tensor with ONE scale).
+// sse: this codebook's [ncand][rows] block.
+template <typename T, bool OVP, bool PT = false>
 __global__ void __launch_bounds__(64)
-k_search_sweep(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const float *__restrict__ xmax,
-               const float *__restrict__ ratios, double *__restrict__ sse, SweepType ty, uint32_t ncand, uint32_t cp)
+k_search_sweep(const uint4 *__restrict__ x, size_t vpr, size_t rows, const float *__restrict__ xmax,
+               const float *__restrict__ ratios, double *__restrict__ sse, SweepType ty, uint32_t ncand, uint32_t cp,
+               long long *__restrict__ pt_slabs = nullptr, int fbits = 38)
 {
     constexpr int EPL = IO<T>::EPL;
     constexpr int G = 4;                                   // elements handled side by side (a 16-bit vector: two groups)
@@ -121,9 +187,9 @@ k_search_sweep(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const flo
     unsigned int *myHn = sHn + (lane & (kSweepRep - 1u)) * 66u;
     long long *myHs = sHs + (lane & (kSweepRep - 1u)) * 66u;
 
-    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    for (size_t row = PT ? 0 : blockIdx.x; row < rows; row += gridDim.x) {
         const float xm = xmax[row];
-        const uint4 *xr = x + row * (size_t)vpr;
+        const uint4 *xr = x + row * vpr;
         // ---- 1. candidate scales (AQ:300, :536): s_c = fl32(fl32(x_max * ratio_c) / gmax), checked usable and non-decreasing
         bool ok = true;
         for (uint32_t c = lane; c < ncand; c += 64u) {
@@ -153,7 +219,8 @@ k_search_sweep(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const flo
         const float s0 = sS[0];
         int ex = 0;
         (void)frexpf(xm, &ex);                              // x_max = f * 2^ex, f in [0.5, 1)
-        const double F = __builtin_ldexp(1.0, 38 - ex), unit = __builtin_ldexp(1.0, ex - 38);
+        const double F = __builtin_ldexp(1.0, fbits - ex), unit = __builtin_ldexp(1.0, ex - fbits);      // (fbits: 38; fewer for a
+                                                                // whole tensor, so that n * 2^(fbits + 8) stays below 2^62)
         float Lx = usable ? ty.lim * s0 * 0.999f : 0.0f;    // |x| < Lx: a step-function element for EVERY candidate
         Lx = fminf(Lx, __builtin_ldexpf(0.999f, ex + 8));   // ... and its fixed-point image stays below 2^46
         float Xo_pos = __builtin_inff(), Xo_neg = -__builtin_inff();
@@ -168,6 +235,11 @@ k_search_sweep(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const flo
         const float X0v = lane < nthr ? sX[lane * cp] : __builtin_inff();
         const float Xlv = lane < nthr ? sX[lane * cp + cl] : __builtin_inff();
         const float rs_unit = __builtin_amdgcn_rcpf(xm / ty.gmax);
+        // exact zeros (half of a ReLU output) all fall into ONE interval and no threshold ever sweeps across them: counted by
+        // ballot -- one LDS address hammered by half the lanes was 40 % of a ReLU tensor's pass
+        uint32_t J0z = 0, zeros = 0;
+        for (uint32_t k = 0; k < nthr; k++)
+            J0z += 0.0f >= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, X0v), (int)k)) ? 1u : 0u;
         // q of one element at candidate cc, from the tables where the step function holds, literally elsewhere
         auto q_at = [&](float xv, float sc_, uint32_t cc, float &d) -> float {
             d = xv / sc_;
@@ -215,8 +287,10 @@ k_search_sweep(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const flo
             uint32_t nsmax = 0;
 #pragma unroll
             for (int e = 0; e < G; e++) {
-                const bool reg = live && !lit[e];
-                const float xv = reg ? xf[e] : 0.0f;
+                const bool reg0 = live && !lit[e];
+                const float xv = reg0 ? xf[e] : 0.0f;
+                const bool reg = reg0 && xv != 0.0f;
+                zeros += (uint32_t)__builtin_popcountll(__ballot(reg0 && xv == 0.0f));
                 Q = __builtin_fma((double)xv, (double)xv, Q);
                 xi[e] = sweep_fixed(xv, F);
                 if (reg) {
@@ -317,9 +391,9 @@ k_search_sweep(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const flo
                 }
             }
         };
-        // ---- 4. the elements
-        for (uint32_t v0 = 0; v0 < vpr; v0 += 64u) {
-            const uint32_t vi = v0 + lane;
+        // ---- 4. the elements (PT: this workgroup's share of the tensor, 64 vectors at a time, grid-strided)
+        for (size_t v0 = PT ? (size_t)blockIdx.x * 64u : 0; v0 < vpr; v0 += PT ? (size_t)gridDim.x * 64u : 64u) {
+            const size_t vi = v0 + lane;
             const bool live = vi < vpr;
             float xf[EPL];
             {
@@ -332,63 +406,93 @@ k_search_sweep(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const flo
                 group(xg, live);
             }
         }
-        // ---- 5. N_k(c), S_k(c) for every candidate: static suffix over the intervals + prefix of the events along c
+        if (lane == 0u && zeros) atomicAdd(&sHn[J0z], zeros);
+        // ---- 5 / 6. counts and sums for every candidate, the closed form (sweep_finish) -- or, for a tensor with ONE scale,
+        //            this workgroup's integer tables and partial sums to its slab (k_sweep_pt_total adds the slabs)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) Q += __shfl_xor(Q, off, 64);
         lds_sync();
-        // lanes along the candidate axis, a wavefront scan per threshold
-        long long hn = 0, hs = 0;                                    // lane l: the histogram entry of interval l + 1
-        if (lane < nthr) {
-#pragma unroll
-            for (int r = 0; r < kSweepRep; r++) { hn += (long long)sHn[r * 66 + lane + 1u]; hs += sHs[r * 66 + lane + 1u]; }
-        }
-        long long bn = hn, bs = hs;                                  // suffix sums over the lanes: B_k = sum_{j > k} H[j] at lane k
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const long long tn = __shfl_down(bn, off, 64), ts = __shfl_down(bs, off, 64);
-            if (lane + (uint32_t)off < 64u) { bn += tn; bs += ts; }
-        }
-        long long n_tot = __shfl(bn, 0, 64), s_tot = __shfl(bs, 0, 64);
-#pragma unroll
-        for (int r = 0; r < kSweepRep; r++) { n_tot += (long long)sHn[r * 66]; s_tot += sHs[r * 66]; }
-        for (uint32_t k = 0; k < nthr; k++) {
-            long long cn = __shfl(bn, (int)k, 64), cs = __shfl(bs, (int)k, 64);          // carry: starts at the static part
-            for (uint32_t c0 = 0; c0 < ncand; c0 += 64u) {
-                const uint32_t c = c0 + lane;
-                long long en = c < ncand ? (long long)sEn[k * cp + c] : 0, es = c < ncand ? sEs[k * cp + c] : 0;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const long long tn = __shfl_up(en, off, 64), ts = __shfl_up(es, off, 64);
-                    if (lane >= (uint32_t)off) { en += tn; es += ts; }
-                }
-                en += cn;
-                es += cs;
-                if (c < ncand) { sEn[k * cp + c] = (int)en; sEs[k * cp + c] = es; }
-                cn = __shfl(en, 63, 64);
-                cs = __shfl(es, 63, 64);
+        if (PT) {
+            long long *slab = pt_slabs + (size_t)blockIdx.x * sweep_slab_cells(nthr, cp);
+            const uint32_t cells_ = nthr * cp;
+            for (uint32_t p = lane; p < cells_; p += 64u) { slab[p] = sEs[p]; slab[cells_ + p] = (long long)sEn[p]; }
+            for (uint32_t j = lane; j < 66u; j += 64u) {
+                long long hn_ = 0, hs_ = 0;
+                for (int r = 0; r < kSweepRep; r++) { hn_ += (long long)sHn[r * 66 + j]; hs_ += sHs[r * 66 + j]; }
+                slab[2u * cells_ + j] = hs_;
+                slab[2u * cells_ + 66u + j] = hn_;
             }
+            double *dsl = reinterpret_cast<double *>(slab + 2u * cells_ + 132u);
+            if (lane == 0u) dsl[0] = Q;
+            dsl[1u + lane] = exc0;
+            dsl[65u + lane] = exc1;
+            return;
         }
-        lds_sync();
-        // ---- 6. the closed form per candidate
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t cc = lane + 64u * h;
-            if (cc < ncand) {
-                const float s = h ? s_b : s_a;
-                double Op = (double)(sV[0] * s);
-                double sum = Q + (double)n_tot * Op * Op - 2.0 * Op * ((double)s_tot * unit);
-                for (uint32_t k = 0; k < nthr; k++) {
-                    const double On = (double)(sV[k + 1u] * s);
-                    const double N = (double)sEn[k * cp + cc], S = (double)sEs[k * cp + cc] * unit;
-                    sum += (On * On - Op * Op) * N - 2.0 * (On - Op) * S;
-                    Op = On;
-                }
-                sum += h ? exc1 : exc0;
-                sse[(size_t)cc * rows + row] = sum;
-            }
-        }
+        sweep_finish(lane, nthr, ncand, cp, sEn, sEs, sHn, sHs, kSweepRep, sS, sV, Q, exc0, exc1, unit, sse + row, rows);
         lds_sync();
     }
+}
+
+// ---- a tensor with ONE scale (per-tensor quantisers: every activation): the same pass spread over many workgroups ---------
+// k_search_sweep<PT> leaves, per workgroup, its integer event / histogram tables and its partial sums in a slab;
+// k_sweep_pt_total adds the slabs cell by cell (integers in any order; the doubles -- sum x^2 and the literal terms -- in slab
+// order: one fixed order), k_sweep_pt_finish runs phases 5 / 6 on the totals.  Bit-reproducible like the row kernel.
+static __global__ void __launch_bounds__(256)
+k_sweep_pt_total(const long long *__restrict__ slabs, uint32_t nslab, uint32_t per_group, uint32_t ncells, uint32_t nint,
+                 long long *__restrict__ out)
+{
+    // blockIdx.y: a group of `per_group` consecutive slabs -> out[group][cell] (a second call with the groups as slabs
+    // finishes the sum: 2048 slabs added by ONE thread per cell were a chain of 2048 load latencies, 0.4 ms per codebook)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= ncells) return;
+    const uint32_t g0 = blockIdx.y * per_group, g1 = min(nslab, g0 + per_group);
+    const long long *p = slabs + (size_t)g0 * ncells + i;
+    if (i < nint) {
+        long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        uint32_t g = g0;
+        for (; g + 3u < g1; g += 4u, p += 4 * (size_t)ncells) {
+            a0 += p[0]; a1 += p[ncells]; a2 += p[2 * (size_t)ncells]; a3 += p[3 * (size_t)ncells];
+        }
+        for (; g < g1; g++, p += ncells) a0 += p[0];
+        out[(size_t)blockIdx.y * ncells + i] = (a0 + a1) + (a2 + a3);
+    } else {
+        double a = 0.0;                                               // doubles: slab order, one fixed order
+        for (uint32_t g = g0; g < g1; g++, p += ncells) a += __longlong_as_double(p[0]);
+        out[(size_t)blockIdx.y * ncells + i] = __double_as_longlong(a);
+    }
+}
+
+static __global__ void __launch_bounds__(64)
+k_sweep_pt_finish(const long long *__restrict__ tot, const float *__restrict__ xmax, const float *__restrict__ ratios,
+                  double *__restrict__ sse, SweepType ty, uint32_t ncand, uint32_t cp, int fbits)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t lane = threadIdx.x, nthr = ty.n_thr, cells = nthr * cp;
+    long long *sEs = reinterpret_cast<long long *>(smem);
+    long long *sHs = sEs + (size_t)nthr * cp;
+    float *sX = reinterpret_cast<float *>(sHs + 66 * kSweepRep);
+    int *sEn = reinterpret_cast<int *>(sX + (size_t)nthr * cp);
+    unsigned int *sHn = reinterpret_cast<unsigned int *>(sEn + (size_t)nthr * cp);
+    float *sS = reinterpret_cast<float *>(sHn + 66 * kSweepRep);
+    float *sT = sS + cp;
+    float *sV = sT + 64;
+    const float xm = xmax[0];
+    for (uint32_t c = lane; c < ncand; c += 64u) sS[c] = make_scale(xm * ratios[c], ty.gmax).s;
+    if (lane < nthr) {
+        const uint4 th = ty.tlist[lane];
+        sV[lane + 1u] = u2f(th.z) + 0.0f;
+        if (lane == 0u) sV[0] = u2f(th.y) + 0.0f;
+    }
+    for (uint32_t p = lane; p < cells; p += 64u) { sEs[p] = tot[p]; sEn[p] = (int)tot[cells + p]; }
+    for (uint32_t j = lane; j < 66u; j += 64u) { sHs[j] = tot[2u * cells + j]; sHn[j] = (unsigned int)tot[2u * cells + 66u + j]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const long long *dt = tot + 2u * cells + 132u;
+    int ex = 0;
+    (void)frexpf(xm, &ex);
+    sweep_finish(lane, nthr, ncand, cp, sEn, sEs, sHn, sHs, 1, sS, sV, __longlong_as_double(dt[0]), __longlong_as_double(dt[1u + lane]),
+                 __longlong_as_double(dt[65u + lane]), __builtin_ldexp(1.0, ex - fbits), sse, 1);
 }
 
 }  // namespace antq

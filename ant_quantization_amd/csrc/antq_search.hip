@@ -235,6 +235,71 @@ static int launch_sweep(const void *x, size_t rows, size_t row_len, const float 
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+template <typename T>
+static bool sweep_pt_shape_ok(const void *x, size_t n, int ncand)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (!g_knob_sweep || sizeof(T) != 4 || ncand < 1 || ncand > kSweepMaxCand) return false;
+    return reinterpret_cast<uintptr_t>(x) % 16 == 0 && n % EPL == 0 && n >= (g_knob_sweep == 2 ? 4096u : (1u << 22)) && n < ((size_t)1 << 31);
+}
+
+// The sweep for a tensor with ONE scale (fp32: 16-bit tensors take the histogram search).  ws: the search workspace (slabs of
+// the workgroups' integer tables, then their totals).  ANTQ_ERR_UNSUPPORTED: not this launch.
+template <typename T, bool OVP>
+static int launch_sweep_pt(const void *x, size_t n, const float *xmax, const float *ratios, int ncand, int ntypes, const float *gmax,
+                           const void *const *plan_host, const void *const *plan_dev, double *sse, void *ws, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (!sweep_pt_shape_ok<T>(x, n, ncand) || ntypes < 1 || ntypes > kMaxTypes || !ws) return ANTQ_ERR_UNSUPPORTED;
+    SweepType ty[kMaxTypes];
+    memset(ty, 0, sizeof(ty));
+    const uint32_t cp = (uint32_t)ncand + 1u;
+    uint32_t cells_max = 0;
+    for (int t = 0; t < ntypes; t++) {
+        const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host[t]);
+        if (!sweep_type_ok(plan_host[t], gmax[t])) return ANTQ_ERR_UNSUPPORTED;
+        const HThr *tl = plan_tlist(plan_host[t]);
+        ty[t].tlist = reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev[t]) + ph->tlist_off);
+        ty[t].grid = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev[t]));
+        ty[t].n_thr = ph->h_nthr;
+        ty[t].m = ph->m;
+        ty[t].gmax = gmax[t];
+        const float flim = ph->fastlim * 0.99999f;
+        ty[t].lim = flim < ph->xlim ? flim : ph->xlim;
+        ty[t].kout_pos = ty[t].kout_neg = -1;
+        for (uint32_t k = 0; k < ph->h_nthr; k++) {
+            const bool lo_out = (tl[k].flags & 1u) != 0u, hi_out = (tl[k].flags & 2u) != 0u;
+            if (k > 0 && !(tl[k].T > tl[k - 1].T)) return ANTQ_ERR_UNSUPPORTED;
+            if (!lo_out && hi_out) { if (ty[t].kout_pos >= 0 || !(tl[k].T > 0.0f)) return ANTQ_ERR_UNSUPPORTED; ty[t].kout_pos = (int)k; }
+            if (lo_out && !hi_out) { if (ty[t].kout_neg >= 0 || !(tl[k].T < 0.0f)) return ANTQ_ERR_UNSUPPORTED; ty[t].kout_neg = (int)k; }
+        }
+        if (sweep_lds_bytes(ph->h_nthr, cp) > 64 * 1024) return ANTQ_ERR_UNSUPPORTED;
+        cells_max = std::max(cells_max, sweep_slab_cells(ph->h_nthr, cp));
+    }
+    const size_t nv = n / EPL;
+    const size_t ws_bytes = antq_search_workspace_bytes();
+    size_t G = std::min<size_t>((nv + 255) / 256, 2048);                        // >= 4 rounds of 64 vectors per workgroup
+    const uint32_t per_group = 64;
+    G = std::min(G, ws_bytes / ((size_t)cells_max * 8) - (2048 / per_group + 2));
+    if (G < 16) return ANTQ_ERR_UNSUPPORTED;
+    const uint32_t ngroups = (uint32_t)((G + per_group - 1) / per_group);
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    const int fbits = std::min(38, 53 - lg);                                    // n * 2^(fbits + 8) <= 2^61
+    long long *slabs = static_cast<long long *>(ws);
+    for (int t = 0; t < ntypes; t++) {
+        const uint32_t ncells = sweep_slab_cells(ty[t].n_thr, cp), nint = 2u * ty[t].n_thr * cp + 132u;
+        long long *part = slabs + G * (size_t)ncells, *tot = part + (size_t)ngroups * ncells;
+        const size_t lds = sweep_lds_bytes(ty[t].n_thr, cp);
+        hipLaunchKernelGGL((k_search_sweep<T, OVP, true>), dim3((unsigned)G), dim3(64), lds, st, static_cast<const uint4 *>(x), nv, (size_t)1,
+                           xmax, ratios, sse + (size_t)t * ncand, ty[t], (uint32_t)ncand, cp, slabs, fbits);
+        hipLaunchKernelGGL(k_sweep_pt_total, dim3((ncells + 255) / 256, ngroups), dim3(256), 0, st, slabs, (uint32_t)G, per_group, ncells, nint, part);
+        hipLaunchKernelGGL(k_sweep_pt_total, dim3((ncells + 255) / 256, 1), dim3(256), 0, st, part, ngroups, ngroups, ncells, nint, tot);
+        hipLaunchKernelGGL(k_sweep_pt_finish, dim3(1), dim3(64), lds, st, tot, xmax, ratios, sse + (size_t)t * ncand, ty[t], (uint32_t)ncand, cp, fbits);
+    }
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
 template <typename T, bool OVP>
 static int launch_search(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                          const float *ratios, int ncand, float gmax, const PlanArgs &pa, const void *plan_host,
@@ -274,6 +339,11 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
         ht.gmax[0] = gmax;
         const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st);
         if (rc != ANTQ_OK || !OVP) return rc;
+    }
+    if (rows == 1 && !run_if) {                  // one scale, no histogram search in front: the threshold sweep over many workgroups
+        const void *ph1[1] = {plan_host}, *pd1[1] = {plan_dev};
+        const int rc = launch_sweep_pt<T, OVP>(x, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, ws, st);
+        if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
     }
     const size_t vpr = row_len / EPL;
     if (vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;
@@ -355,6 +425,14 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
             const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st);
             if (rc != ANTQ_OK || !OVP) return rc;
         }
+    }
+    if (rows == 1 && !run_if) {
+        const int rc = launch_sweep_pt<T, OVP>(x, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, ws, st);
+        if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
+        // (as for rows: a codebook's sums must not depend on its company -- one search per type if some types would sweep)
+        if (sweep_pt_shape_ok<T>(x, row_len, ncand))
+            for (int t = 0; t < ntypes; t++)
+                if (sweep_type_ok(plan_host[t], gmax[t])) return ANTQ_ERR_UNSUPPORTED;
     }
     const size_t vpr = row_len / EPL;
     if (vpr < kSearchMinVpr || vpr > 0xffffffffull) return ANTQ_ERR_UNSUPPORTED;

@@ -38,9 +38,9 @@ FLOORS = {
     "batch_rows_f32": 0.95,
     "encode4_bf16": 0.50,
     "decode4_bf16": 0.50,
-    "absmax_rows_bf16": 0.76,
-    "absmax_tensor_bf16": 0.58,
-    "moments_rows_bf16": 0.53,
+    "absmax_rows_f32": 0.98,
+    "absmax_tensor_f32": 0.83,
+    "moments_rows_f32": 0.81,
     "alpha_grad_rows_bf16": 0.99,
     "alpha_grad_tensor_bf16": 0.88,
     "affine_f32": 0.91,
@@ -116,8 +116,8 @@ def box():
         pass
 
 
-PER_TENSOR = {"hrow_per_tensor_bf16_unordered", "hrow_per_tensor_bf16_ordered", "encode4_bf16", "decode4_bf16", "absmax_rows_bf16",
-              "absmax_tensor_bf16", "moments_rows_bf16", "alpha_grad_rows_bf16", "alpha_grad_tensor_bf16", "affine_f32"}
+PER_TENSOR = {"hrow_per_tensor_bf16_unordered", "hrow_per_tensor_bf16_ordered", "encode4_bf16", "decode4_bf16", "absmax_rows_f32",
+              "absmax_tensor_f32", "moments_rows_f32", "alpha_grad_rows_bf16", "alpha_grad_tensor_bf16", "affine_f32"}
 
 
 def _check(box, name, fn, nbytes):
@@ -215,25 +215,35 @@ def test_floor_codec(box):
     _check(box, "decode4_bf16", dec, x.numel() * 2 + x.numel() // 2)
 
 
+def _f32_tensors(box):
+    """16 x [4096, 4096] fp32 (1 GiB): the read-only reductions are timed on 67 MB launches -- a 33.5 MB bf16 tensor is read in
+    6.7 us, less than the Python binding's host time per call on a busy box, and the ratio then measures the host."""
+    if "f32" not in box:
+        box["f32"] = [box["x"][i].float() for i in range(NB // 2)]
+    return box["f32"]
+
+
 @pytest.mark.parametrize("per_row", [True, False], ids=["rows", "tensor"])
 def test_floor_absmax(box, per_row):
-    L, x = box["_lib"], box["x"]
+    L = box["_lib"]
+    xs = _f32_tensors(box)
 
     def fn():
-        for i in range(NB):
-            L.absmax(x[i], R, C, per_row=per_row)
+        for t in xs:
+            L.absmax(t, R, C, per_row=per_row)
 
-    _check(box, "absmax_%s_bf16" % ("rows" if per_row else "tensor"), fn, x.numel() * 2)
+    _check(box, "absmax_%s_f32" % ("rows" if per_row else "tensor"), fn, len(xs) * R * C * 4)
 
 
 def test_floor_moments(box):
-    L, x = box["_lib"], box["x"]
+    L = box["_lib"]
+    xs = _f32_tensors(box)
 
     def fn():
-        for i in range(NB):
-            L.moments(x[i], R, C, per_row=True)
+        for t in xs:
+            L.moments(t, R, C, per_row=True)
 
-    _check(box, "moments_rows_bf16", fn, x.numel() * 2)
+    _check(box, "moments_rows_f32", fn, len(xs) * R * C * 4)
 
 
 def test_floor_alpha_grad(box):

@@ -164,3 +164,48 @@ def test_calibrate_picks_do_not_depend_on_the_search_path(dev):
     same = (a0 == a1)
     assert float(same.float().mean()) >= 0.995                          # (a differing row: a tie of the direct kernel's own scores)
     assert torch.allclose(s0, s1, rtol=1e-6)
+
+
+def test_sweep_one_scale_fp32_tensors(dev, oracle):
+    """A tensor with ONE scale (every activation quantiser, AQ:51-53, :308-324) in fp32 -- the only dtype the reference itself
+    runs -- through the sweep spread over many workgroups (integer slabs, two-level totals, fixed-order doubles): sums equal to
+    the direct kernels' to their rounding, the same picks, bit-identical from run to run; ReLU outputs (half the elements
+    exactly zero: counted by ballot), GELU outputs, a tensor with specials (NaN wins), and a small one against the oracle."""
+    from ant_quantization_amd import _lib as L, grids
+    torch.manual_seed(65)
+    signed = [L.plan_for(grids.ant_grid(t, 4, True)) for t in ("int", "pot", "flint")]
+    unsigned = [L.plan_for(grids.ant_grid(t, 4, False)) for t in ("int", "pot", "flint")]
+    rt = _ratios(80, 150, 1, dev)
+
+    def both(x, plans, knob_on):
+        n = x.numel()
+        xm = L.absmax(x, 1, n, per_row=False)
+        res = []
+        for knob in (0, knob_on):
+            L.lib().antq_debug_set(19, knob)
+            try:
+                s = L.search_sse_multi(x, 1, n, xm, False, rt, plans, [10.0] * 3)
+                if s is None:
+                    s = torch.stack([L.search_sse(x, 1, n, xm, False, rt, p, 10.0) for p in plans])
+                res.append(s.clone())
+            finally:
+                L.lib().antq_debug_set(19, 1)
+        return res
+
+    for x, plans in ((torch.nn.functional.gelu(torch.randn(1 << 22, device=dev)), signed),
+                     (torch.relu(torch.randn((1 << 22) + 4096, device=dev)), unsigned)):
+        a, b = both(x, plans, 1)                                  # the default rule takes tensors of 4 M elements and more
+        _compare(a, b, "one scale, default rule", rtol=2e-7)
+        assert not torch.equal(a, b), "the sweep did not run: the comparison would prove nothing"
+        assert torch.equal(b, both(x, plans, 1)[1])               # the same bits on every run
+    x = torch.randn(70000 * 4, device=dev) * 0.3
+    a, b = both(x, signed, 2)                                     # forced onto a small tensor
+    _compare(a, b, "one scale, forced", rtol=2e-7)
+    xn = x.cpu().numpy().reshape(1, -1)
+    xm = np.float32([np.abs(xn).max()])
+    for t, name in enumerate(("int", "pot", "flint")):
+        best, alpha, trace = oracle.search_mse(xn, xm, 80, 150, 1, grids.ant_grid(name, 4, True), 10.0, ovp=False, per_row=False)
+        np.testing.assert_allclose((b[t] / x.numel()).cpu().numpy().reshape(-1), trace.reshape(-1), rtol=3e-6)
+    x[12345] = float("nan")
+    a, b = both(x, signed, 2)
+    assert torch.isnan(a).all() and torch.isnan(b).all()

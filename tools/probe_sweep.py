@@ -63,3 +63,25 @@ x[4] = 0.5
 x[5, ::2] = 0.0
 xm = _lib.absmax(x, 64, 1024)
 run("edge rows (zeros / NaN / Inf / 1e30 / constant), fp32", x, 64, 1024, [p for p, _ in ant], [g for _, g in ant], xm, ratios(75, 150, 1), False)
+
+# ---- one scale per tensor (activations), fp32: the sweep over many workgroups against the direct kernels
+print("per-tensor fp32:")
+pu = [(_lib.plan_for(grids.ant_grid(t, 4, False)), 10.0) for t in ("int", "pot", "flint")]
+for nelem, signed in ((64 * 128 * 3072, True), (64 * 128 * 768, True), (64 * 128 * 3072, False), (1 << 20, True)):
+    x = torch.nn.functional.gelu(torch.randn(nelem, device=dev)) if signed else torch.relu(torch.randn(nelem, device=dev))
+    pl = ant if signed else pu
+    xm = _lib.absmax(x, 1, nelem, per_row=False)
+    out = {}
+    for knob in (0, 1):
+        L.antq_debug_set(19, knob)
+        s = _lib.search_sse_multi(x, 1, nelem, xm, False, ratios(80, 150, 1), [p for p, _ in pl], [g for _, g in pl])
+        if s is None:
+            s = torch.stack([_lib.search_sse(x, 1, nelem, xm, False, ratios(80, 150, 1), p, g) for p, g in pl])
+        t = timed(lambda: _lib.search_sse_multi(x, 1, nelem, xm, False, ratios(80, 150, 1), [p for p, _ in pl], [g for _, g in pl]), 3)
+        out[knob] = (s.clone(), t)
+    L.antq_debug_set(19, 1)
+    a, b = out[0][0], out[1][0]
+    rel = ((a - b).abs() / a.abs()).max()
+    print("ANT %s x 70, one scale, %9d elements fp32   direct %8.3f ms  sweep %8.3f ms (x %.1f)  max rel diff %.2e  picks %s" % (
+        "int/pot/flint" if signed else "unsigned int/pot/flint", nelem, out[0][1] * 1e3, out[1][1] * 1e3, out[0][1] / out[1][1], float(rel),
+        "same" if torch.equal(a.argmin(1), b.argmin(1)) else "DIFFER"), flush=True)
