@@ -57,14 +57,19 @@ static bool hist_outlier_bound(const void *plan_host, float gmax, float &bound)
 }
 // The histogram search.  pairs: with OliVe's pair rule; *run_if then receives the device flag the caller's direct launches
 // take as their run condition (set iff the pair list overflowed; the histogram kernels then wrote nothing).
-// antq_calibrate with the abs-max statistic on a tensor the histogram search will take (its own eligibility test, below):
-// the statistic's accumulator (zeroed, stream-ordered) that the counting pass has to fill -- the separate abs-max pass over
-// the tensor is not run.  Consumed by the first histogram search of the call; antq_calibrate fails loudly if nobody took it.
-static thread_local float *g_hist_xmax_out = nullptr;
+// xmax_out (antq_calibrate with the abs-max statistic on a tensor the histogram search takes): the statistic's accumulator
+// (zeroed, stream-ordered) that the counting pass fills on the way -- the separate abs-max pass over the tensor is not run.
+// Passed down EXPLICITLY from antq_calibrate, which makes the eligibility decision once (`HistXmax`): a search that does not
+// take the histogram path with a pending accumulator returns ANTQ_ERR_LAUNCH before it enqueues anything.
+struct HistXmax {
+    float *out = nullptr;        // non-null: the histogram search of this call must fill it
+    bool taken = false;
+};
 
 template <typename T>
 static int launch_hist_search(const void *x, size_t n, const float *xmax, const float *ratios, int ncand, const HistTypes &ht,
-                              double *sse, void *ws, bool pairs, float tmin_over_gmax, const int **run_if, hipStream_t st)
+                              double *sse, void *ws, bool pairs, float tmin_over_gmax, const int **run_if, hipStream_t st,
+                              HistXmax *hx = nullptr)
 {
     if constexpr (std::is_same<T, float>::value) {
         return ANTQ_ERR_UNSUPPORTED;
@@ -91,8 +96,8 @@ static int launch_hist_search(const void *x, size_t n, const float *xmax, const 
             hipLaunchKernelGGL((k_hist_score<T, true>), dim3(nflat), dim3(1024), lds, st, count, xmax, ratios, ncand, ht, sse, hp);
             *run_if = hp.flags;                  // non-zero iff a segment of the pair list overflowed
         } else {
-            float *const xo = g_hist_xmax_out;
-            g_hist_xmax_out = nullptr;
+            float *const xo = (hx && !hx->taken) ? hx->out : nullptr;
+            if (hx && xo) hx->taken = true;
             if (xo)
                 hipLaunchKernelGGL((k_hist16<T, false, true>), dim3(2 * G), dim3(1024), 0, st, static_cast<const uint4 *>(x), nv, G, slabs, hp, xo);
             else
@@ -189,6 +194,9 @@ static bool sweep_shape_ok(const void *x, size_t rows, size_t row_len, int ncand
     constexpr int EPL = IO<T>::EPL;
     if (!g_knob_sweep || rows < 2 || ncand < 1 || ntypes < 1 || ntypes > kMaxTypes) return false;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sweep == 2 ? 256u : 2048u) || row_len > 65536) return false;
+    // (the pair rule: every pair that may hold an outlier under SOME candidate is evaluated literally -- ~1 % of the pairs of a
+    //  3-sigma-clipped tensor, and that alone costs more than the direct kernels' whole pass: forced only, knob 19 = 2)
+    if (OVP && g_knob_sweep != 2) return false;
     return !(OVP && (row_len & 1));                                  // (pairs would straddle rows)
 }
 
@@ -250,7 +258,7 @@ static int launch_sweep_pt(const void *x, size_t n, const float *xmax, const flo
                            const void *const *plan_host, const void *const *plan_dev, double *sse, void *ws, hipStream_t st)
 {
     constexpr int EPL = IO<T>::EPL;
-    if (!sweep_pt_shape_ok<T>(x, n, ncand) || ntypes < 1 || ntypes > kMaxTypes || !ws) return ANTQ_ERR_UNSUPPORTED;
+    if (!sweep_pt_shape_ok<T>(x, n, ncand) || ntypes < 1 || ntypes > kMaxTypes || !ws || (OVP && g_knob_sweep != 2)) return ANTQ_ERR_UNSUPPORTED;
     SweepType ty[kMaxTypes];
     memset(ty, 0, sizeof(ty));
     const uint32_t cp = (uint32_t)ncand + 1u;
@@ -303,7 +311,7 @@ static int launch_sweep_pt(const void *x, size_t n, const float *xmax, const flo
 template <typename T, bool OVP>
 static int launch_search(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                          const float *ratios, int ncand, float gmax, const PlanArgs &pa, const void *plan_host,
-                         const void *plan_dev, double *sse, double *ws, hipStream_t st)
+                         const void *plan_dev, double *sse, double *ws, hipStream_t st, HistXmax *hx = nullptr)
 {
     constexpr int EPL = IO<T>::EPL;
     const size_t lds = (size_t)pa.tab_units * 16;
@@ -337,9 +345,10 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
         ht.pa[0] = pa;
         ht.plan_tab[0] = plan_tab_ptr(plan_dev);
         ht.gmax[0] = gmax;
-        const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st);
+        const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st, hx);
         if (rc != ANTQ_OK || !OVP) return rc;
     }
+    if (hx && hx->out && !hx->taken) return ANTQ_ERR_LAUNCH;     // (the caller counted on the histogram pass for its statistic)
     if (rows == 1 && !run_if) {                  // one scale, no histogram search in front: the threshold sweep over many workgroups
         const void *ph1[1] = {plan_host}, *pd1[1] = {plan_dev};
         const int rc = launch_sweep_pt<T, OVP>(x, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, ws, st);
@@ -391,7 +400,7 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
 template <typename T, bool OVP>
 static int launch_search_multi(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                                const float *ratios, int ncand, int ntypes, const float *gmax, const void *const *plan_host,
-                               const void *const *plan_dev, double *sse, double *ws, hipStream_t st)
+                               const void *const *plan_dev, double *sse, double *ws, hipStream_t st, HistXmax *hx = nullptr)
 {
     constexpr int EPL = IO<T>::EPL;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) return ANTQ_ERR_UNSUPPORTED;
@@ -422,15 +431,16 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
             if (OVP) { ok = ok && hist_outlier_bound(plan_host[t], gmax[t], b); bound = std::min(bound, b); }
         }
         if (ok) {
-            const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st);
+            const int rc = launch_hist_search<T>(x, row_len, xmax, ratios, ncand, ht, sse, ws, OVP, bound, &run_if, st, hx);
             if (rc != ANTQ_OK || !OVP) return rc;
         }
     }
+    if (hx && hx->out && !hx->taken) return ANTQ_ERR_LAUNCH;     // (see launch_search)
     if (rows == 1 && !run_if) {
         const int rc = launch_sweep_pt<T, OVP>(x, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, ws, st);
         if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
         // (as for rows: a codebook's sums must not depend on its company -- one search per type if some types would sweep)
-        if (sweep_pt_shape_ok<T>(x, row_len, ncand))
+        if (sweep_pt_shape_ok<T>(x, row_len, ncand) && !(OVP && g_knob_sweep != 2))
             for (int t = 0; t < ntypes; t++)
                 if (sweep_type_ok(plan_host[t], gmax[t])) return ANTQ_ERR_UNSUPPORTED;
     }
@@ -482,10 +492,10 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
 
 using namespace antq;
 
-extern "C" int antq_search_sse_multi(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
-                                     const float *ratios, int ncand, int ntypes, const float *gmax_host,
-                                     const void *const *plan_host, const void *const *plan_dev, unsigned flags, int dtype,
-                                     double *sse, void *workspace, void *stream)
+static int search_sse_multi_impl(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
+                                 const float *ratios, int ncand, int ntypes, const float *gmax_host,
+                                 const void *const *plan_host, const void *const *plan_dev, unsigned flags, int dtype,
+                                 double *sse, void *workspace, void *stream, HistXmax *hx)
 {
     if (rows == 0 || row_len == 0 || ncand == 0 || ntypes == 0) return ANTQ_OK;
     if (!x || !xmax || !ratios || !gmax_host || !plan_host || !plan_dev || !sse || ncand < 0 || ntypes < 0) return ANTQ_ERR_ARG;
@@ -498,8 +508,8 @@ extern "C" int antq_search_sse_multi(const void *x, size_t rows, size_t row_len,
     const bool ovp = (flags & ANTQ_FLAG_OVP) != 0;
     const int pr = per_row ? 1 : 0;
 #define ANTQ_SM(TT)                                                                                                     \
-    (ovp ? launch_search_multi<TT, true>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, ws, st)   \
-         : launch_search_multi<TT, false>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, ws, st))
+    (ovp ? launch_search_multi<TT, true>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, ws, st, hx)   \
+         : launch_search_multi<TT, false>(x, rows, row_len, xmax, pr, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, sse, ws, st, hx))
     switch (dtype) {
     case ANTQ_F32: return ANTQ_SM(float);
     case ANTQ_BF16: return ANTQ_SM(bf16_tag);
@@ -509,9 +519,18 @@ extern "C" int antq_search_sse_multi(const void *x, size_t rows, size_t row_len,
 #undef ANTQ_SM
 }
 
-extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
-                               const float *ratios, int ncand, float gmax, const void *plan_host, const void *plan_dev,
-                               unsigned flags, int dtype, double *sse, void *workspace, void *stream)
+extern "C" int antq_search_sse_multi(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
+                                     const float *ratios, int ncand, int ntypes, const float *gmax_host,
+                                     const void *const *plan_host, const void *const *plan_dev, unsigned flags, int dtype,
+                                     double *sse, void *workspace, void *stream)
+{
+    return search_sse_multi_impl(x, rows, row_len, xmax, per_row, ratios, ncand, ntypes, gmax_host, plan_host, plan_dev, flags, dtype, sse,
+                                 workspace, stream, nullptr);
+}
+
+static int search_sse_impl(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
+                           const float *ratios, int ncand, float gmax, const void *plan_host, const void *plan_dev,
+                           unsigned flags, int dtype, double *sse, void *workspace, void *stream, HistXmax *hx)
 {
     if (rows == 0 || row_len == 0 || ncand == 0) return ANTQ_OK;
     if (!x || !xmax || !ratios || !plan_host || !plan_dev || !sse || ncand < 0) return ANTQ_ERR_ARG;
@@ -524,17 +543,24 @@ extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const
     const int pr = per_row ? 1 : 0;
     switch (dtype) {
     case ANTQ_F32:
-        return ovp ? launch_search<float, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st)
-                   : launch_search<float, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st);
+        return ovp ? launch_search<float, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st, hx)
+                   : launch_search<float, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st, hx);
     case ANTQ_BF16:
-        return ovp ? launch_search<bf16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st)
-                   : launch_search<bf16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st);
+        return ovp ? launch_search<bf16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st, hx)
+                   : launch_search<bf16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st, hx);
     case ANTQ_F16:
-        return ovp ? launch_search<f16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st)
-                   : launch_search<f16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st);
+        return ovp ? launch_search<f16_tag, true>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st, hx)
+                   : launch_search<f16_tag, false>(x, rows, row_len, xmax, pr, ratios, ncand, gmax, pa, plan_host, plan_dev, sse, ws, st, hx);
     default:
         return ANTQ_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int antq_search_sse(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
+                               const float *ratios, int ncand, float gmax, const void *plan_host, const void *plan_dev,
+                               unsigned flags, int dtype, double *sse, void *workspace, void *stream)
+{
+    return search_sse_impl(x, rows, row_len, xmax, per_row, ratios, ncand, gmax, plan_host, plan_dev, flags, dtype, sse, workspace, stream, nullptr);
 }
 
 // (the direct kernels' workgroup partials, or -- never at the same time -- the histogram path's slabs and counts)
@@ -616,13 +642,11 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
     if (na == 1 && xmax_mode == ANTQ_XMAX_ABSMAX && !(flags & ANTQ_FLAG_OVP) && ncand > 0 && g_knob_hist_xmax)
         xmax_in_hist = dtype == ANTQ_BF16 ? hist_eligible<bf16_tag>(n_per, false, x, 0)
                      : dtype == ANTQ_F16  ? hist_eligible<f16_tag>(n_per, false, x, 0) : false;
-    struct Pending {                               // (whatever way this call ends, nothing stays handed over)
-        ~Pending() { g_hist_xmax_out = nullptr; }
-    } pending_guard;
+    HistXmax hx;                                   // (decided here, once; handed to the search explicitly)
     float *const zero = (xmax_mode == ANTQ_XMAX_ABSMAX && ncand > 0 && (!pr || xmax_in_hist)) ? xmax : nullptr;
     if (ncand > 0)
         hipLaunchKernelGGL(k_calib_ratios, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ratios, lb, step, ncand, zero);
-    if (xmax_in_hist) g_hist_xmax_out = xmax;
+    if (xmax_in_hist) hx.out = xmax;
     else if (xmax_mode == ANTQ_XMAX_ABSMAX)
         rc = zero ? antq_absmax_into(x, xmax, rows * row_len, dtype, stream) : antq_absmax(x, xmax, rows, row_len, pr, dtype, stream);
     else if (xmax_mode == ANTQ_XMAX_3SIGMA) {
@@ -640,19 +664,19 @@ extern "C" int antq_calibrate(const void *x, size_t rows, size_t row_len, int al
         const size_t per_type = (size_t)ncand * na;
         for (int b = 0; b < ntypes; b += kMaxTypes) {
             const int nt = std::min(kMaxTypes, ntypes - b);
-            rc = nt > 1 ? antq_search_sse_multi(x, rows, row_len, xmax, pr, ratios, ncand, nt, gmax_host + b, plan_host + b,
-                                                plan_dev + b, flags, dtype, sse + (size_t)b * per_type, ws_search, stream)
+            rc = nt > 1 ? search_sse_multi_impl(x, rows, row_len, xmax, pr, ratios, ncand, nt, gmax_host + b, plan_host + b,
+                                                plan_dev + b, flags, dtype, sse + (size_t)b * per_type, ws_search, stream, &hx)
                         : ANTQ_ERR_UNSUPPORTED;
             if (rc == ANTQ_ERR_UNSUPPORTED) {
                 for (int t = b; t < b + nt; t++) {
-                    rc = antq_search_sse(x, rows, row_len, xmax, pr, ratios, ncand, gmax_host[t], plan_host[t], plan_dev[t], flags,
-                                         dtype, sse + (size_t)t * per_type, ws_search, stream);
+                    rc = search_sse_impl(x, rows, row_len, xmax, pr, ratios, ncand, gmax_host[t], plan_host[t], plan_dev[t], flags,
+                                         dtype, sse + (size_t)t * per_type, ws_search, stream, &hx);
                     if (rc != ANTQ_OK) return rc;
                 }
             }
             if (rc != ANTQ_OK) return rc;
         }
-        if (g_hist_xmax_out) return ANTQ_ERR_LAUNCH;     // (the histogram search did not run although its own rule said it would)
+        if (hx.out && !hx.taken) return ANTQ_ERR_LAUNCH;  // (cannot happen: every search entry refuses before enqueueing anything)
         if (na == 1) {
             // 3 + 4 for a tensor with one scale: picks, scores and the type pick in one launch
             hipLaunchKernelGGL(k_calib_pick_one_scale, dim3(1), dim3(256), 0, st, sse, xmax, ratios, ncand, (double)n_per, ntypes, best,

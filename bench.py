@@ -446,7 +446,7 @@ def build_model(args, h, _lib, grids):
                 copy=(lambda: _lib.copy(src, dst), lambda: dst.copy_(src)), copy_bytes=2 * src.numel() * 2,
                 workload="%s%s; OliVe 4-bit flint + outliers with outlier-victim pairs, alpha = 3 sigma per row, bf16%s; one step = "
                          "ONE batched launch per rank over its %d units" % (what, " (%d layers)" % args.layers if args.layers else "",
-                                                                           ", quantised in place" if inplace else "", len(ws)),
+                                                                           ", quantised in place (from the second step on the input is the previous step's output -- a fixed point of the quantiser: same bytes moved, already-quantised values)" if inplace else "", len(ws)),
                 sharding="%d units on rank 0 of %d ranks, no data-path collective" % (len(ws), h.world),
                 keep=(ws, outs, alphas, batch, dst))
 

@@ -12,6 +12,9 @@ PY="python"
 
 # the driver's exact command line first (--steps 20 --warmup 5: three plain runs, one under rocprofv3 --kernel-trace with the
 # per-launch durations kept), then the long run
+# (SKIP_DRIVER=1: the part below the kernel trace only -- round 6: the traced runs of a command that times ten configs make
+#  rocprofv3 write tens of thousands of launches; the long runs therefore pass --configs none)
+if [ "${SKIP_DRIVER:-0}" != "1" ]; then
 bash tools/driver_cmd.sh "$TAG" > "$OUT/driver_cmd.log" 2>&1
 tail -32 "$OUT/driver_cmd.log" | head -30
 $PY bench.py --steps 200 --warmup 20 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"
@@ -24,15 +27,16 @@ cut -c1-200 "$OUT/${TAG}_bench_torchrun_n1.json"
 
 # kernel trace of the same command (no PMC in this pass)
 ( cd /tmp && rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- \
-    $PY "$REPO/bench.py" --steps 200 --warmup 20 --no-cpu-baseline --no-traffic > "$OUT/bench_profiled.json" 2> /tmp/prof_kt.err )
+    $PY "$REPO/bench.py" --steps 200 --warmup 20 --no-cpu-baseline --no-traffic --configs none > "$OUT/bench_profiled.json" 2> /tmp/prof_kt.err )
 KS=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/${TAG}_bench_kernel_stats.csv"
 tail -1 "$OUT/bench_profiled.json" | cut -c1-200
+fi
 
 # HBM traffic of the bench command: one counter per pass, kernel trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section)
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rm -rf /tmp/prof_$C && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -- \
-      $PY "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/prof_$C.err )
+      $PY "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --configs headline_olive > /dev/null 2> /tmp/prof_$C.err )
 done
 $PY tools/pmc_summary.py $(find /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE -name '*counter_collection.csv') \
     > "$OUT/${TAG}_pmc_summary.txt" 2>&1
