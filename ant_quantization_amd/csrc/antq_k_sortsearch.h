@@ -1,0 +1,623 @@
+// antq_k_sortsearch.h -- clip search from the SORTED row: every codebook and every candidate of a type selection on one sort
+// Part of libantq's calibration translation unit (antq_search.hip includes it); gfx950 only.
+//
+// search_mse (AQ/quant_modules.py:287-326, OQ:189-233) scores C clip candidates per row, search_adaptive_numeric_type
+// (AQ:328-415, OQ:235-256) does so for every candidate codebook.  For a fixed scale s the quantiser is a step function of x
+// (antq_k_sweep.h), so a candidate's squared error is a closed form in N_k = #{x >= X_k} and S_k = sum{x : x >= X_k} over its
+// x-domain thresholds X_k -- and both are ONE binary search away once the row is sorted and its prefix sums are known:
+//     sum_x (O_J(x) - x)^2 = sum x^2 + n O_0^2 - 2 O_0 S + sum_k [ (O_{k+1}^2 - O_k^2) N_k - 2 (O_{k+1} - O_k) S_k ].
+// The threshold sweep (antq_k_sweep.h) pays per element and per threshold that sweeps across it (LDS atomics; OliVe's 28
+// thresholds over a 75 .. 250 % clip range: half a dozen per element, slower than the direct kernels); here the elements pay
+// one sort (a 4096-element bitonic network: 78 compare-exchange steps, ALL of them on registers) shared by every codebook of
+// the launch, and the (codebook, candidate, threshold) triples pay 13 LDS probes each, whatever the clip range.
+//
+//   chunk    4096 elements of a row (a row is walked chunk by chunk; a tensor with ONE scale is spread over many workgroups)
+//   keys     the float's bits mapped to an unsigned integer of the same order (-0 folded into +0); elements that are no
+//            step-function elements (NaN / Inf / far-clipped: |x| >= lim * s_min) carry the sentinel 0xffffffff: they sort to
+//            the end, count for nothing, and are evaluated literally (the reference sequence) for every candidate
+//   sort     256 threads x 16 keys.  The index bits of the network that are REGISTER bits change with the layout: bits 0-3
+//            (blocked), 4-7, 8-11; a size-2^s merge walks its strides top down through at most three layouts, moving between
+//            them through LDS (20 transposes in all; address = i + (i >> 4): all three layouts nearly conflict-free).  The
+//            first step of a merge (partner i ^ (2^s - 1)) is folded into the transposing READ (the upper half block is read
+//            mirrored), so every comparator sorts ascending: v_min_u32 + v_max_u32 per pair.
+//   sums     x in fixed point (2^-38 of the row statistic's binade, exact for every element within 2^15 of it: antq_k_sweep.h),
+//            prefix sums as 64-bit integers at every fourth position; a probe adds at most three elements to them
+//   search   work item = (codebook, candidate, group of 4 thresholds): 4 interleaved binary searches, the closed form's
+//            terms in double in ONE fixed order -- the sums of a (codebook, candidate) do not depend on which other codebooks
+//            or candidates share the launch
+//   pairs    OliVe's pair rule (OQ:311-320): every element stays in the sorted set with its plain step-function error; a
+//            pair one of whose members can be an outlier under SOME candidate is also put on a list, and each (codebook,
+//            candidate) adds the victim's correction v^2 - (O(v) - v)^2 for the pairs that hold an outlier under IT (exact:
+//            a victim's output is 0 * s).  Pairs with a member that is no step-function element take the literal sequence.
+//
+// Rows whose candidate scales are unusable (zero / denormal / NaN statistic, a non-monotone ratio list) take the literal
+// sequence for every element: slow, never wrong.
+#ifndef ANTQ_K_SORTSEARCH_H
+#define ANTQ_K_SORTSEARCH_H
+
+#include <type_traits>
+
+#include "antq_device.h"
+#include "antq_k_fakequant.h"
+#include "antq_k_search.h"
+#include "antq_k_sweep.h"
+
+namespace antq {
+
+constexpr int kSortB = 12, kSortR = 4;                       // 2^12 keys per chunk, 2^4 per thread
+constexpr int kSortK = 1 << kSortB, kSortEPT = 1 << kSortR, kSortNT = 1 << (kSortB - kSortR);
+constexpr int kSortPad = kSortK + (kSortK >> kSortR);        // dwords of the key buffer (address = i + (i >> R))
+constexpr int kSortKS = 4;                                   // thresholds per work item
+constexpr uint32_t kSortSent = 0xffffffffu;
+constexpr uint32_t kSortTy = 136;                            // dwords of a type's block in LDS
+
+struct SortTypes {
+    SweepType ty[kMaxTypes];
+    int ntypes;
+    uint32_t nthr_pad;           // max n_thr over the types, rounded up to a multiple of kSortKS
+};
+
+// LDS of a workgroup: keys | prefix sums | item partials | literal terms | pair corrections | thresholds | scales | tables
+struct SortLds {
+    uint32_t off_p4, off_acc, off_lit, off_corr, off_x, off_s, off_v, off_misc, total;
+};
+__host__ __device__ inline SortLds sort_lds(uint32_t ntc, uint32_t nthr_pad, int ntypes, bool ovp)
+{
+    SortLds L;
+    uint32_t o = (uint32_t)kSortPad * 4u;                    // keys
+    o = (o + 15u) & ~15u;
+    L.off_p4 = o;    o += ((uint32_t)kSortK / 4u + 1u) * 8u; // prefix sums at every fourth position, and the total
+    o = (o + 15u) & ~15u;
+    L.off_acc = o;   o += ntc * (nthr_pad / (uint32_t)kSortKS) * 8u;
+    L.off_lit = o;   o += ntc * 8u;
+    L.off_corr = o;  o += ovp ? ntc * 4u * 8u : 0u;
+    L.off_x = o;     o += ntc * nthr_pad * 4u;
+    L.off_s = o;     o += ntc * 4u;
+    L.off_v = o;     o += (uint32_t)ntypes * kSortTy * 4u;   // per type: values [66], thresholds T [64], n_thr, kout_pos, kout_neg, gmax, lim, m
+    o = (o + 15u) & ~15u;
+    L.off_misc = o;  o += 256u;                              // scan scratch, counters
+    L.total = o;
+    return L;
+}
+
+// ---- keys --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sort_key(float x)        // order of the unsigned keys == order of the (non-NaN) floats
+{
+    const uint32_t u = x == 0.0f ? 0u : f2u(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float sort_unkey(uint32_t k) { return u2f((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+__device__ __forceinline__ long long sort_key_fixed(uint32_t k, double F)
+{
+    return k == kSortSent ? 0ll : sweep_fixed(sort_unkey(k), F);
+}
+
+// ---- the sorting network -------------------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void sort_static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sort_static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ void sort_ce(uint32_t &a, uint32_t &b)
+{
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+// compare-exchange of the pairs that differ in register bit BIT
+template <int BIT>
+__device__ __forceinline__ void sort_ce_reg(uint32_t (&k)[kSortEPT])
+{
+#pragma unroll
+    for (int r = 0; r < kSortEPT; r++)
+        if (!((r >> BIT) & 1)) sort_ce(k[r], k[r | (1 << BIT)]);
+}
+// first step of a size-2^SB merge inside the registers: partner r ^ (2^SB - 1)
+template <int SB>
+__device__ __forceinline__ void sort_ce_reg_mirror(uint32_t (&k)[kSortEPT])
+{
+#pragma unroll
+    for (int r = 0; r < kSortEPT; r++)
+        if (!((r >> (SB - 1)) & 1)) sort_ce(k[r], k[r ^ ((1 << SB) - 1)]);
+}
+// CE on register bits TOP .. 0
+template <int TOP>
+__device__ __forceinline__ void sort_ce_down(uint32_t (&k)[kSortEPT])
+{
+    if constexpr (TOP >= 0) {
+        sort_ce_reg<TOP>(k);
+        sort_ce_down<TOP - 1>(k);
+    }
+}
+// the layout whose register bits are [lo, lo + R) and hold index bit b
+__host__ __device__ constexpr int sort_lay_lo(int b)
+{
+    return (b / kSortR) * kSortR < kSortB - kSortR ? (b / kSortR) * kSortR : kSortB - kSortR;
+}
+// dword address of the element (thread t, register 0) in layout lo; register r adds sort_lay_off(r, lo) (disjoint bit fields:
+// the padding term i >> R splits over them)
+__device__ __forceinline__ uint32_t sort_lay_base(uint32_t t, int lo)
+{
+    const uint32_t i = ((t >> lo) << (lo + kSortR)) | (t & ((1u << lo) - 1u));
+    return i + (i >> kSortR);
+}
+__host__ __device__ constexpr uint32_t sort_lay_off(int r, int lo) { return ((uint32_t)r << lo) + (((uint32_t)r << lo) >> kSortR); }
+
+template <int LO>
+__device__ __forceinline__ void sort_store(const uint32_t (&k)[kSortEPT], uint32_t *sK, uint32_t t)
+{
+    uint32_t *p = sK + sort_lay_base(t, LO);
+#pragma unroll
+    for (int r = 0; r < kSortEPT; r++) p[sort_lay_off(r, LO)] = k[r];
+}
+// S > 0: the first read of the size-2^S merge -- the upper half block (index bit S - 1 set) comes in mirrored
+template <int LO, int S>
+__device__ __forceinline__ void sort_load(uint32_t (&k)[kSortEPT], const uint32_t *sK, uint32_t t)
+{
+    const uint32_t *p = sK + sort_lay_base(t, LO);
+    if constexpr (S > 0) {
+        const uint32_t *pm = sK + sort_lay_base(t ^ ((1u << LO) - 1u), LO);
+#pragma unroll
+        for (int r = 0; r < kSortEPT; r++) {
+            if ((r >> (S - 1 - LO)) & 1) k[r] = pm[sort_lay_off(r ^ ((1 << (S - 1 - LO)) - 1), LO)];
+            else k[r] = p[sort_lay_off(r, LO)];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kSortEPT; r++) k[r] = p[sort_lay_off(r, LO)];
+    }
+}
+// the strides 2^BB .. 1 of the size-2^S merge; the keys are in layout CUR
+template <int S, int BB, int CUR, bool FIRST>
+__device__ __forceinline__ void sort_steps(uint32_t (&k)[kSortEPT], uint32_t *sK, uint32_t t)
+{
+    if constexpr (BB >= 0) {
+        constexpr int lo = sort_lay_lo(BB);
+        sort_store<CUR>(k, sK, t);
+        __syncthreads();
+        sort_load<lo, FIRST ? S : 0>(k, sK, t);
+        __syncthreads();
+        sort_ce_down<BB - lo>(k);
+        sort_steps<S, lo - 1, lo, false>(k, sK, t);
+    }
+}
+// ascending sort of the workgroup's 4096 keys; in: any arrangement; out: thread t holds sorted[16 t .. 16 t + 15]
+// (the key buffer must be free when this is called, and is free again when it returns)
+__device__ __forceinline__ void sort_wg(uint32_t (&k)[kSortEPT], uint32_t *sK, uint32_t t)
+{
+    sort_static_for<1, kSortR + 1>([&](auto s) {
+        sort_ce_reg_mirror<decltype(s)::value>(k);
+        sort_ce_down<decltype(s)::value - 2>(k);
+    });
+    sort_static_for<kSortR + 1, kSortB + 1>([&](auto s) { sort_steps<decltype(s)::value, decltype(s)::value - 1, 0, true>(k, sK, t); });
+}
+
+// number of keys below X among the chunk's sorted keys (address i + (i >> R))
+__device__ __forceinline__ uint32_t sort_lower_bound(const uint32_t *sK, uint32_t X)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (int step = kSortK / 2; step >= 1; step >>= 1) {
+        const uint32_t i = pos + (uint32_t)step - 1u;
+        pos += sK[i + (i >> kSortR)] < X ? (uint32_t)step : 0u;
+    }
+    return pos + (sK[pos + (pos >> kSortR)] < X ? 1u : 0u);
+}
+
+// ---- the search kernel ---------------------------------------------------------------------------------------------------
+// PT = false: one workgroup per row (rows grid-strided), sse[(type * ncand_all + c) * rows + row] (ncand of the ncand_all
+//             candidates in this launch: `ratios` and `sse` point at the first of them).
+// PT = true : a tensor with ONE scale; workgroup b walks the chunks b, b + gridDim.x, ... and leaves its partial terms in
+//             slab b of `slabs` (doubles: item partials | literal terms | pair corrections | sum x^2); k_sort_pt_total adds the
+//             slabs in slab order, k_sort_pt_finish forms the sums.
+template <typename T, bool OVP, bool PT>
+__global__ void __launch_bounds__(kSortNT)
+k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const float *__restrict__ xmax,
+                const float *__restrict__ ratios, double *__restrict__ sse, SortTypes st, uint32_t ncand, uint32_t ncand_all,
+                double *__restrict__ slabs)
+{
+    constexpr int EPL = IO<T>::EPL;
+    constexpr int VPT = kSortEPT / EPL;                     // vectors per thread and chunk
+    constexpr size_t VPC = kSortK / EPL;                    // vectors per chunk
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t ntypes = (uint32_t)st.ntypes, ntc = ntypes * ncand, nthr_pad = st.nthr_pad, nkg = nthr_pad / (uint32_t)kSortKS;
+    const uint32_t nitems = ntc * nkg;
+    const SortLds L = sort_lds(ntc, nthr_pad, st.ntypes, OVP);
+    char *base = reinterpret_cast<char *>(smem);
+    uint32_t *sK = reinterpret_cast<uint32_t *>(base);
+    long long *sP4 = reinterpret_cast<long long *>(base + L.off_p4);
+    double *sAcc = reinterpret_cast<double *>(base + L.off_acc);
+    double *sLit = reinterpret_cast<double *>(base + L.off_lit);
+    double *sCorr = reinterpret_cast<double *>(base + L.off_corr);
+    uint32_t *sX = reinterpret_cast<uint32_t *>(base + L.off_x);          // [ntc][nthr_pad] keys of the x-domain thresholds
+    float *sS = reinterpret_cast<float *>(base + L.off_s);               // [ntc]
+    float *sV = reinterpret_cast<float *>(base + L.off_v);               // per type: [0..65] values, [66..129] thresholds T
+    unsigned long long *sScan = reinterpret_cast<unsigned long long *>(base + L.off_misc);      // [4] counts, [4..8] sums
+    long long *sScanI = reinterpret_cast<long long *>(base + L.off_misc + 64);
+    double *sScanD = reinterpret_cast<double *>(base + L.off_misc + 128);
+    int *sFlag = reinterpret_cast<int *>(base + L.off_misc + 192);
+
+    // per type: values, grid-domain thresholds and scalars (once per workgroup; constant indices into the kernel argument)
+#pragma unroll
+    for (int t = 0; t < kMaxTypes; t++) {
+        if (t < st.ntypes) {
+            const SweepType ty = st.ty[t];
+            float *v = sV + (uint32_t)t * kSortTy;
+            uint32_t *vu = reinterpret_cast<uint32_t *>(v);
+            if (tid < 64u) {
+                const uint32_t k = tid;
+                if (k < ty.n_thr) {
+                    const uint4 th = ty.tlist[k];
+                    v[66u + k] = u2f(th.x);
+                    v[k + 1u] = u2f(th.z) + 0.0f;
+                    if (k == 0u) v[0] = u2f(th.y) + 0.0f;
+                } else {                                     // beyond the last threshold: the last value again (A = B = 0)
+                    v[66u + k] = 0.0f;
+                    v[k + 1u] = ty.n_thr ? u2f(ty.tlist[ty.n_thr - 1u].z) + 0.0f : 0.0f;
+                }
+            }
+            if (tid == 64u) {
+                vu[130] = ty.n_thr;
+                vu[131] = (uint32_t)ty.kout_pos;
+                vu[132] = (uint32_t)ty.kout_neg;
+                v[133] = ty.gmax;
+                v[134] = ty.lim;
+                vu[135] = ty.m;
+            }
+        }
+    }
+    __syncthreads();
+    auto ty_nthr = [&](uint32_t t) { return reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[130]; };
+    auto ty_kpos = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[131]; };
+    auto ty_kneg = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[132]; };
+    auto ty_gmax = [&](uint32_t t) { return sV[t * kSortTy + 133u]; };
+    auto ty_lim = [&](uint32_t t) { return sV[t * kSortTy + 134u]; };
+    auto ty_m = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[135]; };
+    auto ty_grid = [&](uint32_t t) {
+        const float *g = st.ty[0].grid;
+#pragma unroll
+        for (int u = 1; u < kMaxTypes; u++) g = (uint32_t)u == t ? st.ty[u].grid : g;
+        return g;
+    };
+
+    const size_t nchunks_row = (vpr + VPC - 1) / VPC;
+    for (size_t row = PT ? 0 : blockIdx.x; row < rows; row += PT ? 1 : gridDim.x) {
+        const float xm = xmax[row];
+        const uint4 *xr = x + row * vpr;
+        // A zero or NaN statistic (an all-zero row): every scale is 0 / NaN, x / s is NaN or +-Inf for every element, the scan
+        // keeps its initial 0 and (0 - d) + d is NaN -- every candidate's sum is NaN whatever the row holds (quant_kernel.cu:25-37,
+        // AQ:541-549).  Said directly instead of through 4096 literal evaluations per candidate.
+        if (!PT && (xm == 0.0f || xm != xm)) {
+            for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
+                const uint32_t t = tc / ncand, c = tc - t * ncand;
+                sse[((size_t)t * ncand_all + c) * rows + row] = __builtin_nan("");
+            }
+            continue;
+        }
+        // ---- 1. candidate scales (AQ:300, :536): s = fl32(fl32(x_max * ratio_c) / gmax_t), usable and non-decreasing along c
+        bool ok = true;
+        for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
+            const uint32_t t = tc / ncand, c = tc - t * ncand;
+            const Scale sc = make_scale(xm * ratios[c], ty_gmax(t));
+            sS[tc] = sc.s;
+            ok = ok && sc.ok && (sc.s > 0.0f);
+        }
+        __syncthreads();
+        for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
+            const uint32_t t = tc / ncand, c = tc - t * ncand;
+            if (c > 0u) ok = ok && (sS[tc] >= sS[tc - 1u]);
+        }
+        if (tid == 0u) *sFlag = 0;
+        __syncthreads();
+        if (!ok) atomicOr(sFlag, 1);
+        __syncthreads();
+        const bool usable = *sFlag == 0;
+        // ---- 2. thresholds in the x domain, as keys; partial sums cleared
+        for (uint32_t p = tid; p < ntc * nthr_pad; p += kSortNT) {
+            const uint32_t tc = p / nthr_pad, k = p - tc * nthr_pad, t = tc / ncand;
+            uint32_t key = kSortSent;
+            if (usable && k < ty_nthr(t)) {
+                bool tok;
+                const float X = x_threshold(sV[t * kSortTy + 66u + k], sS[tc], 0.0f, tok);
+                key = sort_key(X);
+            }
+            sX[p] = key;
+        }
+        for (uint32_t p = tid; p < nitems; p += kSortNT) sAcc[p] = 0.0;
+        for (uint32_t p = tid; p < ntc; p += kSortNT) sLit[p] = 0.0;
+        if (OVP)
+            for (uint32_t p = tid; p < 4u * ntc; p += kSortNT) sCorr[p] = 0.0;
+        // ---- 3. per-row constants
+        int ex = 0;
+        (void)frexpf(xm, &ex);                              // x_max = f * 2^ex, f in [0.5, 1)
+        const double F = __builtin_ldexp(1.0, 38 - ex), unit = __builtin_ldexp(1.0, ex - 38);
+        float Lx = 0.0f;                                    // |x| < Lx: a step-function element for EVERY candidate of every type
+        if (usable) {
+            Lx = __builtin_ldexpf(0.999f, ex + 8);          // ... whose fixed-point image stays below 2^46
+            for (uint32_t t = 0; t < ntypes; t++) Lx = fminf(Lx, ty_lim(t) * sS[t * ncand] * 0.999f);
+        }
+        __syncthreads();
+        float XoP = __builtin_inff(), XoN = -__builtin_inff();            // OliVe: outlier under the smallest scale of SOME type
+        if (OVP && usable) {
+            for (uint32_t t = 0; t < ntypes; t++) {
+                if (ty_kpos(t) >= 0) XoP = fminf(XoP, sort_unkey(sX[(t * ncand) * nthr_pad + (uint32_t)ty_kpos(t)]));
+                if (ty_kneg(t) >= 0) XoN = fmaxf(XoN, sort_unkey(sX[(t * ncand) * nthr_pad + (uint32_t)ty_kneg(t)]));
+            }
+        }
+        double Q = 0.0;
+        uint32_t nch_done = 0;                              // (parity of the count scratch: a chunk with nothing to sort has one barrier only)
+
+        // ---- 4. the chunks
+        for (size_t ch = PT ? blockIdx.x : 0; ch < nchunks_row; ch += PT ? gridDim.x : 1) {
+            uint32_t k[kSortEPT];
+            float xs[kSortEPT];
+            uint32_t nreg = 0, nlit = 0, ncap = 0;          // elements; literal elements (pairs count 2); capable pairs
+            uint32_t litmask = 0, capmask = 0;              // per element / per pair (bit = index of the pair's first element)
+#pragma unroll
+            for (int j = 0; j < VPT; j++) {
+                const size_t vi = ch * VPC + (size_t)j * kSortNT + tid;
+                const bool live = vi < vpr;
+                float xf[EPL];
+                {
+                    const uint4 v = live ? xr[vi] : make_uint4(0u, 0u, 0u, 0u);
+                    IO<T>::unpack(v, xf);
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; e += 2) {
+                    const int r = j * EPL + e;
+                    const float a = xf[e], b = xf[e + 1];
+                    bool la = live && !(fabsf(a) < Lx), lb = live && !(fabsf(b) < Lx);
+                    bool cap = false;
+                    if (OVP) {
+                        la = lb = (la || lb);
+                        cap = live && !la && ((a >= XoP) || (a < XoN) || (b >= XoP) || (b < XoN));
+                    }
+                    const bool ra = live && !la, rb = live && !lb;
+                    k[r] = ra ? sort_key(a) : kSortSent;
+                    k[r + 1] = rb ? sort_key(b) : kSortSent;
+                    xs[r] = a;
+                    xs[r + 1] = b;
+                    Q = __builtin_fma((double)(ra ? a : 0.0f), (double)(ra ? a : 0.0f), Q);
+                    Q = __builtin_fma((double)(rb ? b : 0.0f), (double)(rb ? b : 0.0f), Q);
+                    nreg += (ra ? 1u : 0u) + (rb ? 1u : 0u);
+                    nlit += (la ? 1u : 0u) + (lb ? 1u : 0u);
+                    litmask |= (la ? 1u : 0u) << r | (lb ? 1u : 0u) << (r + 1);
+                    if (OVP && cap) { ncap++; capmask |= 1u << r; }
+                }
+            }
+            // counts of the chunk, and this thread's places in the lists: one packed scan (fields of 16 bits, <= 4096 each)
+            unsigned long long pk = (unsigned long long)nreg | (unsigned long long)nlit << 16 | (unsigned long long)ncap << 32, inc = pk;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long tv = (unsigned long long)__shfl_up((long long)inc, off, 64);
+                if (lane >= (uint32_t)off) inc += tv;
+            }
+            const uint32_t par = (nch_done & 1u) * 4u;
+            nch_done++;
+            if (lane == 63u) sScan[par + wave] = inc;
+            __syncthreads();                                 // (also: the previous chunk's searches are done with sK / sP4)
+            unsigned long long before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kSortNT / 64; w++) {
+                const unsigned long long v = sScan[par + w];
+                before += w < wave ? v : 0ull;
+                total += v;
+            }
+            const uint32_t Kreg = (uint32_t)(total & 0xffffu), tot_lit = (uint32_t)((total >> 16) & 0xffffu), tot_cap = (uint32_t)((total >> 32) & 0xffffu);
+            // ---- 4a. literal elements and outlier-capable pairs (rare): lists in the key buffer, then every (type, candidate)
+            if (tot_lit | tot_cap) {
+                const unsigned long long excl = before + inc - pk;
+                uint32_t pl = (uint32_t)((excl >> 16) & 0xffffu), pc = (uint32_t)((excl >> 32) & 0xffffu);
+                float *sList = reinterpret_cast<float *>(sK);             // literal elements from the front, capable pairs from the back
+#pragma unroll
+                for (int r = 0; r < kSortEPT; r++)
+                    if ((litmask >> r) & 1u) sList[pl++] = xs[r];
+                if (OVP) {
+#pragma unroll
+                    for (int r = 0; r < kSortEPT; r += 2)
+                        if ((capmask >> r) & 1u) {
+                            sList[kSortK - 2u - 2u * pc] = xs[r];
+                            sList[kSortK - 1u - 2u * pc] = xs[r + 1];
+                            pc++;
+                        }
+                }
+                __syncthreads();
+                if (tot_lit) {
+                    for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
+                        const uint32_t t = tc / ncand;
+                        const float *grid = ty_grid(t);
+                        const int gm = ty_m(t);
+                        const float s = sS[tc];
+                        double acc = 0.0;
+                        for (uint32_t i = 0; i < tot_lit; i += OVP ? 2u : 1u) {
+                            const float xa_ = sList[i];
+                            float da, db = 0.0f;
+                            float qa = sweep_literal_q(xa_, s, grid, gm, da), qb = 0.0f;
+                            if (OVP) {
+                                const float xb_ = sList[i + 1u];
+                                qb = sweep_literal_q(xb_, s, grid, gm, db);
+                                const bool me = fabsf(qa) > 32.0f, mo = fabsf(qb) > 32.0f;      // OQ:314
+                                const bool ve = mo && !me;
+                                qa = qa * (ve ? 0.0f : 1.0f);
+                                qb = qb * (me ? 0.0f : 1.0f);
+                                acc += sweep_term(qb, db, s, xb_);
+                            }
+                            acc += sweep_term(qa, da, s, xa_);
+                        }
+                        sLit[tc] += acc;
+                    }
+                }
+                if (OVP && tot_cap) {
+                    // work item (type, candidate, j): the pairs j, j + 4, ... in list order
+                    for (uint32_t it = tid; it < 4u * ntc; it += kSortNT) {
+                        const uint32_t tc = it >> 2, j0 = it & 3u, t = tc / ncand;
+                        const uint32_t *X = sX + tc * nthr_pad;
+                        const float s = sS[tc];
+                        const float *v = sV + t * kSortTy;
+                        const uint32_t nthr_t = ty_nthr(t);
+                        const uint32_t kp = ty_kpos(t) >= 0 ? X[ty_kpos(t)] : kSortSent;          // key >= kp: a positive outlier
+                        const uint32_t kn = ty_kneg(t) >= 0 ? X[ty_kneg(t)] : 0u;                 // key <  kn: a negative outlier
+                        double acc = 0.0;
+                        for (uint32_t i = j0; i < tot_cap; i += 4u) {
+                            const float a = sList[kSortK - 2u - 2u * i], b = sList[kSortK - 1u - 2u * i];
+                            const uint32_t ka = sort_key(a), kb = sort_key(b);
+                            const bool me = ka >= kp || ka < kn, mo = kb >= kp || kb < kn;
+                            if (me || mo) {
+                                const float vv = me ? b : a;                                       // the victim (OQ:315-318)
+                                const uint32_t kv = me ? kb : ka;
+                                uint32_t lo = 0, hi = nthr_t;
+                                while (lo < hi) {
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if (kv >= X[mid]) lo = mid + 1u; else hi = mid;
+                                }
+                                const double O = (double)(v[lo] * s), dv = (double)vv;
+                                acc += dv * dv - (O - dv) * (O - dv);
+                            }
+                        }
+                        sCorr[it] += acc;
+                    }
+                }
+                __syncthreads();
+            }
+            if (Kreg == 0u) continue;                        // (uniform) nothing to sort
+            // ---- 4b. sort; sorted keys and prefix sums to LDS
+            sort_wg(k, sK, tid);
+            sort_store<0>(k, sK, tid);
+            long long g[4], mine = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                g[q] = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) g[q] += sort_key_fixed(k[4 * q + e], F);
+                mine += g[q];
+            }
+            long long incs = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long tv = __shfl_up(incs, off, 64);
+                if (lane >= (uint32_t)off) incs += tv;
+            }
+            if (lane == 63u) sScanI[wave] = incs;
+            __syncthreads();
+            long long pre = incs - mine;
+#pragma unroll
+            for (uint32_t w = 0; w < kSortNT / 64; w++) pre += w < wave ? sScanI[w] : 0ll;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                sP4[4u * tid + (uint32_t)q] = pre;
+                pre += g[q];
+            }
+            if (tid == kSortNT - 1u) sP4[kSortK / 4] = pre;
+            __syncthreads();
+            // ---- 4c. the (type, candidate, threshold group) items
+            const long long Stot_i = sP4[kSortK / 4];
+            const double Stot = (double)Stot_i * unit, dn = (double)Kreg;
+            for (uint32_t it = tid; it < nitems; it += kSortNT) {
+                const uint32_t tc = it / nkg, kg = it - tc * nkg, t = tc / ncand;
+                const float s = sS[tc];
+                const float *v = sV + t * kSortTy + kg * (uint32_t)kSortKS;
+                const uint32_t *X = sX + tc * nthr_pad + kg * (uint32_t)kSortKS;
+                uint32_t Xk[kSortKS], pos[kSortKS];
+#pragma unroll
+                for (int j = 0; j < kSortKS; j++) { Xk[j] = X[j]; pos[j] = 0u; }
+#pragma unroll
+                for (int step = kSortK / 2; step >= 1; step >>= 1) {
+                    uint32_t kv[kSortKS];
+#pragma unroll
+                    for (int j = 0; j < kSortKS; j++) {
+                        const uint32_t i = pos[j] + (uint32_t)step - 1u;
+                        kv[j] = sK[i + (i >> kSortR)];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kSortKS; j++) pos[j] += kv[j] < Xk[j] ? (uint32_t)step : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < kSortKS; j++) pos[j] += sK[pos[j] + (pos[j] >> kSortR)] < Xk[j] ? 1u : 0u;
+                double part = 0.0;
+                if (kg == 0u) {
+                    const double O0 = (double)(v[0] * s);
+                    part = dn * O0 * O0 - 2.0 * O0 * Stot;
+                }
+#pragma unroll
+                for (int j = 0; j < kSortKS; j++) {
+                    const uint32_t p = pos[j];
+                    long long slt = sP4[p >> 2];
+                    for (uint32_t i = p & ~3u; i < p; i++) slt += sort_key_fixed(sK[i + (i >> kSortR)], F);
+                    const double N = (double)(Kreg - p), S = (double)(Stot_i - slt) * unit;
+                    const double Oa = (double)(v[j] * s), Ob = (double)(v[j + 1] * s);
+                    part += (Ob * Ob - Oa * Oa) * N - 2.0 * (Ob - Oa) * S;
+                }
+                sAcc[it] += part;
+            }
+            // (the next chunk's first barrier -- or the one below -- orders these reads before the key buffer is reused)
+        }
+        // ---- 5. sum x^2 of the step-function elements: a fixed tree
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) Q += __shfl_xor(Q, off, 64);
+        __syncthreads();
+        if (lane == 0u) sScanD[wave] = Q;
+        __syncthreads();
+        double Qw = 0.0;
+#pragma unroll
+        for (uint32_t w = 0; w < kSortNT / 64; w++) Qw += sScanD[w];
+        // ---- 6. the sums -- or, for a tensor with ONE scale, this workgroup's partial terms to its slab
+        if (PT) {
+            const uint32_t ncell = nitems + ntc + (OVP ? 4u * ntc : 0u) + 1u;
+            double *slab = slabs + (size_t)blockIdx.x * ncell;
+            for (uint32_t p = tid; p < nitems; p += kSortNT) slab[p] = sAcc[p];
+            for (uint32_t p = tid; p < ntc; p += kSortNT) slab[nitems + p] = sLit[p];
+            if (OVP)
+                for (uint32_t p = tid; p < 4u * ntc; p += kSortNT) slab[nitems + ntc + p] = sCorr[p];
+            if (tid == 0u) slab[ncell - 1u] = Qw;
+            return;
+        }
+        for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
+            double sum = Qw;
+            for (uint32_t kg = 0; kg < nkg; kg++) sum += sAcc[tc * nkg + kg];
+            sum += sLit[tc];
+            if (OVP) sum += (sCorr[4u * tc] + sCorr[4u * tc + 1u]) + (sCorr[4u * tc + 2u] + sCorr[4u * tc + 3u]);
+            const uint32_t t = tc / ncand, c = tc - t * ncand;       // (ratios / sse point at this piece's first candidate)
+            sse[((size_t)t * ncand_all + c) * rows + row] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+// slabs of doubles added cell by cell in slab order (blockIdx.y: a group of `per_group` consecutive slabs; a second call
+// with the groups as slabs finishes the sum)
+static __global__ void __launch_bounds__(256)
+k_sort_pt_total(const double *__restrict__ slabs, uint32_t nslab, uint32_t per_group, uint32_t ncell, double *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= ncell) return;
+    const uint32_t g0 = blockIdx.y * per_group, g1 = min(nslab, g0 + per_group);
+    const double *p = slabs + (size_t)g0 * ncell + i;
+    double a = 0.0;
+    for (uint32_t g = g0; g < g1; g++, p += ncell) a += p[0];
+    out[(size_t)blockIdx.y * ncell + i] = a;
+}
+static __global__ void __launch_bounds__(256)
+k_sort_pt_finish(const double *__restrict__ tot, uint32_t ntc, uint32_t nkg, int ovp, uint32_t ncand, uint32_t ncand_all,
+                 double *__restrict__ sse)
+{
+    const uint32_t tc = blockIdx.x * 256u + threadIdx.x;
+    if (tc >= ntc) return;
+    const uint32_t nitems = ntc * nkg, ncell = nitems + ntc + (ovp ? 4u * ntc : 0u) + 1u;
+    double sum = tot[ncell - 1u];
+    for (uint32_t kg = 0; kg < nkg; kg++) sum += tot[tc * nkg + kg];
+    sum += tot[nitems + tc];
+    if (ovp) {
+        const double *c = tot + nitems + ntc + 4u * tc;
+        sum += (c[0] + c[1]) + (c[2] + c[3]);
+    }
+    const uint32_t t = tc / ncand, c = tc - t * ncand;
+    sse[(size_t)t * ncand_all + c] = sum;
+}
+
+}  // namespace antq
+
+#endif  // ANTQ_K_SORTSEARCH_H

@@ -10,6 +10,7 @@
 #include "antq_k_search.h"
 #include "antq_k_hist.h"
 #include "antq_k_sweep.h"
+#include "antq_k_sortsearch.h"
 
 #include <type_traits>
 
@@ -308,6 +309,123 @@ static int launch_sweep_pt(const void *x, size_t n, const float *xmax, const flo
     return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
 }
 
+
+// ---- the sorted-row search (antq_k_sortsearch.h): every codebook and candidate of a launch on ONE sort of the row -------
+// ANTQ_ERR_UNSUPPORTED: not this launch (the caller goes on to the sweep / the direct kernels).  knob 20: 0 off, 1 the default
+// rule, 2 every eligible launch (tests).
+constexpr uint32_t kSortLdsMax = 64 * 1024;
+static bool sort_type_ok(const void *plan_host, float gmax)
+{
+    const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host);
+    return ph->kind == kPlanLut && ph->hdom && ph->h_nthr > 0 && ph->h_nthr <= 64u && gmax > 0.0f;
+}
+static bool sort_fill_types(SortTypes &stt, int ntypes, const float *gmax, const void *const *plan_host, const void *const *plan_dev)
+{
+    memset(&stt, 0, sizeof(stt));
+    if (ntypes < 1 || ntypes > kMaxTypes) return false;
+    stt.ntypes = ntypes;
+    uint32_t nmax = 0;
+    for (int t = 0; t < ntypes; t++) {
+        if (!sort_type_ok(plan_host[t], gmax[t])) return false;
+        const PlanHeader *ph = static_cast<const PlanHeader *>(plan_host[t]);
+        const HThr *tl = plan_tlist(plan_host[t]);
+        SweepType &ty = stt.ty[t];
+        ty.tlist = reinterpret_cast<const uint4 *>(static_cast<const char *>(plan_dev[t]) + ph->tlist_off);
+        ty.grid = reinterpret_cast<const float *>(plan_tab_ptr(plan_dev[t]));
+        ty.n_thr = ph->h_nthr;
+        ty.m = ph->m;
+        ty.gmax = gmax[t];
+        const float flim = ph->fastlim * 0.99999f;
+        ty.lim = flim < ph->xlim ? flim : ph->xlim;
+        ty.kout_pos = ty.kout_neg = -1;
+        for (uint32_t k = 0; k < ph->h_nthr; k++) {
+            const bool lo_out = (tl[k].flags & 1u) != 0u, hi_out = (tl[k].flags & 2u) != 0u;
+            if (k > 0 && !(tl[k].T > tl[k - 1].T)) return false;                     // (ascending: what the kernel's searches assume)
+            if (!lo_out && hi_out) { if (ty.kout_pos >= 0 || !(tl[k].T > 0.0f)) return false; ty.kout_pos = (int)k; }
+            if (lo_out && !hi_out) { if (ty.kout_neg >= 0 || !(tl[k].T < 0.0f)) return false; ty.kout_neg = (int)k; }
+        }
+        nmax = std::max(nmax, ph->h_nthr);
+    }
+    stt.nthr_pad = (nmax + (uint32_t)kSortKS - 1u) / (uint32_t)kSortKS * (uint32_t)kSortKS;
+    return true;
+}
+// candidates per launch so that the workgroup's tables fit (the sums of a candidate do not depend on its company)
+static int sort_piece(const SortTypes &stt, int ncand, bool ovp)
+{
+    int nc = ncand;
+    while (nc > 0 && sort_lds((uint32_t)(stt.ntypes * nc), stt.nthr_pad, stt.ntypes, ovp).total > kSortLdsMax) nc = (nc + 1) / 2 == nc ? nc - 1 : (nc + 1) / 2;
+    return nc;
+}
+template <typename T, bool OVP>
+static bool sort_shape_ok(const void *x, size_t rows, size_t row_len, int ncand, int ntypes)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (!g_knob_sort || rows < 2 || ncand < 1 || ntypes < 1 || ntypes > kMaxTypes) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sort == 2 ? 64u : 2048u)) return false;
+    return !(OVP && (row_len & 1));                                  // (pairs would straddle rows)
+}
+template <typename T, bool OVP>
+static int launch_sorted(const void *x, size_t rows, size_t row_len, const float *xmax, const float *ratios, int ncand, int ntypes,
+                         const float *gmax, const void *const *plan_host, const void *const *plan_dev, double *sse, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (!sort_shape_ok<T, OVP>(x, rows, row_len, ncand, ntypes)) return ANTQ_ERR_UNSUPPORTED;
+    SortTypes stt;
+    if (!sort_fill_types(stt, ntypes, gmax, plan_host, plan_dev)) return ANTQ_ERR_UNSUPPORTED;
+    const int piece = sort_piece(stt, ncand, OVP);
+    if (piece < 1) return ANTQ_ERR_UNSUPPORTED;
+    const unsigned blocks = (unsigned)std::min<size_t>(rows, (size_t)1 << 20);
+    for (int c0 = 0; c0 < ncand; c0 += piece) {
+        const int nc = std::min(piece, ncand - c0);
+        const SortLds L = sort_lds((uint32_t)(ntypes * nc), stt.nthr_pad, ntypes, OVP);
+        hipLaunchKernelGGL((k_search_sorted<T, OVP, false>), dim3(blocks), dim3(kSortNT), L.total, st, static_cast<const uint4 *>(x),
+                           row_len / EPL, rows, xmax, ratios + c0, sse + (size_t)c0 * rows, stt, (uint32_t)nc, (uint32_t)ncand, nullptr);
+    }
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
+template <typename T>
+static bool sort_pt_shape_ok(const void *x, size_t n, int ncand)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (!g_knob_sort || sizeof(T) != 4 || ncand < 1) return false;     // (16-bit tensors with one scale: the histogram search)
+    return reinterpret_cast<uintptr_t>(x) % 16 == 0 && n % EPL == 0 && n >= (g_knob_sort == 2 ? 4096u : (1u << 20)) && n < ((size_t)1 << 40);
+}
+// A tensor with ONE scale.  ws: the search workspace (the workgroups' slabs of partial terms, then their totals).
+template <typename T, bool OVP>
+static int launch_sorted_pt(const void *x, size_t n, const float *xmax, const float *ratios, int ncand, int ntypes, const float *gmax,
+                            const void *const *plan_host, const void *const *plan_dev, double *sse, void *ws, hipStream_t st)
+{
+    constexpr int EPL = IO<T>::EPL;
+    if (!sort_pt_shape_ok<T>(x, n, ncand) || !ws || (OVP && (n & 1))) return ANTQ_ERR_UNSUPPORTED;
+    SortTypes stt;
+    if (!sort_fill_types(stt, ntypes, gmax, plan_host, plan_dev)) return ANTQ_ERR_UNSUPPORTED;
+    const int piece = sort_piece(stt, ncand, OVP);
+    if (piece < 1) return ANTQ_ERR_UNSUPPORTED;
+    const size_t nv = n / EPL, nchunks = (n + kSortK - 1) / kSortK;
+    const uint32_t nkg = stt.nthr_pad / (uint32_t)kSortKS, per_group = 32;
+    const size_t ws_cells = antq_search_workspace_bytes() / 8;
+    double *slabs = static_cast<double *>(ws);
+    for (int c0 = 0; c0 < ncand; c0 += piece) {
+        const int nc = std::min(piece, ncand - c0);
+        const uint32_t ntc = (uint32_t)(ntypes * nc), ncell = ntc * nkg + ntc + (OVP ? 4u * ntc : 0u) + 1u;
+        // a workgroup sets its tables up once (the thresholds of every candidate moved into the x domain: ~ a tenth of a
+        // chunk's work): three chunks and more per workgroup, three workgroups per CU
+        size_t G = std::min<size_t>((nchunks + 2) / 3, 768);
+        G = std::min(G, ws_cells / ncell - (768 / per_group + 2));
+        if (G < 1 || ws_cells / ncell < 768 / per_group + 3) return ANTQ_ERR_UNSUPPORTED;
+        const uint32_t ngroups = (uint32_t)((G + per_group - 1) / per_group);
+        double *part = slabs + G * (size_t)ncell, *tot = part + (size_t)ngroups * ncell;
+        const SortLds L = sort_lds(ntc, stt.nthr_pad, ntypes, OVP);
+        hipLaunchKernelGGL((k_search_sorted<T, OVP, true>), dim3((unsigned)G), dim3(kSortNT), L.total, st, static_cast<const uint4 *>(x), nv,
+                           (size_t)1, xmax, ratios + c0, sse + c0, stt, (uint32_t)nc, (uint32_t)ncand, slabs);
+        hipLaunchKernelGGL(k_sort_pt_total, dim3((ncell + 255) / 256, ngroups), dim3(256), 0, st, slabs, (uint32_t)G, per_group, ncell, part);
+        hipLaunchKernelGGL(k_sort_pt_total, dim3((ncell + 255) / 256, 1), dim3(256), 0, st, part, ngroups, ngroups, ncell, tot);
+        hipLaunchKernelGGL(k_sort_pt_finish, dim3((ntc + 255) / 256), dim3(256), 0, st, tot, ntc, nkg, OVP ? 1 : 0, (uint32_t)nc, (uint32_t)ncand, sse + c0);
+    }
+    return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
+}
+
 template <typename T, bool OVP>
 static int launch_search(const void *x, size_t rows, size_t row_len, const float *xmax, int per_row,
                          const float *ratios, int ncand, float gmax, const PlanArgs &pa, const void *plan_host,
@@ -330,9 +448,11 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
             hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ncand), dim3(256), 0, st, ws, (uint32_t)blocks, kPtCand, sse);
         return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;
     }
-    if (per_row && rows > 1) {                   // per-row scales: the threshold sweep where it applies (antq_k_sweep.h)
+    if (per_row && rows > 1) {                   // per-row scales: the sorted-row search, then the threshold sweep, where they apply
         const void *ph1[1] = {plan_host}, *pd1[1] = {plan_dev};
-        const int rc = launch_sweep<T, OVP>(x, rows, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, st);
+        int rc = launch_sorted<T, OVP>(x, rows, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, st);
+        if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
+        rc = launch_sweep<T, OVP>(x, rows, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, st);
         if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
     }
     if (!per_row) { row_len = rows * row_len; rows = 1; }
@@ -349,9 +469,11 @@ static int launch_search(const void *x, size_t rows, size_t row_len, const float
         if (rc != ANTQ_OK || !OVP) return rc;
     }
     if (hx && hx->out && !hx->taken) return ANTQ_ERR_LAUNCH;     // (the caller counted on the histogram pass for its statistic)
-    if (rows == 1 && !run_if) {                  // one scale, no histogram search in front: the threshold sweep over many workgroups
+    if (rows == 1 && !run_if) {                  // one scale, no histogram search in front: the sorted search / the sweep over many workgroups
         const void *ph1[1] = {plan_host}, *pd1[1] = {plan_dev};
-        const int rc = launch_sweep_pt<T, OVP>(x, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, ws, st);
+        int rc = launch_sorted_pt<T, OVP>(x, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, ws, st);
+        if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
+        rc = launch_sweep_pt<T, OVP>(x, row_len, xmax, ratios, ncand, 1, &gmax, ph1, pd1, sse, ws, st);
         if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
     }
     const size_t vpr = row_len / EPL;
@@ -404,8 +526,14 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
 {
     constexpr int EPL = IO<T>::EPL;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || (per_row ? row_len : rows * row_len) % EPL != 0) return ANTQ_ERR_UNSUPPORTED;
-    if (per_row && rows > 1) {                   // per-row scales: the threshold sweep where it applies (antq_k_sweep.h)
-        const int rc = launch_sweep<T, OVP>(x, rows, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, st);
+    if (per_row && rows > 1) {                   // per-row scales: the sorted-row search, then the threshold sweep, where they apply
+        int rc = launch_sorted<T, OVP>(x, rows, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, st);
+        if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
+        // (a codebook's sums must not depend on its company: one search per type if some of them would take the sorted search)
+        if (sort_shape_ok<T, OVP>(x, rows, row_len, ncand, 1))
+            for (int t = 0; t < ntypes; t++)
+                if (sort_type_ok(plan_host[t], gmax[t])) return ANTQ_ERR_UNSUPPORTED;
+        rc = launch_sweep<T, OVP>(x, rows, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, st);
         if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
         // a codebook's sums must not depend on which other codebooks are searched with it: if one search per type would send
         // SOME of these types through the sweep, the caller has to issue one search per type (it does on this return code)
@@ -437,7 +565,12 @@ static int launch_search_multi(const void *x, size_t rows, size_t row_len, const
     }
     if (hx && hx->out && !hx->taken) return ANTQ_ERR_LAUNCH;     // (see launch_search)
     if (rows == 1 && !run_if) {
-        const int rc = launch_sweep_pt<T, OVP>(x, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, ws, st);
+        int rc = launch_sorted_pt<T, OVP>(x, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, ws, st);
+        if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
+        if (sort_pt_shape_ok<T>(x, row_len, ncand) && !(OVP && (row_len & 1)))
+            for (int t = 0; t < ntypes; t++)
+                if (sort_type_ok(plan_host[t], gmax[t])) return ANTQ_ERR_UNSUPPORTED;
+        rc = launch_sweep_pt<T, OVP>(x, row_len, xmax, ratios, ncand, ntypes, gmax, plan_host, plan_dev, sse, ws, st);
         if (rc != ANTQ_ERR_UNSUPPORTED) return rc;
         // (as for rows: a codebook's sums must not depend on its company -- one search per type if some types would sweep)
         if (sweep_pt_shape_ok<T>(x, row_len, ncand) && !(OVP && g_knob_sweep != 2))
