@@ -5,7 +5,12 @@
 // (AQ:328-415, OQ:235-256) does so for every candidate codebook.  For a fixed scale s the quantiser is a step function of x
 // (antq_k_sweep.h), so a candidate's squared error is a closed form in N_k = #{x >= X_k} and S_k = sum{x : x >= X_k} over its
 // x-domain thresholds X_k -- and both are ONE binary search away once the row is sorted and its prefix sums are known:
-//     sum_x (O_J(x) - x)^2 = sum x^2 + n O_0^2 - 2 O_0 S + sum_k [ (O_{k+1}^2 - O_k^2) N_k - 2 (O_{k+1} - O_k) S_k ].
+//     sum_x (O_J(x) - x)^2 = sum x^2 + n O_b^2 - 2 O_b S + sum_{k >= b} [ (O_{k+1}^2 - O_k^2) N_k - 2 (O_{k+1} - O_k) S_k ]
+//                                                        - sum_{k <  b} [ (O_{k+1}^2 - O_k^2) M_k - 2 (O_{k+1} - O_k) R_k ]
+// (M_k, R_k: count and sum of the elements BELOW X_k; b: the first non-negative threshold, so O_b is the value next to zero.
+// Written around the cell that holds zero, every term counts only the elements beyond its threshold as seen from zero: with
+// the sums anchored at the most negative value O_0, a row whose statistic is large next to its elements -- one huge element in
+// a row of small ones -- cancels n O_0^2 against the rest and loses 1e-6 of the result in double).
 // The threshold sweep (antq_k_sweep.h) pays per element and per threshold that sweeps across it (LDS atomics; OliVe's 28
 // thresholds over a 75 .. 250 % clip range: half a dozen per element, slower than the direct kernels); here the elements pay
 // one sort (a 4096-element bitonic network: 78 compare-exchange steps, ALL of them on registers) shared by every codebook of
@@ -49,17 +54,23 @@ constexpr int kSortK = 1 << kSortB, kSortEPT = 1 << kSortR, kSortNT = 1 << (kSor
 constexpr int kSortPad = kSortK + (kSortK >> kSortR);        // dwords of the key buffer (address = i + (i >> R))
 constexpr int kSortKS = 4;                                   // thresholds per work item
 constexpr uint32_t kSortSent = 0xffffffffu;
-constexpr uint32_t kSortTy = 136;                            // dwords of a type's block in LDS
+// A thread's partial terms live in REGISTERS across the chunks of a row (LDS holds what every thread reads; 10 - 15 KB of
+// accumulators were the difference between two and three workgroups per CU): at most kSortNI (type, candidate, threshold
+// group) items, kSortNC pair-correction items and kSortNL (type, candidate) literal sums per thread -- the launcher cuts the
+// candidate list into pieces that fit.
+constexpr int kSortNI = 6, kSortNC = 3, kSortNL = 2;
+constexpr uint32_t kSortTy = 140;                            // dwords of a type's block in LDS
 
 struct SortTypes {
     SweepType ty[kMaxTypes];
+    uint32_t nneg[kMaxTypes];    // thresholds below zero (PlanHeader::h_nneg): the closed form is written around the cell that holds 0
     int ntypes;
     uint32_t nthr_pad;           // max n_thr over the types, rounded up to a multiple of kSortKS
 };
 
-// LDS of a workgroup: keys | prefix sums | item partials | literal terms | pair corrections | thresholds | scales | tables
+// LDS of a workgroup: keys | prefix sums | thresholds | scales | tables
 struct SortLds {
-    uint32_t off_p4, off_acc, off_lit, off_corr, off_x, off_s, off_v, off_misc, total;
+    uint32_t off_p4, off_x, off_s, off_v, off_misc, total;
 };
 __host__ __device__ inline SortLds sort_lds(uint32_t ntc, uint32_t nthr_pad, int ntypes, bool ovp)
 {
@@ -68,9 +79,7 @@ __host__ __device__ inline SortLds sort_lds(uint32_t ntc, uint32_t nthr_pad, int
     o = (o + 15u) & ~15u;
     L.off_p4 = o;    o += ((uint32_t)kSortK / 4u + 1u) * 8u; // prefix sums at every fourth position, and the total
     o = (o + 15u) & ~15u;
-    L.off_acc = o;   o += ntc * (nthr_pad / (uint32_t)kSortKS) * 8u;
-    L.off_lit = o;   o += ntc * 8u;
-    L.off_corr = o;  o += ovp ? ntc * 4u * 8u : 0u;
+    (void)ovp;
     L.off_x = o;     o += ntc * nthr_pad * 4u;
     L.off_s = o;     o += ntc * 4u;
     L.off_v = o;     o += (uint32_t)ntypes * kSortTy * 4u;   // per type: values [66], thresholds T [64], n_thr, kout_pos, kout_neg, gmax, lim, m
@@ -214,7 +223,7 @@ __device__ __forceinline__ uint32_t sort_lower_bound(const uint32_t *sK, uint32_
 //             slab b of `slabs` (doubles: item partials | literal terms | pair corrections | sum x^2); k_sort_pt_total adds the
 //             slabs in slab order, k_sort_pt_finish forms the sums.
 template <typename T, bool OVP, bool PT>
-__global__ void __launch_bounds__(kSortNT)
+__global__ void __launch_bounds__(kSortNT, 3)        // (three wavefronts per SIMD: three workgroups per CU)
 k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const float *__restrict__ xmax,
                 const float *__restrict__ ratios, double *__restrict__ sse, SortTypes st, uint32_t ncand, uint32_t ncand_all,
                 double *__restrict__ slabs)
@@ -230,9 +239,6 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
     char *base = reinterpret_cast<char *>(smem);
     uint32_t *sK = reinterpret_cast<uint32_t *>(base);
     long long *sP4 = reinterpret_cast<long long *>(base + L.off_p4);
-    double *sAcc = reinterpret_cast<double *>(base + L.off_acc);
-    double *sLit = reinterpret_cast<double *>(base + L.off_lit);
-    double *sCorr = reinterpret_cast<double *>(base + L.off_corr);
     uint32_t *sX = reinterpret_cast<uint32_t *>(base + L.off_x);          // [ntc][nthr_pad] keys of the x-domain thresholds
     float *sS = reinterpret_cast<float *>(base + L.off_s);               // [ntc]
     float *sV = reinterpret_cast<float *>(base + L.off_v);               // per type: [0..65] values, [66..129] thresholds T
@@ -267,6 +273,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                 v[133] = ty.gmax;
                 v[134] = ty.lim;
                 vu[135] = ty.m;
+                vu[136] = st.nneg[t] < ty.n_thr ? st.nneg[t] : ty.n_thr;
             }
         }
     }
@@ -276,6 +283,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
     auto ty_kneg = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[132]; };
     auto ty_gmax = [&](uint32_t t) { return sV[t * kSortTy + 133u]; };
     auto ty_lim = [&](uint32_t t) { return sV[t * kSortTy + 134u]; };
+    auto ty_nneg = [&](uint32_t t) { return reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[136]; };
     auto ty_m = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[135]; };
     auto ty_grid = [&](uint32_t t) {
         const float *g = st.ty[0].grid;
@@ -327,10 +335,13 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
             }
             sX[p] = key;
         }
-        for (uint32_t p = tid; p < nitems; p += kSortNT) sAcc[p] = 0.0;
-        for (uint32_t p = tid; p < ntc; p += kSortNT) sLit[p] = 0.0;
-        if (OVP)
-            for (uint32_t p = tid; p < 4u * ntc; p += kSortNT) sCorr[p] = 0.0;
+        double acc[kSortNI], corr[kSortNC], lit[kSortNL];     // this thread's items it = tid + 256 u (statically indexed: registers)
+#pragma unroll
+        for (int u = 0; u < kSortNI; u++) acc[u] = 0.0;
+#pragma unroll
+        for (int u = 0; u < kSortNC; u++) corr[u] = 0.0;
+#pragma unroll
+        for (int u = 0; u < kSortNL; u++) lit[u] = 0.0;
         // ---- 3. per-row constants
         int ex = 0;
         (void)frexpf(xm, &ex);                              // x_max = f * 2^ex, f in [0.5, 1)
@@ -420,40 +431,69 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
 #pragma unroll
                     for (int r = 0; r < kSortEPT; r += 2)
                         if ((capmask >> r) & 1u) {
-                            sList[kSortK - 2u - 2u * pc] = xs[r];
-                            sList[kSortK - 1u - 2u * pc] = xs[r + 1];
+                            sK[kSortK - 2u - 2u * pc] = sort_key(xs[r]);         // (as keys: what every (type, candidate) compares)
+                            sK[kSortK - 1u - 2u * pc] = sort_key(xs[r + 1]);
                             pc++;
                         }
                 }
                 __syncthreads();
                 if (tot_lit) {
-                    for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
+                    // An element that is a step-function element for THIS candidate (|x / s| < lim) contributes what the closed
+                    // form would have given it -- (O_J - x)^2 in double -- so a candidate's sum does not depend (beyond 1e-13) on
+                    // whether the launch's smallest scale sent the element here; elsewhere: the reference sequence.
+                    for (uint32_t tc = tid, ui = 0; tc < ntc; tc += kSortNT, ui++) {
                         const uint32_t t = tc / ncand;
                         const float *grid = ty_grid(t);
                         const int gm = ty_m(t);
-                        const float s = sS[tc];
-                        double acc = 0.0;
+                        const float s = sS[tc], lim = usable ? ty_lim(t) : 0.0f;
+                        const uint32_t *X = sX + tc * nthr_pad;
+                        const float *v = sV + t * kSortTy;
+                        const uint32_t nthr_t = ty_nthr(t);
+                        auto q_of = [&](float xv, float &d, bool &tab) -> float {
+                            d = xv / s;
+                            tab = fabsf(d) < lim;
+                            if (tab) {
+                                const uint32_t kx = sort_key(xv);
+                                uint32_t lo = 0, hi = nthr_t;
+                                while (lo < hi) {
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if (kx >= X[mid]) lo = mid + 1u; else hi = mid;
+                                }
+                                return v[lo];
+                            }
+                            return sweep_literal_q(xv, s, grid, gm, d);
+                        };
+                        auto term_of = [&](float q, float d, bool tab, float xv) -> double {
+                            if (tab) {
+                                const double e = (double)(q * s) - (double)xv;
+                                return e * e;
+                            }
+                            return sweep_term(q, d, s, xv);
+                        };
+                        double sum_l = 0.0;
                         for (uint32_t i = 0; i < tot_lit; i += OVP ? 2u : 1u) {
                             const float xa_ = sList[i];
                             float da, db = 0.0f;
-                            float qa = sweep_literal_q(xa_, s, grid, gm, da), qb = 0.0f;
+                            bool ta, tb = false;
+                            float qa = q_of(xa_, da, ta), qb = 0.0f;
                             if (OVP) {
                                 const float xb_ = sList[i + 1u];
-                                qb = sweep_literal_q(xb_, s, grid, gm, db);
+                                qb = q_of(xb_, db, tb);
                                 const bool me = fabsf(qa) > 32.0f, mo = fabsf(qb) > 32.0f;      // OQ:314
                                 const bool ve = mo && !me;
                                 qa = qa * (ve ? 0.0f : 1.0f);
                                 qb = qb * (me ? 0.0f : 1.0f);
-                                acc += sweep_term(qb, db, s, xb_);
+                                sum_l += term_of(qb, db, tb, xb_);
                             }
-                            acc += sweep_term(qa, da, s, xa_);
+                            sum_l += term_of(qa, da, ta, xa_);
                         }
-                        sLit[tc] += acc;
+#pragma unroll
+                        for (int u = 0; u < kSortNL; u++) lit[u] += (uint32_t)u == ui ? sum_l : 0.0;
                     }
                 }
                 if (OVP && tot_cap) {
                     // work item (type, candidate, j): the pairs j, j + 4, ... in list order
-                    for (uint32_t it = tid; it < 4u * ntc; it += kSortNT) {
+                    for (uint32_t it = tid, ui = 0; it < 4u * ntc; it += kSortNT, ui++) {
                         const uint32_t tc = it >> 2, j0 = it & 3u, t = tc / ncand;
                         const uint32_t *X = sX + tc * nthr_pad;
                         const float s = sS[tc];
@@ -461,24 +501,24 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                         const uint32_t nthr_t = ty_nthr(t);
                         const uint32_t kp = ty_kpos(t) >= 0 ? X[ty_kpos(t)] : kSortSent;          // key >= kp: a positive outlier
                         const uint32_t kn = ty_kneg(t) >= 0 ? X[ty_kneg(t)] : 0u;                 // key <  kn: a negative outlier
-                        double acc = 0.0;
+                        double sum_c = 0.0;
                         for (uint32_t i = j0; i < tot_cap; i += 4u) {
-                            const float a = sList[kSortK - 2u - 2u * i], b = sList[kSortK - 1u - 2u * i];
-                            const uint32_t ka = sort_key(a), kb = sort_key(b);
+                            const uint32_t ka = sK[kSortK - 2u - 2u * i], kb = sK[kSortK - 1u - 2u * i];
                             const bool me = ka >= kp || ka < kn, mo = kb >= kp || kb < kn;
                             if (me || mo) {
-                                const float vv = me ? b : a;                                       // the victim (OQ:315-318)
-                                const uint32_t kv = me ? kb : ka;
+                                const uint32_t kv = me ? kb : ka;                                  // the victim (OQ:315-318)
+                                const float vv = sort_unkey(kv);
                                 uint32_t lo = 0, hi = nthr_t;
                                 while (lo < hi) {
                                     const uint32_t mid = (lo + hi) >> 1;
                                     if (kv >= X[mid]) lo = mid + 1u; else hi = mid;
                                 }
                                 const double O = (double)(v[lo] * s), dv = (double)vv;
-                                acc += dv * dv - (O - dv) * (O - dv);
+                                sum_c += dv * dv - (O - dv) * (O - dv);
                             }
                         }
-                        sCorr[it] += acc;
+#pragma unroll
+                        for (int u = 0; u < kSortNC; u++) corr[u] += (uint32_t)u == ui ? sum_c : 0.0;
                     }
                 }
                 __syncthreads();
@@ -486,7 +526,11 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
             if (Kreg == 0u) continue;                        // (uniform) nothing to sort
             // ---- 4b. sort; sorted keys and prefix sums to LDS
             sort_wg(k, sK, tid);
-            sort_store<0>(k, sK, tid);
+            {   // sorted keys, UNPADDED (the probes' addresses are then pos + constant): 64 contiguous bytes per thread
+                uint4 *dst = reinterpret_cast<uint4 *>(sK + (size_t)kSortEPT * tid);
+#pragma unroll
+                for (int q = 0; q < kSortEPT / 4; q++) dst[q] = make_uint4(k[4 * q], k[4 * q + 1], k[4 * q + 2], k[4 * q + 3]);
+            }
             long long g[4], mine = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -516,7 +560,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
             // ---- 4c. the (type, candidate, threshold group) items
             const long long Stot_i = sP4[kSortK / 4];
             const double Stot = (double)Stot_i * unit, dn = (double)Kreg;
-            for (uint32_t it = tid; it < nitems; it += kSortNT) {
+            for (uint32_t it = tid, ui = 0; it < nitems; it += kSortNT, ui++) {
                 const uint32_t tc = it / nkg, kg = it - tc * nkg, t = tc / ncand;
                 const float s = sS[tc];
                 const float *v = sV + t * kSortTy + kg * (uint32_t)kSortKS;
@@ -528,30 +572,31 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                 for (int step = kSortK / 2; step >= 1; step >>= 1) {
                     uint32_t kv[kSortKS];
 #pragma unroll
-                    for (int j = 0; j < kSortKS; j++) {
-                        const uint32_t i = pos[j] + (uint32_t)step - 1u;
-                        kv[j] = sK[i + (i >> kSortR)];
-                    }
+                    for (int j = 0; j < kSortKS; j++) kv[j] = sK[pos[j] + (uint32_t)step - 1u];
 #pragma unroll
                     for (int j = 0; j < kSortKS; j++) pos[j] += kv[j] < Xk[j] ? (uint32_t)step : 0u;
                 }
 #pragma unroll
-                for (int j = 0; j < kSortKS; j++) pos[j] += sK[pos[j] + (pos[j] >> kSortR)] < Xk[j] ? 1u : 0u;
+                for (int j = 0; j < kSortKS; j++) pos[j] += sK[pos[j]] < Xk[j] ? 1u : 0u;
+                const uint32_t nb = ty_nneg(t);
                 double part = 0.0;
                 if (kg == 0u) {
-                    const double O0 = (double)(v[0] * s);
-                    part = dn * O0 * O0 - 2.0 * O0 * Stot;
+                    const double Ob_ = (double)(sV[t * kSortTy + nb] * s);
+                    part = dn * Ob_ * Ob_ - 2.0 * Ob_ * Stot;
                 }
 #pragma unroll
                 for (int j = 0; j < kSortKS; j++) {
                     const uint32_t p = pos[j];
                     long long slt = sP4[p >> 2];
-                    for (uint32_t i = p & ~3u; i < p; i++) slt += sort_key_fixed(sK[i + (i >> kSortR)], F);
-                    const double N = (double)(Kreg - p), S = (double)(Stot_i - slt) * unit;
+                    for (uint32_t i = p & ~3u; i < p; i++) slt += sort_key_fixed(sK[i], F);
+                    const bool below = kg * (uint32_t)kSortKS + (uint32_t)j < nb;        // a threshold below zero: the elements BELOW it
+                    const double N = below ? -(double)p : (double)(Kreg - p);
+                    const double S = (double)(below ? -slt : Stot_i - slt) * unit;
                     const double Oa = (double)(v[j] * s), Ob = (double)(v[j + 1] * s);
                     part += (Ob * Ob - Oa * Oa) * N - 2.0 * (Ob - Oa) * S;
                 }
-                sAcc[it] += part;
+#pragma unroll
+                for (int u = 0; u < kSortNI; u++) acc[u] += (uint32_t)u == ui ? part : 0.0;
             }
             // (the next chunk's first barrier -- or the one below -- orders these reads before the key buffer is reused)
         }
@@ -568,18 +613,39 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
         if (PT) {
             const uint32_t ncell = nitems + ntc + (OVP ? 4u * ntc : 0u) + 1u;
             double *slab = slabs + (size_t)blockIdx.x * ncell;
-            for (uint32_t p = tid; p < nitems; p += kSortNT) slab[p] = sAcc[p];
-            for (uint32_t p = tid; p < ntc; p += kSortNT) slab[nitems + p] = sLit[p];
-            if (OVP)
-                for (uint32_t p = tid; p < 4u * ntc; p += kSortNT) slab[nitems + ntc + p] = sCorr[p];
+#pragma unroll
+            for (int u = 0; u < kSortNI; u++)
+                if (tid + (uint32_t)u * kSortNT < nitems) slab[tid + (uint32_t)u * kSortNT] = acc[u];
+#pragma unroll
+            for (int u = 0; u < kSortNL; u++)
+                if (tid + (uint32_t)u * kSortNT < ntc) slab[nitems + tid + (uint32_t)u * kSortNT] = lit[u];
+            if (OVP) {
+#pragma unroll
+                for (int u = 0; u < kSortNC; u++)
+                    if (tid + (uint32_t)u * kSortNT < 4u * ntc) slab[nitems + ntc + tid + (uint32_t)u * kSortNT] = corr[u];
+            }
             if (tid == 0u) slab[ncell - 1u] = Qw;
             return;
         }
-        for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
+        // (the searches are done with the key buffer and the prefix sums: the partial terms meet there)
+        double *fA = reinterpret_cast<double *>(sK), *fC = reinterpret_cast<double *>(sP4);
+#pragma unroll
+        for (int u = 0; u < kSortNI; u++)
+            if (tid + (uint32_t)u * kSortNT < nitems) fA[tid + (uint32_t)u * kSortNT] = acc[u];
+        if (OVP) {
+#pragma unroll
+            for (int u = 0; u < kSortNC; u++)
+                if (tid + (uint32_t)u * kSortNT < 4u * ntc) fC[tid + (uint32_t)u * kSortNT] = corr[u];
+        }
+        __syncthreads();
+        for (uint32_t tc = tid, ui = 0; tc < ntc; tc += kSortNT, ui++) {
             double sum = Qw;
-            for (uint32_t kg = 0; kg < nkg; kg++) sum += sAcc[tc * nkg + kg];
-            sum += sLit[tc];
-            if (OVP) sum += (sCorr[4u * tc] + sCorr[4u * tc + 1u]) + (sCorr[4u * tc + 2u] + sCorr[4u * tc + 3u]);
+            for (uint32_t kg = 0; kg < nkg; kg++) sum += fA[tc * nkg + kg];
+            double l = 0.0;
+#pragma unroll
+            for (int u = 0; u < kSortNL; u++) l = (uint32_t)u == ui ? lit[u] : l;
+            sum += l;
+            if (OVP) sum += (fC[4u * tc] + fC[4u * tc + 1u]) + (fC[4u * tc + 2u] + fC[4u * tc + 3u]);
             const uint32_t t = tc / ncand, c = tc - t * ncand;       // (ratios / sse point at this piece's first candidate)
             sse[((size_t)t * ncand_all + c) * rows + row] = sum;
         }

@@ -338,9 +338,11 @@ static bool sort_fill_types(SortTypes &stt, int ntypes, const float *gmax, const
         const float flim = ph->fastlim * 0.99999f;
         ty.lim = flim < ph->xlim ? flim : ph->xlim;
         ty.kout_pos = ty.kout_neg = -1;
+        stt.nneg[t] = 0;
         for (uint32_t k = 0; k < ph->h_nthr; k++) {
             const bool lo_out = (tl[k].flags & 1u) != 0u, hi_out = (tl[k].flags & 2u) != 0u;
             if (k > 0 && !(tl[k].T > tl[k - 1].T)) return false;                     // (ascending: what the kernel's searches assume)
+            if (tl[k].T < 0.0f) stt.nneg[t] = k + 1u;
             if (!lo_out && hi_out) { if (ty.kout_pos >= 0 || !(tl[k].T > 0.0f)) return false; ty.kout_pos = (int)k; }
             if (lo_out && !hi_out) { if (ty.kout_neg >= 0 || !(tl[k].T < 0.0f)) return false; ty.kout_neg = (int)k; }
         }
@@ -352,8 +354,15 @@ static bool sort_fill_types(SortTypes &stt, int ntypes, const float *gmax, const
 // candidates per launch so that the workgroup's tables fit (the sums of a candidate do not depend on its company)
 static int sort_piece(const SortTypes &stt, int ncand, bool ovp)
 {
+    // ... and a thread's items (partial terms in registers: kSortNI / kSortNC / kSortNL per thread) cover the launch
+    const uint32_t nkg = stt.nthr_pad / (uint32_t)kSortKS;
+    auto fits = [&](int nc) {
+        const uint32_t ntc = (uint32_t)(stt.ntypes * nc);
+        return sort_lds(ntc, stt.nthr_pad, stt.ntypes, ovp).total <= kSortLdsMax && ntc * nkg <= (uint32_t)(kSortNI * kSortNT) &&
+               ntc <= (uint32_t)(kSortNL * kSortNT) && (!ovp || 4u * ntc <= (uint32_t)(kSortNC * kSortNT));
+    };
     int nc = ncand;
-    while (nc > 0 && sort_lds((uint32_t)(stt.ntypes * nc), stt.nthr_pad, stt.ntypes, ovp).total > kSortLdsMax) nc = (nc + 1) / 2 == nc ? nc - 1 : (nc + 1) / 2;
+    while (nc > 0 && !fits(nc)) nc = nc > 1 ? (nc + 1) / 2 : 0;
     return nc;
 }
 template <typename T, bool OVP>
@@ -361,7 +370,9 @@ static bool sort_shape_ok(const void *x, size_t rows, size_t row_len, int ncand,
 {
     constexpr int EPL = IO<T>::EPL;
     if (!g_knob_sort || rows < 2 || ncand < 1 || ntypes < 1 || ntypes > kMaxTypes) return false;
-    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sort == 2 ? 64u : 2048u)) return false;
+    // Where it pays (profiles/r06_sort_scan.log; a row costs its 4096-element chunks whatever it holds): ANT codebooks from rows of
+    // 512 elements (1.4 x the direct kernels; 1.7 x at 768, 2 x at 1024, 5.6 x at 4096), OliVe's from 1024 (1.1 x; 3.3 x at 4096)
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sort == 2 ? 64u : (OVP ? 1024u : 512u))) return false;
     return !(OVP && (row_len & 1));                                  // (pairs would straddle rows)
 }
 template <typename T, bool OVP>

@@ -2660,22 +2660,26 @@ def test_calibration_sums_are_bit_reproducible(antq_lib, dev):
             halves = torch.cat([antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[:75].contiguous(), flint, 10.0),
                                 antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[75:].contiguous(), flint, 10.0)])
             if per_row and rows > 1:
-                # (round 6: rows of 2048 elements and more take the threshold sweep, whose split of the elements into
+                # (round 6: rows of 512 elements and more take the sorted-row search, whose split of the elements into
                 #  step-function and literal ones follows the SMALLEST scale of the launch's candidates -- with a list that starts
-                #  at ratio 0.01 the two halves classify differently and agree to the closed form's rounding, 1e-8, not to the
-                #  bit; still the same bits on every run.  The direct kernels, knob 19 = 0, are split-independent to the bit.)
+                #  at ratio 0.01 the two halves classify differently and agree to the closed form's rounding, not to the bit;
+                #  still the same bits on every run.  The direct kernels, knobs 19 = 20 = 0, are split-independent to the bit.)
                 torch.testing.assert_close(full, halves, rtol=1e-7, atol=0)
                 antq_lib.lib().antq_debug_set(19, 0)
+                antq_lib.lib().antq_debug_set(20, 0)
                 try:
                     f0 = antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150, flint, 10.0)
                     h0 = torch.cat([antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[:75].contiguous(), flint, 10.0),
                                     antq_lib.search_sse(x, rows, row_len, xmax, per_row, r150[75:].contiguous(), flint, 10.0)])
                 finally:
                     antq_lib.lib().antq_debug_set(19, 1)
+                    antq_lib.lib().antq_debug_set(20, 1)
                 assert torch.equal(f0, h0)
-                torch.testing.assert_close(full, f0, rtol=1e-7, atol=0)
+                torch.testing.assert_close(full, f0, rtol=2e-7, atol=0)
             else:
-                torch.testing.assert_close(full, halves, rtol=1e-12, atol=0)
+                # (an fp32 tensor with one scale and >= 1 M elements takes the sorted search too: an element the first half's
+                #  smallest scale makes literal contributes (O - x)^2 in double either way -- equal to the double's rounding)
+                torch.testing.assert_close(full, halves, rtol=1e-10, atol=0)
     finally:
         torch.empty = real_empty
 
@@ -3574,13 +3578,44 @@ def test_search_sums_do_not_depend_on_the_grid_split(antq_lib, dev, oracle):
     long_r = torch.from_numpy(np.float32([np.float32(i * 0.005) for i in range(100, 400)])).to(dev)
     whole = antq_lib.search_sse(xt, 64, 1024, xm, True, long_r, plans[0], 10.0)
     parts = [antq_lib.search_sse(xt, 64, 1024, xm, True, long_r[a:a + 50].contiguous(), plans[0], 10.0) for a in range(0, 300, 50)]
-    assert torch.equal(torch.cat(parts, 0), whole)
+    # (round 6, the sorted-row search: this list starts at ratio 0.5, where a row's largest element sits at the edge of the
+    #  codebook's step-function domain, |x / s| = 2 max|v| -- in the launches whose smallest scale is that one the element is
+    #  evaluated on its own, (O - x)^2 in double, in the others inside the closed form: the same number to the double's
+    #  rounding, not to the bit.  Lists from ratio 0.75 -- every case above -- have no such element and are equal to the bit;
+    #  so are the direct kernels, knobs 19 = 20 = 0, on this list.)
+    torch.testing.assert_close(torch.cat(parts, 0), whole, rtol=1e-12, atol=0)
+    antq_lib.lib().antq_debug_set(19, 0)
+    antq_lib.lib().antq_debug_set(20, 0)
+    try:
+        whole0 = antq_lib.search_sse(xt, 64, 1024, xm, True, long_r, plans[0], 10.0)
+        parts0 = [antq_lib.search_sse(xt, 64, 1024, xm, True, long_r[a:a + 50].contiguous(), plans[0], 10.0) for a in range(0, 300, 50)]
+    finally:
+        antq_lib.lib().antq_debug_set(19, 1)
+        antq_lib.lib().antq_debug_set(20, 1)
+    assert torch.equal(torch.cat(parts0, 0), whole0)
+    torch.testing.assert_close(whole, whole0, rtol=3e-7, atol=0)
     r175 = torch.from_numpy(np.float32([np.float32(i * 0.01) for i in range(75, 250)])).to(dev)
     four = [plans[0], plans[1], antq_lib.plan_for(grids.ant_pot(4, True)), antq_lib.plan_for(grids.ant_int(4, False))]
     multi = antq_lib.search_sse_multi(xt, 64, 1024, xm, True, r175, four, [10.0, 7.0, 10.0, 15.0])
     assert multi is not None and multi.shape[:2] == (4, 175)
+    # (round 6, the sorted-row search: the UNSIGNED codebook's step-function domain ends below this signed tensor's largest
+    #  elements at the small ratios; with it in the launch those elements are evaluated on their own for every codebook --
+    #  (O - x)^2 in double, what the closed form gives them otherwise: equal to the double's rounding (measured 3e-14), and to
+    #  the bit once the unsigned codebook is left out or the direct kernels run)
     for t, (p_, g_) in enumerate(zip(four, [10.0, 7.0, 10.0, 15.0])):
-        assert torch.equal(multi[t], antq_lib.search_sse(xt, 64, 1024, xm, True, r175, p_, g_)), t
+        torch.testing.assert_close(multi[t], antq_lib.search_sse(xt, 64, 1024, xm, True, r175, p_, g_), rtol=1e-12, atol=0)
+    multi3 = antq_lib.search_sse_multi(xt, 64, 1024, xm, True, r175, four[:3], [10.0, 7.0, 10.0])
+    for t, (p_, g_) in enumerate(zip(four[:3], [10.0, 7.0, 10.0])):
+        assert torch.equal(multi3[t], antq_lib.search_sse(xt, 64, 1024, xm, True, r175, p_, g_)), t
+    antq_lib.lib().antq_debug_set(19, 0)
+    antq_lib.lib().antq_debug_set(20, 0)
+    try:
+        multi0 = antq_lib.search_sse_multi(xt, 64, 1024, xm, True, r175, four, [10.0, 7.0, 10.0, 15.0])
+        for t, (p_, g_) in enumerate(zip(four, [10.0, 7.0, 10.0, 15.0])):
+            assert torch.equal(multi0[t], antq_lib.search_sse(xt, 64, 1024, xm, True, r175, p_, g_)), t
+    finally:
+        antq_lib.lib().antq_debug_set(19, 1)
+        antq_lib.lib().antq_debug_set(20, 1)
 
 
 @pytest.mark.parametrize("tree", ["ant", "olive"])

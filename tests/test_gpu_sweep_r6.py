@@ -1,4 +1,6 @@
 """Round 6: the threshold-sweep clip search (csrc/antq_k_sweep.h) against the direct kernels and the oracle.
+(Since the sorted-row search, csrc/antq_k_sortsearch.h / tests/test_gpu_sort_r6.py, takes these launches first, every test here
+switches it off -- knob 20 = 0 -- and the sweep is what runs behind it.)
 
 A per-row clip search scores every candidate by the squared error of the whole row (AQ:287-326, OQ:189-233); the sweep
 kernel forms the same sums from a histogram of threshold crossings instead of C evaluations per element.  Bar: the same
@@ -28,13 +30,13 @@ def _ratios(lb, ub, step, dev):
 def _both(L, x, rows, K, xm, rt, plans, gmaxs, ovp):
     out = []
     for knob in (0, 2):
-        L.lib().antq_debug_set(19, knob)
+        L.lib().antq_debug_set(19, knob); L.lib().antq_debug_set(20, 0)
         try:
             s = L.search_sse_multi(x, rows, K, xm, True, rt, plans, gmaxs, ovp=ovp) if len(plans) > 1 else None
             if s is None:
                 s = torch.stack([L.search_sse(x, rows, K, xm, True, rt, p, g, ovp=ovp) for p, g in zip(plans, gmaxs)])
         finally:
-            L.lib().antq_debug_set(19, 1)
+            L.lib().antq_debug_set(19, 1); L.lib().antq_debug_set(20, 1)
         out.append(s.clone())
     return out
 
@@ -131,11 +133,11 @@ def test_sweep_olive_pairs_against_direct_and_oracle(dev, oracle, dtype_name):
         _compare(a, b, (dtype_name, "olive", ovp))
     # a few rows against the oracle's own search (the reference's op sequence on the fp32 image of the tensor)
     xn = x[:6].float().cpu().numpy()
-    L.lib().antq_debug_set(19, 2)
+    L.lib().antq_debug_set(19, 2); L.lib().antq_debug_set(20, 0)
     try:
         s = L.search_sse_multi(x[:6].contiguous(), 6, K, xm[:6].contiguous(), True, rt, plans, gm, ovp=True)
     finally:
-        L.lib().antq_debug_set(19, 1)
+        L.lib().antq_debug_set(19, 1); L.lib().antq_debug_set(20, 1)
     for t, (g, m) in enumerate(cb):
         best, alpha, trace = oracle.search_mse(xn, xm[:6].cpu().numpy(), 75, 250, 2, g, m, ovp=True, per_row=True)
         got = (s[t] / K).cpu().numpy()                       # [ncand, rows] mean squared error
@@ -152,12 +154,12 @@ def test_calibrate_picks_do_not_depend_on_the_search_path(dev):
     x = torch.distributions.Laplace(0.0, 0.02).sample((128, 4096)).to(dev)
     res = []
     for knob in (0, 1, 2):
-        L.lib().antq_debug_set(19, knob)
+        L.lib().antq_debug_set(19, knob); L.lib().antq_debug_set(20, 0)
         try:
             alpha, score, typ, xmax = L.calibrate(x, 128, 4096, True, plans, [10.0] * 3, 75, 150, 1, xmax="absmax")
             res.append((alpha.clone(), score.clone(), int(typ)))
         finally:
-            L.lib().antq_debug_set(19, 1)
+            L.lib().antq_debug_set(19, 1); L.lib().antq_debug_set(20, 1)
     (a0, s0, t0), (a1, s1, t1), (a2, s2, t2) = res
     assert t0 == t1 == t2
     assert torch.equal(a1, a2) and torch.equal(s1, s2)                  # default rule == forced on these rows
@@ -182,14 +184,14 @@ def test_sweep_one_scale_fp32_tensors(dev, oracle):
         xm = L.absmax(x, 1, n, per_row=False)
         res = []
         for knob in (0, knob_on):
-            L.lib().antq_debug_set(19, knob)
+            L.lib().antq_debug_set(19, knob); L.lib().antq_debug_set(20, 0)
             try:
                 s = L.search_sse_multi(x, 1, n, xm, False, rt, plans, [10.0] * 3)
                 if s is None:
                     s = torch.stack([L.search_sse(x, 1, n, xm, False, rt, p, 10.0) for p in plans])
                 res.append(s.clone())
             finally:
-                L.lib().antq_debug_set(19, 1)
+                L.lib().antq_debug_set(19, 1); L.lib().antq_debug_set(20, 1)
         return res
 
     for x, plans in ((torch.nn.functional.gelu(torch.randn(1 << 22, device=dev)), signed),
