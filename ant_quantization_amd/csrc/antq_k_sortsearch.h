@@ -141,10 +141,11 @@ __device__ __forceinline__ void sort_ce_down(uint32_t (&k)[kSortEPT])
         sort_ce_down<TOP - 1>(k);
     }
 }
-// the layout whose register bits are [lo, lo + R) and hold index bit b
+// A (sub-)sort over BT index bits: the layout whose register bits are [lo, lo + R) and hold index bit b
+template <int BT>
 __host__ __device__ constexpr int sort_lay_lo(int b)
 {
-    return (b / kSortR) * kSortR < kSortB - kSortR ? (b / kSortR) * kSortR : kSortB - kSortR;
+    return (b / kSortR) * kSortR < BT - kSortR ? (b / kSortR) * kSortR : BT - kSortR;
 }
 // dword address of the element (thread t, register 0) in layout lo; register r adds sort_lay_off(r, lo) (disjoint bit fields:
 // the padding term i >> R splits over them)
@@ -179,29 +180,48 @@ __device__ __forceinline__ void sort_load(uint32_t (&k)[kSortEPT], const uint32_
         for (int r = 0; r < kSortEPT; r++) k[r] = p[sort_lay_off(r, LO)];
     }
 }
-// the strides 2^BB .. 1 of the size-2^S merge; the keys are in layout CUR
-template <int S, int BB, int CUR, bool FIRST>
+// WAVE: the keys that meet belong to ONE wavefront (its own 1024 + 64 dwords of the buffer): its LDS traffic is in order,
+// nothing to wait for but the compiler; otherwise the whole workgroup meets
+template <bool WAVE>
+__device__ __forceinline__ void sort_sync()
+{
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wavefront's LDS traffic has landed
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+// the strides 2^BB .. 1 of the size-2^S merge of a sort over BT bits (t: the thread's index among its 2^(BT - R)); the keys
+// are in layout CUR
+template <int BT, bool WAVE, int S, int BB, int CUR, bool FIRST>
 __device__ __forceinline__ void sort_steps(uint32_t (&k)[kSortEPT], uint32_t *sK, uint32_t t)
 {
     if constexpr (BB >= 0) {
-        constexpr int lo = sort_lay_lo(BB);
+        constexpr int lo = sort_lay_lo<BT>(BB);
         sort_store<CUR>(k, sK, t);
-        __syncthreads();
+        sort_sync<WAVE>();
         sort_load<lo, FIRST ? S : 0>(k, sK, t);
-        __syncthreads();
+        sort_sync<WAVE>();
         sort_ce_down<BB - lo>(k);
-        sort_steps<S, lo - 1, lo, false>(k, sK, t);
+        sort_steps<BT, WAVE, S, lo - 1, lo, false>(k, sK, t);
     }
 }
 // ascending sort of the workgroup's 4096 keys; in: any arrangement; out: thread t holds sorted[16 t .. 16 t + 15]
-// (the key buffer must be free when this is called, and is free again when it returns)
+// (the key buffer must be free when this is called, and is free again when it returns).  Sizes 2 .. 16 in the registers,
+// 32 .. 1024 inside each wavefront (14 transposes through its own quarter of the buffer, no workgroup barrier), 2048 and
+// 4096 across the workgroup (6 transposes, 12 barriers).
 __device__ __forceinline__ void sort_wg(uint32_t (&k)[kSortEPT], uint32_t *sK, uint32_t t)
 {
+    constexpr int BW = 6 + kSortR;                          // index bits inside a wavefront
     sort_static_for<1, kSortR + 1>([&](auto s) {
         sort_ce_reg_mirror<decltype(s)::value>(k);
         sort_ce_down<decltype(s)::value - 2>(k);
     });
-    sort_static_for<kSortR + 1, kSortB + 1>([&](auto s) { sort_steps<decltype(s)::value, decltype(s)::value - 1, 0, true>(k, sK, t); });
+    uint32_t *sW = sK + (t >> 6) * ((1u << BW) + (1u << (BW - kSortR)));
+    sort_static_for<kSortR + 1, BW + 1>([&](auto s) { sort_steps<BW, true, decltype(s)::value, decltype(s)::value - 1, 0, true>(k, sW, t & 63u); });
+    sort_static_for<BW + 1, kSortB + 1>([&](auto s) { sort_steps<kSortB, false, decltype(s)::value, decltype(s)::value - 1, 0, true>(k, sK, t); });
 }
 
 // number of keys below X among the chunk's sorted keys (address i + (i >> R))

@@ -44,7 +44,10 @@ FLOORS = {
     "alpha_grad_rows_bf16": 0.99,
     "alpha_grad_tensor_bf16": 0.88,
     "affine_f32": 0.91,
-    "search_sse_rows_f32": 2.80,
+    "search_sse_rows_f32": 4.40,                 # (the sorted-row search since round 6: seen 5.1-5.6; the sweep was 3.5)
+    "search_multi_rows_f32": 9.0,                # 3 ANT codebooks x 70 candidates on ONE sort of every row
+    "search_olive_pairs_rows_bf16": 2.9,         # 2 OliVe codebooks x 88 candidates, pair rule
+    "calibrate_tensor_f32_sorted": 0.040,        # a 16.8 M-element fp32 tensor with one scale: statistic + 3 x 70 + picks
     "calibrate_tensor_bf16_hist": 0.16,
 }
 _measured = {}
@@ -284,6 +287,42 @@ def test_floor_search_rows(box):
     xm = L.absmax(t, R, C)
     ratios = (torch.arange(80, 150, device=t.device, dtype=torch.float64) * 0.01).float()
     _check(box, "search_sse_rows_f32", lambda: L.search_sse(t, R, C, xm, True, ratios, plan, 10.0), t.numel() * 70 * 4)
+
+
+def test_floor_search_type_selection_rows(box):
+    """The type selection of a per-channel weight (AQ:328-415): three codebooks x 70 candidates per row, one launch."""
+    L, x = box["_lib"], box["x"]
+    g = box["grids"]
+    plans = [L.plan_for(g.ant_grid(t, 4, True)) for t in ("int", "pot", "flint")]
+    t = x[0].float()
+    xm = L.absmax(t, R, C)
+    ratios = (torch.arange(80, 150, device=t.device, dtype=torch.float64) * 0.01).float()
+    _check(box, "search_multi_rows_f32", lambda: L.search_sse_multi(t, R, C, xm, True, ratios, plans, [10.0] * 3), t.numel() * 210 * 4)
+
+
+def test_floor_search_olive_pairs_rows(box):
+    """OliVe's search of a per-channel weight (OQ:189-256): int / flint + outliers x 88 candidates, the pair rule."""
+    import numpy as np
+    L, x = box["_lib"], box["x"]
+    g = box["grids"]
+    oo = g.olive_outliers(4, True)
+    cb = [(np.concatenate([g.olive_grid(t, 4, True), oo]), float(g.olive_grid(t, 4, True).max())) for t in ("int", "flint")]
+    plans, gm = [L.plan_for(c) for c, _ in cb], [m for _, m in cb]
+    t = x[1]
+    xm = L.xmax_3sigma(t, R, C, per_row=True)
+    ratios = (torch.arange(75, 250, 2, device=t.device, dtype=torch.float64) * 0.01).float()
+    _check(box, "search_olive_pairs_rows_bf16", lambda: L.search_sse_multi(t, R, C, xm, True, ratios, plans, gm, ovp=True), t.numel() * 176 * 2)
+
+
+def test_floor_calibrate_one_scale_fp32(box):
+    """The first-call calibration of an fp32 activation (AQ:308-324 for three codebooks): abs-max, the sorted search over
+    many workgroups, the picks -- one C call."""
+    L, x = box["_lib"], box["x"]
+    g = box["grids"]
+    plans = [L.plan_for(g.ant_grid(t, 4, True)) for t in ("int", "pot", "flint")]
+    t = x[0].float().reshape(1, -1)
+    _check(box, "calibrate_tensor_f32_sorted",
+           lambda: L.calibrate(t, 1, t.numel(), False, plans, [10.0] * 3, 80, 150, 1, xmax="absmax"), t.numel() * 4)
 
 
 def test_floor_calibrate_hist(box):
