@@ -537,6 +537,17 @@ def run_configs(h, _lib, grids, want):
         out.append(e)
         return e
 
+    def centry(name, what, kernel, launches, elems, ncand_total, fn, **extra):
+        """A calibration pass (first-call clip search, AQ:287-415 / OQ:189-256): compute-bound (sort + binary searches per
+        row), so no HBM fraction -- the time of one pass and the (element x candidate) evaluations per second it replaces."""
+        secs, reps = timed(fn)
+        e = {"name": name, "what": what, "kernel": kernel, "launches_per_pass": launches, "elements": int(elems),
+             "candidates_per_element": int(ncand_total), "timed_passes": reps, "pass_ms": round(secs * 1e3, 3),
+             "gcand_evals_per_s": round(elems * ncand_total / secs / 1e9, 1), "bound": "valu"}
+        e.update(extra)
+        out.append(e)
+        return e
+
     def on(name):
         return want is None or name in want
 
@@ -610,6 +621,20 @@ def run_configs(h, _lib, grids, want):
             entry("C3_opt6.7b_rank0of8_%s" % tag, "configs[3]: OPT-6.7B, the 24 weight tensors rank 0 of 8 owns (LPT by bytes, 805 M "
                   "elements), OliVe 4-bit flint + outliers, outlier-victim pairs, alpha = 3 sigma per row, %s; ONE batched launch" % tag,
                   bt.kernels(), sum(w.numel() for w in ws), bpe, bt.run)
+            if tag == "bf16" and on("calib_C3"):
+                # the first-call calibration of the same tensors (OQ:189-256): mean +- 3 sigma per row, int and flint (+ outliers)
+                # x 88 clip ratios with the pair rule, per-row picks, the type pick -- one antq_calibrate per tensor
+                oi = _lib.plan_for(np.concatenate([grids.olive_int(4, True), go]))
+                pls, gms = [oi, olive], [float(grids.olive_int(4, True).max()), float(gn.max())]
+
+                def cal():
+                    for w in ws:
+                        _lib.calibrate(w, w.shape[0], w.shape[1], True, pls, gms, 75, 250, 2, xmax="3sigma", ovp=True)
+
+                e = centry("calib_C3_opt6.7b_rank0of8_bf16", "first-call calibration of those 24 tensors: 3-sigma statistic, OliVe int / "
+                           "flint + outliers x 88 clip ratios with the pair rule, per-row picks, type pick (one antq_calibrate per tensor: "
+                           "k_moments + the sorted-row search + picks)", "k_search_sorted<bf16,true,false>", 24, sum(w.numel() for w in ws), 176, cal)
+                e["x8_for_the_192_tensors_ms"] = round(e["pass_ms"] * 8, 1)
             del ws, outs, al, bt
 
     # (v) configs[4]: the 70 B-parameter bf16 stack, rank 0's row block of every matrix at 8 ranks (17.1 GB in, 17.1 GB out)
@@ -630,6 +655,22 @@ def run_configs(h, _lib, grids, want):
               % (sum(w.numel() for w in ws) / 1e9, sum(w.numel() for w in ws) * 2 / 1e9), bt.kernels(),
               sum(w.numel() for w in ws), 4, bt.run)
         del ws, outs, al, bt
+    # (vi) first-call calibration (N1): the type selection of a per-channel weight and of an fp32 activation
+    if on("calib"):
+        ant3 = [_lib.plan_for(grids.ant_grid(t, 4, True)) for t in ("int", "pot", "flint")]
+        gen = torch.Generator(device=dev).manual_seed(6)
+        w = torch.randn(ROWS, COLS, device=dev, generator=gen) * 0.02
+        centry("calib_type_selection_4096x4096_f32", "antq_calibrate of one [4096,4096] fp32 weight, per-channel: abs-max, ANT int / pot / "
+               "flint x 75 clip ratios (AQ:287-415), per-row picks, type pick", "k_search_sorted<float,false,false>", 1, w.numel(), 225,
+               lambda: _lib.calibrate(w, ROWS, COLS, True, ant3, [10.0] * 3, 75, 150, 1, xmax="absmax"))
+        a = torch.nn.functional.gelu(torch.randn(64 * 128 * 3072, device=dev, generator=gen))
+        centry("calib_activation_64x128x3072_f32", "antq_calibrate of one [64,128,3072] fp32 activation with ONE scale (configs[2]'s "
+               "largest): abs-max, ANT int / pot / flint x 75 clip ratios, picks", "k_search_sorted<float,false,true>", 1, a.numel(), 225,
+               lambda: _lib.calibrate(a, 1, a.numel(), False, ant3, [10.0] * 3, 75, 150, 1, xmax="absmax"))
+        ab = a.to(torch.bfloat16)
+        centry("calib_activation_64x128x3072_bf16", "the same activation in bf16: the 65 536-bin histogram search", "k_hist16 + k_hist_score",
+               1, ab.numel(), 225, lambda: _lib.calibrate(ab, 1, ab.numel(), False, ant3, [10.0] * 3, 75, 150, 1, xmax="absmax"))
+        del w, a, ab
     torch.cuda.empty_cache()
     return out
 

@@ -16,6 +16,9 @@ r = j["roofline"]; p = j["config"]["per_tensor_launches"]
 print("driver cmd: frac %.4f launch_us %.2f copy %.1f GB/s x%.4f | per-tensor unordered %.4f ordered %.4f" % (
     r["frac"], r["launch_us"], r["copy_ceiling"]["antq_copy_GBps"], r["copy_ceiling"]["frac_of_copy_ceiling"], p["frac"], p["ordered"]["frac"]))
 for e in j["config"].get("configs", []):
+    if "pass_ms" in e:       # a calibration pass: compute-bound, no HBM fraction
+        print("   %-34s %8.3f ms  %8.1f G candidate-evals/s  %s" % (e["name"], e["pass_ms"], e["gcand_evals_per_s"], e["kernel"]))
+        continue
     print("   %-34s %8.2f us  frac %.4f  %s%s" % (e["name"], e["launch_us"], e["frac"], e["kernel"],
           "  traffic x%.4f" % e["traffic_over_algorithmic"] if e.get("traffic_over_algorithmic") else ""))
 PY
