@@ -7,7 +7,9 @@
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
+# ONLY_SORT=1: just the sections of the sorted-row search (round 6)
 {
+  if [ "${ONLY_SORT:-0}" != "1" ]; then
   echo "== test_fuzz_every_launch_form_long_rows, ${1:-1500} seeds"
   ANTQ_FUZZ_SEEDS=${1:-1500} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line -s \
       -k fuzz_every_launch_form 2>&1 | grep -E "MISMATCH|Error|passed|failed" | cut -c1-900 | head -60
@@ -33,4 +35,13 @@ mkdir -p gpurun_out
       -k "calibration_fuzz or quantizer_end_to_end or type_selection_on_one_read or sharded_per_tensor or bert_base_real_shapes or calibrate_one_call" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
   ANTQ_DEBUG_KNOBS=19=2 ANTQ_FUZZ_SEEDS=${4:-150} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k calibration_pass_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+  fi
+  echo "== round 6: the calibration fuzz tests with the SORTED-ROW clip search forced for every eligible launch (ANTQ_DEBUG_KNOBS=20=2: rows from 64 elements, one-scale fp32 tensors from 4096, OliVe pairs included)"
+  ANTQ_DEBUG_KNOBS=20=2 ANTQ_FUZZ_SEEDS=${3:-300} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k "calibration_fuzz or quantizer_end_to_end or type_selection_on_one_read or sharded_per_tensor or bert_base_real_shapes or calibrate_one_call" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+  ANTQ_DEBUG_KNOBS=20=2 ANTQ_FUZZ_SEEDS=${4:-150} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k calibration_pass_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
+  echo "== ... and under its default rule (rows >= 512 / 1024, fp32 one-scale tensors >= 1 M elements)"
+  ANTQ_FUZZ_SEEDS=${3:-300} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
+      -k "calibration_fuzz" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
 } | tee gpurun_out/fuzz_campaign.log
