@@ -21,11 +21,29 @@ import torch
 
 
 class HostMirrorMixin:
+    # Host-side state of a Quantizer that is never a Parameter, a buffer or a submodule.  torch.nn.Module.__setattr__ spends
+    # ~2.5 us per assignment on type checks and registry look-ups -- ~2000 assignments in BERT-base's calibrating forward,
+    # 5 ms of a 38 ms host-bound call (profiles/r06_first_forward_host.log) -- so plain values of these names go straight into
+    # the instance dictionary (what Module.__setattr__ ends up doing for them anyway).
+    _PLAIN = frozenset((
+        "mode", "name", "is_signed", "is_perchannel", "is_enable", "is_enable_activation", "is_enable_weight", "weights_at_rest",
+        "_steady", "_plan", "_gmax", "_grid_key", "_searched", "_type_search", "_pending", "_calib_ready", "_calib_ctx",
+        "_sign_probe", "_defer_allowed", "_grad_call", "_hm", "_rest_stamp", "_rest_src", "_alpha32_stamp", "_bank", "_auto_bank",
+        "_spec_out", "_rest_out", "_alpha32"))
+
+    def __setattr__(self, name, value):
+        if name in HostMirrorMixin._PLAIN and not isinstance(value, (torch.Tensor, torch.nn.Module)):
+            self.__dict__[name] = value
+        else:
+            super().__setattr__(name, value)
+
     def _hm_setup(self, **values):
         self._hm = {name: [self._hm_key(name), value] for name, value in values.items()}
 
     def _hm_key(self, name):
-        t = getattr(self, name)
+        t = self._buffers.get(name)                  # (the mirrored values are buffers: past Module.__getattr__'s miss-then-search)
+        if t is None:
+            t = getattr(self, name)
         return (t.data_ptr(), t._version, t.device)
 
     def _hm_get(self, name):

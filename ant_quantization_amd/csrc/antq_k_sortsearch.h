@@ -255,6 +255,9 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t ntypes = (uint32_t)st.ntypes, ntc = ntypes * ncand, nthr_pad = st.nthr_pad, nkg = nthr_pad / (uint32_t)kSortKS;
     const uint32_t nitems = ntc * nkg;
+    // (type, candidate) of a flat index without an integer division (~20 instructions each on this machine; two of them per
+    // threshold were a tenth of the kernel): at most kMaxTypes = 4 types
+    auto type_of = [&](uint32_t tc) { return (tc >= ncand ? 1u : 0u) + (tc >= 2u * ncand ? 1u : 0u) + (tc >= 3u * ncand ? 1u : 0u); };
     const SortLds L = sort_lds(ntc, nthr_pad, st.ntypes, OVP);
     char *base = reinterpret_cast<char *>(smem);
     uint32_t *sK = reinterpret_cast<uint32_t *>(base);
@@ -321,7 +324,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
         // AQ:541-549).  Said directly instead of through 4096 literal evaluations per candidate.
         if (!PT && (xm == 0.0f || xm != xm)) {
             for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
-                const uint32_t t = tc / ncand, c = tc - t * ncand;
+                const uint32_t t = type_of(tc), c = tc - t * ncand;
                 sse[((size_t)t * ncand_all + c) * rows + row] = __builtin_nan("");
             }
             continue;
@@ -329,14 +332,14 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
         // ---- 1. candidate scales (AQ:300, :536): s = fl32(fl32(x_max * ratio_c) / gmax_t), usable and non-decreasing along c
         bool ok = true;
         for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
-            const uint32_t t = tc / ncand, c = tc - t * ncand;
+            const uint32_t t = type_of(tc), c = tc - t * ncand;
             const Scale sc = make_scale(xm * ratios[c], ty_gmax(t));
             sS[tc] = sc.s;
             ok = ok && sc.ok && (sc.s > 0.0f);
         }
         __syncthreads();
         for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
-            const uint32_t t = tc / ncand, c = tc - t * ncand;
+            const uint32_t t = type_of(tc), c = tc - t * ncand;
             if (c > 0u) ok = ok && (sS[tc] >= sS[tc - 1u]);
         }
         if (tid == 0u) *sFlag = 0;
@@ -345,8 +348,9 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
         __syncthreads();
         const bool usable = *sFlag == 0;
         // ---- 2. thresholds in the x domain, as keys; partial sums cleared
-        for (uint32_t p = tid; p < ntc * nthr_pad; p += kSortNT) {
-            const uint32_t tc = p / nthr_pad, k = p - tc * nthr_pad, t = tc / ncand;
+        const uint32_t q_thr = kSortNT / nthr_pad, r_thr = kSortNT - q_thr * nthr_pad;      // (uniform: scalar divisions)
+        for (uint32_t p = tid, tc = tid / nthr_pad, k = tid - (tid / nthr_pad) * nthr_pad; p < ntc * nthr_pad; p += kSortNT) {
+            const uint32_t t = type_of(tc);
             uint32_t key = kSortSent;
             if (usable && k < ty_nthr(t)) {
                 bool tok;
@@ -354,6 +358,9 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                 key = sort_key(X);
             }
             sX[p] = key;
+            k += r_thr;
+            tc += q_thr + (k >= nthr_pad ? 1u : 0u);
+            k -= k >= nthr_pad ? nthr_pad : 0u;
         }
         double acc[kSortNI], corr[kSortNC], lit[kSortNL];     // this thread's items it = tid + 256 u (statically indexed: registers)
 #pragma unroll
@@ -462,7 +469,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                     // form would have given it -- (O_J - x)^2 in double -- so a candidate's sum does not depend (beyond 1e-13) on
                     // whether the launch's smallest scale sent the element here; elsewhere: the reference sequence.
                     for (uint32_t tc = tid, ui = 0; tc < ntc; tc += kSortNT, ui++) {
-                        const uint32_t t = tc / ncand;
+                        const uint32_t t = type_of(tc);
                         const float *grid = ty_grid(t);
                         const int gm = ty_m(t);
                         const float s = sS[tc], lim = usable ? ty_lim(t) : 0.0f;
@@ -514,7 +521,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                 if (OVP && tot_cap) {
                     // work item (type, candidate, j): the pairs j, j + 4, ... in list order
                     for (uint32_t it = tid, ui = 0; it < 4u * ntc; it += kSortNT, ui++) {
-                        const uint32_t tc = it >> 2, j0 = it & 3u, t = tc / ncand;
+                        const uint32_t tc = it >> 2, j0 = it & 3u, t = type_of(tc);
                         const uint32_t *X = sX + tc * nthr_pad;
                         const float s = sS[tc];
                         const float *v = sV + t * kSortTy;
@@ -580,8 +587,9 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
             // ---- 4c. the (type, candidate, threshold group) items
             const long long Stot_i = sP4[kSortK / 4];
             const double Stot = (double)Stot_i * unit, dn = (double)Kreg;
-            for (uint32_t it = tid, ui = 0; it < nitems; it += kSortNT, ui++) {
-                const uint32_t tc = it / nkg, kg = it - tc * nkg, t = tc / ncand;
+            const uint32_t q_it = kSortNT / nkg, r_it = kSortNT - q_it * nkg;
+            for (uint32_t it = tid, ui = 0, tc = tid / nkg, kg = tid - (tid / nkg) * nkg; it < nitems; it += kSortNT, ui++) {
+                const uint32_t t = type_of(tc);
                 const float s = sS[tc];
                 const float *v = sV + t * kSortTy + kg * (uint32_t)kSortKS;
                 const uint32_t *X = sX + tc * nthr_pad + kg * (uint32_t)kSortKS;
@@ -617,6 +625,9 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                 }
 #pragma unroll
                 for (int u = 0; u < kSortNI; u++) acc[u] += (uint32_t)u == ui ? part : 0.0;
+                kg += r_it;
+                tc += q_it + (kg >= nkg ? 1u : 0u);
+                kg -= kg >= nkg ? nkg : 0u;
             }
             // (the next chunk's first barrier -- or the one below -- orders these reads before the key buffer is reused)
         }
@@ -666,7 +677,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
             for (int u = 0; u < kSortNL; u++) l = (uint32_t)u == ui ? lit[u] : l;
             sum += l;
             if (OVP) sum += (fC[4u * tc] + fC[4u * tc + 1u]) + (fC[4u * tc + 2u] + fC[4u * tc + 3u]);
-            const uint32_t t = tc / ncand, c = tc - t * ncand;       // (ratios / sse point at this piece's first candidate)
+            const uint32_t t = type_of(tc), c = tc - t * ncand;       // (ratios / sse point at this piece's first candidate)
             sse[((size_t)t * ncand_all + c) * rows + row] = sum;
         }
         __syncthreads();

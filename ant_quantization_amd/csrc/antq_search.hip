@@ -372,7 +372,7 @@ static bool sort_shape_ok(const void *x, size_t rows, size_t row_len, int ncand,
     if (!g_knob_sort || rows < 2 || ncand < 1 || ntypes < 1 || ntypes > kMaxTypes) return false;
     // Where it pays (profiles/r06_sort_scan.log; a row costs its 4096-element chunks whatever it holds): ANT codebooks from rows of
     // 512 elements (1.4 x the direct kernels; 1.7 x at 768, 2 x at 1024, 5.6 x at 4096), OliVe's from 1024 (1.1 x; 3.3 x at 4096)
-    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sort == 2 ? 64u : (OVP ? 1024u : 512u))) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sort == 2 ? 128u : (OVP ? 1024u : 512u))) return false;
     return !(OVP && (row_len & 1));                                  // (pairs would straddle rows)
 }
 template <typename T, bool OVP>

@@ -72,7 +72,7 @@ def test_sorted_equals_direct_ant_codebooks(dev, dtype_name):
     types = ("int", "pot", "flint", "float")
     plans = [L.plan_for(grids.ant_grid(t, 4, True)) for t in types]
     # one chunk, a ragged second chunk, short rows, rows of several chunks, a row that is no multiple of anything
-    for rows, K, lb, ub in ((96, 4096, 80, 150), (33, 4096 + 64, 75, 150), (64, 512, 95, 101), (17, 3 * 4096, 75, 76), (40, 264, 75, 150),
+    for rows, K, lb, ub in ((96, 4096, 80, 150), (33, 4096 + 64, 75, 150), (64, 512, 95, 101), (70, 128, 75, 150), (17, 3 * 4096, 75, 76), (40, 264, 75, 150),
                             (9, 11008, 60, 150)):
         x = (torch.randn(rows, K, device=dev) * 0.03)
         x[::7] *= 0.2

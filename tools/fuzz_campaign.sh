@@ -36,7 +36,7 @@ mkdir -p gpurun_out
   ANTQ_DEBUG_KNOBS=19=2 ANTQ_FUZZ_SEEDS=${4:-150} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k calibration_pass_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
   fi
-  echo "== round 6: the calibration fuzz tests with the SORTED-ROW clip search forced for every eligible launch (ANTQ_DEBUG_KNOBS=20=2: rows from 64 elements, one-scale fp32 tensors from 4096, OliVe pairs included)"
+  echo "== round 6: the calibration fuzz tests with the SORTED-ROW clip search forced for every eligible launch (ANTQ_DEBUG_KNOBS=20=2: rows from 128 elements, one-scale fp32 tensors from 4096, OliVe pairs included)"
   ANTQ_DEBUG_KNOBS=20=2 ANTQ_FUZZ_SEEDS=${3:-300} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k "calibration_fuzz or quantizer_end_to_end or type_selection_on_one_read or sharded_per_tensor or bert_base_real_shapes or calibrate_one_call" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
   ANTQ_DEBUG_KNOBS=20=2 ANTQ_FUZZ_SEEDS=${4:-150} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
