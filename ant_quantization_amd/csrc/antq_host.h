@@ -32,6 +32,7 @@ extern thread_local int g_knob_lane_u;        // vectors per lane of the one-lau
 extern thread_local int g_knob_h;             // 0 disables the 16-bit-domain row kernels (antq_k_hrow.h; A/B measurements)
 extern thread_local int g_knob_hist;          // clip search of 16-bit per-tensor quantisers on the tensor's histogram: 0 off, 1 when it pays, 2 always (tests)
 extern thread_local int g_knob_sweep;         // 0: per-row clip searches through the direct kernels instead of the threshold sweep (A/B, tests)
+extern thread_local int g_knob_sort_short;    // 0: rows of <= 1024 elements through the 4096-key sorted search instead of the one-row-per-wavefront kernel (A/B)
 extern thread_local int g_knob_sort;          // clip searches from the sorted row (antq_k_sortsearch.h): 0 off, 1 the default rule, 2 every eligible launch (tests)
 extern thread_local int g_knob_tk_group, g_knob_tk_blocks;   // A/B of the one-launch reductions (antq_k_reduce.h)
 extern thread_local int g_knob_rows_stream;   // 0: row abs-max of 128..1024-vector rows through the round-5 kernel (A/B)

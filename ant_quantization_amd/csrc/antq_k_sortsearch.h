@@ -684,6 +684,259 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
     }
 }
 
+// ---- short rows: one row per WAVEFRONT -----------------------------------------------------------------------------------
+// A row of at most 1024 elements (BERT-base's 768-wide weights, most convolutions) wastes three quarters of the 4096-key
+// sort above -- and the per-row work that does not shrink with the row (every threshold of every candidate moved into the x
+// domain, the probes, the closed form) wants all four wavefronts busy.  Here each wavefront takes a row of its own: the
+// sizes 2 .. 1024 of the same network (the in-wave phases of sort_wg, no workgroup barrier anywhere), 11-probe searches, a
+// (codebook, candidate)'s thresholds moved into the x domain right where they are used (each is used once), one lane per
+// (codebook, candidate) walking its threshold groups in order.  Codebooks without the pair rule (the ANT family).
+// Literal elements (rare) are read again from the row when a candidate's sum is formed.
+constexpr int kSortBS = 6 + kSortR, kSortKSh = 1 << kSortBS;          // 1024 keys per wavefront
+__host__ __device__ inline uint32_t sort_short_wave_bytes(uint32_t ntc)
+{
+    return ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u + ((uint32_t)kSortKSh / 4u + 2u) * 8u + ((ntc + 3u) & ~3u) * 4u;
+}
+template <typename T>
+__global__ void __launch_bounds__(256, 4)
+k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const float *__restrict__ xmax,
+                      const float *__restrict__ ratios, double *__restrict__ sse, SortTypes st, uint32_t ncand, uint32_t ncand_all)
+{
+    constexpr int EPL = IO<T>::EPL;
+    constexpr int VPT = kSortEPT / EPL;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t ntypes = (uint32_t)st.ntypes, ntc = ntypes * ncand, nthr_pad = st.nthr_pad, nkg = nthr_pad / (uint32_t)kSortKS;
+    char *base = reinterpret_cast<char *>(smem);
+    float *sV = reinterpret_cast<float *>(base);                                       // per type (as above), shared by the waves
+    char *wb = base + (((uint32_t)st.ntypes * kSortTy * 4u + 15u) & ~15u) + wave * sort_short_wave_bytes(ntc);
+    uint32_t *sK = reinterpret_cast<uint32_t *>(wb);                                   // this wavefront's keys
+    long long *sP4 = reinterpret_cast<long long *>(wb + ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u);
+    float *sS = reinterpret_cast<float *>(wb + ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u + ((uint32_t)kSortKSh / 4u + 2u) * 8u);
+#pragma unroll
+    for (int t = 0; t < kMaxTypes; t++) {
+        if (t < st.ntypes) {
+            const SweepType ty = st.ty[t];
+            float *v = sV + (uint32_t)t * kSortTy;
+            uint32_t *vu = reinterpret_cast<uint32_t *>(v);
+            if (tid < 64u) {
+                const uint32_t k = tid;
+                if (k < ty.n_thr) {
+                    const uint4 th = ty.tlist[k];
+                    v[66u + k] = u2f(th.x);
+                    v[k + 1u] = u2f(th.z) + 0.0f;
+                    if (k == 0u) v[0] = u2f(th.y) + 0.0f;
+                } else {
+                    v[66u + k] = 0.0f;
+                    v[k + 1u] = ty.n_thr ? u2f(ty.tlist[ty.n_thr - 1u].z) + 0.0f : 0.0f;
+                }
+            }
+            if (tid == 64u) {
+                vu[130] = ty.n_thr;
+                v[133] = ty.gmax;
+                v[134] = ty.lim;
+                vu[135] = ty.m;
+                vu[136] = st.nneg[t] < ty.n_thr ? st.nneg[t] : ty.n_thr;
+            }
+        }
+    }
+    __syncthreads();                                        // (the only workgroup barrier: from here on every wavefront is on its own)
+    auto ty_nthr = [&](uint32_t t) { return reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[130]; };
+    auto ty_gmax = [&](uint32_t t) { return sV[t * kSortTy + 133u]; };
+    auto ty_lim = [&](uint32_t t) { return sV[t * kSortTy + 134u]; };
+    auto ty_m = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[135]; };
+    auto ty_nneg = [&](uint32_t t) { return reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[136]; };
+    auto ty_grid = [&](uint32_t t) {
+        const float *g = st.ty[0].grid;
+#pragma unroll
+        for (int u = 1; u < kMaxTypes; u++) g = (uint32_t)u == t ? st.ty[u].grid : g;
+        return g;
+    };
+    auto type_of = [&](uint32_t tc) { return (tc >= ncand ? 1u : 0u) + (tc >= 2u * ncand ? 1u : 0u) + (tc >= 3u * ncand ? 1u : 0u); };
+
+    for (size_t row = (size_t)blockIdx.x * 4u + wave; row < rows; row += (size_t)gridDim.x * 4u) {
+        const float xm = xmax[row];
+        const uint4 *xr = x + row * (size_t)vpr;
+        if (xm == 0.0f || xm != xm) {                        // (a zero / NaN statistic: NaN for every candidate, see above)
+            for (uint32_t tc = lane; tc < ntc; tc += 64u) {
+                const uint32_t t = type_of(tc), c = tc - t * ncand;
+                sse[((size_t)t * ncand_all + c) * rows + row] = __builtin_nan("");
+            }
+            continue;
+        }
+        // ---- candidate scales
+        bool ok = true;
+        for (uint32_t tc = lane; tc < ntc; tc += 64u) {
+            const uint32_t t = type_of(tc), c = tc - t * ncand;
+            const Scale sc = make_scale(xm * ratios[c], ty_gmax(t));
+            sS[tc] = sc.s;
+            ok = ok && sc.ok && (sc.s > 0.0f);
+        }
+        sort_sync<true>();
+        for (uint32_t tc = lane; tc < ntc; tc += 64u) {
+            const uint32_t t = type_of(tc), c = tc - t * ncand;
+            if (c > 0u) ok = ok && (sS[tc] >= sS[tc - 1u]);
+        }
+        const bool usable = __ballot(ok) == ~0ull;
+        int ex = 0;
+        (void)frexpf(xm, &ex);
+        const double F = __builtin_ldexp(1.0, 38 - ex), unit = __builtin_ldexp(1.0, ex - 38);
+        float Lx = 0.0f;
+        if (usable) {
+            Lx = __builtin_ldexpf(0.999f, ex + 8);
+            for (uint32_t t = 0; t < ntypes; t++) Lx = fminf(Lx, ty_lim(t) * sS[t * ncand] * 0.999f);
+        }
+        // ---- the row: 16 elements per lane
+        uint32_t k[kSortEPT];
+        uint32_t nreg = 0, nlit = 0;
+        double Q = 0.0;
+#pragma unroll
+        for (int j = 0; j < VPT; j++) {
+            const uint32_t vi = (uint32_t)j * 64u + lane;
+            const bool live = vi < vpr;
+            float xf[EPL];
+            {
+                const uint4 v = live ? xr[vi] : make_uint4(0u, 0u, 0u, 0u);
+                IO<T>::unpack(v, xf);
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const float a = xf[e];
+                const bool la = live && !(fabsf(a) < Lx), ra = live && !la;
+                k[j * EPL + e] = ra ? sort_key(a) : kSortSent;
+                Q = __builtin_fma((double)(ra ? a : 0.0f), (double)(ra ? a : 0.0f), Q);
+                nreg += ra ? 1u : 0u;
+                nlit += la ? 1u : 0u;
+            }
+        }
+        uint32_t pk = nreg | nlit << 16;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            pk += (uint32_t)__shfl_xor((int)pk, off, 64);
+            Q += __shfl_xor(Q, off, 64);
+        }
+        const uint32_t Kreg = pk & 0xffffu, tot_lit = pk >> 16;
+        long long Stot_i = 0;
+        if (Kreg) {
+            // ---- the in-wave sort (sizes 2 .. 16 in the registers, 32 .. 1024 through this wavefront's buffer), prefix sums
+            sort_static_for<1, kSortR + 1>([&](auto s_) {
+                sort_ce_reg_mirror<decltype(s_)::value>(k);
+                sort_ce_down<decltype(s_)::value - 2>(k);
+            });
+            sort_static_for<kSortR + 1, kSortBS + 1>([&](auto s_) { sort_steps<kSortBS, true, decltype(s_)::value, decltype(s_)::value - 1, 0, true>(k, sK, lane); });
+            {
+                uint4 *dst = reinterpret_cast<uint4 *>(sK + (size_t)kSortEPT * lane);
+#pragma unroll
+                for (int q = 0; q < kSortEPT / 4; q++) dst[q] = make_uint4(k[4 * q], k[4 * q + 1], k[4 * q + 2], k[4 * q + 3]);
+            }
+            long long g[4], mine = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                g[q] = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) g[q] += sort_key_fixed(k[4 * q + e], F);
+                mine += g[q];
+            }
+            long long incs = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long tv = __shfl_up(incs, off, 64);
+                if (lane >= (uint32_t)off) incs += tv;
+            }
+            long long pre = incs - mine;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                sP4[4u * lane + (uint32_t)q] = pre;
+                pre += g[q];
+            }
+            Stot_i = __shfl(incs, 63, 64);
+            if (lane == 63u) sP4[kSortKSh / 4] = pre;
+            sort_sync<true>();
+        }
+        const double Stot = (double)Stot_i * unit, dn = (double)Kreg;
+        // ---- one lane per (codebook, candidate): its threshold groups in order, then the literal elements
+        for (uint32_t tc = lane; tc < ntc; tc += 64u) {
+            const uint32_t t = type_of(tc), c = tc - t * ncand;
+            const float s = sS[tc];
+            const float *v = sV + t * kSortTy;
+            const uint32_t nthr_t = ty_nthr(t), nb = ty_nneg(t);
+            double sum = Q;
+            if (Kreg) {
+                for (uint32_t kg = 0; kg < nkg; kg++) {
+                    uint32_t Xk[kSortKS], pos[kSortKS];
+#pragma unroll
+                    for (int j = 0; j < kSortKS; j++) {
+                        const uint32_t kk = kg * (uint32_t)kSortKS + (uint32_t)j;
+                        bool tok;
+                        Xk[j] = (usable && kk < nthr_t) ? sort_key(x_threshold(v[66u + kk], s, 0.0f, tok)) : kSortSent;
+                        pos[j] = 0u;
+                    }
+#pragma unroll
+                    for (int step = kSortKSh / 2; step >= 1; step >>= 1) {
+                        uint32_t kv[kSortKS];
+#pragma unroll
+                        for (int j = 0; j < kSortKS; j++) kv[j] = sK[pos[j] + (uint32_t)step - 1u];
+#pragma unroll
+                        for (int j = 0; j < kSortKS; j++) pos[j] += kv[j] < Xk[j] ? (uint32_t)step : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < kSortKS; j++) pos[j] += sK[pos[j]] < Xk[j] ? 1u : 0u;
+                    double part = 0.0;
+                    if (kg == 0u) {
+                        const double Ob_ = (double)(v[nb] * s);
+                        part = dn * Ob_ * Ob_ - 2.0 * Ob_ * Stot;
+                    }
+#pragma unroll
+                    for (int j = 0; j < kSortKS; j++) {
+                        const uint32_t kk = kg * (uint32_t)kSortKS + (uint32_t)j, p = pos[j];
+                        long long slt = sP4[p >> 2];
+                        for (uint32_t i = p & ~3u; i < p; i++) slt += sort_key_fixed(sK[i], F);
+                        const bool below = kk < nb;
+                        const double N = below ? -(double)p : (double)(Kreg - p);
+                        const double S = (double)(below ? -slt : Stot_i - slt) * unit;
+                        const double Oa = (double)(v[kk] * s), Ob = (double)(v[kk + 1u] * s);
+                        part += (Ob * Ob - Oa * Oa) * N - 2.0 * (Ob - Oa) * S;
+                    }
+                    sum += part;
+                }
+            }
+            if (tot_lit) {
+                // the literal elements of the row, in element order (every lane reads the same vector: a broadcast)
+                const float *grid = ty_grid(t);
+                const int gm = ty_m(t);
+                const float lim = usable ? ty_lim(t) : 0.0f;
+                double sum_l = 0.0;
+                for (uint32_t vi = 0; vi < vpr; vi++) {
+                    float xf[EPL];
+                    IO<T>::unpack(xr[vi], xf);
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) {
+                        const float xv = xf[e];
+                        if (!(fabsf(xv) < Lx)) {
+                            float d = xv / s;
+                            if (fabsf(d) < lim) {             // a step-function element for THIS candidate: (O_J - x)^2 in double
+                                uint32_t lo = 0, hi = nthr_t;
+                                while (lo < hi) {             // RN(x / s) >= T_k  <=>  x >= X_k: the cell from the grid-domain thresholds
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if (d >= v[66u + mid]) lo = mid + 1u; else hi = mid;
+                                }
+                                const double er = (double)(v[lo] * s) - (double)xv;
+                                sum_l += er * er;
+                            } else {
+                                const float q = sweep_literal_q(xv, s, grid, gm, d);
+                                sum_l += sweep_term(q, d, s, xv);
+                            }
+                        }
+                    }
+                }
+                sum += sum_l;
+            }
+            sse[((size_t)t * ncand_all + c) * rows + row] = sum;
+        }
+        sort_sync<true>();
+    }
+}
+
 // slabs of doubles added cell by cell in slab order (blockIdx.y: a group of `per_group` consecutive slabs; a second call
 // with the groups as slabs finishes the sum)
 static __global__ void __launch_bounds__(256)

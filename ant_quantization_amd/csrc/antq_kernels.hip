@@ -50,6 +50,7 @@ thread_local int g_knob_hist_xmax = 1;
 thread_local int g_knob_rows_stream = 1;
 thread_local int g_knob_tk_group = 0;     // A/B: workgroups per ticket group of the one-launch reductions (0 = default)
 thread_local int g_knob_tk_blocks = 0;
+thread_local int g_knob_sort_short = 1;
 thread_local int g_knob_sort = 1;         // clip searches from the sorted row (antq_k_sortsearch.h): 0 off, 1 default rule, 2 every eligible launch
 thread_local int g_knob_sweep = 1;        // per-row clip searches through the threshold-sweep kernel (antq_k_sweep.h): 0 = the direct kernels (A/B, tests)    // A/B: workgroups of the one-launch reductions (0 = default)
 
@@ -256,6 +257,7 @@ extern "C" int antq_debug_set(int key, int value)
     else if (key == 18) g_knob_tk_blocks = value;
     else if (key == 19) g_knob_sweep = value;
     else if (key == 20) g_knob_sort = value;
+    else if (key == 21) g_knob_sort_short = value;
     else return ANTQ_ERR_ARG;
     return ANTQ_OK;
 }

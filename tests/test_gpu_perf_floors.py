@@ -46,6 +46,7 @@ FLOORS = {
     "affine_f32": 0.91,
     "search_sse_rows_f32": 4.40,                 # (the sorted-row search since round 6: seen 5.1-5.6; the sweep was 3.5)
     "search_multi_rows_f32": 9.0,                # 3 ANT codebooks x 70 candidates on ONE sort of every row
+    "search_short_rows_f32": 4.7,                # 3 ANT codebooks x 70 on rows of 768 elements: one row per wavefront
     "search_olive_pairs_rows_bf16": 2.9,         # 2 OliVe codebooks x 88 candidates, pair rule
     "calibrate_tensor_f32_sorted": 0.040,        # a 16.8 M-element fp32 tensor with one scale: statistic + 3 x 70 + picks
     "calibrate_tensor_bf16_hist": 0.16,
@@ -298,6 +299,17 @@ def test_floor_search_type_selection_rows(box):
     xm = L.absmax(t, R, C)
     ratios = (torch.arange(80, 150, device=t.device, dtype=torch.float64) * 0.01).float()
     _check(box, "search_multi_rows_f32", lambda: L.search_sse_multi(t, R, C, xm, True, ratios, plans, [10.0] * 3), t.numel() * 210 * 4)
+
+
+def test_floor_search_short_rows(box):
+    """The type selection of BERT-base's 768-wide weights: rows of 768 elements, one row per wavefront."""
+    L, x = box["_lib"], box["x"]
+    g = box["grids"]
+    plans = [L.plan_for(g.ant_grid(t, 4, True)) for t in ("int", "pot", "flint")]
+    t = x[0].float().reshape(-1)[: 16384 * 768].reshape(16384, 768).contiguous()
+    xm = L.absmax(t, 16384, 768)
+    ratios = (torch.arange(80, 150, device=t.device, dtype=torch.float64) * 0.01).float()
+    _check(box, "search_short_rows_f32", lambda: L.search_sse_multi(t, 16384, 768, xm, True, ratios, plans, [10.0] * 3), t.numel() * 210 * 4)
 
 
 def test_floor_search_olive_pairs_rows(box):

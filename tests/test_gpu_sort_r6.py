@@ -95,6 +95,17 @@ def test_sorted_equals_direct_ant_codebooks(dev, dtype_name):
     xm = L.absmax(x, 48, 3072)
     a, b = _both(L, x, 48, 3072, xm, rt, pu, [10.0] * 2, False)
     _compare(a, b, (dtype_name, "unsigned"))
+    # rows of <= 1024 elements run one row per wavefront (k_search_sorted_short); knob 21 = 0 sends them through the 4096-key
+    # kernel instead: the same sums to the closed form's rounding (the sum of x^2 is grouped differently), the same picks
+    x = (torch.randn(200, 768, device=dev) * 0.03).to(dt)
+    xm = L.absmax(x, 200, 768)
+    _, short = _both(L, x, 200, 768, xm, rt, plans[:3], [10.0] * 3, False)
+    L.lib().antq_debug_set(21, 0)
+    try:
+        _, long_ = _both(L, x, 200, 768, xm, rt, plans[:3], [10.0] * 3, False)
+    finally:
+        L.lib().antq_debug_set(21, 1)
+    torch.testing.assert_close(short, long_, rtol=1e-13, atol=0)      # (16-bit inputs: sums of exact squares -- to the bit)
     # a long candidate list goes out in pieces
     a, b = _both(L, x, 48, 3072, xm, _ratios(20, 300, 1, dev), pu, [10.0] * 2, False)
     _compare(a, b, (dtype_name, "280 candidates"))

@@ -24,6 +24,8 @@ def search(x, rows, K, xm, per_row, rt, plans, gmaxs, ovp):
 
 
 MODES = (("direct", 0, 0), ("sweep", 1, 0), ("sorted", 1, 2))
+if "--long" in sys.argv:          # rows of <= 1024 elements through the 4096-key kernel (knob 21 = 0) instead of one row per wavefront
+    L.antq_debug_set(21, 0)
 
 
 def run(name, x, rows, K, plans, gmaxs, xm, rt, ovp, per_row=True):
