@@ -621,7 +621,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                     const double N = below ? -(double)p : (double)(Kreg - p);
                     const double S = (double)(below ? -slt : Stot_i - slt) * unit;
                     const double Oa = (double)(v[j] * s), Ob = (double)(v[j + 1] * s);
-                    part += (Ob * Ob - Oa * Oa) * N - 2.0 * (Ob - Oa) * S;
+                    part += (Ob - Oa) * ((Ob + Oa) * N - 2.0 * S);                          // (O_b^2 - O_a^2) N - 2 (O_b - O_a) S
                 }
 #pragma unroll
                 for (int u = 0; u < kSortNI; u++) acc[u] += (uint32_t)u == ui ? part : 0.0;
@@ -789,6 +789,7 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
         // ---- the row: 16 elements per lane
         uint32_t k[kSortEPT];
         uint32_t nreg = 0, nlit = 0;
+        float lx0 = 0.0f, lx1 = 0.0f;                        // this lane's first two literal elements (a short list in LDS, below)
         double Q = 0.0;
 #pragma unroll
         for (int j = 0; j < VPT; j++) {
@@ -806,9 +807,12 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
                 k[j * EPL + e] = ra ? sort_key(a) : kSortSent;
                 Q = __builtin_fma((double)(ra ? a : 0.0f), (double)(ra ? a : 0.0f), Q);
                 nreg += ra ? 1u : 0u;
+                lx0 = (la && nlit == 0u) ? a : lx0;
+                lx1 = (la && nlit == 1u) ? a : lx1;
                 nlit += la ? 1u : 0u;
             }
         }
+        const uint32_t my_lit = nlit;
         uint32_t pk = nreg | nlit << 16;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -853,6 +857,22 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
             if (lane == 63u) sP4[kSortKSh / 4] = pre;
             sort_sync<true>();
         }
+        // A few literal elements (a ratio list that starts below ~0.5: the row's largest elements): a list in the 64 dwords
+        // behind the sorted keys, lane by lane; more than that -- or more than two in one lane -- are read again from the row
+        const bool lit_list = tot_lit != 0u && tot_lit <= 64u && __ballot(my_lit > 2u) == 0ull;
+        float *sL = reinterpret_cast<float *>(sK + kSortKSh);
+        if (lit_list) {
+            uint32_t inc = my_lit;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t tv = (uint32_t)__shfl_up((int)inc, off, 64);
+                if (lane >= (uint32_t)off) inc += tv;
+            }
+            const uint32_t at = inc - my_lit;
+            if (my_lit > 0u) sL[at] = lx0;
+            if (my_lit > 1u) sL[at + 1u] = lx1;
+            sort_sync<true>();
+        }
         const double Stot = (double)Stot_i * unit, dn = (double)Kreg;
         // ---- one lane per (codebook, candidate): its threshold groups in order, then the literal elements
         for (uint32_t tc = lane; tc < ntc; tc += 64u) {
@@ -895,38 +915,41 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
                         const double N = below ? -(double)p : (double)(Kreg - p);
                         const double S = (double)(below ? -slt : Stot_i - slt) * unit;
                         const double Oa = (double)(v[kk] * s), Ob = (double)(v[kk + 1u] * s);
-                        part += (Ob * Ob - Oa * Oa) * N - 2.0 * (Ob - Oa) * S;
+                        part += (Ob - Oa) * ((Ob + Oa) * N - 2.0 * S);
                     }
                     sum += part;
                 }
             }
             if (tot_lit) {
-                // the literal elements of the row, in element order (every lane reads the same vector: a broadcast)
                 const float *grid = ty_grid(t);
                 const int gm = ty_m(t);
                 const float lim = usable ? ty_lim(t) : 0.0f;
                 double sum_l = 0.0;
-                for (uint32_t vi = 0; vi < vpr; vi++) {
-                    float xf[EPL];
-                    IO<T>::unpack(xr[vi], xf);
-#pragma unroll
-                    for (int e = 0; e < EPL; e++) {
-                        const float xv = xf[e];
-                        if (!(fabsf(xv) < Lx)) {
-                            float d = xv / s;
-                            if (fabsf(d) < lim) {             // a step-function element for THIS candidate: (O_J - x)^2 in double
-                                uint32_t lo = 0, hi = nthr_t;
-                                while (lo < hi) {             // RN(x / s) >= T_k  <=>  x >= X_k: the cell from the grid-domain thresholds
-                                    const uint32_t mid = (lo + hi) >> 1;
-                                    if (d >= v[66u + mid]) lo = mid + 1u; else hi = mid;
-                                }
-                                const double er = (double)(v[lo] * s) - (double)xv;
-                                sum_l += er * er;
-                            } else {
-                                const float q = sweep_literal_q(xv, s, grid, gm, d);
-                                sum_l += sweep_term(q, d, s, xv);
-                            }
+                auto lit_term = [&](float xv) {
+                    float d = xv / s;
+                    if (fabsf(d) < lim) {                     // a step-function element for THIS candidate: (O_J - x)^2 in double
+                        uint32_t lo = 0, hi = nthr_t;
+                        while (lo < hi) {                     // RN(x / s) >= T_k  <=>  x >= X_k: the cell from the grid-domain thresholds
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (d >= v[66u + mid]) lo = mid + 1u; else hi = mid;
                         }
+                        const double er = (double)(v[lo] * s) - (double)xv;
+                        sum_l += er * er;
+                    } else {
+                        const float q = sweep_literal_q(xv, s, grid, gm, d);
+                        sum_l += sweep_term(q, d, s, xv);
+                    }
+                };
+                if (lit_list) {
+                    for (uint32_t i = 0; i < tot_lit; i++) lit_term(sL[i]);
+                } else {
+                    // the literal elements of the row, in element order (every lane reads the same vector: a broadcast)
+                    for (uint32_t vi = 0; vi < vpr; vi++) {
+                        float xf[EPL];
+                        IO<T>::unpack(xr[vi], xf);
+#pragma unroll
+                        for (int e = 0; e < EPL; e++)
+                            if (!(fabsf(xf[e]) < Lx)) lit_term(xf[e]);
                     }
                 }
                 sum += sum_l;

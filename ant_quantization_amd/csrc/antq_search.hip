@@ -249,7 +249,7 @@ static bool sweep_pt_shape_ok(const void *x, size_t n, int ncand)
 {
     constexpr int EPL = IO<T>::EPL;
     if (!g_knob_sweep || sizeof(T) != 4 || ncand < 1 || ncand > kSweepMaxCand) return false;
-    return reinterpret_cast<uintptr_t>(x) % 16 == 0 && n % EPL == 0 && n >= (g_knob_sweep == 2 ? 4096u : (1u << 22)) && n < ((size_t)1 << 31);
+    return reinterpret_cast<uintptr_t>(x) % 16 == 0 && n % EPL == 0 && n >= (g_knob_sweep == 2 ? 16384u : (1u << 22)) && n < ((size_t)1 << 31);      // (below 16 workgroups' worth the launcher declines: G < 16)
 }
 
 // The sweep for a tensor with ONE scale (fp32: 16-bit tensors take the histogram search).  ws: the search workspace (slabs of

@@ -106,6 +106,15 @@ def test_sorted_equals_direct_ant_codebooks(dev, dtype_name):
     finally:
         L.lib().antq_debug_set(21, 1)
     torch.testing.assert_close(short, long_, rtol=1e-13, atol=0)      # (16-bit inputs: sums of exact squares -- to the bit)
+    # a ratio list that starts at 0.3: each row's largest elements lie beyond the step function's domain for the small scales
+    # (a dozen per row: the short list behind the sorted keys; knob 21 = 0: the 4096-key kernel's list)
+    for k21 in (1, 0):
+        L.lib().antq_debug_set(21, k21)
+        try:
+            a, b = _both(L, x, 200, 768, xm, _ratios(30, 150, 1, dev), plans[:3], [10.0] * 3, False)
+        finally:
+            L.lib().antq_debug_set(21, 1)
+        _compare(a, b, (dtype_name, "ratios from 0.3, rows of 768", k21))
     # a long candidate list goes out in pieces
     a, b = _both(L, x, 48, 3072, xm, _ratios(20, 300, 1, dev), pu, [10.0] * 2, False)
     _compare(a, b, (dtype_name, "280 candidates"))
