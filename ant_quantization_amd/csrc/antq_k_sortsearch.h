@@ -224,18 +224,6 @@ __device__ __forceinline__ void sort_wg(uint32_t (&k)[kSortEPT], uint32_t *sK, u
     sort_static_for<BW + 1, kSortB + 1>([&](auto s) { sort_steps<kSortB, false, decltype(s)::value, decltype(s)::value - 1, 0, true>(k, sK, t); });
 }
 
-// number of keys below X among the chunk's sorted keys (address i + (i >> R))
-__device__ __forceinline__ uint32_t sort_lower_bound(const uint32_t *sK, uint32_t X)
-{
-    uint32_t pos = 0;
-#pragma unroll
-    for (int step = kSortK / 2; step >= 1; step >>= 1) {
-        const uint32_t i = pos + (uint32_t)step - 1u;
-        pos += sK[i + (i >> kSortR)] < X ? (uint32_t)step : 0u;
-    }
-    return pos + (sK[pos + (pos >> kSortR)] < X ? 1u : 0u);
-}
-
 // ---- the search kernel ---------------------------------------------------------------------------------------------------
 // PT = false: one workgroup per row (rows grid-strided), sse[(type * ncand_all + c) * rows + row] (ncand of the ncand_all
 //             candidates in this launch: `ratios` and `sse` point at the first of them).
