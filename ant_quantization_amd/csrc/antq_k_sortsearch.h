@@ -59,7 +59,13 @@ constexpr uint32_t kSortSent = 0xffffffffu;
 // group) items, kSortNC pair-correction items and kSortNL (type, candidate) literal sums per thread -- the launcher cuts the
 // candidate list into pieces that fit.
 constexpr int kSortNI = 6, kSortNC = 3, kSortNL = 2;
-constexpr uint32_t kSortTy = 140;                            // dwords of a type's block in LDS
+constexpr uint32_t kSortTy = 268;                            // dwords of a type's block in LDS: values [66], thresholds T [64], scalars [130..139]
+                                                             // (n_thr, kout_pos, kout_neg, gmax, lim, m, nneg, even-mantissa masks [137..138]),
+                                                             // rounding boundaries M_k as doubles [140..267]
+// Prefix sums at every 2^PSH-th sorted position.  A probe converts the (up to 2^PSH - 1) keys between the stored position and
+// its own back to fixed point -- 10 instructions each, a quarter of a look-up at every fourth -- so codebooks without the pair
+// rule keep every SECOND position (8 KB more LDS: still three workgroups per CU); OliVe's tables leave no room for that.
+__host__ __device__ constexpr int sort_psh(bool ovp) { return ovp ? 2 : 1; }
 
 struct SortTypes {
     SweepType ty[kMaxTypes];
@@ -77,11 +83,11 @@ __host__ __device__ inline SortLds sort_lds(uint32_t ntc, uint32_t nthr_pad, int
     SortLds L;
     uint32_t o = (uint32_t)kSortPad * 4u;                    // keys
     o = (o + 15u) & ~15u;
-    L.off_p4 = o;    o += ((uint32_t)kSortK / 4u + 1u) * 8u; // prefix sums at every fourth position, and the total
+    L.off_p4 = o;    o += (((uint32_t)kSortK >> sort_psh(ovp)) + 1u) * 8u;      // prefix sums, and the total
     o = (o + 15u) & ~15u;
-    (void)ovp;
     L.off_x = o;     o += ntc * nthr_pad * 4u;
     L.off_s = o;     o += ntc * 4u;
+    o = (o + 15u) & ~15u;
     L.off_v = o;     o += (uint32_t)ntypes * kSortTy * 4u;   // per type: values [66], thresholds T [64], n_thr, kout_pos, kout_neg, gmax, lim, m
     o = (o + 15u) & ~15u;
     L.off_misc = o;  o += 256u;                              // scan scratch, counters
@@ -99,6 +105,55 @@ __device__ __forceinline__ float sort_unkey(uint32_t k) { return u2f((k & 0x8000
 __device__ __forceinline__ long long sort_key_fixed(uint32_t k, double F)
 {
     return k == kSortSent ? 0ll : sweep_fixed(sort_unkey(k), F);
+}
+
+// x_threshold (antq_k_fakequant.h) with the rounding boundary M = (pred(T) + T) / 2 and T's mantissa parity precomputed per
+// threshold (they do not depend on the scale): the same float
+__device__ __forceinline__ float sort_x_threshold(double M, bool t_even, double sd)
+{
+    const double prod = M * sd;                        // exact
+    const float xf = (float)prod;
+    const double back = (double)xf;
+    const bool take = (back > prod) || (back == prod && t_even);
+    return take ? xf : f_up(xf);
+}
+// a type's block: what every thread of a workgroup fills once (tid < 64: one threshold each; tid == 64: the scalars)
+__device__ __forceinline__ void sort_fill_type(float *v, const SweepType &ty, uint32_t nneg, uint32_t tid)
+{
+    uint32_t *vu = reinterpret_cast<uint32_t *>(v);
+    double *vm = reinterpret_cast<double *>(v + 140);
+    if (tid < 64u) {
+        const uint32_t k = tid;
+        float T = 0.0f;
+        if (k < ty.n_thr) {
+            const uint4 th = ty.tlist[k];
+            T = u2f(th.x);
+            v[k + 1u] = u2f(th.z) + 0.0f;
+            if (k == 0u) v[0] = u2f(th.y) + 0.0f;
+        } else {                                         // beyond the last threshold: the last value again (A = B = 0)
+            v[k + 1u] = ty.n_thr ? u2f(ty.tlist[ty.n_thr - 1u].z) + 0.0f : 0.0f;
+        }
+        v[66u + k] = T;
+        vm[k] = 0.5 * ((double)f_dn(T) + (double)T);
+        const unsigned long long ev = __ballot((f2u(T) & 1u) == 0u);
+        if (k == 0u) { vu[137] = (uint32_t)ev; vu[138] = (uint32_t)(ev >> 32); }
+    }
+    if (tid == 64u) {
+        vu[130] = ty.n_thr;
+        vu[131] = (uint32_t)ty.kout_pos;
+        vu[132] = (uint32_t)ty.kout_neg;
+        v[133] = ty.gmax;
+        v[134] = ty.lim;
+        vu[135] = ty.m;
+        vu[136] = nneg < ty.n_thr ? nneg : ty.n_thr;
+    }
+}
+__device__ __forceinline__ uint32_t sort_threshold_key(const float *v, uint32_t k, double sd)
+{
+    const uint32_t *vu = reinterpret_cast<const uint32_t *>(v);
+    const double M = reinterpret_cast<const double *>(v + 140)[k];
+    const bool even = ((vu[137u + (k >> 5)] >> (k & 31u)) & 1u) != 0u;
+    return sort_key(sort_x_threshold(M, even, sd));
 }
 
 // ---- the sorting network -------------------------------------------------------------------------------------------------
@@ -258,36 +313,11 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
     double *sScanD = reinterpret_cast<double *>(base + L.off_misc + 128);
     int *sFlag = reinterpret_cast<int *>(base + L.off_misc + 192);
 
-    // per type: values, grid-domain thresholds and scalars (once per workgroup; constant indices into the kernel argument)
+    // per type: values, grid-domain thresholds, rounding boundaries and scalars (once per workgroup; constant indices into the
+    // kernel argument)
 #pragma unroll
-    for (int t = 0; t < kMaxTypes; t++) {
-        if (t < st.ntypes) {
-            const SweepType ty = st.ty[t];
-            float *v = sV + (uint32_t)t * kSortTy;
-            uint32_t *vu = reinterpret_cast<uint32_t *>(v);
-            if (tid < 64u) {
-                const uint32_t k = tid;
-                if (k < ty.n_thr) {
-                    const uint4 th = ty.tlist[k];
-                    v[66u + k] = u2f(th.x);
-                    v[k + 1u] = u2f(th.z) + 0.0f;
-                    if (k == 0u) v[0] = u2f(th.y) + 0.0f;
-                } else {                                     // beyond the last threshold: the last value again (A = B = 0)
-                    v[66u + k] = 0.0f;
-                    v[k + 1u] = ty.n_thr ? u2f(ty.tlist[ty.n_thr - 1u].z) + 0.0f : 0.0f;
-                }
-            }
-            if (tid == 64u) {
-                vu[130] = ty.n_thr;
-                vu[131] = (uint32_t)ty.kout_pos;
-                vu[132] = (uint32_t)ty.kout_neg;
-                v[133] = ty.gmax;
-                v[134] = ty.lim;
-                vu[135] = ty.m;
-                vu[136] = st.nneg[t] < ty.n_thr ? st.nneg[t] : ty.n_thr;
-            }
-        }
-    }
+    for (int t = 0; t < kMaxTypes; t++)
+        if (t < st.ntypes) sort_fill_type(sV + (uint32_t)t * kSortTy, st.ty[t], st.nneg[t], tid);
     __syncthreads();
     auto ty_nthr = [&](uint32_t t) { return reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[130]; };
     auto ty_kpos = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[131]; };
@@ -341,9 +371,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
             const uint32_t t = type_of(tc);
             uint32_t key = kSortSent;
             if (usable && k < ty_nthr(t)) {
-                bool tok;
-                const float X = x_threshold(sV[t * kSortTy + 66u + k], sS[tc], 0.0f, tok);
-                key = sort_key(X);
+                key = sort_threshold_key(sV + t * kSortTy, k, (double)sS[tc]);
             }
             sX[p] = key;
             k += r_thr;
@@ -546,12 +574,13 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
 #pragma unroll
                 for (int q = 0; q < kSortEPT / 4; q++) dst[q] = make_uint4(k[4 * q], k[4 * q + 1], k[4 * q + 2], k[4 * q + 3]);
             }
-            long long g[4], mine = 0;
+            constexpr int PSH = sort_psh(OVP), NG = kSortEPT >> PSH;
+            long long g[NG], mine = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NG; q++) {
                 g[q] = 0;
 #pragma unroll
-                for (int e = 0; e < 4; e++) g[q] += sort_key_fixed(k[4 * q + e], F);
+                for (int e = 0; e < (1 << PSH); e++) g[q] += sort_key_fixed(k[(q << PSH) + e], F);
                 mine += g[q];
             }
             long long incs = mine;
@@ -566,14 +595,14 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
 #pragma unroll
             for (uint32_t w = 0; w < kSortNT / 64; w++) pre += w < wave ? sScanI[w] : 0ll;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                sP4[4u * tid + (uint32_t)q] = pre;
+            for (int q = 0; q < NG; q++) {
+                sP4[(uint32_t)NG * tid + (uint32_t)q] = pre;
                 pre += g[q];
             }
-            if (tid == kSortNT - 1u) sP4[kSortK / 4] = pre;
+            if (tid == kSortNT - 1u) sP4[kSortK >> PSH] = pre;
             __syncthreads();
             // ---- 4c. the (type, candidate, threshold group) items
-            const long long Stot_i = sP4[kSortK / 4];
+            const long long Stot_i = sP4[kSortK >> PSH];
             const double Stot = (double)Stot_i * unit, dn = (double)Kreg;
             const uint32_t q_it = kSortNT / nkg, r_it = kSortNT - q_it * nkg;
             for (uint32_t it = tid, ui = 0, tc = tid / nkg, kg = tid - (tid / nkg) * nkg; it < nitems; it += kSortNT, ui++) {
@@ -603,8 +632,12 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
 #pragma unroll
                 for (int j = 0; j < kSortKS; j++) {
                     const uint32_t p = pos[j];
-                    long long slt = sP4[p >> 2];
-                    for (uint32_t i = p & ~3u; i < p; i++) slt += sort_key_fixed(sK[i], F);
+                    long long slt = sP4[p >> PSH];
+                    if constexpr (PSH == 1) {
+                        if (p & 1u) slt += sort_key_fixed(sK[p - 1u], F);
+                    } else {
+                        for (uint32_t i = p & ~3u; i < p; i++) slt += sort_key_fixed(sK[i], F);
+                    }
                     const bool below = kg * (uint32_t)kSortKS + (uint32_t)j < nb;        // a threshold below zero: the elements BELOW it
                     const double N = below ? -(double)p : (double)(Kreg - p);
                     const double S = (double)(below ? -slt : Stot_i - slt) * unit;
@@ -683,7 +716,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
 constexpr int kSortBS = 6 + kSortR, kSortKSh = 1 << kSortBS;          // 1024 keys per wavefront
 __host__ __device__ inline uint32_t sort_short_wave_bytes(uint32_t ntc)
 {
-    return ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u + ((uint32_t)kSortKSh / 4u + 2u) * 8u + ((ntc + 3u) & ~3u) * 4u;
+    return ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u + ((uint32_t)kSortKSh / 2u + 2u) * 8u + ((ntc + 3u) & ~3u) * 4u;
 }
 template <typename T>
 __global__ void __launch_bounds__(256, 4)
@@ -700,34 +733,10 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
     char *wb = base + (((uint32_t)st.ntypes * kSortTy * 4u + 15u) & ~15u) + wave * sort_short_wave_bytes(ntc);
     uint32_t *sK = reinterpret_cast<uint32_t *>(wb);                                   // this wavefront's keys
     long long *sP4 = reinterpret_cast<long long *>(wb + ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u);
-    float *sS = reinterpret_cast<float *>(wb + ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u + ((uint32_t)kSortKSh / 4u + 2u) * 8u);
+    float *sS = reinterpret_cast<float *>(wb + ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u + ((uint32_t)kSortKSh / 2u + 2u) * 8u);
 #pragma unroll
-    for (int t = 0; t < kMaxTypes; t++) {
-        if (t < st.ntypes) {
-            const SweepType ty = st.ty[t];
-            float *v = sV + (uint32_t)t * kSortTy;
-            uint32_t *vu = reinterpret_cast<uint32_t *>(v);
-            if (tid < 64u) {
-                const uint32_t k = tid;
-                if (k < ty.n_thr) {
-                    const uint4 th = ty.tlist[k];
-                    v[66u + k] = u2f(th.x);
-                    v[k + 1u] = u2f(th.z) + 0.0f;
-                    if (k == 0u) v[0] = u2f(th.y) + 0.0f;
-                } else {
-                    v[66u + k] = 0.0f;
-                    v[k + 1u] = ty.n_thr ? u2f(ty.tlist[ty.n_thr - 1u].z) + 0.0f : 0.0f;
-                }
-            }
-            if (tid == 64u) {
-                vu[130] = ty.n_thr;
-                v[133] = ty.gmax;
-                v[134] = ty.lim;
-                vu[135] = ty.m;
-                vu[136] = st.nneg[t] < ty.n_thr ? st.nneg[t] : ty.n_thr;
-            }
-        }
-    }
+    for (int t = 0; t < kMaxTypes; t++)
+        if (t < st.ntypes) sort_fill_type(sV + (uint32_t)t * kSortTy, st.ty[t], st.nneg[t], tid);
     __syncthreads();                                        // (the only workgroup barrier: from here on every wavefront is on its own)
     auto ty_nthr = [&](uint32_t t) { return reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[130]; };
     auto ty_gmax = [&](uint32_t t) { return sV[t * kSortTy + 133u]; };
@@ -821,12 +830,10 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
 #pragma unroll
                 for (int q = 0; q < kSortEPT / 4; q++) dst[q] = make_uint4(k[4 * q], k[4 * q + 1], k[4 * q + 2], k[4 * q + 3]);
             }
-            long long g[4], mine = 0;
+            long long g[8], mine = 0;                        // prefix sums at every second sorted position
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                g[q] = 0;
-#pragma unroll
-                for (int e = 0; e < 4; e++) g[q] += sort_key_fixed(k[4 * q + e], F);
+            for (int q = 0; q < 8; q++) {
+                g[q] = sort_key_fixed(k[2 * q], F) + sort_key_fixed(k[2 * q + 1], F);
                 mine += g[q];
             }
             long long incs = mine;
@@ -837,12 +844,12 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
             }
             long long pre = incs - mine;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                sP4[4u * lane + (uint32_t)q] = pre;
+            for (int q = 0; q < 8; q++) {
+                sP4[8u * lane + (uint32_t)q] = pre;
                 pre += g[q];
             }
             Stot_i = __shfl(incs, 63, 64);
-            if (lane == 63u) sP4[kSortKSh / 4] = pre;
+            if (lane == 63u) sP4[kSortKSh / 2] = pre;
             sort_sync<true>();
         }
         // A few literal elements (a ratio list that starts below ~0.5: the row's largest elements): a list in the 64 dwords
@@ -866,6 +873,7 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
         for (uint32_t tc = lane; tc < ntc; tc += 64u) {
             const uint32_t t = type_of(tc), c = tc - t * ncand;
             const float s = sS[tc];
+            const double sd = (double)s;
             const float *v = sV + t * kSortTy;
             const uint32_t nthr_t = ty_nthr(t), nb = ty_nneg(t);
             double sum = Q;
@@ -875,8 +883,7 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
 #pragma unroll
                     for (int j = 0; j < kSortKS; j++) {
                         const uint32_t kk = kg * (uint32_t)kSortKS + (uint32_t)j;
-                        bool tok;
-                        Xk[j] = (usable && kk < nthr_t) ? sort_key(x_threshold(v[66u + kk], s, 0.0f, tok)) : kSortSent;
+                        Xk[j] = (usable && kk < nthr_t) ? sort_threshold_key(v, kk, sd) : kSortSent;
                         pos[j] = 0u;
                     }
 #pragma unroll
@@ -897,8 +904,8 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
 #pragma unroll
                     for (int j = 0; j < kSortKS; j++) {
                         const uint32_t kk = kg * (uint32_t)kSortKS + (uint32_t)j, p = pos[j];
-                        long long slt = sP4[p >> 2];
-                        for (uint32_t i = p & ~3u; i < p; i++) slt += sort_key_fixed(sK[i], F);
+                        long long slt = sP4[p >> 1];
+                        if (p & 1u) slt += sort_key_fixed(sK[p - 1u], F);
                         const bool below = kk < nb;
                         const double N = below ? -(double)p : (double)(Kreg - p);
                         const double S = (double)(below ? -slt : Stot_i - slt) * unit;

@@ -20,7 +20,10 @@ xo.view(-1)[idx] *= 30.0
 xm3 = _lib.xmax_3sigma(xo, 4096, 4096, per_row=True)
 a = torch.nn.functional.gelu(torch.randn(64 * 128 * 3072, device=dev))
 am = _lib.absmax(a, 1, a.numel(), per_row=False)
+xs = torch.randn(16384, 768, device=dev) * 0.02
+xsm = _lib.absmax(xs, 16384, 768)
 for _ in range(3):
+    _lib.search_sse_multi(xs, 16384, 768, xsm, True, ratios(80, 150, 1), [p for p, _ in ant], [g for _, g in ant])
     _lib.search_sse_multi(x, 4096, 4096, xm, True, ratios(80, 150, 1), [p for p, _ in ant], [g for _, g in ant])
     _lib.search_sse_multi(xo, 4096, 4096, xm3, True, ratios(75, 250, 2), [p for p, _ in oli], [g for _, g in oli], ovp=True)
     _lib.search_sse_multi(a, 1, a.numel(), am, False, ratios(80, 150, 1), [p for p, _ in ant], [g for _, g in ant])
