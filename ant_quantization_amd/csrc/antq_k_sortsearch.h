@@ -610,19 +610,22 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                 const float s = sS[tc];
                 const float *v = sV + t * kSortTy + kg * (uint32_t)kSortKS;
                 const uint32_t *X = sX + tc * nthr_pad + kg * (uint32_t)kSortKS;
+                // (the running ADDRESS is the search state: a probe is ds_read_b32 with an immediate offset, a step is compare +
+                //  select + add -- an index would cost a shift-add per probe on top)
                 uint32_t Xk[kSortKS], pos[kSortKS];
+                const uint32_t *ap[kSortKS];
 #pragma unroll
-                for (int j = 0; j < kSortKS; j++) { Xk[j] = X[j]; pos[j] = 0u; }
+                for (int j = 0; j < kSortKS; j++) { Xk[j] = X[j]; ap[j] = sK; }
 #pragma unroll
                 for (int step = kSortK / 2; step >= 1; step >>= 1) {
                     uint32_t kv[kSortKS];
 #pragma unroll
-                    for (int j = 0; j < kSortKS; j++) kv[j] = sK[pos[j] + (uint32_t)step - 1u];
+                    for (int j = 0; j < kSortKS; j++) kv[j] = ap[j][step - 1];
 #pragma unroll
-                    for (int j = 0; j < kSortKS; j++) pos[j] += kv[j] < Xk[j] ? (uint32_t)step : 0u;
+                    for (int j = 0; j < kSortKS; j++) ap[j] += kv[j] < Xk[j] ? step : 0;
                 }
 #pragma unroll
-                for (int j = 0; j < kSortKS; j++) pos[j] += sK[pos[j]] < Xk[j] ? 1u : 0u;
+                for (int j = 0; j < kSortKS; j++) pos[j] = (uint32_t)(ap[j] - sK) + (ap[j][0] < Xk[j] ? 1u : 0u);
                 const uint32_t nb = ty_nneg(t);
                 double part = 0.0;
                 if (kg == 0u) {
@@ -884,18 +887,20 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
                     for (int j = 0; j < kSortKS; j++) {
                         const uint32_t kk = kg * (uint32_t)kSortKS + (uint32_t)j;
                         Xk[j] = (usable && kk < nthr_t) ? sort_threshold_key(v, kk, sd) : kSortSent;
-                        pos[j] = 0u;
                     }
+                    const uint32_t *ap[kSortKS];
+#pragma unroll
+                    for (int j = 0; j < kSortKS; j++) ap[j] = sK;
 #pragma unroll
                     for (int step = kSortKSh / 2; step >= 1; step >>= 1) {
                         uint32_t kv[kSortKS];
 #pragma unroll
-                        for (int j = 0; j < kSortKS; j++) kv[j] = sK[pos[j] + (uint32_t)step - 1u];
+                        for (int j = 0; j < kSortKS; j++) kv[j] = ap[j][step - 1];
 #pragma unroll
-                        for (int j = 0; j < kSortKS; j++) pos[j] += kv[j] < Xk[j] ? (uint32_t)step : 0u;
+                        for (int j = 0; j < kSortKS; j++) ap[j] += kv[j] < Xk[j] ? step : 0;
                     }
 #pragma unroll
-                    for (int j = 0; j < kSortKS; j++) pos[j] += sK[pos[j]] < Xk[j] ? 1u : 0u;
+                    for (int j = 0; j < kSortKS; j++) pos[j] = (uint32_t)(ap[j] - sK) + (ap[j][0] < Xk[j] ? 1u : 0u);
                     double part = 0.0;
                     if (kg == 0u) {
                         const double Ob_ = (double)(v[nb] * s);
