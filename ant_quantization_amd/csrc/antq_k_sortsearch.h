@@ -21,12 +21,14 @@
 //            step-function elements (NaN / Inf / far-clipped: |x| >= lim * s_min) carry the sentinel 0xffffffff: they sort to
 //            the end, count for nothing, and are evaluated literally (the reference sequence) for every candidate
 //   sort     256 threads x 16 keys.  The index bits of the network that are REGISTER bits change with the layout: bits 0-3
-//            (blocked), 4-7, 8-11; a size-2^s merge walks its strides top down through at most three layouts, moving between
-//            them through LDS (20 transposes in all; address = i + (i >> 4): all three layouts nearly conflict-free).  The
+//            (blocked), 4-7, 8-11 (6-9 inside a wavefront); a size-2^s merge walks its strides top down through at most three
+//            layouts, moving between them through LDS (20 transposes in all, 14 of them inside a wavefront's own quarter of
+//            the buffer without a workgroup barrier; address = i + (i >> 4): every layout nearly conflict-free).  The
 //            first step of a merge (partner i ^ (2^s - 1)) is folded into the transposing READ (the upper half block is read
 //            mirrored), so every comparator sorts ascending: v_min_u32 + v_max_u32 per pair.
 //   sums     x in fixed point (2^-38 of the row statistic's binade, exact for every element within 2^15 of it: antq_k_sweep.h),
-//            prefix sums as 64-bit integers at every fourth position; a probe adds at most three elements to them
+//            prefix sums as 64-bit integers at every second sorted position (every fourth with the pair rule: sort_psh); a
+//            probe adds the one (three) elements in between
 //   search   work item = (codebook, candidate, group of 4 thresholds): 4 interleaved binary searches, the closed form's
 //            terms in double in ONE fixed order -- the sums of a (codebook, candidate) do not depend on which other codebooks
 //            or candidates share the launch
@@ -35,8 +37,10 @@
 //            candidate) adds the victim's correction v^2 - (O(v) - v)^2 for the pairs that hold an outlier under IT (exact:
 //            a victim's output is 0 * s).  Pairs with a member that is no step-function element take the literal sequence.
 //
-// Rows whose candidate scales are unusable (zero / denormal / NaN statistic, a non-monotone ratio list) take the literal
-// sequence for every element: slow, never wrong.
+// Rows whose candidate scales are unusable (an Inf / denormal statistic, a non-monotone ratio list) take the literal sequence
+// for every element: slow (0.2 - 1 ms per such row), never wrong; a zero or NaN statistic gives NaN for every candidate, said
+// directly.  Rows of at most 1024 elements under codebooks without the pair rule: k_search_sorted_short below (one row per
+// wavefront).  A tensor with ONE scale: the PT form of the kernel + k_sort_pt_total / k_sort_pt_finish.
 #ifndef ANTQ_K_SORTSEARCH_H
 #define ANTQ_K_SORTSEARCH_H
 
