@@ -63,9 +63,11 @@ constexpr uint32_t kSortSent = 0xffffffffu;
 // group) items, kSortNC pair-correction items and kSortNL (type, candidate) literal sums per thread -- the launcher cuts the
 // candidate list into pieces that fit.
 constexpr int kSortNI = 6, kSortNC = 3, kSortNL = 2;
-constexpr uint32_t kSortTy = 268;                            // dwords of a type's block in LDS: values [66], thresholds T [64], scalars [130..139]
+constexpr uint32_t kSortTy = 332;                            // dwords of a type's block in LDS: values [66], thresholds T [64], scalars [130..139]
                                                              // (n_thr, kout_pos, kout_neg, gmax, lim, m, nneg, even-mantissa masks [137..138]),
-                                                             // rounding boundaries M_k as doubles [140..267]
+                                                             // rounding boundaries M_k as doubles [140..267], the codebook in scan order
+                                                             // [268..331] (literal elements; codebooks of more than 64 values: from memory)
+constexpr uint32_t kSortGridLds = 64;
 // Prefix sums at every 2^PSH-th sorted position.  A probe converts the (up to 2^PSH - 1) keys between the stored position and
 // its own back to fixed point -- 10 instructions each, a quarter of a look-up at every fourth -- so codebooks without the pair
 // rule keep every SECOND position (8 KB more LDS: still three workgroups per CU); OliVe's tables leave no room for that.
@@ -139,6 +141,7 @@ __device__ __forceinline__ void sort_fill_type(float *v, const SweepType &ty, ui
         }
         v[66u + k] = T;
         vm[k] = 0.5 * ((double)f_dn(T) + (double)T);
+        v[268u + k] = k < ty.m ? ty.grid[k] : 0.0f;
         const unsigned long long ev = __ballot((f2u(T) & 1u) == 0u);
         if (k == 0u) { vu[137] = (uint32_t)ev; vu[138] = (uint32_t)(ev >> 32); }
     }
@@ -158,6 +161,22 @@ __device__ __forceinline__ uint32_t sort_threshold_key(const float *v, uint32_t 
     const double M = reinterpret_cast<const double *>(v + 140)[k];
     const bool even = ((vu[137u + (k >> 5)] >> (k & 31u)) & 1u) != 0u;
     return sort_key(sort_x_threshold(M, even, sd));
+}
+
+// the reference scan (quant_kernel.cu:25-37) for a literal element: the codebook from LDS where it fits (a scan that waits for
+// a load from memory per value took 2000 cycles per element and candidate: 5 ms for a 64 x 1024 tensor with one Inf row)
+__device__ __forceinline__ float sort_literal_q(float xv, float s, const float *v, const float *grid, int m, float &d)
+{
+    if (m > (int)kSortGridLds) return sweep_literal_q(xv, s, grid, m, d);
+    d = xv / s;
+    float sub_min = 102400.0f, z_min = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < m; i++) {
+        const float g = v[268 + i];
+        const float sub_v = fabsf(d - g);
+        if (sub_v <= sub_min) { sub_min = sub_v; z_min = g; }
+    }
+    return z_min;
 }
 
 // ---- the sorting network -------------------------------------------------------------------------------------------------
@@ -508,7 +527,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                                 }
                                 return v[lo];
                             }
-                            return sweep_literal_q(xv, s, grid, gm, d);
+                            return sort_literal_q(xv, s, v, grid, gm, d);
                         };
                         auto term_of = [&](float q, float d, bool tab, float xv) -> double {
                             if (tab) {
@@ -940,7 +959,7 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
                         const double er = (double)(v[lo] * s) - (double)xv;
                         sum_l += er * er;
                     } else {
-                        const float q = sweep_literal_q(xv, s, grid, gm, d);
+                        const float q = sort_literal_q(xv, s, v, grid, gm, d);
                         sum_l += sweep_term(q, d, s, xv);
                     }
                 };
