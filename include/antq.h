@@ -471,7 +471,14 @@ int antq_copy(const void *src_dev, void *dst_dev, size_t bytes, void *stream);
  *   key 15: antq_calibrate with the abs-max statistic on a tensor the histogram search takes: 1 (default) the counting pass
  *           also finds the maximum (no separate abs-max pass), 0 the abs-max pass runs as everywhere else (A/B; same value)
  *   key 13: experiment switch of the kernel under development (0 = off; 1: the 16-bit-domain encoder's 8-vector tasks store
- *           their codes nontemporally instead of through the cache) */
+ *           their codes nontemporally instead of through the cache)
+ *   key 16-18: the streaming row abs-max (16) and the ticket groups / workgroups of the one-launch reductions (17, 18), A/B
+ *   key 19: the threshold-sweep clip search (round 6, first generation): 0 off, 1 (default) where it paid, 2 every eligible
+ *           launch -- runs only where key 20 leaves a launch to it
+ *   key 20: the sorted-row clip search (round 6: per-row searches from rows of 128 elements, OliVe's pair rule from 576, fp32
+ *           tensors with one scale from 1 M elements): 0 off, 1 (default), 2 every eligible launch (rows from 128 elements
+ *           with or without the pair rule, one-scale fp32 tensors from 4096)
+ *   key 21: 0 sends rows of <= 1024 elements through the 4096-key kernel instead of one row per wavefront (A/B) */
 int antq_debug_set(int key, int value);
 
 /* Load the library's GPU code objects for the current device now (HIP would load each of them at the first launch of one
