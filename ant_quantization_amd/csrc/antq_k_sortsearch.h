@@ -69,9 +69,13 @@ constexpr uint32_t kSortTy = 332;                            // dwords of a type
                                                              // [268..331] (literal elements; codebooks of more than 64 values: from memory)
 constexpr uint32_t kSortGridLds = 64;
 // Prefix sums at every 2^PSH-th sorted position.  A probe converts the (up to 2^PSH - 1) keys between the stored position and
-// its own back to fixed point -- 10 instructions each, a quarter of a look-up at every fourth -- so codebooks without the pair
-// rule keep every SECOND position (8 KB more LDS: still three workgroups per CU); OliVe's tables leave no room for that.
-__host__ __device__ constexpr int sort_psh(bool ovp) { return ovp ? 2 : 1; }
+// its own back to fixed point -- 10 instructions each, a quarter of a look-up at every fourth -- so every SECOND position is
+// kept (8 KB more LDS than every fourth).  With the pair rule that only fits next to three workgroups per CU because OliVe's
+// launches do not keep their 20 KB table of x-domain thresholds (sort_inline): a (codebook, candidate, threshold) is moved
+// into the x domain by the item that probes it -- once per chunk instead of once per row, which a row of several chunks
+// pays back through the cheaper probes -- and the pair rule's own look-ups work in the grid domain (RN(x / s) >= T_k <=> x >= X_k).
+__host__ __device__ constexpr int sort_psh(bool ovp) { (void)ovp; return 1; }
+__host__ __device__ constexpr bool sort_inline(bool ovp) { return ovp; }
 
 struct SortTypes {
     SweepType ty[kMaxTypes];
@@ -91,7 +95,7 @@ __host__ __device__ inline SortLds sort_lds(uint32_t ntc, uint32_t nthr_pad, int
     o = (o + 15u) & ~15u;
     L.off_p4 = o;    o += (((uint32_t)kSortK >> sort_psh(ovp)) + 1u) * 8u;      // prefix sums, and the total
     o = (o + 15u) & ~15u;
-    L.off_x = o;     o += ntc * nthr_pad * 4u;
+    L.off_x = o;     o += sort_inline(ovp) ? ntc * 2u * 4u : ntc * nthr_pad * 4u;     // thresholds as keys (inline: the two outlier bounds only)
     L.off_s = o;     o += ntc * 4u;
     o = (o + 15u) & ~15u;
     L.off_v = o;     o += (uint32_t)ntypes * kSortTy * 4u;   // per type: values [66], thresholds T [64], n_thr, kout_pos, kout_neg, gmax, lim, m
@@ -389,8 +393,19 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
         __syncthreads();
         const bool usable = *sFlag == 0;
         // ---- 2. thresholds in the x domain, as keys; partial sums cleared
+        constexpr bool INL = sort_inline(OVP);
+        if constexpr (INL) {
+            // (per (type, candidate) only the two bounds of the outlier region: key >= kp a positive outlier, key < kn a negative one)
+            for (uint32_t tc = tid; tc < ntc; tc += kSortNT) {
+                const uint32_t t = type_of(tc);
+                const float *v = sV + t * kSortTy;
+                const double sd = (double)sS[tc];
+                sX[2u * tc] = (usable && ty_kpos(t) >= 0) ? sort_threshold_key(v, (uint32_t)ty_kpos(t), sd) : kSortSent;
+                sX[2u * tc + 1u] = (usable && ty_kneg(t) >= 0) ? sort_threshold_key(v, (uint32_t)ty_kneg(t), sd) : 0u;
+            }
+        }
         const uint32_t q_thr = kSortNT / nthr_pad, r_thr = kSortNT - q_thr * nthr_pad;      // (uniform: scalar divisions)
-        for (uint32_t p = tid, tc = tid / nthr_pad, k = tid - (tid / nthr_pad) * nthr_pad; p < ntc * nthr_pad; p += kSortNT) {
+        for (uint32_t p = tid, tc = tid / nthr_pad, k = tid - (tid / nthr_pad) * nthr_pad; !INL && p < ntc * nthr_pad; p += kSortNT) {
             const uint32_t t = type_of(tc);
             uint32_t key = kSortSent;
             if (usable && k < ty_nthr(t)) {
@@ -421,8 +436,13 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
         float XoP = __builtin_inff(), XoN = -__builtin_inff();            // OliVe: outlier under the smallest scale of SOME type
         if (OVP && usable) {
             for (uint32_t t = 0; t < ntypes; t++) {
-                if (ty_kpos(t) >= 0) XoP = fminf(XoP, sort_unkey(sX[(t * ncand) * nthr_pad + (uint32_t)ty_kpos(t)]));
-                if (ty_kneg(t) >= 0) XoN = fmaxf(XoN, sort_unkey(sX[(t * ncand) * nthr_pad + (uint32_t)ty_kneg(t)]));
+                if (INL) {
+                    if (ty_kpos(t) >= 0) XoP = fminf(XoP, sort_unkey(sX[2u * (t * ncand)]));
+                    if (ty_kneg(t) >= 0) XoN = fmaxf(XoN, sort_unkey(sX[2u * (t * ncand) + 1u]));
+                } else {
+                    if (ty_kpos(t) >= 0) XoP = fminf(XoP, sort_unkey(sX[(t * ncand) * nthr_pad + (uint32_t)ty_kpos(t)]));
+                    if (ty_kneg(t) >= 0) XoN = fmaxf(XoN, sort_unkey(sX[(t * ncand) * nthr_pad + (uint32_t)ty_kneg(t)]));
+                }
             }
         }
         double Q = 0.0;
@@ -512,7 +532,7 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                         const float *grid = ty_grid(t);
                         const int gm = ty_m(t);
                         const float s = sS[tc], lim = usable ? ty_lim(t) : 0.0f;
-                        const uint32_t *X = sX + tc * nthr_pad;
+                        const uint32_t *X = sX + (INL ? 0u : tc * nthr_pad);
                         const float *v = sV + t * kSortTy;
                         const uint32_t nthr_t = ty_nthr(t);
                         auto q_of = [&](float xv, float &d, bool &tab) -> float {
@@ -521,9 +541,9 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                             if (tab) {
                                 const uint32_t kx = sort_key(xv);
                                 uint32_t lo = 0, hi = nthr_t;
-                                while (lo < hi) {
+                                while (lo < hi) {             // (inline thresholds: RN(x / s) >= T_k <=> x >= X_k)
                                     const uint32_t mid = (lo + hi) >> 1;
-                                    if (kx >= X[mid]) lo = mid + 1u; else hi = mid;
+                                    if (INL ? d >= v[66u + mid] : kx >= X[mid]) lo = mid + 1u; else hi = mid;
                                 }
                                 return v[lo];
                             }
@@ -561,12 +581,12 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                     // work item (type, candidate, j): the pairs j, j + 4, ... in list order
                     for (uint32_t it = tid, ui = 0; it < 4u * ntc; it += kSortNT, ui++) {
                         const uint32_t tc = it >> 2, j0 = it & 3u, t = type_of(tc);
-                        const uint32_t *X = sX + tc * nthr_pad;
+                        const uint32_t *X = sX + (INL ? 0u : tc * nthr_pad);
                         const float s = sS[tc];
                         const float *v = sV + t * kSortTy;
                         const uint32_t nthr_t = ty_nthr(t);
-                        const uint32_t kp = ty_kpos(t) >= 0 ? X[ty_kpos(t)] : kSortSent;          // key >= kp: a positive outlier
-                        const uint32_t kn = ty_kneg(t) >= 0 ? X[ty_kneg(t)] : 0u;                 // key <  kn: a negative outlier
+                        const uint32_t kp = INL ? sX[2u * tc] : (ty_kpos(t) >= 0 ? X[ty_kpos(t)] : kSortSent);      // key >= kp: a positive outlier
+                        const uint32_t kn = INL ? sX[2u * tc + 1u] : (ty_kneg(t) >= 0 ? X[ty_kneg(t)] : 0u);       // key <  kn: a negative outlier
                         double sum_c = 0.0;
                         for (uint32_t i = j0; i < tot_cap; i += 4u) {
                             const uint32_t ka = sK[kSortK - 2u - 2u * i], kb = sK[kSortK - 1u - 2u * i];
@@ -574,10 +594,11 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                             if (me || mo) {
                                 const uint32_t kv = me ? kb : ka;                                  // the victim (OQ:315-318)
                                 const float vv = sort_unkey(kv);
+                                const float dvv = vv / s;
                                 uint32_t lo = 0, hi = nthr_t;
                                 while (lo < hi) {
                                     const uint32_t mid = (lo + hi) >> 1;
-                                    if (kv >= X[mid]) lo = mid + 1u; else hi = mid;
+                                    if (INL ? dvv >= v[66u + mid] : kv >= X[mid]) lo = mid + 1u; else hi = mid;
                                 }
                                 const double O = (double)(v[lo] * s), dv = (double)vv;
                                 sum_c += dv * dv - (O - dv) * (O - dv);
@@ -632,13 +653,21 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
                 const uint32_t t = type_of(tc);
                 const float s = sS[tc];
                 const float *v = sV + t * kSortTy + kg * (uint32_t)kSortKS;
-                const uint32_t *X = sX + tc * nthr_pad + kg * (uint32_t)kSortKS;
+                const uint32_t *X = sX + (INL ? 0u : tc * nthr_pad + kg * (uint32_t)kSortKS);
                 // (the running ADDRESS is the search state: a probe is ds_read_b32 with an immediate offset, a step is compare +
                 //  select + add -- an index would cost a shift-add per probe on top)
                 uint32_t Xk[kSortKS], pos[kSortKS];
                 const uint32_t *ap[kSortKS];
 #pragma unroll
-                for (int j = 0; j < kSortKS; j++) { Xk[j] = X[j]; ap[j] = sK; }
+                for (int j = 0; j < kSortKS; j++) {
+                    if constexpr (INL) {
+                        const uint32_t kk = kg * (uint32_t)kSortKS + (uint32_t)j;
+                        Xk[j] = (usable && kk < ty_nthr(t)) ? sort_threshold_key(sV + t * kSortTy, kk, (double)s) : kSortSent;
+                    } else {
+                        Xk[j] = X[j];
+                    }
+                    ap[j] = sK;
+                }
 #pragma unroll
                 for (int step = kSortK / 2; step >= 1; step >>= 1) {
                     uint32_t kv[kSortKS];
