@@ -313,7 +313,8 @@ __device__ __forceinline__ void sort_wg(uint32_t (&k)[kSortEPT], uint32_t *sK, u
 //             slab b of `slabs` (doubles: item partials | literal terms | pair corrections | sum x^2); k_sort_pt_total adds the
 //             slabs in slab order, k_sort_pt_finish forms the sums.
 template <typename T, bool OVP, bool PT>
-__global__ void __launch_bounds__(kSortNT, 3)        // (three wavefronts per SIMD: three workgroups per CU)
+__global__ void __launch_bounds__(kSortNT, 3)        // (three wavefronts per SIMD: three workgroups per CU; four with the pair
+                                                      //  rule -- 128 registers, 236 bytes of scratch -- measured 0.246 against 0.221 ms)
 k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const float *__restrict__ xmax,
                 const float *__restrict__ ratios, double *__restrict__ sse, SortTypes st, uint32_t ncand, uint32_t ncand_all,
                 double *__restrict__ slabs)
