@@ -767,14 +767,16 @@ k_search_sorted(const uint4 *__restrict__ x, size_t vpr, size_t rows, const floa
 // domain, the probes, the closed form) wants all four wavefronts busy.  Here each wavefront takes a row of its own: the
 // sizes 2 .. 1024 of the same network (the in-wave phases of sort_wg, no workgroup barrier anywhere), 11-probe searches, a
 // (codebook, candidate)'s thresholds moved into the x domain right where they are used (each is used once), one lane per
-// (codebook, candidate) walking its threshold groups in order.  Codebooks without the pair rule (the ANT family).
-// Literal elements (rare) are read again from the row when a candidate's sum is formed.
+// (codebook, candidate) walking its threshold groups in order.  Literal elements (rare) are kept in a short list or read
+// again from the row when a candidate's sum is formed.  With OliVe's pair rule (OVP): the outlier-capable pairs in the 64
+// dwords behind the sorted keys (at most 32 of them, at most four per lane: a 3-sigma-clipped row of 1024 holds ~25), the
+// victims' corrections from that list; more than that, and literal pairs, are read again from the row.
 constexpr int kSortBS = 6 + kSortR, kSortKSh = 1 << kSortBS;          // 1024 keys per wavefront
 __host__ __device__ inline uint32_t sort_short_wave_bytes(uint32_t ntc)
 {
     return ((uint32_t)kSortKSh + (uint32_t)(kSortKSh >> kSortR)) * 4u + ((uint32_t)kSortKSh / 2u + 2u) * 8u + ((ntc + 3u) & ~3u) * 4u;
 }
-template <typename T>
+template <typename T, bool OVP>
 __global__ void __launch_bounds__(256, 4)
 k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, const float *__restrict__ xmax,
                       const float *__restrict__ ratios, double *__restrict__ sse, SortTypes st, uint32_t ncand, uint32_t ncand_all)
@@ -795,6 +797,8 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
         if (t < st.ntypes) sort_fill_type(sV + (uint32_t)t * kSortTy, st.ty[t], st.nneg[t], tid);
     __syncthreads();                                        // (the only workgroup barrier: from here on every wavefront is on its own)
     auto ty_nthr = [&](uint32_t t) { return reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[130]; };
+    auto ty_kpos = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[131]; };
+    auto ty_kneg = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[132]; };
     auto ty_gmax = [&](uint32_t t) { return sV[t * kSortTy + 133u]; };
     auto ty_lim = [&](uint32_t t) { return sV[t * kSortTy + 134u]; };
     auto ty_m = [&](uint32_t t) { return (int)reinterpret_cast<const uint32_t *>(sV + t * kSortTy)[135]; };
@@ -839,10 +843,19 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
             Lx = __builtin_ldexpf(0.999f, ex + 8);
             for (uint32_t t = 0; t < ntypes; t++) Lx = fminf(Lx, ty_lim(t) * sS[t * ncand] * 0.999f);
         }
+        float XoP = __builtin_inff(), XoN = -__builtin_inff();            // OliVe: an outlier under the smallest scale of SOME type
+        if (OVP && usable) {
+            for (uint32_t t = 0; t < ntypes; t++) {
+                const double sd0 = (double)sS[t * ncand];
+                if (ty_kpos(t) >= 0) XoP = fminf(XoP, sort_unkey(sort_threshold_key(sV + t * kSortTy, (uint32_t)ty_kpos(t), sd0)));
+                if (ty_kneg(t) >= 0) XoN = fmaxf(XoN, sort_unkey(sort_threshold_key(sV + t * kSortTy, (uint32_t)ty_kneg(t), sd0)));
+            }
+        }
         // ---- the row: 16 elements per lane
         uint32_t k[kSortEPT];
-        uint32_t nreg = 0, nlit = 0;
+        uint32_t nreg = 0, nlit = 0, ncap = 0;
         float lx0 = 0.0f, lx1 = 0.0f;                        // this lane's first two literal elements (a short list in LDS, below)
+        uint32_t ca[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0};   // ... and its first four outlier-capable pairs, as keys (statically indexed)
         double Q = 0.0;
 #pragma unroll
         for (int j = 0; j < VPT; j++) {
@@ -853,26 +866,49 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
                 const uint4 v = live ? xr[vi] : make_uint4(0u, 0u, 0u, 0u);
                 IO<T>::unpack(v, xf);
             }
+            if constexpr (OVP) {
 #pragma unroll
-            for (int e = 0; e < EPL; e++) {
-                const float a = xf[e];
-                const bool la = live && !(fabsf(a) < Lx), ra = live && !la;
-                k[j * EPL + e] = ra ? sort_key(a) : kSortSent;
-                Q = __builtin_fma((double)(ra ? a : 0.0f), (double)(ra ? a : 0.0f), Q);
-                nreg += ra ? 1u : 0u;
-                lx0 = (la && nlit == 0u) ? a : lx0;
-                lx1 = (la && nlit == 1u) ? a : lx1;
-                nlit += la ? 1u : 0u;
+                for (int e = 0; e < EPL; e += 2) {
+                    const float a = xf[e], b = xf[e + 1];
+                    const bool lp = live && (!(fabsf(a) < Lx) || !(fabsf(b) < Lx)), rp = live && !lp;       // a literal pair / a regular one
+                    const bool cap = rp && ((a >= XoP) || (a < XoN) || (b >= XoP) || (b < XoN));
+                    const uint32_t ka = sort_key(a), kb = sort_key(b);
+                    k[j * EPL + e] = rp ? ka : kSortSent;
+                    k[j * EPL + e + 1] = rp ? kb : kSortSent;
+                    Q = __builtin_fma((double)(rp ? a : 0.0f), (double)(rp ? a : 0.0f), Q);
+                    Q = __builtin_fma((double)(rp ? b : 0.0f), (double)(rp ? b : 0.0f), Q);
+                    nreg += rp ? 2u : 0u;
+                    nlit += lp ? 2u : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        ca[u] = (cap && ncap == (uint32_t)u) ? ka : ca[u];
+                        cb[u] = (cap && ncap == (uint32_t)u) ? kb : cb[u];
+                    }
+                    ncap += cap ? 1u : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    const float a = xf[e];
+                    const bool la = live && !(fabsf(a) < Lx), ra = live && !la;
+                    k[j * EPL + e] = ra ? sort_key(a) : kSortSent;
+                    Q = __builtin_fma((double)(ra ? a : 0.0f), (double)(ra ? a : 0.0f), Q);
+                    nreg += ra ? 1u : 0u;
+                    lx0 = (la && nlit == 0u) ? a : lx0;
+                    lx1 = (la && nlit == 1u) ? a : lx1;
+                    nlit += la ? 1u : 0u;
+                }
             }
         }
-        const uint32_t my_lit = nlit;
-        uint32_t pk = nreg | nlit << 16;
+        const uint32_t my_lit = nlit, my_cap = ncap;
+        uint32_t pk = nreg | nlit << 16, pc = ncap;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             pk += (uint32_t)__shfl_xor((int)pk, off, 64);
+            if (OVP) pc += (uint32_t)__shfl_xor((int)pc, off, 64);
             Q += __shfl_xor(Q, off, 64);
         }
-        const uint32_t Kreg = pk & 0xffffu, tot_lit = pk >> 16;
+        const uint32_t Kreg = pk & 0xffffu, tot_lit = pk >> 16, tot_cap = OVP ? pc : 0u;
         long long Stot_i = 0;
         if (Kreg) {
             // ---- the in-wave sort (sizes 2 .. 16 in the registers, 32 .. 1024 through this wavefront's buffer), prefix sums
@@ -910,8 +946,23 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
         }
         // A few literal elements (a ratio list that starts below ~0.5: the row's largest elements): a list in the 64 dwords
         // behind the sorted keys, lane by lane; more than that -- or more than two in one lane -- are read again from the row
-        const bool lit_list = tot_lit != 0u && tot_lit <= 64u && __ballot(my_lit > 2u) == 0ull;
+        const bool lit_list = !OVP && tot_lit != 0u && tot_lit <= 64u && __ballot(my_lit > 2u) == 0ull;
+        const bool cap_list = OVP && tot_cap != 0u && tot_cap <= 32u && __ballot(my_cap > 4u) == 0ull;
         float *sL = reinterpret_cast<float *>(sK + kSortKSh);
+        if (cap_list) {
+            uint32_t inc = my_cap;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t tv = (uint32_t)__shfl_up((int)inc, off, 64);
+                if (lane >= (uint32_t)off) inc += tv;
+            }
+            const uint32_t at = inc - my_cap;
+            uint32_t *sC = sK + kSortKSh;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (my_cap > (uint32_t)u) { sC[2u * (at + (uint32_t)u)] = ca[u]; sC[2u * (at + (uint32_t)u) + 1u] = cb[u]; }
+            sort_sync<true>();
+        }
         if (lit_list) {
             uint32_t inc = my_lit;
 #pragma unroll
@@ -973,7 +1024,71 @@ k_search_sorted_short(const uint4 *__restrict__ x, uint32_t vpr, size_t rows, co
                     sum += part;
                 }
             }
-            if (tot_lit) {
+            if constexpr (OVP) {
+                // the pair rule (OQ:311-320): victims' corrections from the list -- or, with the literal pairs, from the row
+                const uint32_t kp = (usable && ty_kpos(t) >= 0) ? sort_threshold_key(v, (uint32_t)ty_kpos(t), sd) : kSortSent;
+                const uint32_t kn = (usable && ty_kneg(t) >= 0) ? sort_threshold_key(v, (uint32_t)ty_kneg(t), sd) : 0u;
+                auto cell_of = [&](float d) {                 // RN(x / s) >= T_k  <=>  x >= X_k
+                    uint32_t lo = 0, hi = nthr_t;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (d >= v[66u + mid]) lo = mid + 1u; else hi = mid;
+                    }
+                    return lo;
+                };
+                auto correction = [&](uint32_t ka, uint32_t kb) -> double {
+                    const bool me = ka >= kp || ka < kn, mo = kb >= kp || kb < kn;
+                    if (!(me || mo)) return 0.0;
+                    const float vv = sort_unkey(me ? kb : ka);                 // the victim (OQ:315-318)
+                    const double O = (double)(v[cell_of(vv / s)] * s), dv = (double)vv;
+                    return dv * dv - (O - dv) * (O - dv);
+                };
+                double sum_c = 0.0, sum_l = 0.0;
+                if (cap_list) {
+                    const uint32_t *sC = sK + kSortKSh;
+                    for (uint32_t i = 0; i < tot_cap; i++) sum_c += correction(sC[2u * i], sC[2u * i + 1u]);
+                }
+                if (tot_lit != 0u || (tot_cap != 0u && !cap_list)) {
+                    const float *grid = ty_grid(t);
+                    const int gm = ty_m(t);
+                    const float lim = usable ? ty_lim(t) : 0.0f;
+                    auto q_of = [&](float xv, float &d, bool &tab) -> float {
+                        d = xv / s;
+                        tab = fabsf(d) < lim;
+                        return tab ? v[cell_of(d)] : sort_literal_q(xv, s, v, grid, gm, d);
+                    };
+                    auto term_of = [&](float q, float d, bool tab, float xv) -> double {
+                        if (tab) {
+                            const double er = (double)(q * s) - (double)xv;
+                            return er * er;
+                        }
+                        return sweep_term(q, d, s, xv);
+                    };
+                    for (uint32_t vi = 0; vi < vpr; vi++) {
+                        float xf[EPL];
+                        IO<T>::unpack(xr[vi], xf);
+#pragma unroll
+                        for (int e = 0; e < EPL; e += 2) {
+                            const float a = xf[e], b = xf[e + 1];
+                            if (!(fabsf(a) < Lx) || !(fabsf(b) < Lx)) {      // a literal pair: the reference sequence with the pair rule
+                                float da, db;
+                                bool ta, tb;
+                                float qa = q_of(a, da, ta), qb = q_of(b, db, tb);
+                                const bool me = fabsf(qa) > 32.0f, mo = fabsf(qb) > 32.0f;      // OQ:314
+                                const bool ve = mo && !me;
+                                qa = qa * (ve ? 0.0f : 1.0f);
+                                qb = qb * (me ? 0.0f : 1.0f);
+                                sum_l += term_of(qb, db, tb, b);
+                                sum_l += term_of(qa, da, ta, a);
+                            } else if (!cap_list) {
+                                sum_c += correction(sort_key(a), sort_key(b));
+                            }
+                        }
+                    }
+                }
+                sum += sum_c;
+                sum += sum_l;
+            } else if (tot_lit) {
                 const float *grid = ty_grid(t);
                 const int gm = ty_m(t);
                 const float lim = usable ? ty_lim(t) : 0.0f;

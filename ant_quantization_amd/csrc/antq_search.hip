@@ -372,9 +372,9 @@ static bool sort_shape_ok(const void *x, size_t rows, size_t row_len, int ncand,
     if (!g_knob_sort || rows < 2 || ncand < 1 || ntypes < 1 || ntypes > kMaxTypes) return false;
     // Where it pays (profiles/r06_sort_scan.log): ANT codebooks from rows of 128 elements -- up to 1024 elements one row per
     // wavefront (2.5 x the direct kernels at 128 and 256, 3.7 x at 512, 3.9 x at 768, 4.7 x at 1024), above that one row per
-    // workgroup in 4096-element chunks (3.1 x at 1152, 5.9 x at 4096); OliVe's pair rule, always one row per workgroup, from 576
-    // (1.3 x at 576 and 768, 1.5 x at 1024, 2.3 x at 2048, 3.9 x at 4096; 1.0 x at 512, 0.7 x at 256)
-    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sort == 2 ? 128u : (OVP ? 576u : 128u))) return false;
+    // workgroup in 4096-element chunks (3.1 x at 1152, 5.9 x at 4096); OliVe's pair rule from 256 (2.1 x; 3.1 x at 512, 3.2 x at
+    // 768, 3.9 x at 1024 one row per wavefront; 2.5 x at 1152, 5.4 x at 4096 one row per workgroup)
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || row_len % EPL != 0 || row_len < (g_knob_sort == 2 ? 128u : (OVP ? 256u : 128u))) return false;
     return !(OVP && (row_len & 1));                                  // (pairs would straddle rows)
 }
 template <typename T, bool OVP>
@@ -385,7 +385,7 @@ static int launch_sorted(const void *x, size_t rows, size_t row_len, const float
     if (!sort_shape_ok<T, OVP>(x, rows, row_len, ncand, ntypes)) return ANTQ_ERR_UNSUPPORTED;
     SortTypes stt;
     if (!sort_fill_types(stt, ntypes, gmax, plan_host, plan_dev)) return ANTQ_ERR_UNSUPPORTED;
-    if constexpr (!OVP) {
+    {
         // rows of at most 1024 elements: one row per wavefront (k_search_sorted_short; knob 21 = 0: the 4096-key kernel, A/B)
         if (row_len <= (size_t)kSortKSh && g_knob_sort_short) {
             int piece = ncand;
@@ -394,7 +394,7 @@ static int launch_sorted(const void *x, size_t rows, size_t row_len, const float
             const unsigned blocks = (unsigned)std::min<size_t>((rows + 3) / 4, (size_t)1 << 20);
             for (int c0 = 0; c0 < ncand; c0 += piece) {
                 const int nc = std::min(piece, ncand - c0);
-                hipLaunchKernelGGL((k_search_sorted_short<T>), dim3(blocks), dim3(256), lds_of(nc), st, static_cast<const uint4 *>(x),
+                hipLaunchKernelGGL((k_search_sorted_short<T, OVP>), dim3(blocks), dim3(256), lds_of(nc), st, static_cast<const uint4 *>(x),
                                    (uint32_t)(row_len / EPL), rows, xmax, ratios + c0, sse + (size_t)c0 * rows, stt, (uint32_t)nc, (uint32_t)ncand);
             }
             return hipGetLastError() == hipSuccess ? ANTQ_OK : ANTQ_ERR_LAUNCH;

@@ -160,12 +160,16 @@ def test_sorted_olive_pairs_against_direct_and_oracle(dev, oracle, dtype_name):
     oo = grids.olive_outliers(4, True)
     cb = [(np.concatenate([grids.olive_grid(t, 4, True), oo]), float(grids.olive_grid(t, 4, True).max())) for t in ("int", "flint")]
     plans, gm = [L.plan_for(g) for g, _ in cb], [m for _, m in cb]
-    for rows, K in ((40, 2048), (12, 4096 + 512), (6, 3 * 4096)):
+    # (rows of <= 1024 elements: one row per wavefront, the outlier-capable pairs in a 32-pair list -- or, the 20 x 1024 case
+    #  with an outlier in every fourth pair, read again from the row)
+    for rows, K in ((40, 2048), (12, 4096 + 512), (6, 3 * 4096), (64, 768), (50, 1024), (33, 576), (20, 1024)):
         x = torch.randn(rows, K, device=dev) * 0.02
         idx = torch.randint(0, x.numel(), (x.numel() // 300,), device=dev)
         x.view(-1)[idx] *= torch.empty(idx.numel(), device=dev).uniform_(8, 64)
         x[0, 10:14] = torch.tensor([0.9, -1.1, 0.8, 0.7], device=dev)          # both members outliers
         x[1, 20] = 3.0e4                                                          # far beyond the codebook: a literal pair
+        if (rows, K) == (20, 1024):
+            x[:, ::8] *= 12.0                                                     # an outlier in every fourth pair: the list overflows
         x = x.to(dt)
         xm = L.xmax_3sigma(x, rows, K, per_row=True)
         rt = _ratios(75, 250, 2, dev)
@@ -176,7 +180,12 @@ def test_sorted_olive_pairs_against_direct_and_oracle(dev, oracle, dtype_name):
             #  noise of the size of the reference's own reduction noise, tests/calib_check.py -- the closed form does not)
             _compare(a, b, (dtype_name, "olive", ovp, rows, K), rtol=1.2e-6, tie=5.9e-7)
     # a few rows against the oracle's own search (the reference's op sequence on the fp32 image of the tensor)
-    rows, K = 6, 2048
+    for rows, K in ((6, 2048), (6, 768)):
+        _oracle_rows(L, oracle, dev, dt, cb, plans, gm, rows, K)
+
+
+def _oracle_rows(L, oracle, dev, dt, cb, plans, gm, rows, K):
+    import torch
     x = torch.randn(rows, K, device=dev) * 0.02
     idx = torch.randint(0, x.numel(), (x.numel() // 300,), device=dev)
     x.view(-1)[idx] *= torch.empty(idx.numel(), device=dev).uniform_(8, 64)

@@ -41,7 +41,7 @@ mkdir -p gpurun_out
       -k "calibration_fuzz or quantizer_end_to_end or type_selection_on_one_read or sharded_per_tensor or bert_base_real_shapes or calibrate_one_call" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
   ANTQ_DEBUG_KNOBS=20=2 ANTQ_FUZZ_SEEDS=${4:-150} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k calibration_pass_fuzz 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
-  echo "== ... and under its default rule (rows >= 128 (ANT) / 576 (OliVe), fp32 one-scale tensors >= 1 M elements)"
+  echo "== ... and under its default rule (rows >= 128 (ANT) / 256 (OliVe), fp32 one-scale tensors >= 1 M elements)"
   ANTQ_FUZZ_SEEDS=${3:-300} timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line \
       -k "calibration_fuzz" 2>&1 | grep -E "Error|passed|failed" | cut -c1-600
 } | tee gpurun_out/fuzz_campaign.log
