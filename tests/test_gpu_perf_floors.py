@@ -44,11 +44,12 @@ FLOORS = {
     "alpha_grad_rows_bf16": 0.99,
     "alpha_grad_tensor_bf16": 0.88,
     "affine_f32": 0.91,
-    "search_sse_rows_f32": 4.40,                 # (the sorted-row search since round 6: seen 5.1-5.6; the sweep was 3.5)
-    "search_multi_rows_f32": 9.0,                # 3 ANT codebooks x 70 candidates on ONE sort of every row
-    "search_short_rows_f32": 4.7,                # 3 ANT codebooks x 70 on rows of 768 elements: one row per wavefront
-    "search_olive_pairs_rows_bf16": 2.9,         # 2 OliVe codebooks x 88 candidates, pair rule
-    "calibrate_tensor_f32_sorted": 0.040,        # a 16.8 M-element fp32 tensor with one scale: statistic + 3 x 70 + picks
+    "search_sse_rows_f32": 4.50,                 # (the sorted-row search since round 6: seen 5.1-5.6; the sweep was 3.5)
+    "search_multi_rows_f32": 9.8,                # 3 ANT codebooks x 70 candidates on ONE sort of every row
+    "search_short_rows_f32": 5.3,                # 3 ANT codebooks x 70 on rows of 768 elements: one row per wavefront
+    "search_olive_short_rows_bf16": 1.9,         # the same on rows of 768 elements: one row per wavefront, the pair list behind the keys
+    "search_olive_pairs_rows_bf16": 3.3,         # 2 OliVe codebooks x 88 candidates, pair rule
+    "calibrate_tensor_f32_sorted": 0.044,        # a 16.8 M-element fp32 tensor with one scale: statistic + 3 x 70 + picks
     "calibrate_tensor_bf16_hist": 0.16,
 }
 _measured = {}
@@ -324,6 +325,20 @@ def test_floor_search_olive_pairs_rows(box):
     xm = L.xmax_3sigma(t, R, C, per_row=True)
     ratios = (torch.arange(75, 250, 2, device=t.device, dtype=torch.float64) * 0.01).float()
     _check(box, "search_olive_pairs_rows_bf16", lambda: L.search_sse_multi(t, R, C, xm, True, ratios, plans, gm, ovp=True), t.numel() * 176 * 2)
+
+
+def test_floor_search_olive_short_rows(box):
+    """OliVe's search on BERT-sized rows (768 elements): one row per wavefront with the pair rule."""
+    import numpy as np
+    L, x = box["_lib"], box["x"]
+    g = box["grids"]
+    oo = g.olive_outliers(4, True)
+    cb = [(np.concatenate([g.olive_grid(t, 4, True), oo]), float(g.olive_grid(t, 4, True).max())) for t in ("int", "flint")]
+    plans, gm = [L.plan_for(c) for c, _ in cb], [m for _, m in cb]
+    t = x[1].reshape(-1)[: 16384 * 768].reshape(16384, 768).contiguous()
+    xm = L.xmax_3sigma(t, 16384, 768, per_row=True)
+    ratios = (torch.arange(75, 250, 2, device=t.device, dtype=torch.float64) * 0.01).float()
+    _check(box, "search_olive_short_rows_bf16", lambda: L.search_sse_multi(t, 16384, 768, xm, True, ratios, plans, gm, ovp=True), t.numel() * 176 * 2)
 
 
 def test_floor_calibrate_one_scale_fp32(box):
