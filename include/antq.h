@@ -256,6 +256,12 @@ int antq_alpha_grad(const void *x_dev, const void *out_dev, const void *gout_dev
  * outlier-capable element and the scoring corrects the victims' terms from that list; a tensor with too many such pairs
  * (> ~8 %) is searched by the element-by-element kernels instead (decided on the device, no synchronisation).  The workspace
  * holds the slabs and the list: always size it with antq_search_workspace_bytes() (48.3 MiB since ABI 6; 8 MiB before).
+ * Per-row searches on rows of >= 128 elements (>= 256 with ANTQ_FLAG_OVP) of codebooks with a threshold list, and fp32
+ * tensors with ONE scale from 2^20 elements, are scored from the SORTED row / 4096-element chunk (round 6): counts and sums
+ * of the elements beyond every x-domain threshold by binary search into integer prefix sums, the squared error in closed
+ * form in double -- the terms are not rounded to fp32 one by one, so these sums lie within 1e-14 of the exact float64 sum of
+ * the reference's per-element outputs where the element-by-element kernels lie within 2e-7 (the reference's own fp32
+ * reduction: 3e-7).  Same arguments, same workspace, bit-identical from run to run.
  * ------------------------------------------------------------------------- */
 size_t antq_search_workspace_bytes(void);
 int antq_search_sse(const void *x_dev, size_t rows, size_t row_len,
