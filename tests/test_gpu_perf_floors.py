@@ -27,22 +27,25 @@ NB = 32                       # 32 x 33.5 MB bf16 = 1 GiB in, far beyond the 256
 
 # family -> floor on rate / reference copy rate: 5 points (7 for the one-launch-per-tensor families, 10-20 % for the two
 # compute-bound calibration kernels) under the LOWEST ratio seen on four boxes in round 6 (profiles/r06_perf_floors_*.json)
+# (round 6, later: on the two boxes whose copy kernel reached 6.49 TB/s -- 4-6 % above the others -- the HBM-bound families
+#  fell 4-6 points against it, `alpha_grad_rows_bf16` to 0.989 / 0.997 under a floor of 0.99: the read-side floors sit 5-7
+#  points under THOSE boxes' ratios now; a kernel that loses 20 points still fails)
 FLOORS = {
-    "hbatch_ant_bf16": 0.97,
-    "hbatch_olive_bf16": 0.96,
+    "hbatch_ant_bf16": 0.95,
+    "hbatch_olive_bf16": 0.94,
     "hrow_per_tensor_bf16_unordered": 1.02,
     "hrow_per_tensor_bf16_ordered": 0.85,
     "batch_d_group16_f32": 0.93,
     "batch_d_group16_bf16": 0.92,
-    "hbatch_dyn_rows_bf16": 0.94,
+    "hbatch_dyn_rows_bf16": 0.92,
     "batch_rows_f32": 0.95,
     "encode4_bf16": 0.50,
     "decode4_bf16": 0.50,
-    "absmax_rows_f32": 0.98,
-    "absmax_tensor_f32": 0.83,
+    "absmax_rows_f32": 0.95,
+    "absmax_tensor_f32": 0.80,
     "moments_rows_f32": 0.81,
-    "alpha_grad_rows_bf16": 0.99,
-    "alpha_grad_tensor_bf16": 0.88,
+    "alpha_grad_rows_bf16": 0.93,
+    "alpha_grad_tensor_bf16": 0.84,
     "affine_f32": 0.91,
     "search_sse_rows_f32": 4.50,                 # (the sorted-row search since round 6: seen 5.1-5.6; the sweep was 3.5)
     "search_multi_rows_f32": 9.8,                # 3 ANT codebooks x 70 candidates on ONE sort of every row
