@@ -627,14 +627,21 @@ def run_configs(h, _lib, grids, want):
                 oi = _lib.plan_for(np.concatenate([grids.olive_int(4, True), go]))
                 pls, gms = [oi, olive], [float(grids.olive_int(4, True).max()), float(gn.max())]
 
-                def cal():
+                jobs = [(w, w.shape[0], w.shape[1], True, pls, gms, 75, 250, 2) for w in ws]
+
+                def cal():          # (what enable_quantization's first forward does with a model's weights: ONE C call)
+                    _lib.calibrate_batch(jobs, xmax="3sigma", ovp=True)
+
+                def cal_each():
                     for w in ws:
                         _lib.calibrate(w, w.shape[0], w.shape[1], True, pls, gms, 75, 250, 2, xmax="3sigma", ovp=True)
 
                 e = centry("calib_C3_opt6.7b_rank0of8_bf16", "first-call calibration of those 24 tensors: 3-sigma statistic, OliVe int / "
-                           "flint + outliers x 88 clip ratios with the pair rule, per-row picks, type pick (one antq_calibrate per tensor: "
-                           "k_moments + the sorted-row search + picks)", "k_search_sorted<bf16,true,false>", 24, sum(w.numel() for w in ws), 176, cal)
+                           "flint + outliers x 88 clip ratios with the pair rule, per-row picks, type pick (antq_calibrate_batch: one C call, "
+                           "per tensor k_moments + the sorted-row search + picks)", "k_search_sorted<bf16,true,false>", 24 * 6,
+                           sum(w.numel() for w in ws), 176, cal)
                 e["x8_for_the_192_tensors_ms"] = round(e["pass_ms"] * 8, 1)
+                e["one_antq_calibrate_per_tensor_ms"] = round(timed(cal_each)[0] * 1e3, 3)
             del ws, outs, al, bt
 
     # (v) configs[4]: the 70 B-parameter bf16 stack, rank 0's row block of every matrix at 8 ranks (17.1 GB in, 17.1 GB out)

@@ -228,6 +228,8 @@ def main():
             def full():
                 for w in ws:
                     _lib.calibrate(w, w.shape[0], w.shape[1], True, pls, gms, 75, 250, 2, xmax="3sigma", ovp=True)
+            jobs = [(w, w.shape[0], w.shape[1], True, pls, gms, 75, 250, 2) for w in ws]
+            t_batch = timed(lambda: _lib.calibrate_batch(jobs, xmax="3sigma", ovp=True), 2)
             t_ref, t_one, t_full = timed(stat_ref, 3), timed(stat_one, 3), timed(full, 2)
             evals = elems * 88 * 2
             scale = 192 / len(ws)
@@ -235,6 +237,7 @@ def main():
                 "C3 OPT-6.7B calibration, clip statistic, %d tensors" % len(ws), t_ref * 1e3, t_one * 1e3), flush=True)
             print("%-58s %8.1f ms = %6.1f G candidate-evals/s (statistic + 2 types x 88 ratios + picks, antq_calibrate); x %d for the 192 tensors: %.0f ms" % (
                 "C3 OPT-6.7B calibration, whole (these %d tensors)" % len(ws), t_full * 1e3, evals / t_full / 1e9, int(scale), t_full * 1e3 * scale), flush=True)
+            print("%-58s %8.1f ms; x %d for the 192 tensors: %.0f ms" % ("   the same in ONE C call (antq_calibrate_batch)", t_batch * 1e3, int(scale), t_batch * 1e3 * scale), flush=True)
         del ws, outs, al, bt
 
     # ---------------- C4: 70B-parameter bf16 Linear stack, OliVe flint4 OVP: this rank's 1/8 share (LPT by bytes)
