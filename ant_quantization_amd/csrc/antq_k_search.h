@@ -496,6 +496,8 @@ k_calib_type_score_pick(const float *__restrict__ best_score, size_t na, int nty
     for (int t = 0; t < ntypes; t++) {
         const float *p = best_score + (size_t)t * na;
         double s = 0.0;
+        // (eight loads in flight, the additions in the same order: one load latency per row block made this 16 us for 4096 rows)
+#pragma unroll 8
         for (size_t r = threadIdx.x; r < na; r += 256u) s += (double)p[r];
         part[threadIdx.x] = s;
         __syncthreads();
